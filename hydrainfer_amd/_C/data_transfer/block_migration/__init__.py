@@ -1,0 +1,124 @@
+"""hydrainfer._C.data_transfer.block_migration — drop-in surface
+(reference stub: hydrainfer/_C/data_transfer/block_migration/__init__.pyi:6-18;
+CUDA original: csrc/data_transfer/block_migration.cpp:55-59, 69-80, 194-245).
+
+Wire format kept: an IPC handle travels through Python/Ray as `list[int]` of 64 byte
+values (block_migration.cpp:34-49).  A torch allocation may sit at an offset inside its
+hipMalloc segment; the offset is appended to the list as 8 extra little-endian bytes
+(72 ints) — the reference assumes offset 0, which holds only for a tensor that owns its
+segment, and silently reads the wrong bytes otherwise."""
+import ctypes
+from typing import List
+
+import torch
+from torch import Tensor
+
+from hydrainfer_amd import _lib
+
+cudaMemoryIpcHandle = List[int]
+_registered: List[int] = []
+
+
+def get_ipc_mem_handle(tensor: Tensor) -> cudaMemoryIpcHandle:
+    _lib.require_gpu(tensor)
+    buf = (ctypes.c_uint8 * _lib.HX_IPC_HANDLE_BYTES)()
+    off = ctypes.c_int64(0)
+    with torch.cuda.device(tensor.device):
+        _lib.check(_lib.lib().hx_ipc_get_mem_handle(tensor.data_ptr(), buf, ctypes.byref(off)),
+                   "get_ipc_mem_handle")
+    return list(buf) + list(int(off.value).to_bytes(8, "little"))
+
+
+def _open(handle: cudaMemoryIpcHandle) -> int:
+    if len(handle) not in (_lib.HX_IPC_HANDLE_BYTES, _lib.HX_IPC_HANDLE_BYTES + 8):
+        raise _lib.HydraHipError("IPC handle must be 64 (+8 offset) byte values")
+    buf = (ctypes.c_uint8 * _lib.HX_IPC_HANDLE_BYTES)(*handle[:_lib.HX_IPC_HANDLE_BYTES])
+    off = int.from_bytes(bytes(handle[_lib.HX_IPC_HANDLE_BYTES:]), "little") if len(handle) > 64 else 0
+    ptr = ctypes.c_void_p(0)
+    _lib.check(_lib.lib().hx_ipc_open_mem_handle(buf, ctypes.byref(ptr)), "open ipc handle")
+    return int(ptr.value) + off
+
+
+def register_ipc_mem_handle(kv_cache_handle_vec: cudaMemoryIpcHandle) -> int:
+    """Maps a peer handle and returns its index (block_migration.cpp:69-80)."""
+    _registered.append(_open(kv_cache_handle_vec))
+    return len(_registered) - 1
+
+
+def migrate_blocks(src_block_table: List[int], dst_block_table: List[int],
+                   src_cache: cudaMemoryIpcHandle, dst_cache: Tensor,
+                   src_cache_n_blocks: int) -> None:
+    """dst_cache[l, t, dst_block_table[i]] = src[l, t, src_block_table[i]] on the current stream."""
+    _lib.require_gpu(dst_cache)
+    if dst_cache.dim() != 6 or not dst_cache.is_contiguous():
+        raise _lib.HydraHipError("migrate_blocks: dst_cache must be a contiguous 6-D pool")
+    if len(src_block_table) != len(dst_block_table):
+        raise _lib.HydraHipError("migrate_blocks: block tables must have equal length")
+    n = len(src_block_table)
+    if n == 0:
+        return
+    with torch.cuda.device(dst_cache.device):
+        src_ptr = _open(src_cache)
+        n_layers, n_tokens, dst_n_blocks, block_size, n_heads, head_size = dst_cache.shape
+        block_bytes = block_size * n_heads * head_size * dst_cache.element_size()
+        src_tbl = (ctypes.c_int32 * n)(*src_block_table)
+        dst_tbl = (ctypes.c_int32 * n)(*dst_block_table)
+        _lib.check(_lib.lib().hx_migrate_blocks(
+            src_tbl, dst_tbl, n, src_ptr, dst_cache.data_ptr(), n_layers, n_tokens,
+            int(src_cache_n_blocks), dst_n_blocks, block_bytes, _lib.current_stream()),
+            "migrate_blocks")
+
+
+def migrate_blocks_local(src_block_table: List[int], dst_block_table: List[int],
+                         src_cache: Tensor, dst_cache: Tensor) -> None:
+    """Same copy with a directly addressable source pool (same process / peer-enabled)."""
+    _lib.require_gpu(src_cache, dst_cache)
+    if dst_cache.dim() != 6 or not dst_cache.is_contiguous() or not src_cache.is_contiguous():
+        raise _lib.HydraHipError("migrate_blocks: pools must be contiguous 6-D")
+    n = len(src_block_table)
+    if n != len(dst_block_table):
+        raise _lib.HydraHipError("migrate_blocks: block tables must have equal length")
+    if n == 0:
+        return
+    n_layers, n_tokens, dst_n_blocks, block_size, n_heads, head_size = dst_cache.shape
+    block_bytes = block_size * n_heads * head_size * dst_cache.element_size()
+    src_tbl = (ctypes.c_int32 * n)(*src_block_table)
+    dst_tbl = (ctypes.c_int32 * n)(*dst_block_table)
+    with torch.cuda.device(dst_cache.device):
+        _lib.check(_lib.lib().hx_migrate_blocks(
+            src_tbl, dst_tbl, n, src_cache.data_ptr(), dst_cache.data_ptr(), n_layers, n_tokens,
+            src_cache.size(2), dst_n_blocks, block_bytes, _lib.current_stream()), "migrate_blocks")
+
+
+def pack_blocks(block_table: List[int], cache: Tensor, staging: Tensor) -> None:
+    """staging[l, t, i] = cache[l, t, block_table[i]] — send side of the RCCL path."""
+    _lib.require_gpu(cache, staging)
+    n = len(block_table)
+    if n == 0:
+        return
+    n_layers, n_tokens, n_blocks, block_size, n_heads, head_size = cache.shape
+    block_bytes = block_size * n_heads * head_size * cache.element_size()
+    if staging.numel() * staging.element_size() < n_layers * n_tokens * n * block_bytes:
+        raise _lib.HydraHipError("pack_blocks: staging buffer too small")
+    tbl = (ctypes.c_int32 * n)(*block_table)
+    with torch.cuda.device(cache.device):
+        _lib.check(_lib.lib().hx_pack_blocks(
+            tbl, n, cache.data_ptr(), staging.data_ptr(), n_layers, n_tokens, n_blocks,
+            block_bytes, _lib.current_stream()), "pack_blocks")
+
+
+def unpack_blocks(block_table: List[int], staging: Tensor, cache: Tensor) -> None:
+    """cache[l, t, block_table[i]] = staging[l, t, i] — receive side of the RCCL path."""
+    _lib.require_gpu(cache, staging)
+    n = len(block_table)
+    if n == 0:
+        return
+    n_layers, n_tokens, n_blocks, block_size, n_heads, head_size = cache.shape
+    block_bytes = block_size * n_heads * head_size * cache.element_size()
+    if staging.numel() * staging.element_size() < n_layers * n_tokens * n * block_bytes:
+        raise _lib.HydraHipError("unpack_blocks: staging buffer too small")
+    tbl = (ctypes.c_int32 * n)(*block_table)
+    with torch.cuda.device(cache.device):
+        _lib.check(_lib.lib().hx_unpack_blocks(
+            tbl, n, staging.data_ptr(), cache.data_ptr(), n_layers, n_tokens, n_blocks,
+            block_bytes, _lib.current_stream()), "unpack_blocks")

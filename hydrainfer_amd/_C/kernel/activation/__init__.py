@@ -1,0 +1,32 @@
+"""hydrainfer._C.kernel.activation — drop-in surface
+(reference stub: hydrainfer/_C/kernel/activation/__init__.pyi:3-4;
+CUDA original: csrc/kernel/activation/activation.cu:35-56)."""
+import torch
+from torch import Tensor
+
+from hydrainfer_amd import _lib
+
+
+def silu(input: Tensor) -> Tensor:
+    _lib.require_gpu(input)
+    if input.dim() != 2 or input.stride(1) != 1:
+        raise _lib.HydraHipError("silu: input must be 2-D with a contiguous last dimension")
+    out = torch.empty(input.shape, dtype=input.dtype, device=input.device)
+    _lib.check(_lib.lib().hx_silu(
+        out.data_ptr(), input.data_ptr(), input.size(0), input.size(1), input.stride(0),
+        _lib.dtype_code(input), _lib.current_stream()), "silu")
+    return out
+
+
+def silu_and_mul(gate: Tensor, up: Tensor) -> Tensor:
+    """Extension: (T)silu(gate) * up in one pass (model_forward.py:36 fused)."""
+    _lib.require_gpu(gate, up)
+    if gate.dim() != 2 or gate.shape != up.shape or gate.stride(1) != 1 or up.stride(1) != 1:
+        raise _lib.HydraHipError("silu_and_mul: gate/up must be 2-D, same shape, contiguous last dim")
+    if gate.dtype != up.dtype:
+        raise _lib.HydraHipError("silu_and_mul: dtype mismatch")
+    out = torch.empty(gate.shape, dtype=gate.dtype, device=gate.device)
+    _lib.check(_lib.lib().hx_silu_and_mul(
+        out.data_ptr(), gate.data_ptr(), up.data_ptr(), gate.size(0), gate.size(1),
+        gate.stride(0), up.stride(0), _lib.dtype_code(gate), _lib.current_stream()), "silu_and_mul")
+    return out

@@ -1,0 +1,107 @@
+"""hydrainfer._C.kernel.flash_attn — drop-in surface
+(reference stub: hydrainfer/_C/kernel/flash_attn/__init__.pyi:23-40;
+CUDA original: csrc/kernel/flash_attn/flash_api.cpp:216-355).
+
+Positional-only in practice, like the pybind original ("pybind module can't be called
+by key value form", __init__.pyi:22).  Argument validation mirrors the TORCH_CHECKs of
+flash_api.cpp:236-283 and raises RuntimeError (HydraHipError) in every failure case."""
+import ctypes
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from hydrainfer_amd import _lib
+
+
+def _i32(t: Tensor, name: str) -> Tensor:
+    if t.dtype != torch.int32:
+        raise _lib.HydraHipError(f"{name} must have dtype int32")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def mha_varlen_fwd(out: Tensor, q: Tensor, k: Tensor, v: Tensor, cu_seqlens_q: Tensor,
+                   cu_seqlens_k: Tensor, block_table_: Optional[Tensor],
+                   cu_block_lens: Optional[Tensor], alibi_slopes: Optional[Tensor],
+                   max_seqlen_q: int, max_seqlen_k: int, softmax_scale: float, softcap: float,
+                   window_size_left: int, window_size_right: int, num_splits: int) -> None:
+    _lib.require_gpu(out, q, k, v, cu_seqlens_q, cu_seqlens_k, block_table_, cu_block_lens)
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise _lib.HydraHipError("FlashAttention only support fp16 and bf16 data type")
+    if k.dtype != q.dtype or v.dtype != q.dtype or out.dtype != q.dtype:
+        raise _lib.HydraHipError("query, key, value and out must have the same dtype")
+    cu_seqlens_q = _i32(cu_seqlens_q, "cu_seqlens_q")
+    cu_seqlens_k = _i32(cu_seqlens_k, "cu_seqlens_k")
+    for t in (q, k, v, out):
+        if t.stride(-1) != 1:
+            raise _lib.HydraHipError("Input tensor must have contiguous last dimension")
+    if q.dim() != 3 or out.shape != q.shape:
+        raise _lib.HydraHipError("q/out must be [n_tokens, n_heads, head_dim]")
+    if q.stride(1) != q.size(2) or out.stride(1) != out.size(2):
+        raise _lib.HydraHipError("q/out heads must be contiguous")
+    if alibi_slopes is not None:
+        raise _lib.HydraHipError("alibi_slopes is not supported by the MI355X implementation")
+    if softcap != 0:
+        raise _lib.HydraHipError("softcap != 0 is not supported by the MI355X implementation")
+    # flash_api.cpp:80-87: causal iff window (-1, 0); full iff (-1, -1)
+    if window_size_left >= 0 or window_size_right > 0:
+        raise _lib.HydraHipError("local (sliding window) attention is not supported by the MI355X implementation")
+    causal = window_size_left < 0 and window_size_right == 0
+
+    paged = block_table_ is not None
+    a = _lib.hx_attn_args()
+    batch = cu_seqlens_q.numel() - 1
+    if batch <= 0:
+        raise _lib.HydraHipError("batch size must be positive")
+    if cu_seqlens_k.numel() != batch + 1:
+        raise _lib.HydraHipError("cu_seqlens_k must have shape [batch + 1]")
+    n_heads, head_dim = q.size(1), q.size(2)
+    if paged:
+        if cu_block_lens is None:
+            raise _lib.HydraHipError("cu_block_lens is required with block_table")
+        block_table_ = _i32(block_table_, "block_table")
+        cu_block_lens = _i32(cu_block_lens, "cu_block_lens")
+        if k.dim() != 4 or v.shape != k.shape or k.size(3) != head_dim:
+            raise _lib.HydraHipError("paged k/v must be [n_blocks, block_size, n_kv_heads, head_dim]")
+        if k.size(1) % 16 != 0:
+            raise _lib.HydraHipError("Paged KV cache block size must be divisible by 16")
+        a.block_table = block_table_.data_ptr()
+        a.cu_block_lens = cu_block_lens.data_ptr()
+        a.block_size = k.size(1)
+        a.k_block_stride, a.k_row_stride, a.k_head_stride = k.stride(0), k.stride(1), k.stride(2)
+        a.v_block_stride, a.v_row_stride, a.v_head_stride = v.stride(0), v.stride(1), v.stride(2)
+    else:
+        if k.dim() != 3 or v.shape != k.shape or k.size(2) != head_dim:
+            raise _lib.HydraHipError("dense k/v must be [total_k, n_kv_heads, head_dim]")
+        a.block_table = None
+        a.cu_block_lens = None
+        a.block_size = 0
+        a.k_block_stride, a.k_row_stride, a.k_head_stride = 0, k.stride(0), k.stride(1)
+        a.v_block_stride, a.v_row_stride, a.v_head_stride = 0, v.stride(0), v.stride(1)
+    n_kv_heads = k.size(-2)
+    if head_dim % 8 != 0:
+        raise _lib.HydraHipError("FlashAttention forward only supports head dimension divisible by 8")
+    if head_dim > 256:
+        raise _lib.HydraHipError("FlashAttention forward only supports head dimension at most 256")
+    if n_heads % n_kv_heads != 0:
+        raise _lib.HydraHipError("Number of heads in key/value must divide number of heads in query")
+
+    a.out, a.q, a.k, a.v = out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr()
+    a.cu_seqlens_q, a.cu_seqlens_k = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr()
+    a.batch, a.n_heads, a.n_kv_heads, a.head_dim = batch, n_heads, n_kv_heads, head_dim
+    a.max_seqlen_q, a.max_seqlen_k, a.total_q = int(max_seqlen_q), int(max_seqlen_k), q.size(0)
+    a.q_row_stride, a.o_row_stride = q.stride(0), out.stride(0)
+    a.softmax_scale = float(softmax_scale)
+    a.causal = 1 if causal else 0
+    a.dtype = _lib.dtype_code(q)
+    a.num_splits = int(num_splits)
+    a.workspace, a.workspace_bytes = None, 0
+
+    l = _lib.lib()
+    need = l.hx_mha_varlen_fwd_workspace_bytes(ctypes.byref(a))
+    ws = None
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    with torch.cuda.device(q.device):
+        _lib.check(l.hx_mha_varlen_fwd(ctypes.byref(a), _lib.current_stream()), "mha_varlen_fwd")

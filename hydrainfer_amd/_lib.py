@@ -1,0 +1,118 @@
+"""ctypes binding of libhydra_hip.so (the C ABI declared in include/hydra_hip.h).
+
+This is the only place the shared library is opened.  Loading fails loudly: there is
+no CPU or eager-PyTorch fallback anywhere in the product path (the reference instead
+wraps every `hydrainfer._C` import in try/except and silently drops to torch, e.g.
+hydrainfer/layer/causal_attention.py:13-17).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhydra_hip.so")
+
+HX_F32, HX_F16, HX_BF16 = 0, 1, 2
+HX_IPC_HANDLE_BYTES = 64
+
+_DTYPE = {torch.float32: HX_F32, torch.float16: HX_F16, torch.bfloat16: HX_BF16}
+
+
+class HydraHipError(RuntimeError):
+    """Raised for every non-zero hx_status (the reference raises RuntimeError via
+    TORCH_CHECK, or aborts the process via glog CHECK; we always raise)."""
+
+
+class hx_attn_args(ctypes.Structure):
+    _fields_ = [
+        ("out", c_void_p), ("q", c_void_p), ("k", c_void_p), ("v", c_void_p),
+        ("cu_seqlens_q", c_void_p), ("cu_seqlens_k", c_void_p),
+        ("block_table", c_void_p), ("cu_block_lens", c_void_p),
+        ("batch", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32),
+        ("head_dim", c_int32), ("block_size", c_int32), ("max_seqlen_q", c_int32),
+        ("max_seqlen_k", c_int32), ("total_q", c_int32),
+        ("q_row_stride", c_int64), ("o_row_stride", c_int64),
+        ("k_block_stride", c_int64), ("k_row_stride", c_int64), ("k_head_stride", c_int64),
+        ("v_block_stride", c_int64), ("v_row_stride", c_int64), ("v_head_stride", c_int64),
+        ("softmax_scale", c_float), ("causal", c_int32), ("dtype", c_int32),
+        ("num_splits", c_int32), ("workspace", c_void_p), ("workspace_bytes", c_int64),
+    ]
+
+
+_SIGNATURES = {
+    "hx_abi_version": (c_int, []),
+    "hx_strerror": (c_char_p, [c_int]),
+    "hx_last_hip_error": (c_int, []),
+    "hx_set_kv_cache": (c_int, [c_void_p] * 5 + [c_int64] * 8 + [c_int, c_void_p]),
+    "hx_set_image_cache": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_int, c_void_p]),
+    "hx_rms_norm": (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int64, c_int, c_void_p]),
+    "hx_add_rms_norm": (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int64, c_int, c_void_p]),
+    "hx_apply_rotary_pos_emb": (c_int, [c_void_p] * 4 + [c_int64] * 7 + [c_int, c_int, c_void_p]),
+    "hx_silu": (c_int, [c_void_p] * 2 + [c_int64] * 3 + [c_int, c_void_p]),
+    "hx_silu_and_mul": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_void_p]),
+    "hx_mha_varlen_fwd_workspace_bytes": (c_int64, [POINTER(hx_attn_args)]),
+    "hx_mha_varlen_fwd": (c_int, [POINTER(hx_attn_args), c_void_p]),
+    "hx_ipc_get_mem_handle": (c_int, [c_void_p, c_void_p, POINTER(c_int64)]),
+    "hx_ipc_open_mem_handle": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "hx_ipc_close_all": (c_int, []),
+    "hx_migrate_blocks": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 5 + [c_void_p]),
+    "hx_pack_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 4 + [c_void_p]),
+    "hx_unpack_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 4 + [c_void_p]),
+    "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Open libhydra_hip.so once and type every entry point."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HydraHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C hydrainfer_amd/csrc`. There is no fallback path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.hx_abi_version() != 1:
+            raise HydraHipError("libhydra_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        l = lib()
+        msg = l.hx_strerror(status).decode()
+        if status == -7:
+            msg += f" (hipError_t {l.hx_last_hip_error()})"
+        raise HydraHipError(f"{what}: {msg}")
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE[t.dtype]
+    except KeyError:
+        raise HydraHipError(f"failed to dispatch data type {t.dtype}")
+
+
+def require_gpu(*tensors: torch.Tensor) -> None:
+    """The product path is GPU-only; refuse CPU tensors instead of falling back."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HydraHipError(
+                "hydrainfer_amd ops run only on MI355X device tensors; got a CPU tensor "
+                "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,49 @@
+// attn_common.h — MFMA wrappers and parameter block shared by the attention kernels.
+#pragma once
+#include "hx_common.h"
+
+namespace hx {
+
+template <typename T> struct Mfma;
+template <> struct Mfma<F16> {
+  // D[16x16] += A[16x32] * B[32x16]; lane l: A[row l&15][k 8(l>>4)+j], B[k 8(l>>4)+j][col l&15]
+  static __device__ __forceinline__ f32x4 mma(u16x8 a, u16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<BF16> {
+  static __device__ __forceinline__ f32x4 mma(u16x8 a, u16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Finite "minus infinity" for running maxima: keeps exp2(m_old - m_new) == 1 when a
+// lane group has not seen any unmasked key yet (no NaN from inf - inf).
+#define HX_NEG_BIG (-1.0e30f)
+
+struct AttnParams {
+  void* out;
+  const void* q;
+  const void* k;
+  const void* v;
+  const int32_t* cu_q;
+  const int32_t* cu_k;
+  const int32_t* block_table;
+  const int32_t* cu_block_lens;
+  int64_t q_row_stride, o_row_stride;
+  int64_t k_block_stride, k_row_stride, k_head_stride;
+  int64_t v_block_stride, v_row_stride, v_head_stride;
+  int32_t n_heads, group;   // group = n_heads / n_kv_heads
+  int32_t block_size;       // paged: tokens per page (multiple of 16)
+  int32_t causal;
+  float scale_log2;         // softmax_scale * log2(e)
+  int32_t n_splits;
+  float* ws_o;              // [batch, n_heads, n_splits, D] unnormalised partial outputs
+  float* ws_ml;             // [batch, n_heads, n_splits, 2] (max, sum)
+};
+
+}  // namespace hx

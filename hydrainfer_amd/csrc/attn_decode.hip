@@ -1,0 +1,295 @@
+// attn_decode.hip — paged decode attention (q_len == 1 per sequence), the HBM-roofline
+// kernel of the path (replaces the reference's 64x128-tile split-KV flash kernel run
+// with one valid query row: csrc/kernel/flash_attn/src/flash_fwd_kernel.h:435-1019).
+//
+// Design (gfx950):
+//   * grid = (q_head, sequence, kv_split); 4 waves per workgroup, wave w owns KV tiles
+//     t = t0+w, t0+w+4, ... of 16 keys each.
+//   * Block table: each wave reads the page ids of ALL its tiles with one coalesced
+//     vector load (lane j <- page of its j-th tile) and broadcasts them with v_readlane;
+//     no dependent table lookup sits in front of a K/V load.
+//   * K and V stream HBM -> VGPR with 16-byte loads, double-buffered in registers
+//     (tile t+4 is in flight while tile t is computed).  No LDS round trip: every byte
+//     is used exactly once by exactly one wave.
+//   * Q.K^T on MFMA 16x16x32: A = K tile (16 keys x 32 dims per step, loaded directly in
+//     the A-operand lane layout), B = q broadcast into all 16 columns.  The accumulator
+//     gives lane (g=l>>4, c=l&15) the 4 scores of keys 4g..4g+3, replicated over c —
+//     no cross-lane reduction.
+//   * Each 16-lane group g keeps its own online-softmax state (m, l) and an fp32 partial
+//     output for its keys; P.V is fp32 FMA on V rows loaded so that lane (g,c) holds
+//     dims [c*D/16, (c+1)*D/16) of keys 4g+i — p stays in fp32 (the fp32 CPU oracle's
+//     numerics; the reference CUDA kernel rounds P to T first).
+//   * The 16 partial states of a workgroup (4 waves x 4 groups) are merged through LDS
+//     once; kv_splits > 1 write (m, l, o) partials that attn_decode_combine merges.
+#include "attn_common.h"
+
+namespace {
+
+using namespace hx;
+
+template <int D> struct VRow;  // per-lane slice of one V row: D/16 elements
+template <> struct VRow<64> {
+  typedef u16x4 type;
+  static constexpr int NV = 1, E = 4;
+};
+template <> struct VRow<128> {
+  typedef u16x8 type;
+  static constexpr int NV = 1, E = 8;
+};
+template <> struct VRow<256> {
+  typedef u16x8 type;
+  static constexpr int NV = 2, E = 8;  // dims 8c..8c+7 and 128+8c..128+8c+7
+};
+
+template <int D>
+struct KVTile {
+  u16x8 k[D / 32];                         // A-operand fragments, one per 32-dim step
+  typename VRow<D>::type v[4][VRow<D>::NV];  // keys 4g+i, i = 0..3
+};
+
+template <typename T, int D>
+__device__ __forceinline__ void load_tile(KVTile<D>& buf, const AttnParams& p, const u16* kbase,
+                                          const u16* vbase, int page, int row0, int valid,
+                                          int lane) {
+  // valid = number of in-range keys in this tile (>= 1; may exceed 16)
+  const int r = lane & 15, g = lane >> 4, c = lane & 15;
+  const int r_eff = min(r, valid - 1);
+  const u16* kp = kbase + (int64_t)page * p.k_block_stride + (int64_t)(row0 + r_eff) * p.k_row_stride +
+                  8 * g;
+#pragma unroll
+  for (int s = 0; s < D / 32; ++s) buf.k[s] = *reinterpret_cast<const u16x8*>(kp + 32 * s);
+  constexpr int E = VRow<D>::E;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tok = min(4 * g + i, valid - 1);
+    const u16* vp = vbase + (int64_t)page * p.v_block_stride + (int64_t)(row0 + tok) * p.v_row_stride +
+                    E * c;
+#pragma unroll
+    for (int n = 0; n < VRow<D>::NV; ++n)
+      buf.v[i][n] = *reinterpret_cast<const typename VRow<D>::type*>(vp + 128 * n);
+  }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (&qf)[D / 32],
+                                             int valid, float scale_log2, int lane, float& m,
+                                             float& l, float (&o)[D / 16]) {
+  const int g = lane >> 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < D / 32; ++st) s = Mfma<T>::mma(buf.k[st], qf[st], s);
+  float x[4];
+  float mx = m;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x[i] = (4 * g + i < valid) ? s[i] * scale_log2 : -INFINITY;
+    mx = fmaxf(mx, x[i]);
+  }
+  const float alpha = fast_exp2(m - mx);
+  float pr[4];
+  float ps = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pr[i] = fast_exp2(x[i] - mx);
+    ps += pr[i];
+  }
+  m = mx;
+  l = l * alpha + ps;
+  constexpr int E = VRow<D>::E, NV = VRow<D>::NV;
+#pragma unroll
+  for (int n = 0; n < NV; ++n)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float acc = o[n * E + e] * alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = fmaf(pr[i], T::to_float(buf.v[i][n][e]), acc);
+      o[n * E + e] = acc;
+    }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
+  constexpr int NW = 4;
+  constexpr int OE = D / 16;  // fp32 partial-output elements per lane
+  __shared__ float s_m[16], s_l[16];
+  __shared__ float s_o[16][D];
+
+  const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int hk = h / p.group;
+
+  const int kv_len = p.cu_k[b + 1] - p.cu_k[b];
+  const int q_row = p.cu_q[b];
+  const int n_tiles = (kv_len + 15) >> 4;
+  const int per_split = (n_tiles + p.n_splits - 1) / p.n_splits;
+  const int t_begin = split * per_split;
+  const int t_end = min(n_tiles, t_begin + per_split);
+  const int tpp = p.block_size >> 4;  // tiles per page
+  const int32_t* bt = p.block_table + p.cu_block_lens[b];
+
+  const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
+  const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
+
+  // q as the MFMA B operand, identical in all 16 columns
+  u16x8 qf[D / 32];
+  {
+    const u16* qp = reinterpret_cast<const u16*>(p.q) + (int64_t)q_row * p.q_row_stride +
+                    (int64_t)h * D + 8 * g;
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 32 * s);
+  }
+
+  float m = HX_NEG_BIG, l = 0.f;
+  float o[OE];
+#pragma unroll
+  for (int e = 0; e < OE; ++e) o[e] = 0.f;
+
+  // my tiles: t_begin + w + NW*j.  Chunks of 64 tiles per wave share one page-id vector.
+  for (int chunk0 = t_begin + w; chunk0 < t_end; chunk0 += NW * 64) {
+    int my_page = 0;
+    {
+      const int tj = chunk0 + NW * lane;
+      if (tj < t_end) my_page = bt[tj / tpp];
+    }
+    const int n_my = min(64, (t_end - chunk0 + NW - 1) / NW);  // wave-uniform
+
+    KVTile<D> bufA, bufB;
+    int j = 0;
+    {
+      const int t = chunk0;
+      load_tile<T, D>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
+                      (t % tpp) << 4, kv_len - (t << 4), lane);
+    }
+    while (j < n_my) {
+      if (j + 1 < n_my) {
+        const int t = chunk0 + NW * (j + 1);
+        load_tile<T, D>(bufB, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
+                        (t % tpp) << 4, kv_len - (t << 4), lane);
+      }
+      compute_tile<T, D>(bufA, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o);
+      ++j;
+      if (j >= n_my) break;
+      if (j + 1 < n_my) {
+        const int t = chunk0 + NW * (j + 1);
+        load_tile<T, D>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
+                        (t % tpp) << 4, kv_len - (t << 4), lane);
+      }
+      compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o);
+      ++j;
+    }
+  }
+
+  // ---- merge the 16 partial states of this workgroup --------------------------------
+  constexpr int E = VRow<D>::E, NV = VRow<D>::NV;
+  const int slot = w * 4 + g;
+  if (c == 0) {
+    s_m[slot] = m;
+    s_l[slot] = l;
+  }
+#pragma unroll
+  for (int n = 0; n < NV; ++n)
+#pragma unroll
+    for (int e = 0; e < E; ++e) s_o[slot][128 * n + E * c + e] = o[n * E + e];
+  __syncthreads();
+
+  const int d = threadIdx.x;
+  if (d < D) {
+    float M = HX_NEG_BIG;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) M = fmaxf(M, s_m[k]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float wgt = fast_exp2(s_m[k] - M);
+      L = fmaf(s_l[k], wgt, L);
+      O = fmaf(s_o[k][d], wgt, O);
+    }
+    if (p.n_splits == 1) {
+      const float r = (L > 0.f) ? O / L : 0.f;
+      reinterpret_cast<u16*>(p.out)[(int64_t)q_row * p.o_row_stride + (int64_t)h * D + d] =
+          T::from_float(r);
+    } else {
+      const int64_t idx = ((int64_t)b * p.n_heads + h) * p.n_splits + split;
+      p.ws_o[idx * D + d] = O;
+      if (d == 0) {
+        p.ws_ml[idx * 2 + 0] = M;
+        p.ws_ml[idx * 2 + 1] = L;
+      }
+    }
+  }
+}
+
+// one workgroup of D threads per (head, sequence)
+template <typename T, int D>
+__global__ __launch_bounds__(D) void attn_decode_combine_kernel(const AttnParams p) {
+  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const int q_row = p.cu_q[b];
+  const int64_t base = ((int64_t)b * p.n_heads + h) * p.n_splits;
+  float M = HX_NEG_BIG;
+  for (int s = 0; s < p.n_splits; ++s) M = fmaxf(M, p.ws_ml[(base + s) * 2]);
+  float L = 0.f, O = 0.f;
+  for (int s = 0; s < p.n_splits; ++s) {
+    const float wgt = fast_exp2(p.ws_ml[(base + s) * 2] - M);
+    L = fmaf(p.ws_ml[(base + s) * 2 + 1], wgt, L);
+    O = fmaf(p.ws_o[(base + s) * D + d], wgt, O);
+  }
+  const float r = (L > 0.f) ? O / L : 0.f;
+  reinterpret_cast<u16*>(p.out)[(int64_t)q_row * p.o_row_stride + (int64_t)h * D + d] =
+      T::from_float(r);
+}
+
+template <typename T, int D>
+int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
+  dim3 grid(p.n_heads, batch, p.n_splits);
+  attn_decode_kernel<T, D><<<grid, 256, 0, stream>>>(p);
+  int rc = check_launch();
+  if (rc) return rc;
+  if (p.n_splits > 1) {
+    attn_decode_combine_kernel<T, D><<<dim3(p.n_heads, batch), D, 0, stream>>>(p);
+    rc = check_launch();
+  }
+  return rc;
+}
+
+}  // namespace
+
+namespace hx {
+
+bool decode_supported(int head_dim) { return head_dim == 64 || head_dim == 128 || head_dim == 256; }
+
+int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested) {
+  if (requested >= 1) return requested > 128 ? 128 : requested;
+  const int64_t base = (int64_t)batch * n_heads;
+  if (base >= 768) return 1;
+  const int n_tiles = (max_seqlen_k + 15) / 16;
+  int64_t want = (1024 + base - 1) / base;       // ~4 workgroups per CU
+  int64_t cap = n_tiles / 16;                    // >= 16 tiles (4 per wave) per split
+  if (cap < 1) cap = 1;
+  int64_t s = want < cap ? want : cap;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+int launch_attn_decode(const AttnParams& p, int batch, int head_dim, int dtype,
+                       hipStream_t stream) {
+  if (dtype == HX_F16) {
+    switch (head_dim) {
+      case 64: return launch_decode<F16, 64>(p, batch, stream);
+      case 128: return launch_decode<F16, 128>(p, batch, stream);
+      case 256: return launch_decode<F16, 256>(p, batch, stream);
+    }
+  } else if (dtype == HX_BF16) {
+    switch (head_dim) {
+      case 64: return launch_decode<BF16, 64>(p, batch, stream);
+      case 128: return launch_decode<BF16, 128>(p, batch, stream);
+      case 256: return launch_decode<BF16, 256>(p, batch, stream);
+    }
+  } else {
+    return HX_ERR_DTYPE;
+  }
+  return HX_ERR_SHAPE;
+}
+
+}  // namespace hx

@@ -1,0 +1,257 @@
+// attn_fwd.hip — general variable-length attention forward (prefill, chunked prefill,
+// dense vision-tower MHA, and any decode shape the specialised kernel does not take).
+// Replaces csrc/kernel/flash_attn/src/flash_fwd_kernel.h:26-431 (dense) and :435-1019
+// (paged) of the reference; online-softmax recipe as softmax.h:95-145, mask as
+// mask.h:130-211 (bottom-right aligned causal).
+//
+// Design (gfx950, MFMA 16x16x32, "swapped" products so no P transpose is needed):
+//   * workgroup = 4 independent waves; wave w owns 16 query rows; grid =
+//     (ceil(max_q/64), head, sequence).
+//   * S^T[key][query] = K . Q^T : A = K tile loaded HBM->VGPR directly in the A-operand
+//     lane layout (16 keys x 32 dims per step), B = Q^T fragments kept in registers.
+//     The accumulator leaves lane (g=l>>4, c=l&15) with query c, keys 4g..4g+3 of each
+//     16-key sub-tile: row statistics need only two cross-group shuffles (xor 16, 32).
+//   * O^T[dim][query] += V^T . P^T : P^T is used as the B operand straight from the
+//     softmax registers (k-slot j of lane group g <-> key 16*(j>>2)+4g+(j&3)); V^T is the
+//     A operand, read with ds_read_b64_tr_b16 from a wave-private LDS image of the V tile
+//     [32 keys][D] (row stride 2D+32 bytes => conflict-free transposed reads).
+//   * P is rounded to T before P.V exactly like the reference kernel
+//     (flash_fwd_kernel.h:878); accumulation is fp32.
+#include "attn_common.h"
+
+namespace {
+
+using namespace hx;
+
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef short s16x4_t __attribute__((__vector_size__(4 * sizeof(short))));
+
+__device__ __forceinline__ u16x4 lds_tr_read(const char* lds_ptr) {
+  typedef __attribute__((address_space(3))) s16x4_t lds_s4;
+  s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)lds_ptr);
+  return __builtin_bit_cast(u16x4, r);
+}
+
+template <typename T, int D, bool PAGED>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int NS = D / 32;       // QK k-steps
+  constexpr int NDB = D / 16;      // 16-dim output blocks
+  constexpr int RS = 2 * D + 32;   // LDS row stride in bytes
+  constexpr int LPR = D / 8;       // lanes per V row when staging (16 B per lane)
+  constexpr int NVI = D / 16;      // staging instructions per 32-key tile (32*LPR/64)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int mblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int hk = h / p.group;
+
+  const int q_start = p.cu_q[b];
+  const int q_len = p.cu_q[b + 1] - q_start;
+  const int k_start = p.cu_k[b];
+  const int kv_len = p.cu_k[b + 1] - k_start;
+  const int q_row0 = mblk * 64 + w * 16;
+  if (q_row0 >= q_len) return;  // wave-uniform; kernel uses no workgroup barrier
+
+  char* vlds = smem + w * (32 * RS);
+
+  const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
+  const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
+  const int32_t* bt = PAGED ? p.block_table + p.cu_block_lens[b] : nullptr;
+
+  // Q^T fragments (B operand): lane (c,g) holds Q[row c][32s + 8g + j]
+  u16x8 qf[NS];
+  {
+    const int qr = min(q_row0 + c, q_len - 1);
+    const u16* qp = reinterpret_cast<const u16*>(p.q) + (int64_t)(q_start + qr) * p.q_row_stride +
+                    (int64_t)h * D + 8 * g;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 32 * s);
+  }
+
+  // visible keys for query column c: key <= limit_c
+  const int shift = kv_len - q_len;
+  const int limit_c = p.causal ? min(kv_len - 1, q_row0 + c + shift) : kv_len - 1;
+  int last_key = p.causal ? min(kv_len - 1, q_row0 + 15 + shift) : kv_len - 1;  // wave-uniform
+  const int n_tiles = (last_key >= 0) ? (last_key >> 5) + 1 : 0;
+
+  f32x4 acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = HX_NEG_BIG, l = 0.f;
+
+  for (int t = 0; t < n_tiles; ++t) {
+    // ---- sub-tile bases (wave-uniform); fully out-of-range sub-tiles alias the last valid
+    int tok0[2];
+    int64_t kro[2], vro[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int t0 = t * 32 + u * 16;
+      if (t0 >= kv_len) t0 = ((kv_len - 1) >> 4) << 4;
+      tok0[u] = t0;
+      if (PAGED) {
+        const int page = bt[t0 / p.block_size];
+        const int row0 = t0 % p.block_size;
+        kro[u] = (int64_t)page * p.k_block_stride + (int64_t)row0 * p.k_row_stride;
+        vro[u] = (int64_t)page * p.v_block_stride + (int64_t)row0 * p.v_row_stride;
+      } else {
+        kro[u] = (int64_t)(k_start + t0) * p.k_row_stride;
+        vro[u] = (int64_t)(k_start + t0) * p.v_row_stride;
+      }
+    }
+
+    // ---- issue V global loads early (consumed after the softmax)
+    u16x8 vst[NVI];
+#pragma unroll
+    for (int n = 0; n < NVI; ++n) {
+      const int idx = n * 64 + lane;
+      const int row = idx / LPR;        // 0..31 within the tile
+      const int chunk = idx % LPR;
+      const int u = row >> 4;
+      const int rr = min(row & 15, kv_len - 1 - tok0[u]);
+      vst[n] = *reinterpret_cast<const u16x8*>(vbase + vro[u] + (int64_t)rr * p.v_row_stride +
+                                               8 * chunk);
+    }
+
+    // ---- S^T = K . Q^T for the two 16-key sub-tiles
+    f32x4 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rr = min(c, kv_len - 1 - tok0[u]);  // A-operand row = key (lane & 15)
+      const u16* kp = kbase + kro[u] + (int64_t)rr * p.k_row_stride + 8 * g;
+      u16x8 kf[NS];
+#pragma unroll
+      for (int st = 0; st < NS; ++st) kf[st] = *reinterpret_cast<const u16x8*>(kp + 32 * st);
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < NS; ++st) a = Mfma<T>::mma(kf[st], qf[st], a);
+      s[u] = a;
+    }
+
+    // ---- mask + online softmax (per query column c; state replicated over g)
+    float x[8];
+    float mx = HX_NEG_BIG;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = t * 32 + u * 16 + 4 * g + i;
+        const float v = (key <= limit_c) ? s[u][i] * p.scale_log2 : -INFINITY;
+        x[u * 4 + i] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = fast_exp2(m - m_new);
+    m = m_new;
+    u16x8 pf;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float e = fast_exp2(x[j] - m_new);
+      ps += e;
+      pf[j] = T::from_float(e);
+    }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) acc[i] *= alpha;
+
+    // ---- stage V tile into the wave-private LDS image
+#pragma unroll
+    for (int n = 0; n < NVI; ++n) {
+      const int idx = n * 64 + lane;
+      const int row = idx / LPR;
+      const int chunk = idx % LPR;
+      *reinterpret_cast<u16x8*>(vlds + row * RS + chunk * 16) = vst[n];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    // ---- O^T += V^T . P^T
+    const int q4 = c >> 2, p4 = c & 3;
+    const char* vrd = vlds + (4 * g + q4) * RS + p4 * 8;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      const u16x4 lo = lds_tr_read(vrd + db * 32);
+      const u16x4 hi = lds_tr_read(vrd + 16 * RS + db * 32);
+      u16x8 vf;
+      vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+      vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+      acc[db] = Mfma<T>::mma(vf, pf, acc[db]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- epilogue: O[q c][dim 16db + 4g + i] = acc[db][i] / L
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+  if (q_row0 + c < q_len) {
+    u16* op = reinterpret_cast<u16*>(p.out) + (int64_t)(q_start + q_row0 + c) * p.o_row_stride +
+              (int64_t)h * D + 4 * g;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      u16x4 r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = T::from_float(acc[db][i] * inv);
+      *reinterpret_cast<u16x4*>(op + 16 * db) = r;
+    }
+  }
+}
+
+template <typename T, int D>
+int launch_fwd(const AttnParams& p, int batch, int max_seqlen_q, bool paged, hipStream_t stream) {
+  constexpr int RS = 2 * D + 32;
+  const size_t lds = 4 * 32 * RS;
+  dim3 grid((max_seqlen_q + 63) / 64, p.n_heads, batch);
+  if (grid.x == 0) return HX_OK;
+  if (paged) {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return hip_rc(e);
+    }
+    attn_fwd_kernel<T, D, true><<<grid, 256, lds, stream>>>(p);
+  } else {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return hip_rc(e);
+    }
+    attn_fwd_kernel<T, D, false><<<grid, 256, lds, stream>>>(p);
+  }
+  return check_launch();
+}
+
+}  // namespace
+
+namespace hx {
+
+bool fwd_supported(int head_dim) {
+  return head_dim == 32 || head_dim == 64 || head_dim == 96 || head_dim == 128 || head_dim == 256;
+}
+
+int launch_attn_fwd(const AttnParams& p, int batch, int head_dim, int max_seqlen_q, bool paged,
+                    int dtype, hipStream_t stream) {
+#define HX_FWD_CASE(TT, DD) \
+  case DD: return launch_fwd<TT, DD>(p, batch, max_seqlen_q, paged, stream);
+  if (dtype == HX_F16) {
+    switch (head_dim) {
+      HX_FWD_CASE(F16, 32) HX_FWD_CASE(F16, 64) HX_FWD_CASE(F16, 96) HX_FWD_CASE(F16, 128)
+      HX_FWD_CASE(F16, 256)
+    }
+  } else if (dtype == HX_BF16) {
+    switch (head_dim) {
+      HX_FWD_CASE(BF16, 32) HX_FWD_CASE(BF16, 64) HX_FWD_CASE(BF16, 96) HX_FWD_CASE(BF16, 128)
+      HX_FWD_CASE(BF16, 256)
+    }
+  } else {
+    return HX_ERR_DTYPE;
+  }
+#undef HX_FWD_CASE
+  return HX_ERR_SHAPE;
+}
+
+}  // namespace hx

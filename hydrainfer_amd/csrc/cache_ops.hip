@@ -1,0 +1,189 @@
+// cache_ops.hip — paged-cache scatter kernels (set_kv_cache / set_image_cache) and the
+// decode-step metadata advance.  Pure byte movement: HBM-bound, 16 B per lane,
+// one launch per call.
+//
+// Behaviour follows csrc/kernel/kv_cache_kernels/kv_cache_kernels.cu:16-95 and
+// csrc/kernel/cache_kernels/cache_kernels.cu:16-83 of the reference (slot -> block,
+// offset addressing; bit-exact element copy), re-designed as a row-vector copy:
+// a token row (n_heads*head_dim elements) is contiguous in both source and cache,
+// so the kernel moves it as 16-byte vectors instead of per-element index math.
+#include "hx_common.h"
+
+namespace {
+
+using namespace hx;
+
+// One thread moves one 16-byte vector of K and (if NCACHE==2) one of V.
+// grid.x = ceil(vecs_per_row / 256), grid.y = n_tokens.
+template <int NCACHE>
+__global__ __launch_bounds__(256) void scatter_rows_vec16(
+    const int32_t* __restrict__ slot_ids, const uint4* __restrict__ src0,
+    const uint4* __restrict__ src1, uint4* __restrict__ dst0, uint4* __restrict__ dst1,
+    int64_t src0_stride_v, int64_t src1_stride_v, int64_t dst0_block_stride_v,
+    int64_t dst1_block_stride_v, int32_t vecs_per_row, int32_t block_size) {
+  const int token = blockIdx.y;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int slot = slot_ids[token];
+  if (slot < 0 || v >= vecs_per_row) return;
+  const int64_t blk = slot / block_size;
+  const int64_t off = slot % block_size;
+  const int64_t row_in_block = off * (int64_t)vecs_per_row + v;
+  uint4 a = src0[token * src0_stride_v + v];
+  uint4 b;
+  if (NCACHE == 2) b = src1[token * src1_stride_v + v];
+  dst0[blk * dst0_block_stride_v + row_in_block] = a;
+  if (NCACHE == 2) dst1[blk * dst1_block_stride_v + row_in_block] = b;
+}
+
+// Element-granular fallback for rows whose byte size or base alignment is not a
+// multiple of 16 (the reference test grid has none, kept for contract completeness).
+template <typename E, int NCACHE>
+__global__ __launch_bounds__(256) void scatter_rows_elem(
+    const int32_t* __restrict__ slot_ids, const E* __restrict__ src0, const E* __restrict__ src1,
+    E* __restrict__ dst0, E* __restrict__ dst1, int64_t src0_stride, int64_t src1_stride,
+    int64_t dst0_block_stride, int64_t dst1_block_stride, int32_t row_elems,
+    int32_t block_size) {
+  const int token = blockIdx.y;
+  const int slot = slot_ids[token];
+  if (slot < 0) return;
+  const int64_t blk = slot / block_size;
+  const int64_t off = slot % block_size;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < row_elems; i += gridDim.x * 256) {
+    const int64_t r = off * (int64_t)row_elems + i;
+    dst0[blk * dst0_block_stride + r] = src0[token * src0_stride + i];
+    if (NCACHE == 2) dst1[blk * dst1_block_stride + r] = src1[token * src1_stride + i];
+  }
+}
+
+template <int NCACHE>
+int launch_scatter(const int32_t* slot_ids, const void* s0, const void* s1, void* d0, void* d1,
+                   int64_t n_tokens, int64_t row_elems, int64_t block_size, int64_t s0_stride,
+                   int64_t s1_stride, int64_t d0_bstride, int64_t d1_bstride, int dtype,
+                   hipStream_t stream) {
+  const int64_t es = dtype_size(dtype);
+  if (es == 0) return HX_ERR_DTYPE;
+  if (n_tokens == 0 || row_elems == 0) return HX_OK;
+  if (n_tokens > 65535 * 1024LL) return HX_ERR_SHAPE;
+  const int64_t row_bytes = row_elems * es;
+  const bool vec_ok = (row_bytes % 16 == 0) && (s0_stride * es % 16 == 0) &&
+                      (d0_bstride * es % 16 == 0) && aligned16(s0) && aligned16(d0) &&
+                      (NCACHE == 1 || ((s1_stride * es % 16 == 0) && (d1_bstride * es % 16 == 0) &&
+                                       aligned16(s1) && aligned16(d1)));
+  // tokens go on grid.y (max 65535): fold larger counts by looping launches
+  for (int64_t t0 = 0; t0 < n_tokens; t0 += 65535) {
+    const int64_t nt = (n_tokens - t0 < 65535) ? (n_tokens - t0) : 65535;
+    const int32_t* sl = slot_ids + t0;
+    if (vec_ok) {
+      const int vpr = (int)(row_bytes / 16);
+      dim3 grid((vpr + 255) / 256, (unsigned)nt);
+      const int64_t epv = 16 / es;
+      scatter_rows_vec16<NCACHE><<<grid, 256, 0, stream>>>(
+          sl, (const uint4*)((const char*)s0 + t0 * s0_stride * es),
+          NCACHE == 2 ? (const uint4*)((const char*)s1 + t0 * s1_stride * es) : nullptr,
+          (uint4*)d0, (uint4*)d1, s0_stride / epv, s1_stride / epv, d0_bstride / epv,
+          d1_bstride / epv, vpr, (int)block_size);
+    } else {
+      dim3 grid((unsigned)((row_elems + 255) / 256 > 64 ? 64 : (row_elems + 255) / 256),
+                (unsigned)nt);
+      if (es == 2) {
+        scatter_rows_elem<uint16_t, NCACHE><<<grid, 256, 0, stream>>>(
+            sl, (const uint16_t*)s0 + t0 * s0_stride,
+            NCACHE == 2 ? (const uint16_t*)s1 + t0 * s1_stride : nullptr, (uint16_t*)d0,
+            (uint16_t*)d1, s0_stride, s1_stride, d0_bstride, d1_bstride, (int)row_elems,
+            (int)block_size);
+      } else {
+        scatter_rows_elem<uint32_t, NCACHE><<<grid, 256, 0, stream>>>(
+            sl, (const uint32_t*)s0 + t0 * s0_stride,
+            NCACHE == 2 ? (const uint32_t*)s1 + t0 * s1_stride : nullptr, (uint32_t*)d0,
+            (uint32_t*)d1, s0_stride, s1_stride, d0_bstride, d1_bstride, (int)row_elems,
+            (int)block_size);
+      }
+    }
+    int rc = check_launch();
+    if (rc) return rc;
+  }
+  return HX_OK;
+}
+
+// One wave per launch is plenty: batch <= a few hundred sequences.
+__global__ __launch_bounds__(256) void decode_advance_kernel(
+    int32_t* __restrict__ positions, int32_t* __restrict__ kv_lens,
+    int32_t* __restrict__ cu_seqlens_k, int32_t* __restrict__ new_cache_slots,
+    const int32_t* __restrict__ block_table, const int32_t* __restrict__ cu_block_lens,
+    int32_t batch, int32_t block_size) {
+  __shared__ int32_t scan[256];
+  int32_t carry = 0;
+  if (threadIdx.x == 0) cu_seqlens_k[0] = 0;
+  for (int base = 0; base < batch; base += 256) {
+    const int b = base + threadIdx.x;
+    int32_t len = 0;
+    if (b < batch) {
+      const int32_t pos = positions[b] + 1;
+      positions[b] = pos;
+      len = kv_lens[b] + 1;
+      kv_lens[b] = len;
+      const int32_t page = block_table[cu_block_lens[b] + pos / block_size];
+      new_cache_slots[b] = page * block_size + pos % block_size;
+    }
+    scan[threadIdx.x] = len;
+    __syncthreads();
+    // inclusive Hillis-Steele scan over 256 entries
+    for (int off = 1; off < 256; off <<= 1) {
+      int32_t add = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
+      __syncthreads();
+      scan[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (b < batch) cu_seqlens_k[b + 1] = carry + scan[threadIdx.x];
+    carry += scan[255];
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int hx_set_kv_cache(const int32_t* slot_ids, const void* keys, const void* values,
+                               void* key_cache, void* value_cache, int64_t n_tokens,
+                               int64_t n_kv_heads, int64_t head_dim, int64_t block_size,
+                               int64_t k_stride, int64_t v_stride, int64_t kcache_block_stride,
+                               int64_t vcache_block_stride, int dtype, hx_stream stream) {
+  if (!slot_ids || !keys || !values || !key_cache || !value_cache) {
+    return n_tokens == 0 ? HX_OK : HX_ERR_NULL;
+  }
+  if (n_tokens < 0 || n_kv_heads <= 0 || head_dim <= 0 || block_size <= 0) return HX_ERR_SHAPE;
+  const int64_t row = n_kv_heads * head_dim;
+  if (k_stride < row || v_stride < row) return HX_ERR_STRIDE;
+  if (kcache_block_stride < block_size * row || vcache_block_stride < block_size * row)
+    return HX_ERR_STRIDE;
+  return launch_scatter<2>(slot_ids, keys, values, key_cache, value_cache, n_tokens, row,
+                           block_size, k_stride, v_stride, kcache_block_stride,
+                           vcache_block_stride, dtype, (hipStream_t)stream);
+}
+
+extern "C" int hx_set_image_cache(const int32_t* slot_ids, const void* image_tokens,
+                                  void* image_cache, int64_t n_tokens, int64_t n_heads,
+                                  int64_t head_dim, int64_t block_size, int64_t token_stride,
+                                  int64_t cache_block_stride, int dtype, hx_stream stream) {
+  if (!slot_ids || !image_tokens || !image_cache) return n_tokens == 0 ? HX_OK : HX_ERR_NULL;
+  if (n_tokens < 0 || n_heads <= 0 || head_dim <= 0 || block_size <= 0) return HX_ERR_SHAPE;
+  const int64_t row = n_heads * head_dim;
+  if (token_stride < row) return HX_ERR_STRIDE;
+  if (cache_block_stride < block_size * row) return HX_ERR_STRIDE;
+  return launch_scatter<1>(slot_ids, image_tokens, nullptr, image_cache, nullptr, n_tokens, row,
+                           block_size, token_stride, 0, cache_block_stride, 0, dtype,
+                           (hipStream_t)stream);
+}
+
+extern "C" int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_k,
+                                 int32_t* new_cache_slots, const int32_t* block_table,
+                                 const int32_t* cu_block_lens, int32_t batch, int32_t block_size,
+                                 hx_stream stream) {
+  if (!positions || !kv_lens || !cu_seqlens_k || !new_cache_slots || !block_table ||
+      !cu_block_lens)
+    return HX_ERR_NULL;
+  if (batch <= 0 || block_size <= 0) return HX_ERR_SHAPE;
+  decode_advance_kernel<<<1, 256, 0, (hipStream_t)stream>>>(positions, kv_lens, cu_seqlens_k,
+                                                            new_cache_slots, block_table,
+                                                            cu_block_lens, batch, block_size);
+  return hx::check_launch();
+}

@@ -1,0 +1,143 @@
+// hx_api.hip — C-ABI entry points that are not tied to one kernel file: status text,
+// argument validation + dispatch of hx_mha_varlen_fwd (error behaviour mirrors the
+// TORCH_CHECKs of csrc/kernel/flash_attn/flash_api.cpp:236-283 of the reference).
+#include "attn_common.h"
+
+namespace hx {
+
+int& last_hip_error() {
+  static thread_local int e = 0;
+  return e;
+}
+
+bool decode_supported(int head_dim);
+bool fwd_supported(int head_dim);
+int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested);
+int launch_attn_decode(const AttnParams& p, int batch, int head_dim, int dtype,
+                       hipStream_t stream);
+int launch_attn_fwd(const AttnParams& p, int batch, int head_dim, int max_seqlen_q, bool paged,
+                    int dtype, hipStream_t stream);
+
+}  // namespace hx
+
+using namespace hx;
+
+extern "C" int hx_abi_version(void) { return HX_ABI_VERSION; }
+
+extern "C" int hx_last_hip_error(void) { return last_hip_error(); }
+
+extern "C" const char* hx_strerror(int status) {
+  switch (status) {
+    case HX_OK: return "ok";
+    case HX_ERR_DTYPE: return "failed to dispatch data type";
+    case HX_ERR_SHAPE: return "invalid shape / size argument";
+    case HX_ERR_STRIDE: return "unsupported tensor layout (stride / alignment)";
+    case HX_ERR_NULL: return "required pointer argument is null";
+    case HX_ERR_UNSUPPORTED: return "feature not supported by the MI355X implementation";
+    case HX_ERR_WORKSPACE: return "workspace too small";
+    case HX_ERR_HIP: return "HIP runtime error";
+    case HX_ERR_HANDLE: return "invalid IPC memory handle";
+    default: return "unknown hydra_hip status";
+  }
+}
+
+namespace {
+
+// decode kernel applies when every sequence contributes exactly one query row and the
+// cache is paged.
+bool use_decode(const hx_attn_args* a) {
+  return a->block_table != nullptr && a->max_seqlen_q == 1 && a->total_q == a->batch &&
+         decode_supported(a->head_dim);
+}
+
+int validate(const hx_attn_args* a) {
+  if (!a) return HX_ERR_NULL;
+  if (a->dtype != HX_F16 && a->dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (a->batch <= 0) return HX_ERR_SHAPE;
+  if (a->n_heads <= 0 || a->n_kv_heads <= 0 || a->n_heads % a->n_kv_heads != 0)
+    return HX_ERR_SHAPE;
+  if (a->head_dim <= 0 || a->head_dim % 8 != 0 || a->head_dim > 256) return HX_ERR_SHAPE;
+  if (!a->cu_seqlens_q || !a->cu_seqlens_k) return HX_ERR_NULL;
+  if (a->total_q < 0 || a->max_seqlen_q < 0 || a->max_seqlen_k < 0) return HX_ERR_SHAPE;
+  if (a->total_q > 0 && (!a->out || !a->q || !a->k || !a->v)) return HX_ERR_NULL;
+  if (a->block_table) {
+    if (!a->cu_block_lens) return HX_ERR_NULL;
+    if (a->block_size <= 0 || a->block_size % 16 != 0) return HX_ERR_SHAPE;
+  }
+  if (!fwd_supported(a->head_dim)) return HX_ERR_UNSUPPORTED;
+  // 16-byte vector access on q/k/v rows, 8-byte on out
+  const int64_t strides[] = {a->q_row_stride, a->k_row_stride, a->v_row_stride, a->k_head_stride,
+                             a->v_head_stride};
+  for (int64_t s : strides)
+    if (s % 8 != 0) return HX_ERR_STRIDE;
+  if (a->o_row_stride % 4 != 0) return HX_ERR_STRIDE;
+  if (a->block_table && (a->k_block_stride % 8 != 0 || a->v_block_stride % 8 != 0))
+    return HX_ERR_STRIDE;
+  if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v) ||
+      (reinterpret_cast<uintptr_t>(a->out) & 7u))
+    return HX_ERR_STRIDE;
+  return HX_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t hx_mha_varlen_fwd_workspace_bytes(const hx_attn_args* a) {
+  if (validate(a) != HX_OK || !use_decode(a)) return 0;
+  const int splits = decode_pick_splits(a->batch, a->n_heads, a->max_seqlen_k, a->num_splits);
+  if (splits <= 1) return 0;
+  return (int64_t)a->batch * a->n_heads * splits * (a->head_dim + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int hx_mha_varlen_fwd(const hx_attn_args* a, hx_stream stream) {
+  int rc = validate(a);
+  if (rc) return rc;
+  if (a->total_q == 0) return HX_OK;
+
+  AttnParams p;
+  p.out = a->out;
+  p.q = a->q;
+  p.k = a->k;
+  p.v = a->v;
+  p.cu_q = a->cu_seqlens_q;
+  p.cu_k = a->cu_seqlens_k;
+  p.block_table = a->block_table;
+  p.cu_block_lens = a->cu_block_lens;
+  p.q_row_stride = a->q_row_stride;
+  p.o_row_stride = a->o_row_stride;
+  p.k_block_stride = a->k_block_stride;
+  p.k_row_stride = a->k_row_stride;
+  p.k_head_stride = a->k_head_stride;
+  p.v_block_stride = a->v_block_stride;
+  p.v_row_stride = a->v_row_stride;
+  p.v_head_stride = a->v_head_stride;
+  p.n_heads = a->n_heads;
+  p.group = a->n_heads / a->n_kv_heads;
+  p.block_size = a->block_table ? a->block_size : 16;
+  p.causal = a->causal;
+  p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+  p.n_splits = 1;
+  p.ws_o = nullptr;
+  p.ws_ml = nullptr;
+
+  hipStream_t s = (hipStream_t)stream;
+  if (use_decode(a)) {
+    // with q_len == 1 the causal mask admits every cached key (bottom-right aligned),
+    // so causal and non-causal decode coincide.
+    int splits = decode_pick_splits(a->batch, a->n_heads, a->max_seqlen_k, a->num_splits);
+    if (splits > 1) {
+      const int64_t need =
+          (int64_t)a->batch * a->n_heads * splits * (a->head_dim + 2) * (int64_t)sizeof(float);
+      if (!a->workspace || a->workspace_bytes < need) {
+        if (a->num_splits > 1) return HX_ERR_WORKSPACE;
+        splits = 1;  // automatic choice degrades gracefully without scratch
+      } else {
+        p.ws_o = reinterpret_cast<float*>(a->workspace);
+        p.ws_ml = p.ws_o + (int64_t)a->batch * a->n_heads * splits * a->head_dim;
+      }
+    }
+    p.n_splits = splits;
+    return launch_attn_decode(p, a->batch, a->head_dim, a->dtype, s);
+  }
+  return launch_attn_fwd(p, a->batch, a->head_dim, a->max_seqlen_q, a->block_table != nullptr,
+                         a->dtype, s);
+}

@@ -1,0 +1,106 @@
+// hx_common.h — shared device/host helpers for libhydra_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hydra_hip.h"
+
+#define HX_WAVE 64
+
+namespace hx {
+
+// thread-local last hipError_t for hx_last_hip_error()
+int& last_hip_error();
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    last_hip_error() = (int)e;
+    return HX_ERR_HIP;
+  }
+  return HX_OK;
+}
+
+inline int hip_rc(hipError_t e) {
+  if (e != hipSuccess) {
+    last_hip_error() = (int)e;
+    return HX_ERR_HIP;
+  }
+  return HX_OK;
+}
+
+inline int64_t dtype_size(int dtype) {
+  switch (dtype) {
+    case HX_F32: return 4;
+    case HX_F16: return 2;
+    case HX_BF16: return 2;
+    default: return 0;
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------------------------------------------------------------------
+// 16-bit float element traits.  Storage is always raw uint16_t bits; arithmetic
+// in "T precision" means: compute in fp32, round to T after every operation
+// (exact emulation of IEEE T arithmetic for + - * since 24 >= 2*p+2).
+// ---------------------------------------------------------------------------
+typedef uint16_t u16;
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct F16 {
+  static constexpr int kDtype = HX_F16;
+  typedef u16 storage;
+  static __device__ __forceinline__ float to_float(u16 b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+  }
+  static __device__ __forceinline__ u16 from_float(float f) {
+    return __builtin_bit_cast(u16, (_Float16)f);  // RNE
+  }
+};
+
+struct BF16 {
+  static constexpr int kDtype = HX_BF16;
+  typedef u16 storage;
+  static __device__ __forceinline__ float to_float(u16 b) {
+    return __builtin_bit_cast(float, ((uint32_t)b) << 16);
+  }
+  static __device__ __forceinline__ u16 from_float(float f) {
+    return __builtin_bit_cast(u16, (__bf16)f);  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+  }
+};
+
+struct F32 {
+  static constexpr int kDtype = HX_F32;
+  typedef float storage;
+  static __device__ __forceinline__ float to_float(float b) { return b; }
+  static __device__ __forceinline__ float from_float(float f) { return f; }
+};
+
+// round fp32 value to T precision and come back (one "T arithmetic" rounding)
+template <typename T>
+__device__ __forceinline__ float round_to(float f) {
+  return T::to_float(T::from_float(f));
+}
+template <>
+__device__ __forceinline__ float round_to<F32>(float f) { return f; }
+
+// wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+}  // namespace hx

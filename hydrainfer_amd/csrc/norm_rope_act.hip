@@ -1,0 +1,420 @@
+// norm_rope_act.hip — rms_norm, rotary embedding, silu (+ fused silu*mul, add+rms_norm).
+// All HBM-bound row kernels: 16-byte vector loads, one pass over the row held in
+// registers, wave64 shuffle reductions.  Rounding points follow the reference CUDA
+// kernels (csrc/kernel/norm/rms_norm.cu:14-41, csrc/kernel/position_embedding/
+// rope.cu:12-79, csrc/kernel/activation/activation.cu:13-33).
+#include "hx_common.h"
+
+namespace {
+
+using namespace hx;
+
+// ---------------------------------------------------------------------------
+// vector row access: VEC elements of T per lane per step (16 bytes)
+// ---------------------------------------------------------------------------
+template <typename T> struct VecOf;
+template <> struct VecOf<F32> { static constexpr int N = 4; typedef f32x4 type; };
+template <> struct VecOf<F16> { static constexpr int N = 8; typedef u16x8 type; };
+template <> struct VecOf<BF16> { static constexpr int N = 8; typedef u16x8 type; };
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = red[0] + red[1] + red[2] + red[3];
+  return t;
+}
+
+// rms_norm: one 256-thread workgroup per row; the row lives in registers
+// (up to MAXV vectors per thread) between the reduction and the scaling pass.
+// ADD: h = residual + x (T arithmetic), residual <- h, then norm(h).
+template <typename T, int MAXV, bool ADD>
+__global__ __launch_bounds__(256) void rms_norm_vec_kernel(
+    typename T::storage* __restrict__ out, typename T::storage* __restrict__ residual,
+    const typename T::storage* __restrict__ input, const typename T::storage* __restrict__ weight,
+    float eps, int32_t hidden) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int nvec = hidden / N;
+  const V* in_v = reinterpret_cast<const V*>(input + row * hidden);
+  V* res_v = ADD ? reinterpret_cast<V*>(residual + row * hidden) : nullptr;
+  V* out_v = reinterpret_cast<V*>(out + row * hidden);
+  const V* w_v = reinterpret_cast<const V*>(weight);
+
+  float x[MAXV][N];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < nvec) {
+      V v = in_v[i];
+      if (ADD) {
+        V r = res_v[i];
+        V h;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          float s = round_to<T>(T::to_float(v[e]) + T::to_float(r[e]));
+          x[j][e] = s;
+          h[e] = T::from_float(s);
+        }
+        res_v[i] = h;
+      } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) x[j][e] = T::to_float(v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < N; ++e) ss += x[j][e] * x[j][e];
+    }
+  }
+  const float total = block_sum_256(ss, red);
+  const float inv = rsqrtf(total / (float)hidden + eps);
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < nvec) {
+      V w = w_v[i];
+      V o;
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        // (T)(x * s_variance) * weight  — two T roundings (rms_norm.cu:39)
+        float n = round_to<T>(x[j][e] * inv);
+        o[e] = T::from_float(n * T::to_float(w[e]));
+      }
+      out_v[i] = o;
+    }
+  }
+}
+
+// generic (any hidden, any alignment): re-reads the row
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void rms_norm_generic_kernel(
+    typename T::storage* __restrict__ out, typename T::storage* __restrict__ residual,
+    const typename T::storage* __restrict__ input, const typename T::storage* __restrict__ weight,
+    float eps, int64_t hidden) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const typename T::storage* in = input + row * hidden;
+  typename T::storage* res = ADD ? residual + row * hidden : nullptr;
+  float ss = 0.f;
+  for (int64_t i = threadIdx.x; i < hidden; i += 256) {
+    float x = T::to_float(in[i]);
+    if (ADD) {
+      x = round_to<T>(x + T::to_float(res[i]));
+      res[i] = T::from_float(x);
+    }
+    ss += x * x;
+  }
+  const float total = block_sum_256(ss, red);
+  const float inv = rsqrtf(total / (float)hidden + eps);
+  for (int64_t i = threadIdx.x; i < hidden; i += 256) {
+    const float x = ADD ? T::to_float(res[i]) : T::to_float(in[i]);
+    float n = round_to<T>(x * inv);
+    out[row * hidden + i] = T::from_float(n * T::to_float(weight[i]));
+  }
+}
+
+template <typename T, bool ADD>
+int launch_rms(void* out, void* residual, const void* input, const void* weight, float eps,
+               int64_t rows, int64_t hidden, hipStream_t stream) {
+  typedef typename T::storage S;
+  constexpr int N = VecOf<T>::N;
+  if (rows == 0) return HX_OK;
+  const bool vec = (hidden % N == 0) && aligned16(out) && aligned16(input) && aligned16(weight) &&
+                   (!ADD || aligned16(residual));
+  dim3 grid((unsigned)rows);
+  if (vec && hidden / N <= 256 * 1) {
+    rms_norm_vec_kernel<T, 1, ADD><<<grid, 256, 0, stream>>>((S*)out, (S*)residual,
+                                                            (const S*)input, (const S*)weight,
+                                                            eps, (int)hidden);
+  } else if (vec && hidden / N <= 256 * 2) {
+    rms_norm_vec_kernel<T, 2, ADD><<<grid, 256, 0, stream>>>((S*)out, (S*)residual,
+                                                            (const S*)input, (const S*)weight,
+                                                            eps, (int)hidden);
+  } else if (vec && hidden / N <= 256 * 4) {
+    rms_norm_vec_kernel<T, 4, ADD><<<grid, 256, 0, stream>>>((S*)out, (S*)residual,
+                                                            (const S*)input, (const S*)weight,
+                                                            eps, (int)hidden);
+  } else {
+    rms_norm_generic_kernel<T, ADD><<<grid, 256, 0, stream>>>((S*)out, (S*)residual,
+                                                             (const S*)input, (const S*)weight,
+                                                             eps, hidden);
+  }
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// RoPE.  Work item = (token, head (q heads then kv heads), pair index).
+// One thread rotates PV pairs: x' = x*c - y*s ; y' = x*s + y*c with every
+// operation rounded to T (rope.cu:22-27).  fp contraction is disabled so the
+// fp32 path also matches an unfused CPU evaluation bit for bit.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void rotate_pair(float x, float y, float c, float s, float& xo,
+                                            float& yo) {
+#pragma clang fp contract(off)
+  const float xc = round_to<T>(x * c);
+  const float ys = round_to<T>(y * s);
+  const float xs = round_to<T>(x * s);
+  const float yc = round_to<T>(y * c);
+  xo = round_to<T>(xc - ys);
+  yo = round_to<T>(xs + yc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kernel(
+    typename T::storage* __restrict__ q, typename T::storage* __restrict__ k,
+    const int32_t* __restrict__ positions, const typename T::storage* __restrict__ cos_sin,
+    int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t rotary_dim, int64_t q_stride,
+    int64_t k_stride, int32_t interleaved) {
+  const int token = blockIdx.x;
+  const int half = rotary_dim >> 1;
+  const int total = (n_heads + n_kv_heads) * half;
+  const typename T::storage* cs = cos_sin + (int64_t)positions[token] * rotary_dim;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int h = i / half;
+    const int r = i - h * half;
+    typename T::storage* base = (h < n_heads) ? (q + token * q_stride + (int64_t)h * head_dim)
+                                              : (k + token * k_stride +
+                                                 (int64_t)(h - n_heads) * head_dim);
+    const int xi = interleaved ? 2 * r : r;
+    const int yi = interleaved ? 2 * r + 1 : r + half;
+    const float c = T::to_float(cs[r]);
+    const float s = T::to_float(cs[half + r]);
+    float xo, yo;
+    rotate_pair<T>(T::to_float(base[xi]), T::to_float(base[yi]), c, s, xo, yo);
+    base[xi] = T::from_float(xo);
+    base[yi] = T::from_float(yo);
+  }
+}
+
+// Vectorised NeoX (non-interleaved) variant: each thread owns N consecutive pairs:
+// 16-byte loads of x[r..r+N), y[r..r+N), cos[r..), sin[r..).  Requires half % N == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_neox_vec_kernel(
+    typename T::storage* __restrict__ q, typename T::storage* __restrict__ k,
+    const int32_t* __restrict__ positions, const typename T::storage* __restrict__ cos_sin,
+    int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t rotary_dim, int64_t q_stride,
+    int64_t k_stride) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  const int token = blockIdx.x;
+  const int half = rotary_dim >> 1;
+  const int vph = half / N;  // vectors per head-half
+  const int total = (n_heads + n_kv_heads) * vph;
+  const typename T::storage* cs = cos_sin + (int64_t)positions[token] * rotary_dim;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int h = i / vph;
+    const int rv = i - h * vph;
+    typename T::storage* base = (h < n_heads) ? (q + token * q_stride + (int64_t)h * head_dim)
+                                              : (k + token * k_stride +
+                                                 (int64_t)(h - n_heads) * head_dim);
+    V* xp = reinterpret_cast<V*>(base + rv * N);
+    V* yp = reinterpret_cast<V*>(base + half + rv * N);
+    const V cv = *reinterpret_cast<const V*>(cs + rv * N);
+    const V sv = *reinterpret_cast<const V*>(cs + half + rv * N);
+    V xv = *xp, yv = *yp, xo, yo;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      float a, b;
+      rotate_pair<T>(T::to_float(xv[e]), T::to_float(yv[e]), T::to_float(cv[e]),
+                     T::to_float(sv[e]), a, b);
+      xo[e] = T::from_float(a);
+      yo[e] = T::from_float(b);
+    }
+    *xp = xo;
+    *yp = yo;
+  }
+}
+
+template <typename T>
+int launch_rope(void* q, void* k, const int32_t* positions, const void* cos_sin,
+                int64_t n_tokens, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim,
+                int64_t rotary_dim, int64_t q_stride, int64_t k_stride, int interleaved,
+                hipStream_t stream) {
+  typedef typename T::storage S;
+  constexpr int N = VecOf<T>::N;
+  if (n_tokens == 0) return HX_OK;
+  const int64_t half = rotary_dim / 2;
+  const int64_t es = sizeof(S);
+  const bool vec = !interleaved && (half % N == 0) && (head_dim % N == 0) &&
+                   (q_stride * es % 16 == 0) && (k_stride * es % 16 == 0) && aligned16(q) &&
+                   aligned16(k) && aligned16(cos_sin);
+  dim3 grid((unsigned)n_tokens);
+  if (vec) {
+    rope_neox_vec_kernel<T><<<grid, 256, 0, stream>>>((S*)q, (S*)k, positions, (const S*)cos_sin,
+                                                     (int)n_heads, (int)n_kv_heads,
+                                                     (int)head_dim, (int)rotary_dim, q_stride,
+                                                     k_stride);
+  } else {
+    rope_kernel<T><<<grid, 256, 0, stream>>>((S*)q, (S*)k, positions, (const S*)cos_sin,
+                                            (int)n_heads, (int)n_kv_heads, (int)head_dim,
+                                            (int)rotary_dim, q_stride, k_stride, interleaved);
+  }
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// SiLU: (T)(x / (1 + exp(-x))) in fp32 (activation.cu:16-19).  MUL: times `up`
+// in T arithmetic (model_forward.py:36).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
+
+template <typename T, bool MUL>
+__global__ __launch_bounds__(256) void silu_vec_kernel(
+    typename T::storage* __restrict__ out, const typename T::storage* __restrict__ gate,
+    const typename T::storage* __restrict__ up, int32_t nvec, int64_t gate_stride,
+    int64_t up_stride, int64_t out_stride) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  const int64_t row = blockIdx.y;
+  const V* g = reinterpret_cast<const V*>(gate + row * gate_stride);
+  const V* u = MUL ? reinterpret_cast<const V*>(up + row * up_stride) : nullptr;
+  V* o = reinterpret_cast<V*>(out + row * out_stride);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+    V gv = g[i], r;
+    V uv;
+    if (MUL) uv = u[i];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      float a = silu_f32(T::to_float(gv[e]));
+      if (MUL) a = round_to<T>(a) * T::to_float(uv[e]);
+      r[e] = T::from_float(a);
+    }
+    o[i] = r;
+  }
+}
+
+template <typename T, bool MUL>
+__global__ __launch_bounds__(256) void silu_elem_kernel(
+    typename T::storage* __restrict__ out, const typename T::storage* __restrict__ gate,
+    const typename T::storage* __restrict__ up, int64_t n, int64_t gate_stride, int64_t up_stride,
+    int64_t out_stride) {
+  const int64_t row = blockIdx.y;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float a = silu_f32(T::to_float(gate[row * gate_stride + i]));
+    if (MUL) a = round_to<T>(a) * T::to_float(up[row * up_stride + i]);
+    out[row * out_stride + i] = T::from_float(a);
+  }
+}
+
+template <typename T, bool MUL>
+int launch_silu(void* out, const void* gate, const void* up, int64_t rows, int64_t n,
+                int64_t gate_stride, int64_t up_stride, hipStream_t stream) {
+  typedef typename T::storage S;
+  constexpr int N = VecOf<T>::N;
+  if (rows == 0 || n == 0) return HX_OK;
+  const int64_t es = sizeof(S);
+  const bool vec = (n % N == 0) && (gate_stride * es % 16 == 0) && aligned16(out) &&
+                   aligned16(gate) && (!MUL || ((up_stride * es % 16 == 0) && aligned16(up)));
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    S* o = (S*)out + r0 * n;
+    const S* g = (const S*)gate + r0 * gate_stride;
+    const S* u = MUL ? (const S*)up + r0 * up_stride : nullptr;
+    if (vec) {
+      const int nvec = (int)(n / N);
+      int gx = (nvec + 255) / 256;
+      if (gx > 64) gx = 64;
+      silu_vec_kernel<T, MUL><<<dim3(gx, (unsigned)nr), 256, 0, stream>>>(o, g, u, nvec,
+                                                                         gate_stride, up_stride, n);
+    } else {
+      int64_t gx = (n + 255) / 256;
+      if (gx > 64) gx = 64;
+      silu_elem_kernel<T, MUL><<<dim3((unsigned)gx, (unsigned)nr), 256, 0, stream>>>(
+          o, g, u, n, gate_stride, up_stride, n);
+    }
+    int rc = check_launch();
+    if (rc) return rc;
+  }
+  return HX_OK;
+}
+
+}  // namespace
+
+extern "C" int hx_rms_norm(void* out, const void* input, const void* weight, float epsilon,
+                           int64_t rows, int64_t hidden, int dtype, hx_stream stream) {
+  if (rows < 0 || hidden <= 0) return HX_ERR_SHAPE;
+  if (rows == 0) return HX_OK;
+  if (!out || !input || !weight) return HX_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case HX_F32: return launch_rms<F32, false>(out, nullptr, input, weight, epsilon, rows, hidden, s);
+    case HX_F16: return launch_rms<F16, false>(out, nullptr, input, weight, epsilon, rows, hidden, s);
+    case HX_BF16: return launch_rms<BF16, false>(out, nullptr, input, weight, epsilon, rows, hidden, s);
+    default: return HX_ERR_DTYPE;
+  }
+}
+
+extern "C" int hx_add_rms_norm(void* out, void* residual, const void* x, const void* weight,
+                               float epsilon, int64_t rows, int64_t hidden, int dtype,
+                               hx_stream stream) {
+  if (rows < 0 || hidden <= 0) return HX_ERR_SHAPE;
+  if (rows == 0) return HX_OK;
+  if (!out || !residual || !x || !weight) return HX_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case HX_F32: return launch_rms<F32, true>(out, residual, x, weight, epsilon, rows, hidden, s);
+    case HX_F16: return launch_rms<F16, true>(out, residual, x, weight, epsilon, rows, hidden, s);
+    case HX_BF16: return launch_rms<BF16, true>(out, residual, x, weight, epsilon, rows, hidden, s);
+    default: return HX_ERR_DTYPE;
+  }
+}
+
+extern "C" int hx_apply_rotary_pos_emb(void* query, void* key, const int32_t* positions,
+                                       const void* cos_sin, int64_t n_tokens, int64_t n_heads,
+                                       int64_t n_kv_heads, int64_t head_dim, int64_t rotary_dim,
+                                       int64_t q_stride, int64_t k_stride, int interleaved,
+                                       int dtype, hx_stream stream) {
+  if (n_tokens < 0 || n_heads < 0 || n_kv_heads < 0 || head_dim <= 0) return HX_ERR_SHAPE;
+  if (rotary_dim <= 0 || rotary_dim > head_dim || (rotary_dim & 1)) return HX_ERR_SHAPE;
+  if (n_tokens == 0) return HX_OK;
+  if (!query || !key || !positions || !cos_sin) return HX_ERR_NULL;
+  if (q_stride < n_heads * head_dim || k_stride < n_kv_heads * head_dim) return HX_ERR_STRIDE;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case HX_F32:
+      return launch_rope<F32>(query, key, positions, cos_sin, n_tokens, n_heads, n_kv_heads,
+                              head_dim, rotary_dim, q_stride, k_stride, interleaved, s);
+    case HX_F16:
+      return launch_rope<F16>(query, key, positions, cos_sin, n_tokens, n_heads, n_kv_heads,
+                              head_dim, rotary_dim, q_stride, k_stride, interleaved, s);
+    case HX_BF16:
+      return launch_rope<BF16>(query, key, positions, cos_sin, n_tokens, n_heads, n_kv_heads,
+                               head_dim, rotary_dim, q_stride, k_stride, interleaved, s);
+    default: return HX_ERR_DTYPE;
+  }
+}
+
+extern "C" int hx_silu(void* out, const void* input, int64_t rows, int64_t n, int64_t in_stride,
+                       int dtype, hx_stream stream) {
+  if (rows < 0 || n < 0) return HX_ERR_SHAPE;
+  if (rows == 0 || n == 0) return HX_OK;
+  if (!out || !input) return HX_ERR_NULL;
+  if (in_stride < n) return HX_ERR_STRIDE;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case HX_F32: return launch_silu<F32, false>(out, input, nullptr, rows, n, in_stride, 0, s);
+    case HX_F16: return launch_silu<F16, false>(out, input, nullptr, rows, n, in_stride, 0, s);
+    case HX_BF16: return launch_silu<BF16, false>(out, input, nullptr, rows, n, in_stride, 0, s);
+    default: return HX_ERR_DTYPE;
+  }
+}
+
+extern "C" int hx_silu_and_mul(void* out, const void* gate, const void* up, int64_t rows,
+                               int64_t n, int64_t gate_stride, int64_t up_stride, int dtype,
+                               hx_stream stream) {
+  if (rows < 0 || n < 0) return HX_ERR_SHAPE;
+  if (rows == 0 || n == 0) return HX_OK;
+  if (!out || !gate || !up) return HX_ERR_NULL;
+  if (gate_stride < n || up_stride < n) return HX_ERR_STRIDE;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case HX_F32: return launch_silu<F32, true>(out, gate, up, rows, n, gate_stride, up_stride, s);
+    case HX_F16: return launch_silu<F16, true>(out, gate, up, rows, n, gate_stride, up_stride, s);
+    case HX_BF16: return launch_silu<BF16, true>(out, gate, up, rows, n, gate_stride, up_stride, s);
+    default: return HX_ERR_DTYPE;
+  }
+}

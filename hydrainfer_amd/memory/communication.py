@@ -1,0 +1,133 @@
+"""Cache-block migration backends — host-side mirror of hydrainfer/memory/communication.py.
+
+Reference behaviour kept: pull model (the receiver moves the data, the sender side of the
+IPC backend is a no-op), intra-node 'ipc' vs inter-node 'nccl' selection by rank2host.
+MI355X redesign of the data path:
+  * ipc  : ONE gather-copy kernel over the IPC-mapped peer pool (xGMI peer read) instead of
+           n_layers*n_tokens*n_blocks cudaMemcpyAsync calls (communication.py:23-45 ->
+           block_migration.cpp:222-244).
+  * rccl : pack kernel -> ONE send/recv of the packed buffer -> unpack kernel, instead of one
+           P2POp per (block, layer, k/v) view (communication.py:57-74)."""
+from dataclasses import dataclass
+from typing import Dict, List, Literal, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from hydrainfer_amd._C.data_transfer import block_migration
+from hydrainfer_amd.memory.token_cache import VirtualTokenCache
+
+
+class CommunicationBackend:
+    def migrate_blocks(self, src_virtual_cache: VirtualTokenCache,
+                       dst_virtual_cache: VirtualTokenCache, is_send: bool) -> None:
+        raise NotImplementedError()
+
+
+class IPCHandleMemoryBackend(CommunicationBackend):
+    def __init__(self, migrate_stream: "torch.cuda.Stream", cache: Tensor, n_blocks: int):
+        self.migrate_stream = migrate_stream
+        self.cache = cache
+        self.n_blocks = n_blocks
+
+    def migrate_blocks(self, src_virtual_cache, dst_virtual_cache, is_send: bool) -> None:
+        if is_send:
+            return  # pull model: the destination reads the peer pool
+        assert src_virtual_cache.memory_handle is not None
+        with torch.cuda.stream(self.migrate_stream):
+            block_migration.migrate_blocks(
+                src_virtual_cache.block_table, dst_virtual_cache.block_table,
+                src_virtual_cache.memory_handle, self.cache,
+                src_virtual_cache.n_blocks_of_cache_manager)
+
+
+class RCCLBackend(CommunicationBackend):
+    """Packed point-to-point transfer over torch.distributed (backend "nccl" == RCCL on ROCm,
+    "gloo" in CPU tests of the protocol).  pack/unpack are HIP kernels; the staging buffer is
+    reused across calls."""
+
+    def __init__(self, migrate_stream: Optional["torch.cuda.Stream"], cache: Tensor,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.migrate_stream = migrate_stream
+        self.cache = cache
+        self.group = group
+        self._staging: Optional[Tensor] = None
+
+    def _staging_for(self, n_blocks: int) -> Tensor:
+        L, T, _, bs, H, D = self.cache.shape
+        numel = L * T * n_blocks * bs * H * D
+        if self._staging is None or self._staging.numel() < numel:
+            self._staging = torch.empty(numel, dtype=self.cache.dtype, device=self.cache.device)
+        return self._staging[:numel]
+
+    def migrate_blocks(self, src_virtual_cache, dst_virtual_cache, is_send: bool) -> None:
+        table = src_virtual_cache.block_table if is_send else dst_virtual_cache.block_table
+        peer = dst_virtual_cache.rank if is_send else src_virtual_cache.rank
+        if len(table) == 0:
+            return
+        staging = self._staging_for(len(table))
+        ctx = torch.cuda.stream(self.migrate_stream) if self.migrate_stream is not None else _Null()
+        with ctx:
+            if is_send:
+                block_migration.pack_blocks(table, self.cache, staging)
+                dist.send(staging, dst=peer, group=self.group)
+            else:
+                dist.recv(staging, src=peer, group=self.group)
+                block_migration.unpack_blocks(table, staging, self.cache)
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+@dataclass
+class CommunicationBackendManagerContext:
+    migrate_stream: "torch.cuda.Stream"
+    cache: Tensor  # (n_layers, n_tokens, n_blocks, block_size, n_heads, head_size)
+    n_blocks: int
+    rank2host: Dict[int, str]
+
+
+@dataclass
+class CommunicationBackendManagerConfig:
+    intranode_migrate_backend: Literal["auto", "ipc", "nccl"] = "auto"
+    internode_migrate_backend: Literal["nccl"] = "nccl"
+    debug: bool = False
+
+
+def get_migrate_backend(backend: str, context: CommunicationBackendManagerContext) -> CommunicationBackend:
+    if backend == "ipc":
+        return IPCHandleMemoryBackend(context.migrate_stream, context.cache, context.n_blocks)
+    if backend == "nccl":
+        return RCCLBackend(context.migrate_stream, context.cache)
+    raise Exception(f"invalid migrate backend {backend}")
+
+
+class CommunicationBackendManager(CommunicationBackend):
+    def __init__(self, config: CommunicationBackendManagerConfig,
+                 context: CommunicationBackendManagerContext):
+        self.context = context
+        self.rank2host = context.rank2host
+        intranode = config.intranode_migrate_backend
+        if intranode == "auto":
+            intranode = "ipc"  # the HIP library is mandatory, so ipc is always available
+        self.intranode_backend = get_migrate_backend(intranode, context)
+        self.internode_backend = get_migrate_backend(config.internode_migrate_backend, context)
+
+    def in_same_machine(self, rank1: int, rank2: int) -> bool:
+        if rank1 not in self.rank2host or rank2 not in self.rank2host:
+            return False
+        return self.rank2host[rank1] == self.rank2host[rank2]
+
+    def migrate_blocks(self, src_virtual_cache, dst_virtual_cache, is_send: bool) -> None:
+        assert src_virtual_cache.n_cache_tokens == dst_virtual_cache.n_cache_tokens, \
+            f"{src_virtual_cache.n_cache_tokens} {dst_virtual_cache.n_cache_tokens}"
+        if self.in_same_machine(src_virtual_cache.rank, dst_virtual_cache.rank):
+            self.intranode_backend.migrate_blocks(src_virtual_cache, dst_virtual_cache, is_send)
+        else:
+            self.internode_backend.migrate_blocks(src_virtual_cache, dst_virtual_cache, is_send)

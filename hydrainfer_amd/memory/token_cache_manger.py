@@ -1,0 +1,169 @@
+"""TokenCacheBlockManager — host-side mirror of hydrainfer/memory/token_cache_manger.py:51-179.
+
+HBM layout: one contiguous pool
+    (n_layers, n_tokens in {1 image, 2 k/v}, n_blocks, block_size, n_heads, head_size)
+so that every per-layer K or V cache is a contiguous [n_blocks, block_size, H, D] slab and
+a (layer, k/v, block) triple is one contiguous block_size*H*D run — the unit the migration
+gather kernel copies."""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor
+
+from hydrainfer_amd._C.data_transfer.block_migration import get_ipc_mem_handle
+from hydrainfer_amd.memory.block_allocator import BlockAllocator, BlockAllocatorMetrics
+from hydrainfer_amd.memory.communication import (CommunicationBackendManager,
+                                                 CommunicationBackendManagerConfig,
+                                                 CommunicationBackendManagerContext)
+from hydrainfer_amd.memory.shared_cache import SharedCache, SharedCacheConfig
+from hydrainfer_amd.memory.token_cache import TokenCache, VirtualTokenCache
+
+_DTYPES = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}
+
+
+@dataclass
+class TokenCacheManagerMetrics:
+    allocator_metrics: BlockAllocatorMetrics
+    cache_hit_rate: float
+
+
+@dataclass
+class TokenCacheBlockManagerConfig:
+    communication_backend_manager_config: CommunicationBackendManagerConfig = field(
+        default_factory=CommunicationBackendManagerConfig)
+    n_layers: int = 32
+    n_tokens: int = 2
+    n_blocks: int = 1024
+    block_size: int = 16
+    n_heads: int = 32
+    head_size: int = 128
+    dtype: str = "fp16"  # 'bf16' accepted (extension; reference str2dtype knows fp16/fp32 only)
+    device: str = "cuda:0"
+
+
+@dataclass
+class TokenCacheBlockManagerContext:
+    rank: int
+    rank2host: Dict[int, str]
+
+
+class _IncreasingAllocator:
+    def __init__(self, first_value: int = 0):
+        self.next = first_value
+
+    def allocate(self) -> int:
+        v = self.next
+        self.next += 1
+        return v
+
+
+class TokenCacheBlockManager:
+    def __init__(self, config: TokenCacheBlockManagerConfig, context: TokenCacheBlockManagerContext):
+        self.config = config
+        self.context = context
+        self.n_layers, self.n_tokens = config.n_layers, config.n_tokens
+        self.n_blocks, self.block_size = config.n_blocks, config.block_size
+        self.n_heads, self.head_size = config.n_heads, config.head_size
+        self.dtype = _DTYPES[config.dtype]
+        self.device = torch.device(config.device)
+        self.rank = context.rank
+
+        # reference fills the pool with randn ("garbage but finite", token_cache_manger.py:65)
+        self.cache_tensor = torch.randn(
+            size=(self.n_layers, self.n_tokens, self.n_blocks, self.block_size, self.n_heads,
+                  self.head_size), dtype=self.dtype, device=self.device)
+        self.memory_handle: List[int] = get_ipc_mem_handle(self.cache_tensor)
+        self.block_allocator = BlockAllocator(self.n_blocks)
+        self.vid_allocator = _IncreasingAllocator(first_value=1)
+        self.migrate_stream = torch.cuda.Stream(device=self.device)
+        self.migrate_manager = CommunicationBackendManager(
+            config.communication_backend_manager_config,
+            CommunicationBackendManagerContext(migrate_stream=self.migrate_stream,
+                                               cache=self.cache_tensor, n_blocks=self.n_blocks,
+                                               rank2host=context.rank2host))
+        self.shared_cache = SharedCache(SharedCacheConfig(n_blocks=self.n_blocks))
+        self.total_block_queried = 0.0
+        self.total_block_matched = 0.0
+
+    def get_num_avaiable_blocks(self) -> int:
+        return self.block_allocator.get_num_avaiable_blocks() + self.shared_cache.get_num_avaiable_blocks()
+
+    def _allocate_new_blocks(self, n_blocks: int) -> List[int]:
+        return allocate_new_blocks(self.block_allocator, self.shared_cache, n_blocks)
+
+    def allocate_virtual_cache(self, hashes: Optional[List[int]] = None) -> VirtualTokenCache:
+        if hashes is None:
+            n_cached_tokens, matched = 0, []
+        else:
+            ids = self.shared_cache.match(hashes)
+            matched = ids[: ids.index(-1) if -1 in ids else len(ids)]
+            self.shared_cache.pin(matched)
+            n_cached_tokens = len(matched) * self.block_size
+            self.total_block_matched += len(matched)
+            self.total_block_queried += len(hashes)
+        return VirtualTokenCache(vid=self.vid_allocator.allocate(), n_cache_tokens=n_cached_tokens,
+                                 block_table=matched, memory_handle=self.memory_handle,
+                                 rank=self.rank, n_blocks_of_cache_manager=self.n_blocks)
+
+    def v2p(self, virtual_cache: VirtualTokenCache, virtual_cache_ids: List[int]) -> List[int]:
+        return v2p(virtual_cache.block_table, virtual_cache_ids, self.block_size)
+
+    def set_blocks(self, virtual_cache: VirtualTokenCache, virtual_block_ids: List[int],
+                   hashes: List[int]) -> None:
+        assert len(virtual_block_ids) == len(hashes)
+        physical = [virtual_cache.block_table[v] for v in virtual_block_ids]
+        self.shared_cache.insert(hashes=hashes, block_ids=physical)
+
+    def realloc(self, virtual_cache: VirtualTokenCache, n_tokens: int) -> None:
+        realloc(self.block_allocator, self.shared_cache, virtual_cache, n_tokens, self.block_size)
+
+    def get_layer_cache(self, layer_id: int) -> TokenCache:
+        return TokenCache([self.cache_tensor[layer_id, t] for t in range(self.n_tokens)])
+
+    def migrate_blocks(self, src_virtual_cache: VirtualTokenCache,
+                       dst_virtual_cache: VirtualTokenCache, is_send: bool = False) -> None:
+        self.migrate_manager.migrate_blocks(src_virtual_cache, dst_virtual_cache, is_send)
+
+    def synchronize(self) -> None:
+        self.migrate_stream.synchronize()
+
+    @classmethod
+    def compute_n_blocks(cls, config: TokenCacheBlockManagerConfig, memory: int) -> int:
+        itemsize = torch.empty((), dtype=_DTYPES[config.dtype]).element_size()
+        return memory // (config.n_layers * config.n_tokens * config.block_size * config.n_heads *
+                          config.head_size * itemsize)
+
+    def get_metrics(self) -> TokenCacheManagerMetrics:
+        rate = self.total_block_matched / self.total_block_queried if self.total_block_queried else 0.0
+        return TokenCacheManagerMetrics(self.block_allocator.get_metrics(), rate)
+
+
+# --- pure host logic, usable (and tested) without a GPU --------------------------------
+def v2p(block_table: List[int], virtual_cache_ids: List[int], block_size: int) -> List[int]:
+    """slot = table[id // bs] * bs + id % bs  (token_cache_manger.py:126-133)."""
+    return [block_table[i // block_size] * block_size + i % block_size for i in virtual_cache_ids]
+
+
+def allocate_new_blocks(block_allocator: BlockAllocator, shared_cache: SharedCache,
+                        n_blocks: int) -> List[int]:
+    """token_cache_manger.py:93-99: free list first, then evict unpinned shared blocks."""
+    block_ids = block_allocator.allocate(n_blocks)
+    if len(block_ids) < n_blocks:
+        block_ids += shared_cache.allocate(n_blocks)
+    assert len(block_ids) == n_blocks, "not enough blocks"
+    shared_cache.pin(block_ids)
+    return block_ids
+
+
+def realloc(block_allocator: BlockAllocator, shared_cache: SharedCache,
+            virtual_cache: VirtualTokenCache, n_tokens: int, block_size: int) -> None:
+    """token_cache_manger.py:149-158."""
+    n_need = (n_tokens + block_size - 1) // block_size
+    if n_tokens > virtual_cache.n_cache_tokens:
+        virtual_cache.block_table += allocate_new_blocks(
+            block_allocator, shared_cache, n_need - len(virtual_cache.block_table))
+    else:
+        shared_cache.unpin(virtual_cache.block_table[n_need:])
+        virtual_cache.block_table = virtual_cache.block_table[:n_need]
+    virtual_cache.n_cache_tokens = n_tokens

@@ -1,0 +1,225 @@
+/*
+ * hydra_hip.h — C ABI of libhydra_hip.so: the MI355X (gfx950) implementation of
+ * HydraInfer's attention + paged-KV operator surface (`hydrainfer._C.*`).
+ *
+ * Every entry point is `extern "C"`, takes raw device pointers, element
+ * counts/strides (in ELEMENTS unless the name says bytes) and a hipStream_t
+ * passed as `void*`, launches asynchronously on that stream, never
+ * synchronises, never allocates, and returns 0 or a negative hx_status.
+ * No torch types cross this boundary.  `hx_strerror` maps a status to text.
+ *
+ * Each function cites the reference interface it replaces
+ * (paths relative to the dongxianzhe/hydrainfer tree).
+ */
+#ifndef HYDRA_HIP_H
+#define HYDRA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HX_ABI_VERSION 1
+
+typedef enum hx_dtype {
+  HX_F32 = 0,
+  HX_F16 = 1,
+  HX_BF16 = 2,
+} hx_dtype;
+
+typedef enum hx_status {
+  HX_OK = 0,
+  HX_ERR_DTYPE = -1,       /* dtype not supported by this op                */
+  HX_ERR_SHAPE = -2,       /* size / divisibility constraint violated       */
+  HX_ERR_STRIDE = -3,      /* layout (contiguity / alignment) unsupported   */
+  HX_ERR_NULL = -4,        /* required pointer is NULL                      */
+  HX_ERR_UNSUPPORTED = -5, /* feature of the reference op not implemented   */
+  HX_ERR_WORKSPACE = -6,   /* workspace too small                           */
+  HX_ERR_HIP = -7,         /* a HIP runtime call failed (see hx_last_hip_error) */
+  HX_ERR_HANDLE = -8,      /* bad IPC handle                                */
+} hx_status;
+
+typedef void* hx_stream; /* hipStream_t */
+
+int hx_abi_version(void);
+const char* hx_strerror(int status);
+/* hipError_t of the most recent HX_ERR_HIP on this thread (0 if none). */
+int hx_last_hip_error(void);
+
+/* ------------------------------------------------------------------------
+ * Paged cache scatter.
+ * replaces: csrc/kernel/kv_cache_kernels/kv_cache_kernels.cu:60-95 (set_kv_cache)
+ *           hydrainfer/_C/kernel/kv_cache_kernels/__init__.pyi:5-10
+ * cache[slot / block_size, slot % block_size, h, d] = src[token, h, d] for K and V.
+ * keys/values: [n_tokens, n_kv_heads, head_dim], last two dims contiguous, row
+ * stride k_stride / v_stride elements.  Caches: [n_blocks, block_size, n_kv_heads,
+ * head_dim] with block stride cache_block_stride elements (rows inside a block
+ * contiguous).  Bit-exact copy; slots < 0 are skipped.
+ * ---------------------------------------------------------------------- */
+int hx_set_kv_cache(const int32_t* slot_ids, const void* keys, const void* values,
+                    void* key_cache, void* value_cache,
+                    int64_t n_tokens, int64_t n_kv_heads, int64_t head_dim,
+                    int64_t block_size, int64_t k_stride, int64_t v_stride,
+                    int64_t kcache_block_stride, int64_t vcache_block_stride,
+                    int dtype, hx_stream stream);
+
+/* replaces: csrc/kernel/cache_kernels/cache_kernels.cu:55-83 (set_image_cache)
+ *           hydrainfer/_C/kernel/cache_kernels/__init__.pyi:4-7 */
+int hx_set_image_cache(const int32_t* slot_ids, const void* image_tokens, void* image_cache,
+                       int64_t n_tokens, int64_t n_heads, int64_t head_dim,
+                       int64_t block_size, int64_t token_stride, int64_t cache_block_stride,
+                       int dtype, hx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * replaces: csrc/kernel/norm/rms_norm.cu:43-63 (rms_norm)
+ *           hydrainfer/_C/kernel/norm/__init__.pyi:4-9
+ * out[r,i] = (T)(x[r,i] * rsqrt(mean_i(x[r,:]^2) + eps)) * w[i]   (T arithmetic for
+ * the weight multiply, fp32 reduction) — rounding points of rms_norm.cu:39.
+ * out/input contiguous [rows, hidden]; dtype f32/f16/bf16 (bf16 is an extension).
+ * ---------------------------------------------------------------------- */
+int hx_rms_norm(void* out, const void* input, const void* weight, float epsilon,
+                int64_t rows, int64_t hidden, int dtype, hx_stream stream);
+
+/* Extension: h = residual + x written back to `residual`,
+ * out = rms_norm(h).  Same rounding as add-then-hx_rms_norm. */
+int hx_add_rms_norm(void* out, void* residual, const void* x, const void* weight,
+                    float epsilon, int64_t rows, int64_t hidden, int dtype, hx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * replaces: csrc/kernel/position_embedding/rope.cu:82-117 (apply_rotary_pos_emb)
+ *           hydrainfer/_C/kernel/position_embedding/__init__.pyi:5-11
+ * In-place rotation of query [n_tokens, n_heads, head_dim] and key
+ * [n_tokens, n_kv_heads, head_dim] (row strides q_stride / k_stride elements, last two
+ * dims contiguous).  cos_sin: [max_positions, 2, rotary_dim/2] in the tensors' dtype.
+ * x' = x*c - y*s ; y' = x*s + y*c, every operation rounded to T (rope.cu:22-27).
+ * interleaved ? (x,y)=(2i,2i+1) : (i, i+rotary_dim/2).
+ * ---------------------------------------------------------------------- */
+int hx_apply_rotary_pos_emb(void* query, void* key, const int32_t* positions,
+                            const void* cos_sin, int64_t n_tokens, int64_t n_heads,
+                            int64_t n_kv_heads, int64_t head_dim, int64_t rotary_dim,
+                            int64_t q_stride, int64_t k_stride, int interleaved,
+                            int dtype, hx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * replaces: csrc/kernel/activation/activation.cu:52-56 (silu)
+ *           hydrainfer/_C/kernel/activation/__init__.pyi:3-4
+ * out[r,i] = (T)(x / (1 + exp(-x))) computed in fp32; input rows strided by
+ * in_stride elements, out contiguous [rows, n].
+ * ---------------------------------------------------------------------- */
+int hx_silu(void* out, const void* input, int64_t rows, int64_t n, int64_t in_stride,
+            int dtype, hx_stream stream);
+
+/* Extension: out = (T)silu(gate) * up in T arithmetic, i.e. exactly
+ * `silu(gate_proj(h)) * up_proj(h)` of hydrainfer/model/model_forward.py:36. */
+int hx_silu_and_mul(void* out, const void* gate, const void* up, int64_t rows, int64_t n,
+                    int64_t gate_stride, int64_t up_stride, int dtype, hx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * Variable-length attention forward, dense or paged.
+ * replaces: csrc/kernel/flash_attn/flash_api.cpp:216-355 (mha_varlen_fwd)
+ *           hydrainfer/_C/kernel/flash_attn/__init__.pyi:23-40
+ *
+ * out, q : [n_tokens, n_heads, head_dim], row strides o_row_stride / q_row_stride,
+ *          head stride = head_dim (heads contiguous).
+ * dense  : block_table == NULL; k, v: [total_k, n_kv_heads, head_dim] with
+ *          kv_row_stride / kv_head_stride.
+ * paged  : block_table != NULL (flat int32 [sum blocks]) with cu_block_lens int32
+ *          [batch+1]; k, v: [n_blocks, block_size, n_kv_heads, head_dim] with
+ *          kv_block_stride / kv_row_stride / kv_head_stride; block_size % 16 == 0.
+ * cu_seqlens_q / cu_seqlens_k: int32 [batch+1] (device).
+ * causal != 0: key j visible to query i iff j <= i + (kv_len - q_len)
+ *          (bottom-right aligned; reference mask.h:173-193, window (-1,0)).
+ * Unsupported reference features return HX_ERR_UNSUPPORTED: alibi, softcap != 0,
+ * finite left window.
+ * workspace: device scratch of at least hx_mha_varlen_fwd_workspace_bytes() bytes
+ * (used for split-KV partials; may be NULL when that returns 0).
+ * ---------------------------------------------------------------------- */
+typedef struct hx_attn_args {
+  void* out;
+  const void* q;
+  const void* k;
+  const void* v;
+  const int32_t* cu_seqlens_q;
+  const int32_t* cu_seqlens_k;
+  const int32_t* block_table;   /* NULL => dense */
+  const int32_t* cu_block_lens; /* required iff block_table */
+  int32_t batch;
+  int32_t n_heads;
+  int32_t n_kv_heads;
+  int32_t head_dim;
+  int32_t block_size;    /* paged only */
+  int32_t max_seqlen_q;
+  int32_t max_seqlen_k;
+  int32_t total_q;       /* rows of q */
+  int64_t q_row_stride;
+  int64_t o_row_stride;
+  int64_t k_block_stride, k_row_stride, k_head_stride;
+  int64_t v_block_stride, v_row_stride, v_head_stride;
+  float softmax_scale;
+  int32_t causal;
+  int32_t dtype;         /* HX_F16 | HX_BF16 */
+  int32_t num_splits;    /* 0 = choose automatically, 1 = never split */
+  void* workspace;
+  int64_t workspace_bytes;
+} hx_attn_args;
+
+int64_t hx_mha_varlen_fwd_workspace_bytes(const hx_attn_args* args);
+int hx_mha_varlen_fwd(const hx_attn_args* args, hx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * Cache-block migration between GPUs / processes.
+ * replaces: csrc/data_transfer/block_migration.cpp:55-59 (get_ipc_mem_handle),
+ *           :69-80 (register_ipc_mem_handle), :194-245 (migrate_blocks)
+ *           hydrainfer/_C/data_transfer/block_migration/__init__.pyi:6-18
+ * ---------------------------------------------------------------------- */
+#define HX_IPC_HANDLE_BYTES 64
+/* Writes the 64-byte hipIpcMemHandle_t of the allocation containing dev_ptr and the
+ * byte offset of dev_ptr inside it. */
+int hx_ipc_get_mem_handle(const void* dev_ptr, uint8_t handle_out[HX_IPC_HANDLE_BYTES],
+                          int64_t* offset_out);
+/* Opens (or returns the cached mapping of) a peer handle.  Mappings are cached by
+ * handle bytes for the life of the process: the reference re-opens per call
+ * (block_migration.cpp:213-215) which HIP rejects for an already-open handle. */
+int hx_ipc_open_mem_handle(const uint8_t handle[HX_IPC_HANDLE_BYTES], void** dev_ptr_out);
+int hx_ipc_close_all(void);
+
+/* dst[l, t, dst_table[i]] = src[l, t, src_table[i]] for every layer l, token-kind t
+ * (k/v) and i < n_pairs, as ONE gather-copy kernel per <=HX_MIGRATE_MAX_PAIRS pairs.
+ * Pools are contiguous 6-D (n_layers, n_tokens, n_blocks, block_size, n_heads, head_size);
+ * block_bytes = block_size*n_heads*head_size*itemsize (multiple of 16).
+ * src may be an IPC-mapped peer pointer (xGMI read) or a local pointer. */
+#define HX_MIGRATE_MAX_PAIRS 448
+int hx_migrate_blocks(const int32_t* src_table_host, const int32_t* dst_table_host,
+                      int64_t n_pairs, const void* src_pool, void* dst_pool,
+                      int64_t n_layers, int64_t n_tokens, int64_t src_n_blocks,
+                      int64_t dst_n_blocks, int64_t block_bytes, hx_stream stream);
+
+/* Pack / unpack selected blocks to / from a contiguous staging buffer
+ * [n_layers, n_tokens, n_pairs, block_bytes] — the RCCL send/recv path
+ * (replaces the per-(block,layer,k/v) P2POp list of
+ * hydrainfer/memory/communication.py:57-74). */
+int hx_pack_blocks(const int32_t* table_host, int64_t n_pairs, const void* pool, void* staging,
+                   int64_t n_layers, int64_t n_tokens, int64_t n_blocks, int64_t block_bytes,
+                   hx_stream stream);
+int hx_unpack_blocks(const int32_t* table_host, int64_t n_pairs, const void* staging, void* pool,
+                     int64_t n_layers, int64_t n_tokens, int64_t n_blocks, int64_t block_bytes,
+                     hx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * Decode-step metadata advance: device-resident equivalent of one
+ * AttentionParametersBuilder pass for an all-decode batch
+ * (hydrainfer/layer/causal_attention.py:147-168).  For every sequence b:
+ *   positions[b] += 1; kv_len[b] += 1; cu_seqlens_k = prefix-sum(kv_len);
+ *   new_cache_slots[b] = block_table[cu_block_lens[b] + pos/bs]*bs + pos%bs.
+ * Lets a whole decode step live inside one hipGraph.
+ * ---------------------------------------------------------------------- */
+int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_k,
+                      int32_t* new_cache_slots, const int32_t* block_table,
+                      const int32_t* cu_block_lens, int32_t batch, int32_t block_size,
+                      hx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYDRA_HIP_H */

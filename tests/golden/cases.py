@@ -1,0 +1,220 @@
+"""Seeded input builders shared by tests/golden/generate_goldens.py (which runs the
+REFERENCE on them, in the build container only) and by the tests (which run the oracle
+and the HIP path on the very same inputs).  Inputs are regenerated from seeds with
+torch's CPU generator — identical for the same torch build, and every fixture stores an
+input checksum so a drift would be caught rather than silently compared."""
+import hashlib
+import math
+from dataclasses import dataclass
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+DTYPES = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}
+
+
+def checksum(*tensors: torch.Tensor) -> str:
+    h = hashlib.sha256()
+    for t in tensors:
+        t = t.detach().contiguous()
+        if t.dtype == torch.bfloat16:
+            t = t.view(torch.int16)
+        h.update(t.numpy().tobytes())
+    return h.hexdigest()[:16]
+
+
+def to_np(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().contiguous()
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy()
+    return t.numpy()
+
+
+def from_np(a: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype == torch.bfloat16:
+        return t.view(torch.bfloat16)
+    return t
+
+
+# ------------------------------------------------------------------ G1 cache scatter
+def kv_cache_cases() -> List[Dict]:
+    # grid of the reference's tests/memory/test_kv_cache.py:6-12
+    cases = []
+    for block_size in (4, 8, 16):
+        for n_heads, head_dim, n_tokens in ((8, 64, 1), (4, 128, 15), (2, 256, 64), (1, 128, 100)):
+            for dt in ("fp16", "bf16", "fp32"):
+                cases.append(dict(n_blocks=100, block_size=block_size, n_heads=n_heads,
+                                  head_dim=head_dim, n_tokens=n_tokens, dtype=dt))
+    return cases
+
+
+def kv_cache_inputs(case: Dict, seed: int = 0):
+    g = torch.Generator().manual_seed(seed)
+    dt = DTYPES[case["dtype"]]
+    shape = (case["n_blocks"], case["block_size"], case["n_heads"], case["head_dim"])
+    key_cache = torch.randn(shape, generator=g).to(dt)
+    value_cache = torch.randn(shape, generator=g).to(dt)
+    n_slots = case["n_blocks"] * case["block_size"]
+    slot_ids = torch.randperm(n_slots, generator=g)[: case["n_tokens"]].to(torch.int32)
+    # keys/values are strided views of a fused qkv projection, as in model_forward.py:66-75
+    qkv = torch.randn((case["n_tokens"], 3 * case["n_heads"] * case["head_dim"]), generator=g).to(dt)
+    hd = case["n_heads"] * case["head_dim"]
+    keys = qkv[:, hd: 2 * hd].view(-1, case["n_heads"], case["head_dim"])
+    values = qkv[:, 2 * hd:].view(-1, case["n_heads"], case["head_dim"])
+    return slot_ids, keys, values, key_cache, value_cache
+
+
+# ------------------------------------------------------------------ G2 paged attention
+def paged_attention_cases() -> List[Dict]:
+    cases = []
+    # tests/layer/test_attention.py:42-49 seq pairs; both (1,100)+(15,15) style batches
+    seq_sets = [
+        [(1, 100), (15, 15), (111, 234), (1, 1024)],
+        [(1, 1), (1, 17), (1, 16), (1, 255)],          # all-decode batch (decode kernel)
+        [(33, 33), (64, 64), (7, 71)],
+    ]
+    # Fixture size: the reference grid uses 8 query heads (tests/layer/test_attention.py:46);
+    # heads are independent, so the two multi-hundred-token sets use 4 query heads and the
+    # tiny all-decode set keeps 8.
+    for si, seqs in enumerate(seq_sets):
+        hq = 8 if si == 1 else 4
+        for n_kv_heads in (hq, 2, 1):
+            for head_dim in (64, 128, 256):
+                for dt in ("fp16", "bf16"):
+                    if head_dim == 256 and si == 0 and not (n_kv_heads == hq and dt == "fp16"):
+                        continue
+                    if si == 2 and (head_dim == 256 or n_kv_heads == 1):
+                        continue
+                    cases.append(dict(seqs=seqs, n_heads=hq, n_kv_heads=n_kv_heads,
+                                      head_dim=head_dim, dtype=dt, block_size=16, n_blocks=128))
+    cases.append(dict(seqs=[(40, 40), (1, 90)], n_heads=4, n_kv_heads=4, head_dim=128, dtype="fp16",
+                      block_size=32, n_blocks=16))
+    return cases
+
+
+def paged_attention_inputs(case: Dict, seed: int = 0):
+    """Returns q,k,v (new tokens), caches (pre-filled with history), and the metadata lists."""
+    g = torch.Generator().manual_seed(seed)
+    dt = DTYPES[case["dtype"]]
+    bs, nb = case["block_size"], case["n_blocks"]
+    H, HK, D = case["n_heads"], case["n_kv_heads"], case["head_dim"]
+    key_cache = torch.randn((nb, bs, HK, D), generator=g).to(dt)
+    value_cache = torch.randn((nb, bs, HK, D), generator=g).to(dt)
+    perm = torch.randperm(nb, generator=g).tolist()
+    n_tokens = sum(q for q, _ in case["seqs"])
+    q = torch.randn((n_tokens, H * D), generator=g).to(dt)
+    k = torch.randn((n_tokens, HK * D), generator=g).to(dt)
+    v = torch.randn((n_tokens, HK * D), generator=g).to(dt)
+    reqs = []
+    used = 0
+    for q_len, kv_len in case["seqs"]:
+        n_need = (kv_len + bs - 1) // bs
+        table = perm[used: used + n_need]
+        used += n_need
+        slots = [table[p // bs] * bs + p % bs for p in range(kv_len - q_len, kv_len)]
+        reqs.append(dict(q_len=q_len, kv_len=kv_len, block_table=table, new_cache_slots=slots))
+    assert used <= nb
+    return q, k, v, key_cache, value_cache, reqs
+
+
+# ------------------------------------------------------------------ G3 dense attention
+def dense_attention_cases() -> List[Dict]:
+    return [
+        # CLIP ViT-L/14-336 tile: 577 tokens, D=64 (16 heads in the model; heads are independent)
+        dict(batch=1, seq_len=577, n_heads=8, head_dim=64, dtype="fp16"),
+        dict(batch=2, seq_len=577, n_heads=4, head_dim=64, dtype="bf16"),
+        dict(batch=3, seq_len=50, n_heads=4, head_dim=128, dtype="fp16"),
+        dict(batch=2, seq_len=33, n_heads=2, head_dim=32, dtype="bf16"),
+        dict(batch=2, seq_len=70, n_heads=2, head_dim=96, dtype="fp16"),
+    ]
+
+
+def dense_attention_inputs(case: Dict, seed: int = 0):
+    g = torch.Generator().manual_seed(seed)
+    dt = DTYPES[case["dtype"]]
+    hidden = case["n_heads"] * case["head_dim"]
+    shape = (case["batch"], case["seq_len"], hidden)
+    q = torch.randn(shape, generator=g).to(dt)
+    k = torch.randn(shape, generator=g).to(dt)
+    v = torch.randn(shape, generator=g).to(dt)
+    return q, k, v
+
+
+# ------------------------------------------------------------------ G4 rms_norm
+def rms_norm_cases() -> List[Dict]:
+    cases = []
+    for hidden in (1, 2, 32, 333, 334, 1024, 4096, 5120):  # test_rms_norm_kernel.py:6-10 + LLaVA
+        for dt in ("fp32", "fp16", "bf16"):
+            cases.append(dict(rows=7 if hidden >= 1024 else 33, hidden=hidden, dtype=dt, eps=1e-5))
+    return cases
+
+
+def rms_norm_inputs(case: Dict, seed: int = 0):
+    g = torch.Generator().manual_seed(seed)
+    dt = DTYPES[case["dtype"]]
+    x = torch.randn((case["rows"], case["hidden"]), generator=g).to(dt)
+    w = (1.0 + 0.1 * torch.randn((case["hidden"],), generator=g)).to(dt)
+    return x, w
+
+
+# ------------------------------------------------------------------ G5 rope
+def rope_cases() -> List[Dict]:
+    cases = []
+    for n_kv_heads in (32, 8, 1):  # tests/layer/test_rotary_embedding.py:111-120
+        for theta in (1e4, 5e5):
+            for interleaved in (False, True):
+                for dt in ("fp16", "bf16", "fp32"):
+                    cases.append(dict(n_tokens=4, n_heads=32, n_kv_heads=n_kv_heads, head_dim=128,
+                                      rotary_dim=128, theta=theta, interleaved=interleaved,
+                                      max_pos=4096, dtype=dt))
+    cases.append(dict(n_tokens=5, n_heads=4, n_kv_heads=2, head_dim=64, rotary_dim=32, theta=1e4,
+                      interleaved=False, max_pos=128, dtype="fp16"))
+    cases.append(dict(n_tokens=5, n_heads=4, n_kv_heads=2, head_dim=64, rotary_dim=32, theta=1e4,
+                      interleaved=True, max_pos=128, dtype="bf16"))
+    return cases
+
+
+def rope_inputs(case: Dict, seed: int = 0):
+    g = torch.Generator().manual_seed(seed)
+    dt = DTYPES[case["dtype"]]
+    q = torch.randn((case["n_tokens"], case["n_heads"], case["head_dim"]), generator=g).to(dt)
+    k = torch.randn((case["n_tokens"], case["n_kv_heads"], case["head_dim"]), generator=g).to(dt)
+    pos = torch.randint(0, case["max_pos"], (case["n_tokens"],), generator=g).to(torch.int32)
+    return q, k, pos
+
+
+# ------------------------------------------------------------------ G6 silu
+def silu_cases() -> List[Dict]:
+    cases = []
+    for n in (1, 2, 32, 333, 334, 1024, 4096, 11008):  # tests/kernel/test_activation.py:6-9 + LLaVA
+        for dt in ("fp32", "fp16", "bf16"):
+            cases.append(dict(rows=5, n=n, dtype=dt))
+    return cases
+
+
+def silu_inputs(case: Dict, seed: int = 0):
+    g = torch.Generator().manual_seed(seed)
+    x = (3.0 * torch.randn((case["rows"], case["n"]), generator=g)).to(DTYPES[case["dtype"]])
+    return x
+
+
+# ------------------------------------------------------------------ G7 integer trace
+@dataclass
+class TraceConfig:
+    n_requests: int = 32
+    prompt_len: int = 704      # 576 image + 128 text
+    n_decode: int = 6          # decode steps recorded (full run = 255)
+    block_size: int = 16
+    n_blocks: int = 2048
+
+
+def trace_token_ids(cfg: TraceConfig, req: int) -> List[int]:
+    g = torch.Generator().manual_seed(1000 + req)
+    text = torch.randint(1000, 31999, (cfg.prompt_len - 576,), generator=g).tolist()
+    return [32000] * 576 + text
+
+
+def case_name(prefix: str, i: int) -> str:
+    return f"{prefix}_{i:03d}"

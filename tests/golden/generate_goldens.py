@@ -1,0 +1,234 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python handlers
+(/root/reference, imported read-only) on the seeded inputs of tests/golden/cases.py.
+
+Run only in the build container:  python tests/golden/generate_goldens.py
+The reference never travels to the GPU box; only the .npz outputs (data) are committed.
+Third-party modules the reference imports but this image lacks are replaced by empty
+stubs (they are not on the code paths exercised here)."""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))  # repo root
+REFERENCE = os.environ.get("HYDRA_REFERENCE", "/root/reference")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    for name in ("seaborn", "dacite", "ray", "ray.actor", "zmq", "zmq.asyncio", "zmq.sugar",
+                 "zmq.sugar.socket", "hydra", "omegaconf", "shortuuid"):
+        if name not in sys.modules:
+            _stub(name)
+    sys.modules["dacite"].from_dict = lambda *a, **k: None
+    sys.modules["dacite"].Config = object
+    sys.modules["omegaconf"].OmegaConf = object
+    sys.modules["omegaconf"].DictConfig = object
+    sys.modules["ray"].remote = lambda *a, **k: (lambda f: f)
+    sys.modules["ray.actor"].ActorHandle = object
+    sys.modules["zmq.sugar.socket"].Socket = object
+    sys.path.insert(0, REFERENCE)
+    import hydrainfer  # noqa: F401
+    return hydrainfer
+
+
+from tests.golden import cases as C  # noqa: E402
+
+
+def gen_kv_cache(out):
+    from hydrainfer.memory.kv_cache import KVCache
+    from hydrainfer.memory.token_cache import TokenCache
+    for i, case in enumerate(C.kv_cache_cases()):
+        slot_ids, keys, values, kc, vc = C.kv_cache_inputs(case, seed=i)
+        chk = C.checksum(slot_ids, keys.contiguous(), values.contiguous(), kc, vc)
+        KVCache(kc, vc).set_kv_cache(slot_ids, keys, values)  # CPU loop kv_cache.py:44-50
+        n = C.case_name("kv", i)
+        # bit-exact op: the fixture is the checksum of the reference's resulting caches
+        out[n + "_key_cache_chk"] = np.array(C.checksum(kc))
+        out[n + "_value_cache_chk"] = np.array(C.checksum(vc))
+        out[n + "_chk"] = np.array(chk)
+        # image cache: same inputs, single tensor (token_cache.py:53-56)
+        slot_ids, keys, values, kc, vc = C.kv_cache_inputs(case, seed=i)
+        TokenCache([kc]).set_caches(slot_ids, [keys])
+        out[n + "_image_cache_chk"] = np.array(C.checksum(kc))
+
+
+def gen_paged_attention(out):
+    from hydrainfer.layer.causal_attention import (AttentionParametersBuilder,
+                                                   CausalGroupedQueryPageAttention,
+                                                   CausalGroupedQueryPageAttentionConfig)
+    from hydrainfer.memory.kv_cache import KVCache
+    for i, case in enumerate(C.paged_attention_cases()):
+        q, k, v, kc, vc, reqs = C.paged_attention_inputs(case, seed=i)
+        chk = C.checksum(q, k, v, kc, vc)
+        b = AttentionParametersBuilder(case["n_heads"], case["n_kv_heads"], case["head_dim"],
+                                       case["block_size"], torch.device("cpu"))
+        for r in reqs:
+            b.add_request(r["q_len"], r["kv_len"], r["new_cache_slots"], r["block_table"])
+        b.add_kv_cache(KVCache(kc, vc))
+        params = b.build_attention_parameters()[0]
+        attn = CausalGroupedQueryPageAttention(CausalGroupedQueryPageAttentionConfig(
+            case["n_heads"], case["n_kv_heads"], case["head_dim"]))
+        o = attn(q, k, v, params).o
+        n = C.case_name("pattn", i)
+        out[n + "_o"] = C.to_np(o)
+        out[n + "_chk"] = np.array(chk)
+        for f in ("q_cu_seq_lens", "kv_cu_seq_lens", "paged_kv_last_page_len", "new_cache_slots",
+                  "block_tables", "cu_blocks_lens"):
+            out[n + "_" + f] = getattr(params, f).numpy()
+        out[n + "_scalars"] = np.array([params.num_sequences, int(params.all_sequences_decode),
+                                        params.q_max_seq_len, params.kv_max_seq_len])
+        # the cache after set_kv_cache is checked through a checksum (keeps the fixture small)
+        out[n + "_cache_chk"] = np.array(C.checksum(kc, vc))
+
+
+def gen_dense_attention(out):
+    from hydrainfer.layer.multihead_attention import (MultiHeadAttentionConfig,
+                                                      MultiHeadAttentionParameters,
+                                                      TorchMultiHeadAttentionHandler)
+    for i, case in enumerate(C.dense_attention_cases()):
+        q, k, v = C.dense_attention_inputs(case, seed=i)
+        h = TorchMultiHeadAttentionHandler(MultiHeadAttentionConfig(case["n_heads"], case["head_dim"]))
+        o = h(q, k, v, MultiHeadAttentionParameters()).o
+        n = C.case_name("dattn", i)
+        out[n + "_o"] = C.to_np(o)
+        out[n + "_chk"] = np.array(C.checksum(q, k, v))
+
+
+def gen_rms_norm(out):
+    from hydrainfer.layer.norm import rmsnorm
+    for i, case in enumerate(C.rms_norm_cases()):
+        x, w = C.rms_norm_inputs(case, seed=i)
+        o = rmsnorm(x, w, case["eps"])  # CPU -> torch branch, norm.py:18-23
+        n = C.case_name("rms", i)
+        out[n + "_o"] = C.to_np(o)
+        out[n + "_chk"] = np.array(C.checksum(x, w))
+
+
+def gen_rope(out):
+    from hydrainfer.layer.rotary_embedding import (FusedKernelRotaryEmbeddingHandler,
+                                                   TorchRotaryEmbeddingHandler,
+                                                   compute_default_inv_freq)
+    for i, case in enumerate(C.rope_cases()):
+        q, k, pos = C.rope_inputs(case, seed=i)
+        dt = C.DTYPES[case["dtype"]]
+        inv = compute_default_inv_freq(case["rotary_dim"], case["theta"])
+        h = TorchRotaryEmbeddingHandler(case["rotary_dim"], case["max_pos"], inv, case["interleaved"])
+        h = h.to(dt)  # model.to(dtype) casts the registered cos/sin buffer (llava.py:125-126)
+        qo, ko = h(q, k, pos)
+        fused = FusedKernelRotaryEmbeddingHandler(case["rotary_dim"], case["max_pos"], inv,
+                                                  case["interleaved"]).to(dt)
+        n = C.case_name("rope", i)
+        out[n + "_q"] = C.to_np(qo)
+        out[n + "_k"] = C.to_np(ko)
+        # kernel-layout cache [max_pos, 2, rot/2]: only its checksum (rebuilt by the oracle)
+        out[n + "_cos_sin_chk"] = np.array(C.checksum(fused.cos_sin_cache))
+        out[n + "_chk"] = np.array(C.checksum(q, k, pos))
+
+
+def gen_silu(out):
+    from hydrainfer.layer.activation import silu
+    for i, case in enumerate(C.silu_cases()):
+        x = C.silu_inputs(case, seed=i)
+        n = C.case_name("silu", i)
+        out[n + "_o"] = C.to_np(silu(x))
+        out[n + "_chk"] = np.array(C.checksum(x))
+
+
+def gen_trace(out):
+    """G7: integer metadata of a scripted continuous-batching run — block allocator order,
+    v2p slots, prefix hashes and the per-step AttentionParameters tensors."""
+    from hydrainfer.layer.causal_attention import AttentionParametersBuilder
+    from hydrainfer.memory.block_allocator import BlockAllocator
+    from hydrainfer.memory.shared_cache import compute_hash, SharedCache, SharedCacheConfig
+    cfg = C.TraceConfig()
+    bs = cfg.block_size
+    alloc = BlockAllocator(cfg.n_blocks)
+    shared = SharedCache(SharedCacheConfig(n_blocks=cfg.n_blocks))
+    tables, lens = [], []
+
+    def realloc(table, n_tokens):  # TokenCacheBlockManager.realloc growth branch, token_cache_manger.py:149-153
+        need = (n_tokens + bs - 1) // bs - len(table)
+        blocks = alloc.allocate(need)
+        if len(blocks) < need:
+            blocks += shared.allocate(need)
+        shared.pin(blocks)
+        table += blocks
+
+    def v2p(table, ids):  # token_cache_manger.py:126-133
+        return [table[i // bs] * bs + i % bs for i in ids]
+
+    hashes = []
+    for r in range(cfg.n_requests):
+        ids = C.trace_token_ids(cfg, r)
+        hashes.append(np.array(compute_hash(ids, bs, -1), dtype=np.uint64))
+        tables.append([])
+        lens.append(0)
+    out["trace_hashes"] = np.stack(hashes)
+
+    def step(q_lens, tag):
+        b = AttentionParametersBuilder(32, 32, 128, bs, torch.device("cpu"))
+        for r, q_len in enumerate(q_lens):
+            realloc(tables[r], lens[r] + q_len)
+            slots = v2p(tables[r], list(range(lens[r], lens[r] + q_len)))
+            lens[r] += q_len
+            b.add_request(q_len, lens[r], slots, tables[r])
+        b.add_kv_cache(None)
+        p = b.build_attention_parameters()[0]
+        for f in ("q_cu_seq_lens", "kv_cu_seq_lens", "paged_kv_last_page_len", "new_cache_slots",
+                  "block_tables", "cu_blocks_lens"):
+            out[f"trace_{tag}_{f}"] = getattr(p, f).numpy()
+        out[f"trace_{tag}_scalars"] = np.array([p.num_sequences, int(p.all_sequences_decode),
+                                               p.q_max_seq_len, p.kv_max_seq_len])
+
+    step([cfg.prompt_len] * cfg.n_requests, "prefill")
+    for d in range(cfg.n_decode):
+        step([1] * cfg.n_requests, f"decode{d}")
+    # free two requests, admit again: LIFO reuse order (block_allocator.py:25-36)
+    for r in (3, 17):
+        shared.unpin(tables[r])
+        alloc.free(tables[r])
+        tables[r], lens[r] = [], 0
+    realloc(tables[3], 40)
+    realloc(tables[17], 700)
+    out["trace_realloc_3"] = np.array(tables[3], dtype=np.int32)
+    out["trace_realloc_17"] = np.array(tables[17], dtype=np.int32)
+    out["trace_free_blocks_tail"] = np.array(alloc.free_blocks[-8:], dtype=np.int32)
+
+
+def main():
+    import_reference()
+    torch.manual_seed(0)
+    sets = {
+        "g1_cache_scatter": gen_kv_cache,
+        "g2_paged_attention": gen_paged_attention,
+        "g3_dense_attention": gen_dense_attention,
+        "g4_rms_norm": gen_rms_norm,
+        "g5_rope": gen_rope,
+        "g6_silu": gen_silu,
+        "g7_trace": gen_trace,
+    }
+    only = sys.argv[1:]
+    for name, fn in sets.items():
+        if only and name not in only:
+            continue
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

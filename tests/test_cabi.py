@@ -1,0 +1,65 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/hydra_hip.h
+declares (no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from hydrainfer_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    names = []
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if not hdr.endswith(".h"):
+            continue
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"\b(hx_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _declared()
+    assert len(declared) >= 19
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in declared if not hasattr(handle, n)]
+    assert not missing, f"declared in include/ but not exported: {missing}"
+
+
+def test_python_binding_covers_the_header():
+    assert sorted(_lib.exported_symbols()) == _declared()
+    lib = _lib.lib()
+    assert lib.hx_abi_version() == 1
+    assert lib.hx_strerror(0) == b"ok"
+    assert b"data type" in lib.hx_strerror(-1)
+
+
+def test_attn_args_struct_layout_matches_header():
+    # field order/size of hx_attn_args as declared in the header
+    src = open(os.path.join(ROOT, "include", "hydra_hip.h")).read()
+    body = re.search(r"typedef struct hx_attn_args \{(.*?)\} hx_attn_args;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split()[-1] if "," not in decl else None
+        if names is None:
+            first, *rest = decl.split(",")
+            fields.append(first.split()[-1].lstrip("*"))
+            fields += [r.strip().lstrip("*") for r in rest]
+        else:
+            fields.append(names.lstrip("*"))
+    assert fields == [f[0] for f in _lib.hx_attn_args._fields_]
+
+
+def test_cpu_tensors_are_refused_not_emulated():
+    import pytest
+    import torch
+    from hydrainfer_amd._C.kernel.norm import rms_norm
+    x = torch.randn(2, 8)
+    with pytest.raises(_lib.HydraHipError):
+        rms_norm(torch.empty_like(x), x, torch.ones(8), 1e-5)

@@ -1,0 +1,231 @@
+"""GPU parity tests for mha_varlen_fwd (paged causal incl. the decode kernel, dense
+non-causal) against reference-generated fixtures, the oracle, and size-independent
+properties at BASELINE sizes."""
+import math
+
+import pytest
+import torch
+
+from tests.golden import cases as C
+from tests.util import ATTN_TOL, assert_close_t, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _layer(case):
+    from hydrainfer_amd.layer.causal_attention import (AttentionParametersBuilder,
+                                                       CausalGroupedQueryPageAttention,
+                                                       CausalGroupedQueryPageAttentionConfig)
+    from hydrainfer_amd.memory.kv_cache import KVCache
+    return AttentionParametersBuilder, CausalGroupedQueryPageAttention, \
+        CausalGroupedQueryPageAttentionConfig, KVCache
+
+
+def test_paged_causal_attention_goldens():
+    """Reads like the reference's tests/layer/test_attention.py: build params, run the layer,
+    compare output AND cache contents."""
+    g = load_golden("g2_paged_attention")
+    for i, case in enumerate(C.paged_attention_cases()):
+        Builder, Attn, Cfg, KVCache = _layer(case)
+        dt = C.DTYPES[case["dtype"]]
+        n = C.case_name("pattn", i)
+        q, k, v, kc, vc, reqs = C.paged_attention_inputs(case, seed=i)
+        kcd, vcd = kc.to(DEV), vc.to(DEV)
+        b = Builder(case["n_heads"], case["n_kv_heads"], case["head_dim"], case["block_size"],
+                    torch.device(DEV))
+        for r in reqs:
+            b.add_request(r["q_len"], r["kv_len"], r["new_cache_slots"], r["block_table"])
+        b.add_kv_cache(KVCache(kcd, vcd))
+        params = b.build_attention_parameters()[0]
+        attn = Attn(Cfg(case["n_heads"], case["n_kv_heads"], case["head_dim"]))
+        o = attn(q.to(DEV), k.to(DEV), v.to(DEV), params).o
+        torch.cuda.synchronize()
+        assert C.checksum(kcd.cpu(), vcd.cpu()) == str(g[n + "_cache_chk"]), case  # bit-exact cache
+        atol, rtol = ATTN_TOL[dt]
+        assert_close_t(o, C.from_np(g[n + "_o"], dt), atol, rtol, what=str(case))
+
+
+def _random_paged(batch, H, HK, D, kv_lens, q_lens, dt, block_size=16, seed=0, extra_blocks=7):
+    g = torch.Generator().manual_seed(seed)
+    n_blocks = sum((l + block_size - 1) // block_size for l in kv_lens) + extra_blocks
+    kc = torch.randn((n_blocks, block_size, HK, D), generator=g).to(dt)
+    vc = torch.randn((n_blocks, block_size, HK, D), generator=g).to(dt)
+    perm = torch.randperm(n_blocks, generator=g).tolist()
+    tables, cu_b, cu_q, cu_k, used = [], [0], [0], [0], 0
+    for ql, kl in zip(q_lens, kv_lens):
+        nb = (kl + block_size - 1) // block_size
+        tables += perm[used: used + nb]
+        used += nb
+        cu_b.append(cu_b[-1] + nb)
+        cu_q.append(cu_q[-1] + ql)
+        cu_k.append(cu_k[-1] + kl)
+    q = torch.randn((cu_q[-1], H, D), generator=g).to(dt)
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)
+    return q, kc, vc, i32(cu_q), i32(cu_k), i32(tables), i32(cu_b)
+
+
+def _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max_q, max_k, causal=True, num_splits=0):
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    qd = q.to(DEV)
+    out = torch.empty_like(qd)
+    mha_varlen_fwd(out, qd, kc.to(DEV), vc.to(DEV), cu_q.to(DEV), cu_k.to(DEV), bt.to(DEV),
+                   cu_b.to(DEV), None, max_q, max_k, 1.0 / math.sqrt(q.shape[-1]), 0.0, -1,
+                   0 if causal else -1, num_splits)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("heads", [(8, 8), (8, 4), (8, 1)])
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_decode_grid_vs_oracle(dt, heads, D):
+    """Grid of the reference's tests/kernel/test_attention_kernel.py:106-133: batch in
+    {1,2,3,4,8}, random page tables, kv_len in [1,256], q_len = 1."""
+    from oracle import ops
+    H, HK = heads
+    gen = torch.Generator().manual_seed(D + H + HK)
+    for batch in (1, 2, 3, 4, 8):
+        kv_lens = torch.randint(1, 257, (batch,), generator=gen).tolist()
+        q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(batch, H, HK, D, kv_lens, [1] * batch, dt,
+                                                        seed=batch)
+        ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+        for splits in (0, 1, 3):
+            out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, 1, max(kv_lens), num_splits=splits)
+            atol, rtol = ATTN_TOL[dt]
+            assert_close_t(out, ref, atol, rtol, what=f"decode b={batch} D={D} {heads} {dt} splits={splits}")
+
+
+def test_decode_long_context_and_split_kv():
+    from oracle import ops
+    dt = torch.float16
+    kv_lens = [4095, 1, 16, 17, 1000]
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(5, 4, 4, 128, kv_lens, [1] * 5, dt, seed=3)
+    ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+    for splits in (0, 1, 2, 7, 64):
+        out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, 1, max(kv_lens), num_splits=splits)
+        assert_close_t(out, ref, 1e-3, 1e-3, what=f"splits={splits}")
+
+
+def test_mixed_prefill_decode_and_block_sizes():
+    from oracle import ops
+    for dt in (torch.float16, torch.bfloat16):
+        for bs in (16, 32, 64):
+            q_lens, kv_lens = [1, 50, 128, 3, 1], [300, 50, 200, 67, 1]
+            q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(5, 8, 2, 128, kv_lens, q_lens, dt,
+                                                            block_size=bs, seed=bs)
+            ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+            out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
+            atol, rtol = ATTN_TOL[dt]
+            assert_close_t(out, ref, atol, rtol, what=f"mixed bs={bs} {dt}")
+
+
+def test_baseline_shapes_llava_prefill_and_decode():
+    """BASELINE shapes: H=32, D=128; 704-token prompt prefill then decode
+    against ctx 705; 13B head count 40 for decode."""
+    from oracle import ops
+    dt = torch.float16
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(1, 32, 32, 128, [704], [704], dt, seed=11)
+    ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+    out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, 704, 704)
+    assert_close_t(out, ref, 1e-3, 1e-3, what="prefill 704")
+    for H in (32, 40):
+        kv = [705 + 8 * i for i in range(8)]
+        q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(8, H, H, 128, kv, [1] * 8, dt, seed=H)
+        ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+        out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, 1, max(kv))
+        assert_close_t(out, ref, 1e-3, 1e-3, what=f"decode H={H}")
+
+
+def test_dense_noncausal_goldens():
+    from hydrainfer_amd.layer.multihead_attention import (MultiHeadAttention, MultiHeadAttentionConfig,
+                                                          MultiHeadAttentionParameters)
+    g = load_golden("g3_dense_attention")
+    for i, case in enumerate(C.dense_attention_cases()):
+        dt = C.DTYPES[case["dtype"]]
+        q, k, v = C.dense_attention_inputs(case, seed=i)
+        mha = MultiHeadAttention(MultiHeadAttentionConfig(case["n_heads"], case["head_dim"]))
+        o = mha(q.to(DEV), k.to(DEV), v.to(DEV), MultiHeadAttentionParameters()).o
+        atol, rtol = ATTN_TOL[dt]
+        assert_close_t(o, C.from_np(g[C.case_name("dattn", i) + "_o"], dt), atol, rtol, what=str(case))
+
+
+def test_dense_ragged_causal_and_noncausal():
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    from oracle import ops
+    gen = torch.Generator().manual_seed(5)
+    for dt in (torch.float16, torch.bfloat16):
+        lens = [1, 17, 64, 65, 200]
+        cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+        H, HK, D = 4, 2, 64
+        q = torch.randn((sum(lens), H, D), generator=gen).to(dt)
+        k = torch.randn((sum(lens), HK, D), generator=gen).to(dt)
+        v = torch.randn((sum(lens), HK, D), generator=gen).to(dt)
+        for causal in (False, True):
+            out = torch.empty_like(q, device=DEV)
+            mha_varlen_fwd(out, q.to(DEV), k.to(DEV), v.to(DEV), cu.to(DEV), cu.to(DEV), None, None,
+                           None, max(lens), max(lens), 1 / math.sqrt(D), 0.0, -1, 0 if causal else -1, 0)
+            ref = ops.varlen_attention(q, k, v, cu, cu, causal=causal)
+            atol, rtol = ATTN_TOL[dt]
+            assert_close_t(out, ref, atol, rtol, what=f"dense causal={causal} {dt}")
+
+
+def test_softmax_rescale_branch_is_exercised():
+    """A key far above the rest late in the sequence forces the online-softmax rescale
+    (running max jumps) in every kernel variant."""
+    from oracle import ops
+    dt = torch.float16
+    for q_len in (1, 40):
+        kv = 200
+        q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(1, 2, 2, 128, [kv], [q_len], dt, seed=9)
+        # spike the key at position 150: k = 6*q direction
+        page, off = int(bt[150 // 16]), 150 % 16
+        kc[page, off] = (q[-1] * 4).to(dt)
+        ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+        for splits in (1, 2):
+            out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, q_len, kv, num_splits=splits)
+            assert_close_t(out, ref, 1e-3, 1e-3, what=f"spike q_len={q_len} splits={splits}")
+
+
+def test_decode_property_at_full_size():
+    """At BASELINE size (B=32, H=32, D=128, ctx 705..959) the oracle is too slow for every
+    head, so check (a) a sampled subset of sequences against the oracle and (b) linearity in
+    V: attn(K, a*V1 + V2) == a*attn(K, V1) + attn(K, V2) within tolerance."""
+    from oracle import ops
+    dt = torch.float16
+    B, H, D = 32, 32, 128
+    kv = [705 + 8 * i for i in range(B)]
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(B, H, H, D, kv, [1] * B, dt, seed=1)
+    out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, 1, max(kv))
+    for b in (0, 13, 31):
+        sl = slice(b, b + 1)
+        ref = ops.paged_attention(q[sl], kc, vc, torch.tensor([0, 1], dtype=torch.int32),
+                                  torch.tensor([0, kv[b]], dtype=torch.int32),
+                                  bt[int(cu_b[b]):int(cu_b[b + 1])],
+                                  torch.tensor([0, int(cu_b[b + 1] - cu_b[b])], dtype=torch.int32))
+        assert_close_t(out[sl], ref, 1e-3, 1e-3, what=f"full-size seq {b}")
+    v2 = torch.randn(vc.shape, generator=torch.Generator().manual_seed(2)).to(dt)
+    o1 = out.float()
+    o2 = _run(q, kc, v2, cu_q, cu_k, bt, cu_b, 1, max(kv)).float()
+    o3 = _run(q, kc, (0.5 * vc.float() + v2.float()).to(dt), cu_q, cu_k, bt, cu_b, 1, max(kv)).float()
+    assert_close_t(o3, 0.5 * o1 + o2, 3e-3, 3e-3, what="linearity in V")
+
+
+def test_argument_errors_raise():
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    from hydrainfer_amd._lib import HydraHipError
+    q = torch.randn((2, 4, 64), device=DEV, dtype=torch.float16)
+    kc = torch.randn((4, 16, 4, 64), device=DEV, dtype=torch.float16)
+    cu = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV)
+    cuk = torch.tensor([0, 5, 10], dtype=torch.int32, device=DEV)
+    bt = torch.tensor([0, 1], dtype=torch.int32, device=DEV)
+    cub = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV)
+    out = torch.empty_like(q)
+    with pytest.raises(HydraHipError):  # fp32 not supported (flash_api.cpp:236)
+        mha_varlen_fwd(out.float(), q.float(), kc.float(), kc.float(), cu, cuk, bt, cub, None, 1, 5, 0.1, 0.0, -1, 0, 0)
+    with pytest.raises(HydraHipError):  # int64 cu_seqlens (flash_api.cpp:241)
+        mha_varlen_fwd(out, q, kc, kc, cu.long(), cuk, bt, cub, None, 1, 5, 0.1, 0.0, -1, 0, 0)
+    with pytest.raises(HydraHipError):  # block size not divisible by 16 (flash_api.cpp:270)
+        mha_varlen_fwd(out, q, kc[:, :8], kc[:, :8], cu, cuk, bt, cub, None, 1, 5, 0.1, 0.0, -1, 0, 0)
+    with pytest.raises(HydraHipError):  # heads not divisible (flash_api.cpp:283)
+        mha_varlen_fwd(out, q, kc[:, :, :3], kc[:, :, :3], cu, cuk, bt, cub, None, 1, 5, 0.1, 0.0, -1, 0, 0)

@@ -1,0 +1,122 @@
+"""GPU: block migration (gather-copy kernel, IPC handle wire format, pack/unpack)."""
+import multiprocessing as mp
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pools(seed=0, src_blocks=10, dst_blocks=7, dtype=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randn((3, 2, src_blocks, 16, 4, 64), generator=g).to(dtype)
+    dst = torch.randn((3, 2, dst_blocks, 16, 4, 64), generator=g).to(dtype)
+    return src, dst
+
+
+def test_migrate_blocks_local_matches_oracle():
+    from hydrainfer_amd._C.data_transfer import block_migration as bm
+    from oracle import ops
+    for dtype in (torch.float16, torch.bfloat16, torch.float32):
+        src, dst = _pools(dtype=dtype)
+        s_tbl, d_tbl = [9, 0, 4, 3], [1, 6, 2, 0]
+        want = dst.clone()
+        ops.migrate_blocks(s_tbl, d_tbl, src, want)
+        sd, dd = src.to(DEV), dst.to(DEV)
+        bm.migrate_blocks_local(s_tbl, d_tbl, sd, dd)
+        torch.cuda.synchronize()
+        assert torch.equal(dd.cpu(), want)
+
+
+def test_migrate_blocks_same_process_ipc_handle_roundtrip_format():
+    from hydrainfer_amd._C.data_transfer import block_migration as bm
+    src, _ = _pools()
+    sd = src.to(DEV)
+    h = bm.get_ipc_mem_handle(sd)
+    assert isinstance(h, list) and len(h) == 72 and all(isinstance(x, int) and 0 <= x < 256 for x in h)
+
+
+def test_pack_unpack_roundtrip_many_pairs():
+    from hydrainfer_amd._C.data_transfer import block_migration as bm
+    g = torch.Generator().manual_seed(1)
+    n_blocks = 1200  # > HX_MIGRATE_MAX_PAIRS: exercises the chunked launch
+    pool = torch.randn((2, 2, n_blocks, 16, 1, 16), generator=g).to(torch.float16).to(DEV)
+    table = torch.randperm(n_blocks, generator=g)[:1000].tolist()
+    staging = torch.empty((2, 2, len(table), 16, 1, 16), dtype=torch.float16, device=DEV)
+    bm.pack_blocks(table, pool, staging)
+    torch.cuda.synchronize()
+    assert torch.equal(staging, pool[:, :, table])
+    pool2 = torch.zeros_like(pool)
+    bm.unpack_blocks(table, staging, pool2)
+    torch.cuda.synchronize()
+    assert torch.equal(pool2[:, :, table], pool[:, :, table])
+    rest = sorted(set(range(n_blocks)) - set(table))
+    assert float(pool2[:, :, rest].float().abs().sum()) == 0
+
+
+def _ipc_child(handle, src_tbl, dst_tbl, src_n_blocks, q):
+    try:
+        import torch
+        from hydrainfer_amd._C.data_transfer import block_migration as bm
+        dst = torch.zeros((3, 2, 7, 16, 4, 64), dtype=torch.float16, device="cuda:0")
+        bm.migrate_blocks(src_tbl, dst_tbl, handle, dst, src_n_blocks)
+        bm.migrate_blocks(src_tbl, dst_tbl, handle, dst, src_n_blocks)  # handle re-use: cached mapping
+        torch.cuda.synchronize()
+        q.put(dst.cpu())
+    except Exception as e:  # pragma: no cover
+        q.put(repr(e))
+
+
+def test_migrate_blocks_across_processes_via_ipc_handle():
+    """The reference's transport (communication.py:23-45): the receiver process maps the
+    sender's pool from 64 handle bytes passed through Python and pulls blocks."""
+    from hydrainfer_amd._C.data_transfer import block_migration as bm
+    from oracle import ops
+    src, _ = _pools()
+    sd = src.to(DEV)
+    torch.cuda.synchronize()
+    handle = bm.get_ipc_mem_handle(sd)
+    s_tbl, d_tbl = [9, 0, 4], [1, 6, 2]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_ipc_child, args=(handle, s_tbl, d_tbl, src.shape[2], q))
+    p.start()
+    got = q.get(timeout=180)
+    p.join(timeout=60)
+    assert not isinstance(got, str), got
+    want = torch.zeros((3, 2, 7, 16, 4, 64), dtype=torch.float16)
+    ops.migrate_blocks(s_tbl, d_tbl, src, want)
+    assert torch.equal(got, want)
+
+
+def test_decode_advance_matches_builder():
+    """hx_decode_advance == one AttentionParametersBuilder pass for an all-decode batch."""
+    import ctypes
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd.memory import token_cache_manger as tcm
+    bs, B = 16, 300
+    g = torch.Generator().manual_seed(0)
+    lens = torch.randint(1, 200, (B,), generator=g).tolist()
+    tables, cu_b, nxt = [], [0], 0
+    for l in lens:
+        nb = (l + 1 + bs - 1) // bs
+        tables += list(range(nxt, nxt + nb))[::-1]
+        nxt += nb
+        cu_b.append(cu_b[-1] + nb)
+    pos = torch.tensor([l - 1 for l in lens], dtype=torch.int32, device=DEV)
+    kvl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    cu_k = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    slots = torch.zeros(B, dtype=torch.int32, device=DEV)
+    bt = torch.tensor(tables, dtype=torch.int32, device=DEV)
+    cub = torch.tensor(cu_b, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().hx_decode_advance(pos.data_ptr(), kvl.data_ptr(), cu_k.data_ptr(),
+                                            slots.data_ptr(), bt.data_ptr(), cub.data_ptr(), B, bs,
+                                            _lib.current_stream()), "decode_advance")
+    torch.cuda.synchronize()
+    want_slots = [tcm.v2p(tables[cu_b[i]:cu_b[i + 1]], [lens[i]], bs)[0] for i in range(B)]
+    assert slots.tolist() == want_slots
+    assert kvl.tolist() == [l + 1 for l in lens]
+    assert pos.tolist() == lens
+    assert cu_k.tolist() == [0] + torch.tensor([l + 1 for l in lens]).cumsum(0).tolist()

@@ -1,0 +1,166 @@
+"""GPU parity tests (through the C ABI via the hydrainfer._C-shaped shims): cache scatter,
+rms_norm, rope, silu against the reference-generated fixtures and the oracle."""
+import pytest
+import torch
+
+from tests.golden import cases as C
+from tests.util import assert_close_t, assert_ulp_close, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    from hydrainfer_amd._C.kernel import (activation, cache_kernels, kv_cache_kernels, norm,
+                                          position_embedding)
+    return activation, cache_kernels, kv_cache_kernels, norm, position_embedding
+
+
+def test_native_library_is_loaded():
+    from hydrainfer_amd import _lib
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libhydra_hip.so" in maps
+
+
+def test_set_kv_cache_and_image_cache_bit_exact():
+    _, cache_kernels, kv_cache_kernels, _, _ = _ops()
+    g = load_golden("g1_cache_scatter")
+    for i, case in enumerate(C.kv_cache_cases()):
+        n = C.case_name("kv", i)
+        slot_ids, keys, values, kc, vc = C.kv_cache_inputs(case, seed=i)
+        qkv_dev = keys._base.to(DEV) if keys._base is not None else None
+        # rebuild the strided views on the device from the same fused buffer
+        hd = case["n_heads"] * case["head_dim"]
+        kd = qkv_dev[:, hd:2 * hd].view(-1, case["n_heads"], case["head_dim"])
+        vd = qkv_dev[:, 2 * hd:].view(-1, case["n_heads"], case["head_dim"])
+        kcd, vcd = kc.to(DEV), vc.to(DEV)
+        kv_cache_kernels.set_kv_cache(slot_ids.to(DEV), kd, vd, kcd, vcd)
+        assert C.checksum(kcd.cpu()) == str(g[n + "_key_cache_chk"]), case
+        assert C.checksum(vcd.cpu()) == str(g[n + "_value_cache_chk"]), case
+        icd = kc.to(DEV)
+        cache_kernels.set_image_cache(slot_ids.to(DEV), kd, icd)
+        assert C.checksum(icd.cpu()) == str(g[n + "_image_cache_chk"]), case
+
+
+def test_set_kv_cache_edges():
+    _, _, kv_cache_kernels, _, _ = _ops()
+    kc = torch.zeros((4, 16, 2, 64), dtype=torch.float16, device=DEV)
+    vc = torch.zeros_like(kc)
+    # empty input
+    kv_cache_kernels.set_kv_cache(torch.empty(0, dtype=torch.int32, device=DEV),
+                                  torch.empty((0, 2, 64), dtype=torch.float16, device=DEV),
+                                  torch.empty((0, 2, 64), dtype=torch.float16, device=DEV), kc, vc)
+    assert float(kc.abs().sum()) == 0
+    # last slot of the last block, and a non-contiguous per-layer view of a 6-D pool
+    pool = torch.zeros((2, 2, 4, 16, 2, 64), dtype=torch.bfloat16, device=DEV)
+    k = torch.randn((3, 2, 64), device=DEV).to(torch.bfloat16)
+    v = torch.randn((3, 2, 64), device=DEV).to(torch.bfloat16)
+    slots = torch.tensor([63, 0, 17], dtype=torch.int32, device=DEV)
+    kv_cache_kernels.set_kv_cache(slots, k, v, pool[1, 0], pool[1, 1])
+    assert torch.equal(pool[1, 0].view(-1, 2, 64)[slots.long()], k)
+    assert torch.equal(pool[1, 1].view(-1, 2, 64)[slots.long()], v)
+    assert float(pool[0].float().abs().sum()) == 0
+    # wrong dtype for slots is an error, not a silent reinterpretation
+    from hydrainfer_amd._lib import HydraHipError
+    with pytest.raises(HydraHipError):
+        kv_cache_kernels.set_kv_cache(slots.long(), k, v, pool[1, 0], pool[1, 1])
+
+
+def test_rms_norm():
+    from oracle import ops
+    _, _, _, norm, _ = _ops()
+    g = load_golden("g4_rms_norm")
+    for i, case in enumerate(C.rms_norm_cases()):
+        dt = C.DTYPES[case["dtype"]]
+        x, w = C.rms_norm_inputs(case, seed=i)
+        out = torch.empty_like(x, device=DEV)
+        norm.rms_norm(out, x.to(DEV), w.to(DEV), case["eps"])
+        # rounding points of the CUDA kernel (rms_norm.cu:39): bit-equal to the kernel-variant
+        # oracle up to the fp32 reduction order (<= 1 ulp of T, 4 ulp in fp32)
+        assert_ulp_close(out.cpu(), ops.rms_norm_kernel(x, w, case["eps"]),
+                         max_ulp=4 if dt == torch.float32 else 1, min_exact_frac=0.98,
+                         what=str(case))
+        # reference's own bar vs its torch path: 1e-3 (tests/kernel/test_rms_norm_kernel.py:24);
+        # bf16 (extension tier) 1e-2
+        ref = C.from_np(g[C.case_name("rms", i) + "_o"], dt)
+        tol = 1e-2 if dt == torch.bfloat16 else 1e-3
+        assert_close_t(out, ref, tol, tol, what=str(case))
+
+
+def test_add_rms_norm_equals_unfused():
+    _, _, _, norm, _ = _ops()
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        for hidden in (4096, 5120, 334):
+            x = torch.randn((9, hidden), device=DEV).to(dt)
+            r = torch.randn((9, hidden), device=DEV).to(dt)
+            w = (1 + 0.1 * torch.randn(hidden, device=DEV)).to(dt)
+            h = r + x
+            want = torch.empty_like(h)
+            norm.rms_norm(want, h, w, 1e-5)
+            got, res = torch.empty_like(x), r.clone()
+            norm.add_rms_norm(got, res, x, w, 1e-5)
+            assert torch.equal(res, h)
+            assert torch.equal(got, want)
+
+
+def test_rope_bit_exact():
+    from oracle import ops
+    _, _, _, _, pe = _ops()
+    g = load_golden("g5_rope")
+    for i, case in enumerate(C.rope_cases()):
+        dt = C.DTYPES[case["dtype"]]
+        n = C.case_name("rope", i)
+        q, k, pos = C.rope_inputs(case, seed=i)
+        cs = ops.build_cos_sin_cache(case["rotary_dim"], case["max_pos"], case["theta"], dt)
+        qd, kd = q.to(DEV), k.to(DEV)
+        pe.apply_rotary_pos_emb(qd, kd, pos.to(DEV), cs.to(DEV), case["rotary_dim"], case["interleaved"])
+        # T arithmetic with the same rounding points as the reference: bit-exact
+        assert_ulp_close(qd.cpu(), C.from_np(g[n + "_q"], dt), max_ulp=0, what=str(case))
+        assert_ulp_close(kd.cpu(), C.from_np(g[n + "_k"], dt), max_ulp=0, what=str(case))
+
+
+def test_rope_strided_qkv_views():
+    from oracle import ops
+    _, _, _, _, pe = _ops()
+    H, HK, D, n = 32, 32, 128, 17
+    qkv = torch.randn((n, (H + 2 * HK) * D)).to(torch.float16)
+    pos = torch.arange(100, 100 + n, dtype=torch.int32)
+    cs = ops.build_cos_sin_cache(D, 4096, 1e4, torch.float16)
+    q_ref, k_ref = ops.apply_rotary_pos_emb(qkv[:, :H * D].view(n, H, D),
+                                            qkv[:, H * D:(H + HK) * D].view(n, HK, D), pos, cs, D, False)
+    d = qkv.to(DEV)
+    pe.apply_rotary_pos_emb(d[:, :H * D].view(n, H, D), d[:, H * D:(H + HK) * D].view(n, HK, D),
+                            pos.to(DEV), cs.to(DEV), D, False)
+    assert torch.equal(d[:, :H * D].view(n, H, D).cpu(), q_ref)
+    assert torch.equal(d[:, H * D:(H + HK) * D].view(n, HK, D).cpu(), k_ref)
+    assert torch.equal(d[:, (H + HK) * D:].cpu(), qkv[:, (H + HK) * D:])  # v untouched
+
+
+def test_silu():
+    from oracle import ops
+    act, *_ = _ops()
+    g = load_golden("g6_silu")
+    for i, case in enumerate(C.silu_cases()):
+        dt = C.DTYPES[case["dtype"]]
+        x = C.silu_inputs(case, seed=i)
+        out = act.silu(x.to(DEV))
+        assert out.is_contiguous() and out.shape == x.shape
+        ref = C.from_np(g[C.case_name("silu", i) + "_o"], dt)
+        assert_ulp_close(out.cpu(), ref, max_ulp=4 if dt == torch.float32 else 1,
+                         min_exact_frac=0.97, what=str(case))
+        assert_close_t(out, ref, 1e-3, 1e-3 if dt != torch.bfloat16 else 8e-3, what=str(case))
+    # row-strided input (gate half of a fused gate|up projection), activation.cu:36-37
+    x = (3 * torch.randn((6, 2 * 1024))).to(torch.float16)
+    out = act.silu(x.to(DEV)[:, :1024])
+    assert_ulp_close(out.cpu(), ops.silu(x[:, :1024].contiguous()), max_ulp=1, what="strided")
+
+
+def test_silu_and_mul_equals_unfused():
+    act, *_ = _ops()
+    for dt in (torch.float16, torch.bfloat16):
+        gu = (2 * torch.randn((7, 2 * 11008), device=DEV)).to(dt)
+        g_, u_ = gu[:, :11008], gu[:, 11008:]
+        want = act.silu(g_) * u_
+        got = act.silu_and_mul(g_, u_)
+        assert torch.equal(got, want)
