@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json:metric).
+
+A "step" = one batched decode step of a LLaVA-1.5-7B-shaped language model (random weights,
+SURVEY.md §8d) for 32 concurrent requests (576 image + 128 text prompt tokens each) on ONE
+MI355X: embed -> 32 x [rms_norm, qkv GEMM, RoPE, set_kv_cache, paged decode attention,
+o GEMM, add+rms_norm, gate|up GEMM, silu*mul, down GEMM] -> norm -> lm_head -> argmax.
+GEMMs are library GEMMs (hipBLASLt via torch); every other op is libhydra_hip.  The KV
+context starts at the prompt (704 cached tokens) and grows by one per step exactly as in a
+real generation, so K steps cover contexts 705..704+K (K=255 = the whole 256-token
+generation).  Inputs (weights, KV cache, metadata) are resident in HBM before the timed region.
+
+python bench.py [--gpus N --steps K --warmup W]   (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=255)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    p.add_argument("--batch", type=int, default=32)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--skip-prefill", action="store_true",
+                   help="decode against the randn-filled cache instead of a real prefill")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-layers", type=int, default=2)
+    return p.parse_args()
+
+
+def model_shape(name):
+    from hydrainfer_amd.model.llama import LLAVA_1_5_13B, LLAVA_1_5_7B, LlamaShape
+    if name == "7b":
+        return LLAVA_1_5_7B, "LLaVA-1.5-7B"
+    if name == "13b":
+        return LLAVA_1_5_13B, "LLaVA-1.5-13B"
+    return LlamaShape(512, 1024, 2, 4, 4, 128, 2048), "tiny"
+
+
+def synth_prompts(batch, prompt_len, vocab, device):
+    """576 x image_token_id followed by random text ids, distinct seed per request (§8d)."""
+    rows = []
+    for r in range(batch):
+        g = torch.Generator().manual_seed(r)
+        text = torch.randint(1000, min(31999, vocab - 1), (prompt_len - 576,), generator=g)
+        rows.append(torch.cat([torch.full((576,), image_token_id(vocab)), text]))
+    return torch.stack(rows).to(device)
+
+
+def image_token_id(vocab):
+    return 32000 if vocab > 32000 else vocab - 1
+
+
+def time_attention_kernel(runner, start_len, steps):
+    """Average duration of the decode-attention launch over the same context sequence as the
+    timed region, HIP events on the launch stream (torch's current stream)."""
+    import math
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    sh = runner.model.shape
+    B = runner.cfg.batch
+    q = torch.randn((B, sh.num_attention_heads, sh.head_dim), device=runner.dev).to(runner.model.dtype)
+    out = torch.empty_like(q)
+    ap = runner.decode_params.attention_params[0]
+    kc, vc = ap.kv_cache.get_kv_cache()
+    saved = (runner.positions.clone(), runner.kv_lens.clone())
+    runner.positions.fill_(start_len - 1)
+    runner.kv_lens.fill_(start_len)
+    evs = []
+    scale = 1.0 / math.sqrt(sh.head_dim)
+    for s in range(steps + 2):
+        runner._advance()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        mha_varlen_fwd(out, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
+                       ap.cu_blocks_lens, None, 1, runner.max_len, scale, 0.0, -1, 0, 0)
+        e1.record()
+        if s >= 2:
+            evs.append((e0, e1))
+    torch.cuda.synchronize()
+    runner.positions.copy_(saved[0]); runner.kv_lens.copy_(saved[1])
+    return sum(a.elapsed_time(b) for a, b in evs) / len(evs)   # ms
+
+
+def cpu_baseline(shape, dtype, batch, ctx, n_layers):
+    """The oracle (reference's eager-PyTorch CPU path restated) timed on this host's cores:
+    one decode step of `n_layers` of the decoder layers + final norm + lm_head at the mid-run
+    context, extrapolated linearly to all layers."""
+    from oracle.model import OracleAttnMeta, OracleLlama
+    g = torch.Generator().manual_seed(0)
+    # torch's default (all hardware threads) can be far from the fastest setting for M=32
+    # GEMMs on a many-core host: calibrate the thread count on one projection-sized GEMM and
+    # report the count actually used.
+    xa = torch.randn((batch, shape.hidden_size), generator=g).to(dtype)
+    wa = torch.randn((shape.intermediate_size, shape.hidden_size), generator=g).to(dtype)
+    best_t, best = None, float("inf")
+    for t in sorted({min(os.cpu_count(), n) for n in (8, 16, 32, 64, 128, os.cpu_count())}):
+        torch.set_num_threads(t)
+        torch.nn.functional.linear(xa, wa)
+        t0 = time.perf_counter()
+        torch.nn.functional.linear(xa, wa)
+        dt_ = time.perf_counter() - t0
+        if dt_ < best:
+            best_t, best = t, dt_
+        if dt_ > 2.0:
+            break
+    torch.set_num_threads(best_t)
+    n_threads = best_t
+    h, i = shape.hidden_size, shape.intermediate_size
+    q = shape.num_attention_heads * shape.head_dim
+    kv = shape.num_key_value_heads * shape.head_dim
+
+    def w(*s):
+        return (torch.randn(s, generator=g) * 0.02).to(dtype)
+    sd = {"model.embed_tokens.weight": w(shape.vocab_size, h), "lm_head.weight": w(shape.vocab_size, h),
+          "model.norm.weight": torch.ones(h, dtype=dtype)}
+    for l in range(n_layers):
+        p = f"model.layers.{l}."
+        sd.update({p + "self_attn.q_proj.weight": w(q, h), p + "self_attn.k_proj.weight": w(kv, h),
+                   p + "self_attn.v_proj.weight": w(kv, h), p + "self_attn.o_proj.weight": w(h, q),
+                   p + "mlp.gate_proj.weight": w(i, h), p + "mlp.up_proj.weight": w(i, h),
+                   p + "mlp.down_proj.weight": w(h, i),
+                   p + "input_layernorm.weight": torch.ones(h, dtype=dtype),
+                   p + "post_attention_layernorm.weight": torch.ones(h, dtype=dtype)})
+    model = OracleLlama(shape, sd, dtype, n_layers=n_layers)
+    bs = 16
+    nb_seq = (ctx + bs - 1) // bs
+    n_blocks = batch * nb_seq
+    caches = [(torch.randn((n_blocks, bs, shape.num_key_value_heads, shape.head_dim), generator=g).to(dtype),
+               torch.randn((n_blocks, bs, shape.num_key_value_heads, shape.head_dim), generator=g).to(dtype))
+              for _ in range(n_layers)]
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)
+    bt = list(range(n_blocks))
+    slots = [bt[b * nb_seq + (ctx - 1) // bs] * bs + (ctx - 1) % bs for b in range(batch)]
+    meta = OracleAttnMeta(i32(list(range(batch + 1))), i32([ctx * b for b in range(batch + 1)]),
+                          i32(slots), i32(bt), i32([nb_seq * b for b in range(batch + 1)]))
+    ids = torch.randint(0, shape.vocab_size, (batch,), generator=g, dtype=torch.int64)
+    pos = i32([ctx - 1] * batch)
+
+    def run(nl):
+        model.n_layers = nl
+        t0 = time.perf_counter()
+        with torch.inference_mode():
+            model.forward(ids, pos, meta, caches)
+        return time.perf_counter() - t0
+    run(n_layers)                                # warm
+    t_full = min(run(n_layers) for _ in range(2))
+    t_head = min(run(0) for _ in range(2))       # embed + final norm + lm_head only
+    per_layer = (t_full - t_head) / n_layers
+    step_s = t_head + per_layer * shape.num_hidden_layers
+    return {"value": round(batch / step_s, 3), "unit": "tokens/s", "cores": n_threads,
+            "kind": "port",
+            "sample": f"one decode step, batch {batch}, ctx {ctx}: {n_layers} of "
+                      f"{shape.num_hidden_layers} decoder layers + lm_head timed with torch CPU "
+                      f"({str(dtype).split('.')[-1]} weights, fp32 attention as the reference's torch "
+                      f"handler), per-layer time extrapolated x{shape.num_hidden_layers}; "
+                      f"{t_full + t_head:.1f}s of CPU work per repetition"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    n_gpus = world if world > 1 else 1
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd.model.llama import LlamaForCausalLM
+    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
+    _lib.lib()   # no library, no benchmark
+
+    shape, model_name = model_shape(args.model)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    prompt_len, n_generate = 704, 256
+    steps = min(args.steps, n_generate - 1)
+    cfg = RunnerConfig(batch=args.batch, prompt_len=prompt_len, n_generate=n_generate,
+                       use_graph=not args.no_graph)
+    model = LlamaForCausalLM.random_init(shape, dtype, dev, seed=0)
+    runner = DecodeRunner(model, cfg, seed=rank)
+
+    prompts = synth_prompts(args.batch, prompt_len, shape.vocab_size, dev)
+    ttft_ms = None
+    if args.skip_prefill:
+        runner.set_state(prompt_len, prompts[:, -1])
+    else:
+        g = torch.Generator(device=dev).manual_seed(100 + rank)
+        img = (torch.randn((args.batch, 576, shape.hidden_size), generator=g, device=dev) * 0.02).to(dtype)
+        runner.prefill(prompts, img, image_token_id(shape.vocab_size))   # also warms every kernel / GEMM heuristic
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.prefill(prompts, img, image_token_id(shape.vocab_size))
+        torch.cuda.synchronize()
+        ttft_ms = (time.perf_counter() - t0) * 1e3   # prefill of the whole 32-request batch
+    state = (runner.positions.clone(), runner.kv_lens.clone(), runner.input_ids.clone())
+
+    def reset():
+        runner.positions.copy_(state[0]); runner.kv_lens.copy_(state[1]); runner.input_ids.copy_(state[2])
+        runner.tokens = []
+
+    # ---- warmup (untimed): graph capture + W steps, then rewind to the post-prefill state
+    if cfg.use_graph:
+        runner.capture()
+    for _ in range(args.warmup):
+        runner.step(record=False)
+    reset()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step(record=False)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    barrier()
+
+    ms_per_step = elapsed / steps * 1e3
+    tokens = args.batch * steps * n_gpus
+    value = tokens / elapsed
+
+    # ---- roofline of the dominant hand-written kernel + whole-step fraction (rank 0)
+    out = None
+    if rank == 0:
+        ctxs_per_step = [[prompt_len + s + 1] * args.batch for s in range(steps)]
+        attn_bytes = sum(runner.attention_bytes(c) for c in ctxs_per_step) / steps
+        attn_ms = time_attention_kernel(runner, prompt_len, steps)
+        attn_gbs = attn_bytes / (attn_ms * 1e-3) / 1e9
+        step_bytes = sum(runner.step_bytes(sum(c)) for c in ctxs_per_step) / steps
+        step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+        mid_ctx = prompt_len + (steps + 1) // 2
+        out = {
+            "metric": "decode output tokens/s, LLaVA-1.5-7B image+text requests (576 image + 128 text "
+                      "prompt, 256 generated), batch 32 per GPU" if args.model == "7b" else
+                      f"decode output tokens/s, {model_name}, batch {args.batch} per GPU",
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": n_gpus, "steps": steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{model_name}-shaped random weights, batch {args.batch} "
+                                   f"decode, paged KV block_size=16, ctx {prompt_len + 1}..{prompt_len + steps}"
+                                   f" (BASELINE configs[1]: collocated prefill+decode on 1 MI355X)",
+                       "global_batch": args.batch * n_gpus, "prompt_tokens": prompt_len,
+                       "generated_tokens": n_generate, "hip_graph": cfg.use_graph,
+                       "parallelism": f"replicas x{n_gpus} (independent requests, no data-path collective)"},
+            "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (paged decode attention)",
+                         "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_launch_us": round(attn_ms * 1e3, 2),
+                         "algorithmic_bytes_per_launch": int(attn_bytes)},
+            "whole_step": {"algorithmic_bytes": int(step_bytes), "achieved_GBps": round(step_gbs, 1),
+                           "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
+                           "weight_bytes": model.weight_bytes()},
+            "prefill_batch_ms": None if ttft_ms is None else round(ttft_ms, 2),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(shape, dtype, args.batch, mid_ctx, args.cpu_layers)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

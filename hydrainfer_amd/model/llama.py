@@ -1,0 +1,200 @@
+"""Llama decoder (the language half of LLaVA-1.5) — the caller of the hot path.
+
+Mirrors hydrainfer/model/llama.py:21-104 + hydrainfer/model/model_forward.py:39-105:
+    h = h + o_proj(Attn(rope(q_proj, k_proj), v_proj)) ; h = h + down(silu(gate) * up)
+with pre-RMSNorm, greedy argmax inside the model (llama.py:99-104), last-layer token
+selection for prefill (model_forward.py:101-103).
+
+MI355X-first differences (all rounding-neutral with respect to the reference's unfused ops):
+  * q/k/v and gate/up weights are stored fused ([3h, h] and [2i, h]) so a layer is 4 library
+    GEMMs instead of 7; `from_reference_state_dict` builds them from the reference's names.
+  * residual-add + RMSNorm, RoPE (in place on the qkv buffer), set_kv_cache + attention and
+    silu*mul each run as one HIP launch.
+GEMMs are plain library GEMMs (torch.matmul -> hipBLASLt); everything else is libhydra_hip."""
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor
+
+from hydrainfer_amd._C.kernel.activation import silu_and_mul
+from hydrainfer_amd._C.kernel.norm import add_rms_norm, rms_norm
+from hydrainfer_amd._C.kernel.position_embedding import apply_rotary_pos_emb
+from hydrainfer_amd.layer.causal_attention import AttentionParameters
+from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+
+
+@dataclass
+class LlamaShape:
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    head_dim: int
+    vocab_size: int
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    max_position_embeddings: int = 4096
+
+
+# SURVEY.md §8 model constants
+LLAVA_1_5_7B = LlamaShape(4096, 11008, 32, 32, 32, 128, 32064)
+LLAVA_1_5_13B = LlamaShape(5120, 13824, 40, 40, 40, 128, 32064)
+
+
+@dataclass
+class LanguageModelParameters:
+    """hydrainfer/model/parameters.py:21-29 (fields used by the language model)."""
+    attention_params: List[AttentionParameters]
+    all_sequences_decode: bool
+    selected_token_ids: Optional[Tensor] = None  # int64 index tensor on the device
+
+
+def build_cos_sin(shape: LlamaShape, dtype: torch.dtype, device) -> Tensor:
+    inv = 1.0 / torch.pow(shape.rope_theta,
+                          torch.arange(0, shape.head_dim, 2, dtype=torch.float) / shape.head_dim)
+    t = torch.arange(shape.max_position_embeddings, dtype=torch.float)
+    freqs = torch.einsum("i,j->ij", t, inv)
+    cs = torch.cat([freqs.cos()[:, None, :], freqs.sin()[:, None, :]], dim=1)
+    return cs.to(dtype).to(device)
+
+
+class LlamaForCausalLM:
+    """Weights live in fused device tensors; `state` maps fused names to tensors."""
+
+    def __init__(self, shape: LlamaShape, dtype: torch.dtype, device, state: Dict[str, Tensor]):
+        self.shape, self.dtype, self.device = shape, dtype, torch.device(device)
+        self.state = state
+        self.cos_sin = build_cos_sin(shape, dtype, self.device)
+        self.q_size = shape.num_attention_heads * shape.head_dim
+        self.kv_size = shape.num_key_value_heads * shape.head_dim
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def random_init(cls, shape: LlamaShape, dtype: torch.dtype, device, seed: int = 0,
+                    std: float = 0.02) -> "LlamaForCausalLM":
+        """N(0, std) linears/embeddings, norm weights 1 (SURVEY.md §8d synthetic weights)."""
+        g = torch.Generator(device=device).manual_seed(seed)
+        h, i, L = shape.hidden_size, shape.intermediate_size, shape.num_hidden_layers
+        q, kv = shape.num_attention_heads * shape.head_dim, shape.num_key_value_heads * shape.head_dim
+
+        def w(*size):
+            return (torch.randn(size, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+
+        st: Dict[str, Tensor] = {"embed": w(shape.vocab_size, h), "lm_head": w(shape.vocab_size, h),
+                                 "norm": torch.ones(h, dtype=dtype, device=device)}
+        for l in range(L):
+            st[f"l{l}.wqkv"] = w(q + 2 * kv, h)
+            st[f"l{l}.wo"] = w(h, q)
+            st[f"l{l}.wgu"] = w(2 * i, h)
+            st[f"l{l}.wdown"] = w(h, i)
+            st[f"l{l}.norm1"] = torch.ones(h, dtype=dtype, device=device)
+            st[f"l{l}.norm2"] = torch.ones(h, dtype=dtype, device=device)
+        return cls(shape, dtype, device, st)
+
+    @classmethod
+    def from_reference_state_dict(cls, shape: LlamaShape, sd: Dict[str, Tensor], dtype, device,
+                                  prefix: str = "") -> "LlamaForCausalLM":
+        """Names of hydrainfer/model/llama.py (== HF Llama): model.layers.N.self_attn.q_proj.weight ..."""
+        def t(name):
+            return sd[prefix + name].to(dtype).to(device)
+        st = {"embed": t("model.embed_tokens.weight"), "lm_head": t("lm_head.weight"),
+              "norm": t("model.norm.weight")}
+        for l in range(shape.num_hidden_layers):
+            p = f"model.layers.{l}."
+            st[f"l{l}.wqkv"] = torch.cat([t(p + "self_attn.q_proj.weight"), t(p + "self_attn.k_proj.weight"),
+                                          t(p + "self_attn.v_proj.weight")], dim=0).contiguous()
+            st[f"l{l}.wo"] = t(p + "self_attn.o_proj.weight")
+            st[f"l{l}.wgu"] = torch.cat([t(p + "mlp.gate_proj.weight"), t(p + "mlp.up_proj.weight")],
+                                        dim=0).contiguous()
+            st[f"l{l}.wdown"] = t(p + "mlp.down_proj.weight")
+            st[f"l{l}.norm1"] = t(p + "input_layernorm.weight")
+            st[f"l{l}.norm2"] = t(p + "post_attention_layernorm.weight")
+        return cls(shape, dtype, device, st)
+
+    def to_reference_state_dict(self) -> Dict[str, Tensor]:
+        """Unfused CPU copy under the reference's parameter names (consumed by the oracle)."""
+        s, q, kv, i = self.state, self.q_size, self.kv_size, self.shape.intermediate_size
+        sd = {"model.embed_tokens.weight": s["embed"].cpu(), "lm_head.weight": s["lm_head"].cpu(),
+              "model.norm.weight": s["norm"].cpu()}
+        for l in range(self.shape.num_hidden_layers):
+            p = f"model.layers.{l}."
+            wqkv, wgu = s[f"l{l}.wqkv"].cpu(), s[f"l{l}.wgu"].cpu()
+            sd[p + "self_attn.q_proj.weight"] = wqkv[:q]
+            sd[p + "self_attn.k_proj.weight"] = wqkv[q:q + kv]
+            sd[p + "self_attn.v_proj.weight"] = wqkv[q + kv:]
+            sd[p + "self_attn.o_proj.weight"] = s[f"l{l}.wo"].cpu()
+            sd[p + "mlp.gate_proj.weight"] = wgu[:i]
+            sd[p + "mlp.up_proj.weight"] = wgu[i:]
+            sd[p + "mlp.down_proj.weight"] = s[f"l{l}.wdown"].cpu()
+            sd[p + "input_layernorm.weight"] = s[f"l{l}.norm1"].cpu()
+            sd[p + "post_attention_layernorm.weight"] = s[f"l{l}.norm2"].cpu()
+        return sd
+
+    def weight_bytes(self) -> int:
+        """Bytes a decode step must stream: all linears + lm_head (embedding gather ignored),
+        the `W` term of SURVEY.md §8d."""
+        n = sum(v.numel() for k, v in self.state.items() if k != "embed" and v.dim() == 2)
+        return n * self.state["lm_head"].element_size()
+
+    # ------------------------------------------------------------------ forward
+    def embed(self, input_ids: Tensor) -> Tensor:
+        return torch.nn.functional.embedding(input_ids, self.state["embed"])
+
+    def forward_hidden(self, input_ids_or_embeds: Tensor, position_ids: Tensor,
+                       model_params: LanguageModelParameters) -> Tensor:
+        sh, st = self.shape, self.state
+        if input_ids_or_embeds.dtype in (torch.int32, torch.int64):
+            h = self.embed(input_ids_or_embeds)
+        else:
+            h = input_ids_or_embeds
+        if not h.is_contiguous():
+            h = h.contiguous()
+        n = h.shape[0]
+        H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
+        q_size, kv_size, inter = self.q_size, self.kv_size, sh.intermediate_size
+        eps = sh.rms_norm_eps
+        L = sh.num_hidden_layers
+
+        x = torch.empty_like(h)
+        rms_norm(x, h, st["l0.norm1"], eps)
+        for l in range(L):
+            ap = model_params.attention_params[l]
+            qkv = torch.matmul(x, st[f"l{l}.wqkv"].t())
+            q = qkv[:, :q_size].view(n, H, D)
+            k = qkv[:, q_size:q_size + kv_size].view(n, HK, D)
+            v = qkv[:, q_size + kv_size:].view(n, HK, D)
+            apply_rotary_pos_emb(q, k, position_ids, self.cos_sin, D, False)
+            ap.kv_cache.set_kv_cache(ap.new_cache_slots, k, v)
+            kc, vc = ap.kv_cache.get_kv_cache()
+            o = torch.empty((n, H, D), dtype=h.dtype, device=h.device)
+            mha_varlen_fwd(o, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
+                           ap.cu_blocks_lens, None, ap.q_max_seq_len, ap.kv_max_seq_len,
+                           D ** -0.5, 0, -1, 0, 0)
+            a = torch.matmul(o.view(n, q_size), st[f"l{l}.wo"].t())
+            # h += a ; x = norm2(h)
+            add_rms_norm(x, h, a, st[f"l{l}.norm2"], eps)
+            if (not model_params.all_sequences_decode) and l == L - 1 \
+                    and model_params.selected_token_ids is not None:
+                # last layer of a prefill: only sampled tokens go through the MLP
+                h = h[model_params.selected_token_ids].contiguous()
+                x = x[model_params.selected_token_ids].contiguous()
+            gu = torch.matmul(x, st[f"l{l}.wgu"].t())
+            act = silu_and_mul(gu[:, :inter], gu[:, inter:])
+            m = torch.matmul(act, st[f"l{l}.wdown"].t())
+            nxt = st[f"l{l + 1}.norm1"] if l + 1 < L else st["norm"]
+            if x.shape != h.shape:
+                x = torch.empty_like(h)
+            add_rms_norm(x, h, m, nxt, eps)   # h += m ; x = next norm (final norm after last layer)
+        return x
+
+    def forward_logits(self, input_ids_or_embeds, position_ids, model_params) -> Tensor:
+        return torch.matmul(self.forward_hidden(input_ids_or_embeds, position_ids, model_params),
+                            self.state["lm_head"].t())
+
+    def forward(self, input_ids_or_embeds, position_ids, model_params) -> Tensor:
+        """Returns sampled token ids (greedy), like the reference model."""
+        return torch.argmax(self.forward_logits(input_ids_or_embeds, position_ids, model_params), dim=-1)
+
+    __call__ = forward

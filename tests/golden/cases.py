@@ -218,3 +218,55 @@ def trace_token_ids(cfg: TraceConfig, req: int) -> List[int]:
 
 def case_name(prefix: str, i: int) -> str:
     return f"{prefix}_{i:03d}"
+
+
+# ------------------------------------------------------------------ G8 tiny Llama end-to-end
+TINY_LLAMA = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                  num_key_value_heads=2, head_dim=128, vocab_size=512, rms_norm_eps=1e-5,
+                  rope_theta=10000.0, max_position_embeddings=4096)
+TINY_PROMPTS = (40, 23)   # two requests prefilled together, then decoded together
+TINY_DECODE_STEPS = 6
+TINY_BLOCKS, TINY_BLOCK_SIZE = 16, 16
+
+
+def tiny_llama_state_dict(dtype: torch.dtype, seed: int = 0, std: float = 0.08) -> Dict[str, torch.Tensor]:
+    """Reference-named (HF Llama) random weights; std chosen so logits have usable margins."""
+    g = torch.Generator().manual_seed(seed)
+    t = TINY_LLAMA
+    h, i, L = t["hidden_size"], t["intermediate_size"], t["num_hidden_layers"]
+    q = t["num_attention_heads"] * t["head_dim"]
+    kv = t["num_key_value_heads"] * t["head_dim"]
+
+    def w(*size):
+        return (torch.randn(size, generator=g) * std).to(dtype)
+
+    sd = {"model.embed_tokens.weight": (torch.randn((t["vocab_size"], h), generator=g)).to(dtype),
+          "lm_head.weight": w(t["vocab_size"], h),
+          "model.norm.weight": (1 + 0.1 * torch.randn(h, generator=g)).to(dtype)}
+    for l in range(L):
+        p = f"model.layers.{l}."
+        sd[p + "self_attn.q_proj.weight"] = w(q, h)
+        sd[p + "self_attn.k_proj.weight"] = w(kv, h)
+        sd[p + "self_attn.v_proj.weight"] = w(kv, h)
+        sd[p + "self_attn.o_proj.weight"] = w(h, q)
+        sd[p + "mlp.gate_proj.weight"] = w(i, h)
+        sd[p + "mlp.up_proj.weight"] = w(i, h)
+        sd[p + "mlp.down_proj.weight"] = w(h, i)
+        sd[p + "input_layernorm.weight"] = (1 + 0.1 * torch.randn(h, generator=g)).to(dtype)
+        sd[p + "post_attention_layernorm.weight"] = (1 + 0.1 * torch.randn(h, generator=g)).to(dtype)
+    return sd
+
+
+def tiny_prompt_ids(req: int) -> List[int]:
+    g = torch.Generator().manual_seed(500 + req)
+    return torch.randint(0, TINY_LLAMA["vocab_size"], (TINY_PROMPTS[req],), generator=g).tolist()
+
+
+def tiny_block_tables() -> List[List[int]]:
+    """LIFO allocator order for prompt+decode tokens (all blocks of a request taken at once)."""
+    tables, nxt = [], TINY_BLOCKS - 1
+    for p in TINY_PROMPTS:
+        n = (p + TINY_DECODE_STEPS + TINY_BLOCK_SIZE - 1) // TINY_BLOCK_SIZE
+        tables.append([nxt - j for j in range(n)][::-1])
+        nxt -= n
+    return tables

@@ -207,6 +207,72 @@ def gen_trace(out):
     out["trace_free_blocks_tail"] = np.array(alloc.free_blocks[-8:], dtype=np.int32)
 
 
+def gen_tiny_llama(out):
+    """G8: the reference's LlamaForCausalLM (hydrainfer/model/llama.py) on CPU — prefill of two
+    requests then greedy decode; logits captured by hooking lm_head (the model returns ids only)."""
+    from transformers import LlamaConfig
+    from hydrainfer.layer.causal_attention import AttentionParametersBuilder
+    from hydrainfer.memory.kv_cache import KVCache
+    from hydrainfer.model.llama import LlamaForCausalLM
+    from hydrainfer.model.parameters import LanguageModelParameters
+    t = C.TINY_LLAMA
+    bs = C.TINY_BLOCK_SIZE
+    for dname in ("fp16", "bf16"):
+        dt = C.DTYPES[dname]
+        cfg = LlamaConfig(hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
+                          num_hidden_layers=t["num_hidden_layers"],
+                          num_attention_heads=t["num_attention_heads"],
+                          num_key_value_heads=t["num_key_value_heads"], vocab_size=t["vocab_size"],
+                          rms_norm_eps=t["rms_norm_eps"],
+                          max_position_embeddings=t["max_position_embeddings"])
+        cfg.head_dim = t["head_dim"]
+        cfg.rope_theta = t["rope_theta"]
+        model = LlamaForCausalLM(cfg)
+        sd = C.tiny_llama_state_dict(dt)
+        missing = model.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys and all("rotary" in k or "cos_sin" in k for k in missing.missing_keys), missing
+        model.to(dt).eval()
+        logits_log = []
+        model.lm_head.register_forward_hook(lambda m, i, o: logits_log.append(o.detach().float().clone()))
+        L, HK, D = t["num_hidden_layers"], t["num_key_value_heads"], t["head_dim"]
+        gen = torch.Generator().manual_seed(77)
+        pool = torch.randn((L, 2, C.TINY_BLOCKS, bs, HK, D), generator=gen).to(dt)
+        out[f"tiny_{dname}_pool_chk"] = np.array(C.checksum(pool))  # before any KV write
+        tables = C.tiny_block_tables()
+        lens = [0, 0]
+        tokens = []
+
+        def run(ids_per_req):
+            b = AttentionParametersBuilder(t["num_attention_heads"], HK, D, bs, torch.device("cpu"))
+            ids, pos, sel, n = [], [], [], 0
+            for r, new in enumerate(ids_per_req):
+                slots = [tables[r][p // bs] * bs + p % bs for p in range(lens[r], lens[r] + len(new))]
+                pos += list(range(lens[r], lens[r] + len(new)))
+                lens[r] += len(new)
+                b.add_request(len(new), lens[r], slots, tables[r][: (lens[r] + bs - 1) // bs])
+                ids += new
+                n += len(new)
+                sel.append(n - 1)
+            for l in range(L):
+                b.add_kv_cache(KVCache(pool[l, 0], pool[l, 1]))
+            ap = b.build_attention_parameters()
+            params = LanguageModelParameters(
+                input_ids_or_input_embeds=None, position_ids=None, image_features=None,
+                image_overwrite_mask=None, attention_params=ap,
+                all_sequences_decode=all(len(x) == 1 for x in ids_per_req), selected_token_ids=sel)
+            with torch.inference_mode():
+                return model(torch.tensor(ids, dtype=torch.int), torch.tensor(pos, dtype=torch.int), params)
+
+        nxt = run([C.tiny_prompt_ids(0), C.tiny_prompt_ids(1)])
+        tokens.append(nxt.tolist())
+        for _ in range(C.TINY_DECODE_STEPS - 1):
+            nxt = run([[int(nxt[0])], [int(nxt[1])]])
+            tokens.append(nxt.tolist())
+        out[f"tiny_{dname}_tokens"] = np.array(tokens, dtype=np.int64)
+        out[f"tiny_{dname}_logits"] = torch.stack(logits_log).numpy()  # [steps, 2, vocab] fp32
+        out[f"tiny_{dname}_pool_end_chk"] = np.array(C.checksum(pool))  # after all KV writes
+
+
 def main():
     import_reference()
     torch.manual_seed(0)
@@ -218,6 +284,7 @@ def main():
         "g5_rope": gen_rope,
         "g6_silu": gen_silu,
         "g7_trace": gen_trace,
+        "g8_tiny_llama": gen_tiny_llama,
     }
     only = sys.argv[1:]
     for name, fn in sets.items():
