@@ -17,6 +17,7 @@ _OP_MODULES = [
     "_C.kernel.norm",
     "_C.kernel.position_embedding",
     "_C.kernel.activation",
+    "_C.kernel.moe",
     "_C.data_transfer.block_migration",
 ]
 

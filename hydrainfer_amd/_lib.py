@@ -45,11 +45,13 @@ _SIGNATURES = {
     "hx_abi_version": (c_int, []),
     "hx_strerror": (c_char_p, [c_int]),
     "hx_last_hip_error": (c_int, []),
+    "hx_debug_set_option": (c_int, [c_char_p, c_int]),
     "hx_set_kv_cache": (c_int, [c_void_p] * 5 + [c_int64] * 8 + [c_int, c_void_p]),
     "hx_set_image_cache": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_int, c_void_p]),
     "hx_rms_norm": (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int64, c_int, c_void_p]),
     "hx_add_rms_norm": (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int64, c_int, c_void_p]),
     "hx_apply_rotary_pos_emb": (c_int, [c_void_p] * 4 + [c_int64] * 7 + [c_int, c_int, c_void_p]),
+    "hx_rope_set_kv_cache": (c_int, [c_void_p] * 8 + [c_int64] * 11 + [c_int, c_void_p]),
     "hx_silu": (c_int, [c_void_p] * 2 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_silu_and_mul": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_void_p]),
     "hx_mha_varlen_fwd_workspace_bytes": (c_int64, [POINTER(hx_attn_args)]),
@@ -60,6 +62,14 @@ _SIGNATURES = {
     "hx_migrate_blocks": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 5 + [c_void_p]),
     "hx_pack_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 4 + [c_void_p]),
     "hx_unpack_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 4 + [c_void_p]),
+    "hx_topk_softmax": (c_int, [c_void_p] * 3 + [c_int64] * 3 + [c_void_p]),
+    "hx_grouped_topk_sigmoid": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_float, c_void_p]),
+    "hx_moe_sort_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "hx_moe_row_id_map_from_indices": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "hx_moe_row_id_map_from_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "hx_moe_permute": (c_int, [c_void_p] * 3 + [c_int64] * 3 + [c_int, c_void_p]),
+    "hx_moe_unpermute": (c_int, [c_void_p] * 4 + [c_int64] * 3 + [c_int, c_void_p]),
+    "hx_moe_sum_out": (c_int, [c_void_p] * 2 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_void_p]),
 }
 

@@ -21,6 +21,7 @@
 //     numerics; the reference CUDA kernel rounds P to T first).
 //   * The 16 partial states of a workgroup (4 waves x 4 groups) are merged through LDS
 //     once; kv_splits > 1 write (m, l, o) partials that attn_decode_combine merges.
+#include <cstring>
 #include "attn_common.h"
 
 namespace {
@@ -47,7 +48,13 @@ struct KVTile {
   typename VRow<D>::type v[4][VRow<D>::NV];  // keys 4g+i, i = 0..3
 };
 
-template <typename T, int D>
+template <bool NT, typename V>
+__device__ __forceinline__ V ld(const V* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+template <typename T, int D, bool NT>
 __device__ __forceinline__ void load_tile(KVTile<D>& buf, const AttnParams& p, const u16* kbase,
                                           const u16* vbase, int page, int row0, int valid,
                                           int lane) {
@@ -57,7 +64,7 @@ __device__ __forceinline__ void load_tile(KVTile<D>& buf, const AttnParams& p, c
   const u16* kp = kbase + (int64_t)page * p.k_block_stride + (int64_t)(row0 + r_eff) * p.k_row_stride +
                   8 * g;
 #pragma unroll
-  for (int s = 0; s < D / 32; ++s) buf.k[s] = *reinterpret_cast<const u16x8*>(kp + 32 * s);
+  for (int s = 0; s < D / 32; ++s) buf.k[s] = ld<NT>(reinterpret_cast<const u16x8*>(kp + 32 * s));
   constexpr int E = VRow<D>::E;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -66,7 +73,7 @@ __device__ __forceinline__ void load_tile(KVTile<D>& buf, const AttnParams& p, c
                     E * c;
 #pragma unroll
     for (int n = 0; n < VRow<D>::NV; ++n)
-      buf.v[i][n] = *reinterpret_cast<const typename VRow<D>::type*>(vp + 128 * n);
+      buf.v[i][n] = ld<NT>(reinterpret_cast<const typename VRow<D>::type*>(vp + 128 * n));
   }
 }
 
@@ -107,12 +114,12 @@ __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (
     }
 }
 
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
-  constexpr int NW = 4;
+template <typename T, int D, int NW, bool NT>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p) {
   constexpr int OE = D / 16;  // fp32 partial-output elements per lane
-  __shared__ float s_m[16], s_l[16];
-  __shared__ float s_o[16][D];
+  constexpr int NP = NW * 4;  // partial softmax states per workgroup
+  __shared__ float s_m[NP], s_l[NP];
+  __shared__ float s_o[NP][D];
 
   const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
   const int lane = threadIdx.x & 63;
@@ -159,13 +166,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
     int j = 0;
     {
       const int t = chunk0;
-      load_tile<T, D>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
+      load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
                       (t % tpp) << 4, kv_len - (t << 4), lane);
     }
     while (j < n_my) {
       if (j + 1 < n_my) {
         const int t = chunk0 + NW * (j + 1);
-        load_tile<T, D>(bufB, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
+        load_tile<T, D, NT>(bufB, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
                         (t % tpp) << 4, kv_len - (t << 4), lane);
       }
       compute_tile<T, D>(bufA, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o);
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
       if (j >= n_my) break;
       if (j + 1 < n_my) {
         const int t = chunk0 + NW * (j + 1);
-        load_tile<T, D>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
+        load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
                         (t % tpp) << 4, kv_len - (t << 4), lane);
       }
       compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o);
@@ -198,10 +205,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnParams p) {
   if (d < D) {
     float M = HX_NEG_BIG;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) M = fmaxf(M, s_m[k]);
+    for (int k = 0; k < NP; ++k) M = fmaxf(M, s_m[k]);
     float L = 0.f, O = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < NP; ++k) {
       const float wgt = fast_exp2(s_m[k] - M);
       L = fmaf(s_l[k], wgt, L);
       O = fmaf(s_o[k][d], wgt, O);
@@ -240,10 +247,19 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const AttnParams
       T::from_float(r);
 }
 
+int g_decode_waves = 4;  // tuning knobs (hx_debug_set_option)
+int g_decode_nt = 1;   // K/V are read once: non-temporal loads measured +4 % (profiles/r1_attn_decode_variants.txt)
+
 template <typename T, int D>
 int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
   dim3 grid(p.n_heads, batch, p.n_splits);
-  attn_decode_kernel<T, D><<<grid, 256, 0, stream>>>(p);
+  if (g_decode_waves == 8) {
+    if (g_decode_nt) attn_decode_kernel<T, D, 8, true><<<grid, 512, 0, stream>>>(p);
+    else attn_decode_kernel<T, D, 8, false><<<grid, 512, 0, stream>>>(p);
+  } else {
+    if (g_decode_nt) attn_decode_kernel<T, D, 4, true><<<grid, 256, 0, stream>>>(p);
+    else attn_decode_kernel<T, D, 4, false><<<grid, 256, 0, stream>>>(p);
+  }
   int rc = check_launch();
   if (rc) return rc;
   if (p.n_splits > 1) {
@@ -256,6 +272,12 @@ int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
 }  // namespace
 
 namespace hx {
+
+int decode_set_option(const char* name, int value) {
+  if (!strcmp(name, "decode_waves")) { g_decode_waves = (value == 8) ? 8 : 4; return HX_OK; }
+  if (!strcmp(name, "decode_nt")) { g_decode_nt = value ? 1 : 0; return HX_OK; }
+  return HX_ERR_UNSUPPORTED;
+}
 
 bool decode_supported(int head_dim) { return head_dim == 64 || head_dim == 128 || head_dim == 256; }
 

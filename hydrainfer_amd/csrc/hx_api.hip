@@ -11,6 +11,7 @@ int& last_hip_error() {
 }
 
 bool decode_supported(int head_dim);
+int decode_set_option(const char* name, int value);
 bool fwd_supported(int head_dim);
 int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested);
 int launch_attn_decode(const AttnParams& p, int batch, int head_dim, int dtype,
@@ -25,6 +26,11 @@ using namespace hx;
 extern "C" int hx_abi_version(void) { return HX_ABI_VERSION; }
 
 extern "C" int hx_last_hip_error(void) { return last_hip_error(); }
+
+extern "C" int hx_debug_set_option(const char* name, int value) {
+  if (!name) return HX_ERR_NULL;
+  return decode_set_option(name, value);
+}
 
 extern "C" const char* hx_strerror(int status) {
   switch (status) {

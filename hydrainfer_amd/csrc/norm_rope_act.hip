@@ -229,6 +229,73 @@ __global__ __launch_bounds__(256) void rope_neox_vec_kernel(
   }
 }
 
+
+// Fused RoPE + set_kv_cache: rotates q and k in place exactly like
+// rope_neox_vec_kernel, and in the same pass writes the rotated k row and the v row of the
+// token into the paged cache at slot = block*block_size + offset.  One launch replaces two.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_cache_neox_vec_kernel(
+    typename T::storage* __restrict__ q, typename T::storage* __restrict__ k,
+    const typename T::storage* __restrict__ v, const int32_t* __restrict__ positions,
+    const typename T::storage* __restrict__ cos_sin, const int32_t* __restrict__ slot_ids,
+    typename T::storage* __restrict__ key_cache, typename T::storage* __restrict__ value_cache,
+    int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int32_t rotary_dim, int64_t q_stride,
+    int64_t k_stride, int64_t v_stride, int64_t kc_block_stride, int64_t vc_block_stride,
+    int32_t block_size) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  const int token = blockIdx.x;
+  const int half = rotary_dim >> 1;
+  const int vph = half / N;
+  const int total = (n_heads + n_kv_heads) * vph;
+  const typename T::storage* cs = cos_sin + (int64_t)positions[token] * rotary_dim;
+  const int slot = slot_ids[token];
+  const int64_t row_elems = (int64_t)n_kv_heads * head_dim;
+  const int64_t blk = slot / block_size, off = slot % block_size;
+  typename T::storage* kc_row = key_cache + blk * kc_block_stride + off * row_elems;
+  typename T::storage* vc_row = value_cache + blk * vc_block_stride + off * row_elems;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int h = i / vph;
+    const int rv = i - h * vph;
+    const bool is_k = h >= n_heads;
+    typename T::storage* base = !is_k ? (q + token * q_stride + (int64_t)h * head_dim)
+                                      : (k + token * k_stride + (int64_t)(h - n_heads) * head_dim);
+    V* xp = reinterpret_cast<V*>(base + rv * N);
+    V* yp = reinterpret_cast<V*>(base + half + rv * N);
+    const V cv = *reinterpret_cast<const V*>(cs + rv * N);
+    const V sv = *reinterpret_cast<const V*>(cs + half + rv * N);
+    V xv = *xp, yv = *yp, xo, yo;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      float a, b;
+      rotate_pair<T>(T::to_float(xv[e]), T::to_float(yv[e]), T::to_float(cv[e]),
+                     T::to_float(sv[e]), a, b);
+      xo[e] = T::from_float(a);
+      yo[e] = T::from_float(b);
+    }
+    *xp = xo;
+    *yp = yo;
+    if (is_k && slot >= 0) {
+      typename T::storage* crow = kc_row + (int64_t)(h - n_heads) * head_dim;
+      *reinterpret_cast<V*>(crow + rv * N) = xo;
+      *reinterpret_cast<V*>(crow + half + rv * N) = yo;
+    }
+  }
+  if (slot >= 0) {
+    // pass-through dims of k (rotary_dim < head_dim) and the whole v row
+    const int tail_v = (head_dim - rotary_dim) / N;
+    for (int i = threadIdx.x; i < n_kv_heads * tail_v; i += 256) {
+      const int h = i / tail_v, t = i - h * tail_v;
+      const int64_t o = (int64_t)h * head_dim + rotary_dim + t * N;
+      *reinterpret_cast<V*>(kc_row + o) = *reinterpret_cast<const V*>(k + token * k_stride + o);
+    }
+    const int vvec = (int)(row_elems / N);
+    const V* vs = reinterpret_cast<const V*>(v + token * v_stride);
+    V* vd = reinterpret_cast<V*>(vc_row);
+    for (int i = threadIdx.x; i < vvec; i += 256) vd[i] = vs[i];
+  }
+}
+
 template <typename T>
 int launch_rope(void* q, void* k, const int32_t* positions, const void* cos_sin,
                 int64_t n_tokens, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim,
@@ -417,4 +484,50 @@ extern "C" int hx_silu_and_mul(void* out, const void* gate, const void* up, int6
     case HX_BF16: return launch_silu<BF16, true>(out, gate, up, rows, n, gate_stride, up_stride, s);
     default: return HX_ERR_DTYPE;
   }
+}
+
+extern "C" int hx_rope_set_kv_cache(void* query, void* key, const void* value,
+                                    const int32_t* positions, const void* cos_sin,
+                                    const int32_t* slot_ids, void* key_cache, void* value_cache,
+                                    int64_t n_tokens, int64_t n_heads, int64_t n_kv_heads,
+                                    int64_t head_dim, int64_t rotary_dim, int64_t q_stride,
+                                    int64_t k_stride, int64_t v_stride, int64_t block_size,
+                                    int64_t kcache_block_stride, int64_t vcache_block_stride,
+                                    int dtype, hx_stream stream) {
+  if (n_tokens < 0 || n_heads < 0 || n_kv_heads <= 0 || head_dim <= 0 || block_size <= 0)
+    return HX_ERR_SHAPE;
+  if (rotary_dim <= 0 || rotary_dim > head_dim || (rotary_dim & 1)) return HX_ERR_SHAPE;
+  if (n_tokens == 0) return HX_OK;
+  if (!query || !key || !value || !positions || !cos_sin || !slot_ids || !key_cache || !value_cache)
+    return HX_ERR_NULL;
+  const int64_t es = dtype_size(dtype);
+  if (es == 0) return HX_ERR_DTYPE;
+  const int64_t N = 16 / es;
+  // vector path only: this op exists for the LLaVA decode/prefill shapes
+  if ((rotary_dim / 2) % N || head_dim % N || (head_dim - rotary_dim) % N) return HX_ERR_SHAPE;
+  if (q_stride % N || k_stride % N || v_stride % N || kcache_block_stride % N ||
+      vcache_block_stride % N)
+    return HX_ERR_STRIDE;
+  if (!aligned16(query) || !aligned16(key) || !aligned16(value) || !aligned16(cos_sin) ||
+      !aligned16(key_cache) || !aligned16(value_cache))
+    return HX_ERR_STRIDE;
+  if (q_stride < n_heads * head_dim || k_stride < n_kv_heads * head_dim ||
+      v_stride < n_kv_heads * head_dim)
+    return HX_ERR_STRIDE;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)n_tokens);
+#define HX_RC(TT)                                                                              \
+  rope_cache_neox_vec_kernel<TT><<<grid, 256, 0, s>>>(                                         \
+      (TT::storage*)query, (TT::storage*)key, (const TT::storage*)value, positions,            \
+      (const TT::storage*)cos_sin, slot_ids, (TT::storage*)key_cache,                          \
+      (TT::storage*)value_cache, (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)rotary_dim, \
+      q_stride, k_stride, v_stride, kcache_block_stride, vcache_block_stride, (int)block_size)
+  switch (dtype) {
+    case HX_F32: HX_RC(F32); break;
+    case HX_F16: HX_RC(F16); break;
+    case HX_BF16: HX_RC(BF16); break;
+    default: return HX_ERR_DTYPE;
+  }
+#undef HX_RC
+  return check_launch();
 }

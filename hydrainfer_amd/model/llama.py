@@ -19,7 +19,7 @@ from torch import Tensor
 
 from hydrainfer_amd._C.kernel.activation import silu_and_mul
 from hydrainfer_amd._C.kernel.norm import add_rms_norm, rms_norm
-from hydrainfer_amd._C.kernel.position_embedding import apply_rotary_pos_emb
+from hydrainfer_amd._C.kernel.position_embedding import rope_set_kv_cache
 from hydrainfer_amd.layer.causal_attention import AttentionParameters
 from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
 
@@ -165,9 +165,9 @@ class LlamaForCausalLM:
             q = qkv[:, :q_size].view(n, H, D)
             k = qkv[:, q_size:q_size + kv_size].view(n, HK, D)
             v = qkv[:, q_size + kv_size:].view(n, HK, D)
-            apply_rotary_pos_emb(q, k, position_ids, self.cos_sin, D, False)
-            ap.kv_cache.set_kv_cache(ap.new_cache_slots, k, v)
             kc, vc = ap.kv_cache.get_kv_cache()
+            # RoPE in place + append k/v to the paged cache, one launch
+            rope_set_kv_cache(q, k, v, position_ids, self.cos_sin, D, ap.new_cache_slots, kc, vc)
             o = torch.empty((n, H, D), dtype=h.dtype, device=h.device)
             mha_varlen_fwd(o, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
                            ap.cu_blocks_lens, None, ap.q_max_seq_len, ap.kv_max_seq_len,

@@ -46,6 +46,10 @@ int hx_abi_version(void);
 const char* hx_strerror(int status);
 /* hipError_t of the most recent HX_ERR_HIP on this thread (0 if none). */
 int hx_last_hip_error(void);
+/* Tuning knobs for A/B measurements in one process (not part of the reference surface):
+ * "decode_waves" = 4|8 waves per decode-attention workgroup, "decode_nt" = 0|1 non-temporal
+ * K/V loads.  Results are identical for every setting. */
+int hx_debug_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------
  * Paged cache scatter.
@@ -100,6 +104,17 @@ int hx_apply_rotary_pos_emb(void* query, void* key, const int32_t* positions,
                             int64_t n_kv_heads, int64_t head_dim, int64_t rotary_dim,
                             int64_t q_stride, int64_t k_stride, int interleaved,
                             int dtype, hx_stream stream);
+
+/* Extension: apply_rotary_pos_emb (NeoX layout) on query/key in place AND
+ * set_kv_cache(slot_ids, key, value) in one launch — the two consecutive calls of
+ * hydrainfer/model/model_forward.py:78-83 + hydrainfer/layer/causal_attention.py:401-403.
+ * Bit-identical to the two separate ops.  Vector path only (dims multiples of 16 bytes). */
+int hx_rope_set_kv_cache(void* query, void* key, const void* value, const int32_t* positions,
+                         const void* cos_sin, const int32_t* slot_ids, void* key_cache,
+                         void* value_cache, int64_t n_tokens, int64_t n_heads, int64_t n_kv_heads,
+                         int64_t head_dim, int64_t rotary_dim, int64_t q_stride, int64_t k_stride,
+                         int64_t v_stride, int64_t block_size, int64_t kcache_block_stride,
+                         int64_t vcache_block_stride, int dtype, hx_stream stream);
 
 /* ------------------------------------------------------------------------
  * replaces: csrc/kernel/activation/activation.cu:52-56 (silu)
@@ -218,6 +233,53 @@ int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_
                       int32_t* new_cache_slots, const int32_t* block_table,
                       const int32_t* cu_block_lens, int32_t batch, int32_t block_size,
                       hx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * MoE routing / permutation ops (named in north_star; no production caller in the reference).
+ * replaces: csrc/kernel/moe/moe_kernel.h:6-39, moe_kernels_pybind.cpp:7-15
+ *           hydrainfer/_C/kernel/moe/__init__.pyi:4-145
+ * ---------------------------------------------------------------------- */
+/* gating_logits f32 [n_tokens, n_experts] -> topk_weights f32 / topk_indices i32
+ * [n_tokens, topk]: softmax over experts then iterative arg-max, lower index wins ties
+ * (topk_softmax_kernel.cu:108-180).  n_experts <= 1024 (any value, not only powers of 2). */
+int hx_topk_softmax(const float* gating_logits, float* topk_weights, int32_t* topk_indices,
+                    int64_t n_tokens, int64_t n_experts, int64_t topk, hx_stream stream);
+/* DeepSeek-V3 routing (grouped_topk_sigmoid_kernel.cu:15-181): score = sigmoid(logit);
+ * choice = score + bias; drop (n_groups - topk_group) groups ranked by the sum of their two
+ * largest choices (ties: higher group dropped first); top-k over the kept experts by choice
+ * (ties: lower expert); weights = score of the chosen experts, NOT renormalised;
+ * scaling_factor is accepted and, like the reference (:180), not applied. */
+int hx_grouped_topk_sigmoid(const float* gating_logits, const float* correction_bias,
+                            float* topk_weights, int32_t* topk_indices, int64_t n_tokens,
+                            int64_t n_experts, int64_t n_groups, int64_t topk_group,
+                            int64_t topk, float scaling_factor, hx_stream stream);
+/* row_id_map i32 [topk, n_tokens] from a STABLE sort of the flattened topk_indices by expert
+ * (permutation_index_kernel.cu:39-77): the element with flat index f = t*topk + k that lands at
+ * sorted position p gives row_id_map[k*n_tokens + t] = p. */
+int64_t hx_moe_sort_workspace_bytes(int64_t n_tokens, int64_t topk);
+int hx_moe_row_id_map_from_indices(const int32_t* topk_indices, int32_t* row_id_map,
+                                   int64_t n_tokens, int64_t topk, void* workspace,
+                                   int64_t workspace_bytes, hx_stream stream);
+/* row_id_map i32 [n_experts, n_tokens] from a boolean routing map [n_tokens, n_experts]
+ * (permutation_mask_kernel.cu:43-130): running count in expert-major, token-minor order where
+ * routed, -1 elsewhere.  workspace >= 4*n_experts bytes. */
+int hx_moe_row_id_map_from_mask(const uint8_t* routing_map, int32_t* row_id_map,
+                                int64_t n_tokens, int64_t n_experts, void* workspace,
+                                int64_t workspace_bytes, hx_stream stream);
+/* permuted[row_id_map[r*n_tokens + t], :] = tokens[t, :] for every map row r with entry >= 0
+ * (n_rows = topk for an index map, n_experts for a mask map). */
+int hx_moe_permute(const void* tokens, void* permuted, const int32_t* row_id_map,
+                   int64_t n_tokens, int64_t n_rows, int64_t dim, int dtype, hx_stream stream);
+/* out[t,:] = sum_r probs[t,r] * permuted[row_id_map[r*n_tokens + t], :] over entries >= 0,
+ * product and running sum in T arithmetic like the reference's frag_sum
+ * (permutation_index_kernel.cu:146-160); probs has the tokens' dtype, [n_tokens, n_rows],
+ * NULL = weight 1. */
+int hx_moe_unpermute(const void* permuted, void* out, const int32_t* row_id_map,
+                     const void* probs, int64_t n_tokens, int64_t n_rows, int64_t dim,
+                     int dtype, hx_stream stream);
+/* out[t,:] = sum_k in[t,k,:], fp32 accumulate (align_block_kernel.cu:242-272, sum_out). */
+int hx_moe_sum_out(const void* in, void* out, int64_t n_tokens, int64_t topk, int64_t dim,
+                   int dtype, hx_stream stream);
 
 #ifdef __cplusplus
 }

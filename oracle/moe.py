@@ -1,0 +1,93 @@
+"""oracle/moe.py — CPU restatement of the reference's MoE routing / permutation semantics.
+
+TEST INFRASTRUCTURE ONLY (see oracle/ops.py).
+
+Parity status: PARITY UNPINNED against the reference's CUDA kernels — they need nvcc and the
+un-vendored cutlass submodule and the reference has no Python implementation of these ops.
+What is restated here are (a) the torch oracles the reference's own tests define
+(tests/kernel/test_moe.py:18-21 topk_softmax_ref, :55-88 permute/unpermute index refs,
+:118-141 mask refs) and (b) grouped_topk_sigmoid transcribed from the kernel's control flow
+(csrc/kernel/moe/grouped_topk_sigmoid_kernel.cu:64-180), including its tie-breaks."""
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+
+def topk_softmax(gating_logits: Tensor, topk: int) -> Tuple[Tensor, Tensor]:
+    """tests/kernel/test_moe.py:18-21; ties resolved to the lower index
+    (topk_softmax_kernel.cu:152-157) — done here with a stable sort."""
+    p = torch.softmax(gating_logits, dim=-1)
+    idx = torch.argsort(p, dim=-1, descending=True, stable=True)[:, :topk]
+    return torch.gather(p, 1, idx), idx.to(torch.int32)
+
+
+def grouped_topk_sigmoid(logits: Tensor, bias: Tensor, n_groups: int, topk_group: int,
+                         topk: int) -> Tuple[Tensor, Tensor]:
+    n_tokens, n_experts = logits.shape
+    per = n_experts // n_groups
+    scores = 1.0 / (1.0 + torch.exp(-logits))
+    weights = torch.empty((n_tokens, topk))
+    indices = torch.empty((n_tokens, topk), dtype=torch.int32)
+    FMAX = torch.finfo(torch.float32).max
+    for t in range(n_tokens):
+        choice = (scores[t] + bias).clone()
+        for _ in range(n_groups - topk_group):
+            best_sum, best_g = None, None
+            for g in range(n_groups):
+                top2 = torch.topk(choice[g * per:(g + 1) * per], min(2, per)).values
+                s = float(top2[0]) + (float(top2[1]) if per > 1 else -FMAX)
+                if choice[g * per] == FMAX:
+                    s = float("inf")
+                if best_sum is None or s < best_sum or (s == best_sum and g > best_g):
+                    best_sum, best_g = s, g
+            choice[best_g * per:(best_g + 1) * per] = FMAX
+        for k in range(topk):
+            c = choice.clone()
+            c[c == FMAX] = -FMAX
+            m = c.max()
+            col = int(torch.nonzero(c == m)[0])   # lowest index among equals
+            weights[t, k] = scores[t, col]
+            indices[t, k] = col
+            choice[col] = -FMAX
+    return weights, indices
+
+
+def permute_index(tokens: Tensor, topk_indices: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """tests/kernel/test_moe.py:55-70.  Also returns the [topk, n_tokens] row_id_map the kernel
+    produces (permutation_index_kernel.cu:56-77)."""
+    n_tokens, topk = topk_indices.shape
+    sorted_idx = topk_indices.reshape(-1).argsort(stable=True)
+    token_idx = sorted_idx.div(topk, rounding_mode="floor")
+    row_id_map = torch.empty((topk, n_tokens), dtype=torch.int32)
+    p = torch.arange(n_tokens * topk, dtype=torch.int32)
+    row_id_map[sorted_idx % topk, token_idx] = p
+    return tokens[token_idx], sorted_idx.to(torch.int32), row_id_map
+
+
+def unpermute_index(permuted: Tensor, sorted_idx: Tensor, probs: Tensor, n_tokens: int, topk: int) -> Tensor:
+    """tests/kernel/test_moe.py:72-88."""
+    tokens = torch.zeros_like(permuted)
+    tokens[sorted_idx.long()] = permuted
+    tokens = tokens.reshape(n_tokens, topk, -1) * probs[:, :, None]
+    return tokens.sum(dim=1)
+
+
+def permute_mask(tokens: Tensor, routing_map: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """tests/kernel/test_moe.py:118-126 + the [n_experts, n_tokens] map of
+    permutation_mask_kernel.cu:43-130 (-1 where not routed)."""
+    n_tokens, n_experts = routing_map.shape
+    token_idx = torch.arange(n_tokens, dtype=torch.int32)[None, :].expand(n_experts, n_tokens)
+    sorted_idx = token_idx.masked_select(routing_map.t())
+    row_id_map = torch.full((n_experts, n_tokens), -1, dtype=torch.int32)
+    row_id_map[routing_map.t()] = torch.arange(sorted_idx.numel(), dtype=torch.int32)
+    return tokens[sorted_idx.long()], sorted_idx, row_id_map
+
+
+def unpermute_mask(permuted: Tensor, permuted_probs: Tensor, sorted_idx: Tensor, n_tokens: int) -> Tensor:
+    """tests/kernel/test_moe.py:128-141."""
+    dim = permuted.shape[1]
+    tokens = torch.zeros((n_tokens, dim), dtype=permuted.dtype)
+    tokens.scatter_add_(0, sorted_idx[:, None].expand(-1, dim).to(torch.int64),
+                        permuted * permuted_probs[:, None])
+    return tokens

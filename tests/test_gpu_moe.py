@@ -1,0 +1,111 @@
+"""GPU: MoE ops against the reference's own test oracles restated in oracle/moe.py, on the
+grids of the reference's tests/kernel/test_moe.py:7-158."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("n_tokens", [1, 10, 16, 128, 1024])
+@pytest.mark.parametrize("n_experts", [4, 8, 16, 32, 64, 128, 256, 60])
+@pytest.mark.parametrize("topk", [1, 2, 4])
+def test_topk_softmax(n_tokens, n_experts, topk):
+    from hydrainfer_amd._C.kernel.moe import topk_softmax
+    from oracle import moe
+    g = torch.Generator().manual_seed(n_tokens * 1000 + n_experts + topk)
+    logits = torch.randn((n_tokens, n_experts), generator=g)
+    w_ref, i_ref = moe.topk_softmax(logits, topk)
+    w = torch.empty((n_tokens, topk), device=DEV)
+    i = torch.empty((n_tokens, topk), dtype=torch.int32, device=DEV)
+    topk_softmax(logits.to(DEV), w, i)
+    assert torch.equal(i.cpu(), i_ref)                      # indices exact (test_moe.py:31-32)
+    assert torch.allclose(w.cpu(), w_ref, rtol=1e-5, atol=1e-7)
+
+
+def test_topk_softmax_ties_pick_lower_index():
+    from hydrainfer_amd._C.kernel.moe import topk_softmax
+    logits = torch.zeros((3, 128), device=DEV)
+    logits[1, 70] = 1.0
+    logits[1, 5] = 1.0
+    w = torch.empty((3, 4), device=DEV)
+    i = torch.empty((3, 4), dtype=torch.int32, device=DEV)
+    topk_softmax(logits, w, i)
+    assert i[0].tolist() == [0, 1, 2, 3]
+    assert i[1].tolist() == [5, 70, 0, 1]
+
+
+@pytest.mark.parametrize("cfg", [(128, 4, 2, 8), (128, 8, 4, 8), (256, 8, 4, 8), (256, 16, 4, 6), (64, 8, 3, 4)])
+def test_grouped_topk_sigmoid(cfg):
+    from hydrainfer_amd._C.kernel.moe import grouped_topk_sigmoid
+    from oracle import moe
+    n_experts, n_groups, topk_group, topk = cfg
+    g = torch.Generator().manual_seed(n_experts + n_groups)
+    logits = torch.randn((37, n_experts), generator=g)
+    bias = 0.1 * torch.randn((n_experts,), generator=g)
+    w_ref, i_ref = moe.grouped_topk_sigmoid(logits, bias, n_groups, topk_group, topk)
+    w = torch.empty((37, topk), device=DEV)
+    i = torch.empty((37, topk), dtype=torch.int32, device=DEV)
+    grouped_topk_sigmoid(logits.to(DEV), bias.to(DEV), n_groups, topk_group, topk, 2.5, w, i)
+    assert torch.equal(i.cpu(), i_ref)
+    assert torch.allclose(w.cpu(), w_ref, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_tokens", [1, 2, 16, 300])
+@pytest.mark.parametrize("dim", [16, 64, 7])
+@pytest.mark.parametrize("n_experts", [4, 8, 16])
+@pytest.mark.parametrize("topk", [1, 2, 4])
+@pytest.mark.parametrize("dtype", [torch.float, torch.half, torch.bfloat16])
+def test_permute_index(n_tokens, dim, n_experts, topk, dtype):
+    from hydrainfer_amd._C.kernel.moe import permute_with_index_map, unpermute_with_index_map
+    from oracle import moe
+    g = torch.Generator().manual_seed(n_tokens + dim + n_experts + topk)
+    tokens = torch.randn((n_tokens, dim), generator=g).to(dtype)
+    gating = torch.randn((n_tokens, n_experts), generator=g).to(dtype)
+    weights, indices = gating.float().topk(topk, dim=-1)
+    probs = weights.softmax(dim=-1).to(dtype)
+    indices = indices.to(torch.int32)
+    p_ref, sorted_ref, map_ref = moe.permute_index(tokens, indices)
+    p, rmap = permute_with_index_map(tokens.to(DEV), indices.to(DEV))
+    assert torch.equal(rmap.cpu(), map_ref)            # stable sort => identical map
+    assert torch.equal(p.cpu(), p_ref)                 # pure copy: bit-exact
+    out = unpermute_with_index_map(p, rmap, probs.to(DEV))
+    out_ref = moe.unpermute_index(p_ref, sorted_ref, probs, n_tokens, topk)
+    assert torch.allclose(out.cpu().float(), out_ref.float(), atol=1e-2, rtol=1e-2)
+    assert torch.allclose(tokens.float(), out.cpu().float(), atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("n_tokens", [1, 2, 16, 700])
+@pytest.mark.parametrize("dim", [16, 64])
+@pytest.mark.parametrize("n_experts", [4, 8, 16])
+@pytest.mark.parametrize("topk", [1, 2, 4])
+@pytest.mark.parametrize("dtype", [torch.float, torch.half, torch.bfloat16])
+def test_permute_mask(n_tokens, dim, n_experts, topk, dtype):
+    from hydrainfer_amd._C.kernel.moe import permute_with_mask_map, unpermute_with_mask_map
+    from oracle import moe
+    g = torch.Generator().manual_seed(n_tokens + dim + n_experts + topk)
+    tokens = torch.randn((n_tokens, dim), generator=g).to(dtype)
+    gating = torch.randn((n_tokens, n_experts), generator=g)
+    _, indices = gating.topk(topk, dim=-1)
+    probs = torch.zeros_like(gating).scatter(1, indices, 1 / topk).to(dtype)
+    routing = torch.zeros_like(gating, dtype=torch.int).scatter(1, indices, 1).to(torch.bool)
+    p_ref, sorted_ref, map_ref = moe.permute_mask(tokens, routing)
+    p, rmap = permute_with_mask_map(tokens.to(DEV), routing.to(DEV), topk)
+    assert torch.equal(rmap.cpu(), map_ref)
+    assert torch.equal(p.cpu(), p_ref)
+    out = unpermute_with_mask_map(p, rmap, probs.to(DEV))
+    permuted_probs = probs.t().masked_select(routing.t())
+    out_ref = moe.unpermute_mask(p_ref, permuted_probs, sorted_ref, n_tokens)
+    assert torch.allclose(out.cpu().float(), out_ref.float(), atol=1e-2, rtol=1e-2)
+    assert torch.allclose(tokens.float(), out.cpu().float(), atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("topk", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("dtype", [torch.float, torch.half, torch.bfloat16])
+def test_sum_out(topk, dtype):
+    from hydrainfer_amd._C.kernel.moe import sum_out
+    x = torch.randn((33, topk, 72)).to(dtype)
+    out = torch.empty((33, 72), dtype=dtype, device=DEV)
+    sum_out(x.to(DEV), out)
+    ref = x.float().sum(dim=1).to(dtype)
+    assert torch.allclose(out.cpu().float(), ref.float(), atol=1e-2, rtol=1e-2)

@@ -164,3 +164,26 @@ def test_silu_and_mul_equals_unfused():
         want = act.silu(g_) * u_
         got = act.silu_and_mul(g_, u_)
         assert torch.equal(got, want)
+
+
+def test_rope_set_kv_cache_equals_two_ops():
+    from oracle import ops
+    from hydrainfer_amd._C.kernel import kv_cache_kernels, position_embedding as pe
+    for dt in (torch.float16, torch.bfloat16):
+        H, HK, D, n, bs = 32, 32, 128, 37, 16
+        qkv = torch.randn((n, (H + 2 * HK) * D)).to(dt).to(DEV)
+        pos = torch.randint(0, 4096, (n,), dtype=torch.int32).to(DEV)
+        cs = ops.build_cos_sin_cache(D, 4096, 1e4, dt).to(DEV)
+        slots = torch.randperm(20 * bs)[:n].to(torch.int32).to(DEV)
+        kc = torch.randn((20, bs, HK, D)).to(dt).to(DEV)
+        vc = torch.randn((20, bs, HK, D)).to(dt).to(DEV)
+        a, b = qkv.clone(), qkv.clone()
+        kc2, vc2 = kc.clone(), vc.clone()
+        view = lambda t: (t[:, :H * D].view(n, H, D), t[:, H * D:(H + HK) * D].view(n, HK, D),
+                          t[:, (H + HK) * D:].view(n, HK, D))
+        qa, ka, va = view(a)
+        pe.apply_rotary_pos_emb(qa, ka, pos, cs, D, False)
+        kv_cache_kernels.set_kv_cache(slots, ka, va, kc, vc)
+        qb, kb, vb = view(b)
+        pe.rope_set_kv_cache(qb, kb, vb, pos, cs, D, slots, kc2, vc2)
+        assert torch.equal(a, b) and torch.equal(kc, kc2) and torch.equal(vc, vc2)
