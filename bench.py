@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--skip-prefill", action="store_true",
                    help="decode against the randn-filled cache instead of a real prefill")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-ttft", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=2)
     return p.parse_args()
 
@@ -94,6 +95,79 @@ def time_attention_kernel(runner, start_len, steps):
     torch.cuda.synchronize()
     runner.positions.copy_(saved[0]); runner.kv_lens.copy_(saved[1])
     return sum(a.elapsed_time(b) for a, b in evs) / len(evs)   # ms
+
+
+def measure_ttft(runner, prompts, shape, dtype, dev, rank, reps=7):
+    """p50 time-to-first-token of ONE image+text request on an idle replica: CLIP ViT-L/14-336
+    encode (23 layers, dense HIP attention) + projector + 704-token prefill + greedy sample."""
+    from hydrainfer_amd.model.clip import CLIP_VIT_L_14_336, ClipShape, LlavaVisionModel
+    import dataclasses
+    import numpy as np
+    if shape.hidden_size < 1024:     # tiny smoke configuration
+        cshape = ClipShape(hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                           num_attention_heads=2, image_size=336, patch_size=14,
+                           projector_hidden_size=shape.hidden_size)
+    else:
+        cshape = dataclasses.replace(CLIP_VIT_L_14_336, projector_hidden_size=shape.hidden_size)
+    vision = LlavaVisionModel.random_init(cshape, dtype, dev, seed=1)
+    rng = np.random.RandomState(0)     # hydrainfer/utils/image_utils.py:4-7
+    img = rng.randint(0, 256, (336, 336, 3)).astype(np.float32) / 255.0
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+    pixels = torch.from_numpy((img - mean) / std).permute(2, 0, 1)[None].to(dev)
+    times, enc_times = [], []
+    B = runner.cfg.batch
+    for i in range(reps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        feats = vision(pixels)                                   # [1, 576, hidden]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        full = feats.expand(B, -1, -1)
+        first = runner.prefill(prompts, full, image_token_id(shape.vocab_size), requests=[0])
+        first[0].item()                                          # token reaches the host
+        t2 = time.perf_counter()
+        if i >= 2:
+            times.append((t2 - t0) * 1e3)
+            enc_times.append((t1 - t0) * 1e3)
+    times.sort(); enc_times.sort()
+    return {"p50_ms": round(times[len(times) // 2], 3), "encode_p50_ms": round(enc_times[len(enc_times) // 2], 3),
+            "what": "1 request: CLIP encode (eager) + 704-token prefill (eager) + sample, idle replica",
+            "reps": reps}
+
+
+def measure_migration(ctx, runner, dev, reps=5):
+    """P->D KV migration of one 704-token request between neighbouring ranks (rank r pulls from
+    r-1) through the IPC-mapped peer pool over xGMI: one gather-copy kernel per transfer."""
+    try:
+        from hydrainfer_amd._C.data_transfer import block_migration as bm
+        from hydrainfer_amd import parallel
+        bs, P = runner.cfg.block_size, runner.cfg.prompt_len
+        n_blk = (P + bs - 1) // bs
+        handle = bm.get_ipc_mem_handle(runner.pool)
+        infos = ctx.all_gather_object({"handle": handle, "table": runner.tables[0][:n_blk],
+                                       "n_blocks": runner.pool.shape[2]})
+        peer = infos[parallel.migration_peer(ctx.rank, ctx.world_size)]
+        # destination: the blocks of local request 1 (rewritten by nothing afterwards)
+        dst_table = runner.tables[1][:n_blk]
+        nbytes = runner.pool[:, :, :n_blk].numel() * runner.pool.element_size()
+        ts = []
+        for i in range(reps + 1):
+            ctx.barrier(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bm.migrate_blocks(peer["table"], dst_table, peer["handle"], runner.pool, peer["n_blocks"])
+            e1.record(); torch.cuda.synchronize()
+            if i >= 1:
+                ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        ms = ctx.max_over_ranks(ts[len(ts) // 2], dev)
+        return {"bytes_per_request": int(nbytes), "p50_ms": round(ms, 3),
+                "GBps_per_link": round(nbytes / ms / 1e6, 1),
+                "what": "all ranks pull one 704-token request's KV (44 blocks x 32 layers x k/v) "
+                        "from their ring neighbour concurrently, IPC-mapped peer pool, 1 launch"}
+    except Exception as e:   # never let the optional leg break the benchmark line
+        return {"error": repr(e)[:300]}
 
 
 def cpu_baseline(shape, dtype, batch, ctx, n_layers):
@@ -173,16 +247,12 @@ def cpu_baseline(shape, dtype, batch, ctx, n_layers):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    n_gpus = world if world > 1 else 1
+    from hydrainfer_amd import parallel
+    ctx = parallel.init_from_env()
+    world, rank, local_rank = ctx.world_size, ctx.rank, ctx.local_rank
+    n_gpus = world
+    if os.environ.get("HX_SINGLE_DEVICE") == "1":   # test mode: all ranks share cuda:0
+        local_rank = 0
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -227,8 +297,7 @@ def main():
     reset()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        ctx.barrier()
         torch.cuda.synchronize()
 
     barrier()
@@ -236,12 +305,11 @@ def main():
     for _ in range(steps):
         runner.step(record=False)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0, dev)
     barrier()
+
+    ttft = None if args.skip_prefill or args.no_ttft else measure_ttft(runner, prompts, shape, dtype, dev, rank)
+    migration = measure_migration(ctx, runner, dev) if world > 1 else None
 
     ms_per_step = elapsed / steps * 1e3
     tokens = args.batch * steps * n_gpus
@@ -279,13 +347,12 @@ def main():
                            "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
                            "weight_bytes": model.weight_bytes()},
             "prefill_batch_ms": None if ttft_ms is None else round(ttft_ms, 2),
+            "ttft": ttft, "migration": migration,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, dtype, args.batch, mid_ctx, args.cpu_layers)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctx.shutdown()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,117 @@
+"""CLIP vision tower + LLaVA projector — the caller of the dense attention path.
+
+Mirrors hydrainfer/model/clip.py:10-135 (pre-LN encoder layers, quick-GELU MLP, class +
+position embeddings, layers 0..vision_feature_layer) and hydrainfer/model/llava.py:30-41,99-107
+(2-layer GELU projector, CLS token dropped).  Attention runs on the HIP dense kernel
+(mha_varlen_fwd, non-causal, hydrainfer/layer/multihead_attention.py:114-160); conv / LayerNorm
+/ linears are library ops (host PyTorch-ROCm)."""
+from dataclasses import dataclass
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from hydrainfer_amd.layer.multihead_attention import (MultiHeadAttention, MultiHeadAttentionConfig,
+                                                      MultiHeadAttentionParameters)
+
+
+@dataclass
+class ClipShape:
+    hidden_size: int = 1024
+    intermediate_size: int = 4096
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    image_size: int = 336
+    patch_size: int = 14
+    num_channels: int = 3
+    layer_norm_eps: float = 1e-5
+    vision_feature_layer: int = -2
+    projector_hidden_size: int = 4096   # language-model hidden size
+
+    @property
+    def num_positions(self) -> int:
+        return (self.image_size // self.patch_size) ** 2 + 1
+
+
+CLIP_VIT_L_14_336 = ClipShape()
+
+
+class LlavaVisionModel:
+    """state: reference-named tensors ('vision_tower.vision_model....', 'multi_modal_projector....')."""
+
+    def __init__(self, shape: ClipShape, dtype: torch.dtype, device, state: Dict[str, Tensor]):
+        self.shape, self.dtype, self.device, self.state = shape, dtype, torch.device(device), state
+        self.attn = MultiHeadAttention(MultiHeadAttentionConfig(
+            shape.num_attention_heads, shape.hidden_size // shape.num_attention_heads))
+        L = shape.num_hidden_layers
+        self.n_run = (shape.vision_feature_layer + L) % L + 1   # clip.py:106-108
+
+    @classmethod
+    def random_init(cls, shape: ClipShape, dtype, device, seed: int = 0, std: float = 0.02):
+        return cls(shape, dtype, device,
+                   {k: v.to(dtype).to(device) for k, v in random_state_dict(shape, seed, std).items()})
+
+    def _layer(self, l: int, h: Tensor) -> Tensor:
+        s, sh = self.state, self.shape
+        p = f"vision_tower.vision_model.encoder.layers.{l}."
+        x = F.layer_norm(h, (sh.hidden_size,), s[p + "layer_norm1.weight"], s[p + "layer_norm1.bias"],
+                         sh.layer_norm_eps)
+        q = F.linear(x, s[p + "self_attn.q_proj.weight"], s[p + "self_attn.q_proj.bias"])
+        k = F.linear(x, s[p + "self_attn.k_proj.weight"], s[p + "self_attn.k_proj.bias"])
+        v = F.linear(x, s[p + "self_attn.v_proj.weight"], s[p + "self_attn.v_proj.bias"])
+        o = self.attn(q, k, v, MultiHeadAttentionParameters()).o
+        h = h + F.linear(o, s[p + "self_attn.out_proj.weight"], s[p + "self_attn.out_proj.bias"])
+        x = F.layer_norm(h, (sh.hidden_size,), s[p + "layer_norm2.weight"], s[p + "layer_norm2.bias"],
+                         sh.layer_norm_eps)
+        x = F.linear(x, s[p + "mlp.fc1.weight"], s[p + "mlp.fc1.bias"])
+        x = x * torch.sigmoid(1.702 * x)                       # QuickGELU, activation.py:17-22
+        return h + F.linear(x, s[p + "mlp.fc2.weight"], s[p + "mlp.fc2.bias"])
+
+    def forward(self, pixel_values: Tensor) -> Tensor:
+        """pixel_values (n_images, C, H, W) -> image_features (n_images, n_patches, lm_hidden)."""
+        s, sh = self.state, self.shape
+        pre = "vision_tower.vision_model."
+        n = pixel_values.shape[0]
+        patches = F.conv2d(pixel_values.to(self.dtype), s[pre + "embeddings.patch_embedding.weight"],
+                           stride=sh.patch_size).flatten(2).transpose(1, 2)
+        cls_tok = s[pre + "embeddings.class_embedding"].expand(n, 1, -1)
+        h = torch.cat([cls_tok, patches], dim=1) + s[pre + "embeddings.position_embedding.weight"][None]
+        h = F.layer_norm(h, (sh.hidden_size,), s[pre + "pre_layrnorm.weight"], s[pre + "pre_layrnorm.bias"],
+                         sh.layer_norm_eps)
+        for l in range(self.n_run):
+            h = self._layer(l, h)
+        feat = h[:, 1:]                                        # drop CLS (llava.py:104)
+        x = F.linear(feat, s["multi_modal_projector.linear_1.weight"], s["multi_modal_projector.linear_1.bias"])
+        x = F.gelu(x)
+        return F.linear(x, s["multi_modal_projector.linear_2.weight"], s["multi_modal_projector.linear_2.bias"])
+
+    __call__ = forward
+
+
+def random_state_dict(shape: ClipShape, seed: int = 0, std: float = 0.02) -> Dict[str, Tensor]:
+    """fp32 CPU state dict under the reference's parameter names; LayerNorm weight 1 / bias 0
+    (SURVEY.md §8d synthetic weights)."""
+    g = torch.Generator().manual_seed(seed)
+    h, i = shape.hidden_size, shape.intermediate_size
+
+    def w(*size):
+        return torch.randn(size, generator=g) * std
+    pre = "vision_tower.vision_model."
+    sd = {pre + "embeddings.class_embedding": w(h),
+          pre + "embeddings.patch_embedding.weight": w(h, shape.num_channels, shape.patch_size, shape.patch_size),
+          pre + "embeddings.position_embedding.weight": w(shape.num_positions, h),
+          pre + "pre_layrnorm.weight": torch.ones(h), pre + "pre_layrnorm.bias": torch.zeros(h)}
+    for l in range(shape.num_hidden_layers):
+        p = pre + f"encoder.layers.{l}."
+        for name in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"self_attn.{name}.weight"] = w(h, h)
+            sd[p + f"self_attn.{name}.bias"] = w(h)
+        sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = w(i, h), w(i)
+        sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = w(h, i), w(h)
+        for ln in ("layer_norm1", "layer_norm2"):
+            sd[p + ln + ".weight"], sd[p + ln + ".bias"] = torch.ones(h), torch.zeros(h)
+    ph = shape.projector_hidden_size
+    sd["multi_modal_projector.linear_1.weight"], sd["multi_modal_projector.linear_1.bias"] = w(ph, h), w(ph)
+    sd["multi_modal_projector.linear_2.weight"], sd["multi_modal_projector.linear_2.bias"] = w(ph, ph), w(ph)
+    return sd

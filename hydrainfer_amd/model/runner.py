@@ -100,16 +100,18 @@ class DecodeRunner:
 
     # ------------------------------------------------------------------ prefill
     def prefill(self, prompt_ids: Tensor, image_features: Optional[Tensor] = None,
-                image_token_id: int = 32000) -> Tensor:
+                image_token_id: int = 32000, requests: Optional[List[int]] = None) -> Tensor:
         """prompt_ids int64 [B, prompt_len] on the device.  Requests are packed into batches
-        under the token budget; returns the first sampled token of every request [B]."""
+        under the token budget; returns the first sampled token of every request [B].
+        `requests` restricts the pass to a subset (decode state is then left untouched)."""
         cfg, sh, bs = self.cfg, self.model.shape, self.cfg.block_size
         B, P = cfg.batch, cfg.prompt_len
         per_batch = max(1, cfg.prefill_token_budget // P)
         first = torch.empty(B, dtype=torch.int64, device=self.dev)
         n_prompt_blocks = (P + bs - 1) // bs
-        for r0 in range(0, B, per_batch):
-            rs = list(range(r0, min(B, r0 + per_batch)))
+        todo = list(range(B)) if requests is None else list(requests)
+        for r0 in range(0, len(todo), per_batch):
+            rs = todo[r0: r0 + per_batch]
             b = AttentionParametersBuilder(sh.num_attention_heads, sh.num_key_value_heads,
                                            sh.head_dim, bs, self.dev)
             for r in rs:
@@ -129,6 +131,8 @@ class DecodeRunner:
             params = LanguageModelParameters(attention_params=ap, all_sequences_decode=False,
                                              selected_token_ids=sel)
             first[rs] = self.model(embeds, pos, params)
+        if requests is not None:
+            return first
         self.positions.fill_(P - 1)
         self.kv_lens.fill_(P)
         self.input_ids.copy_(first)

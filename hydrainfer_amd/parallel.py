@@ -1,0 +1,96 @@
+"""One-process-per-GPU helpers for the replica / E-P-D layout.
+
+The hot path shards by request: every rank holds a full model replica and there is NO
+data-path collective.  The only inter-rank traffic is point-to-point block migration
+(hydrainfer/cluster/epdnode.py:362-405) plus the control-plane exchanges below (handles,
+timing), which use torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" on CPU)."""
+import os
+from dataclasses import dataclass
+from typing import Any, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class DistContext:
+    rank: int = 0
+    world_size: int = 1
+    local_rank: int = 0
+    backend: Optional[str] = None
+
+    @property
+    def enabled(self) -> bool:
+        return self.world_size > 1
+
+    def barrier(self) -> None:
+        if self.enabled:
+            dist.barrier()
+
+    def max_over_ranks(self, value: float, device: Optional[torch.device] = None) -> float:
+        """The contract's timing rule: take the MAX over ranks."""
+        if not self.enabled:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=device if self.backend == "nccl" else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value: float, device: Optional[torch.device] = None) -> float:
+        if not self.enabled:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=device if self.backend == "nccl" else None)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def all_gather_object(self, obj: Any) -> List[Any]:
+        """Control-plane exchange (IPC handles, block tables) — the reference ships these over
+        Ray RPC (epdnode.py:366-380)."""
+        if not self.enabled:
+            return [obj]
+        out: List[Any] = [None] * self.world_size
+        dist.all_gather_object(out, obj)
+        return out
+
+    def shutdown(self) -> None:
+        if self.enabled and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def init_from_env(backend: Optional[str] = None) -> DistContext:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return DistContext(rank=0, world_size=1, local_rank=local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        # HX_DIST_BACKEND=gloo lets the control plane run where RCCL cannot (e.g. two ranks
+        # sharing one GPU in a test); the data path (IPC peer reads) is unaffected.
+        backend = os.environ.get("HX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    kwargs = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        kwargs["device_id"] = torch.device(f"cuda:{local_rank}")
+    dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return DistContext(rank=rank, world_size=world, local_rank=local_rank, backend=backend)
+
+
+def migration_peer(rank: int, world_size: int) -> int:
+    """Pull-model ring used by the benchmark's migration leg: rank r pulls from r-1."""
+    return (rank - 1) % world_size
+
+
+def epd_roles(world_size: int) -> List[str]:
+    """Node typing per GPU count: 1 -> EPD, 2 -> EP + D, 3 -> E + P + D
+    (hydrainfer/cluster/cluster.py:63-79); 4 -> E + P + 2D and 8 -> 2E + 2P + 4D
+    (BASELINE configs[3..4]; the reference's auto mode leaves >= 4 undefined)."""
+    table = {1: ["EPD"], 2: ["EP", "D"], 3: ["E", "P", "D"], 4: ["E", "P", "D", "D"],
+             8: ["E", "E", "P", "P", "D", "D", "D", "D"]}
+    if world_size in table:
+        return table[world_size]
+    n_e = max(1, world_size // 4)
+    n_p = max(1, world_size // 4)
+    return ["E"] * n_e + ["P"] * n_p + ["D"] * (world_size - n_e - n_p)

@@ -270,3 +270,19 @@ def tiny_block_tables() -> List[List[int]]:
         tables.append([nxt - j for j in range(n)][::-1])
         nxt -= n
     return tables
+
+
+# ------------------------------------------------------------------ G9 tiny CLIP + projector
+TINY_CLIP = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                 image_size=56, patch_size=14, num_channels=3, layer_norm_eps=1e-5,
+                 vision_feature_layer=-2, projector_hidden_size=256)
+
+
+def tiny_clip_pixels(n_images: int = 2) -> torch.Tensor:
+    # the reference's synthetic image generator (hydrainfer/utils/image_utils.py:4-7), CLIP-normalised
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (n_images, TINY_CLIP["image_size"], TINY_CLIP["image_size"], 3)).astype(np.float32)
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+    x = (img / 255.0 - mean) / std
+    return torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()

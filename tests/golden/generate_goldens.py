@@ -273,6 +273,41 @@ def gen_tiny_llama(out):
         out[f"tiny_{dname}_pool_end_chk"] = np.array(C.checksum(pool))  # after all KV writes
 
 
+def gen_tiny_clip(out):
+    """G9: the reference's CLIPVisionModel + LlavaMultiModalProjector on CPU (tiny config)."""
+    from transformers import CLIPVisionConfig
+    from hydrainfer.model.clip import CLIPVisionModel
+    from hydrainfer.model.llava import LlavaMultiModalProjector
+    from hydrainfer.model.parameters import VisionModelParameters
+    from hydrainfer_amd.model.clip import ClipShape, random_state_dict
+    t = C.TINY_CLIP
+    shape = ClipShape(**t)
+    vcfg = CLIPVisionConfig(hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
+                            num_hidden_layers=t["num_hidden_layers"],
+                            num_attention_heads=t["num_attention_heads"], image_size=t["image_size"],
+                            patch_size=t["patch_size"], layer_norm_eps=t["layer_norm_eps"])
+
+    class _Cfg:  # the two attributes LlavaMultiModalProjector reads (llava.py:33-34)
+        vision_config = vcfg
+        text_config = type("T", (), {"hidden_size": t["projector_hidden_size"]})()
+
+    sd32 = random_state_dict(shape, seed=3, std=0.05)
+    pixels = C.tiny_clip_pixels()
+    for dname in ("fp16", "bf16"):
+        dt = C.DTYPES[dname]
+        tower, proj = CLIPVisionModel(vcfg), LlavaMultiModalProjector(_Cfg)
+        tower.load_state_dict({k[len("vision_tower."):]: v for k, v in sd32.items()
+                               if k.startswith("vision_tower.")}, strict=False)
+        proj.load_state_dict({k[len("multi_modal_projector."):]: v for k, v in sd32.items()
+                              if k.startswith("multi_modal_projector.")})
+        tower.to(dt).eval(); proj.to(dt).eval()
+        with torch.inference_mode():
+            h, _ = tower(pixels, t["vision_feature_layer"], VisionModelParameters())
+            feat = proj(h[:, 1:])
+        out[f"clip_{dname}_features"] = C.to_np(feat)
+    out["clip_pixels_chk"] = np.array(C.checksum(pixels))
+
+
 def main():
     import_reference()
     torch.manual_seed(0)
@@ -285,6 +320,7 @@ def main():
         "g6_silu": gen_silu,
         "g7_trace": gen_trace,
         "g8_tiny_llama": gen_tiny_llama,
+        "g9_tiny_clip": gen_tiny_clip,
     }
     only = sys.argv[1:]
     for name, fn in sets.items():

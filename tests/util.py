@@ -31,7 +31,7 @@ def assert_ulp_close(actual: torch.Tensor, expected: torch.Tensor, max_ulp: int 
     d = (_ordered_bits(a) - _ordered_bits(e)).abs()
     worst = int(d.max()) if d.numel() else 0
     assert worst <= max_ulp, f"{what}: max ulp distance {worst} > {max_ulp}"
-    if d.numel():
+    if d.numel() >= 256:   # a fraction is meaningless for a handful of elements
         frac = float((d == 0).float().mean())
         assert frac >= min_exact_frac, f"{what}: only {frac:.4f} bit-exact (< {min_exact_frac})"
 
