@@ -40,6 +40,7 @@ def parse():
                    help="decode against the randn-filled cache instead of a real prefill")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ttft", action="store_true")
+    p.add_argument("--no-migration", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=2)
     return p.parse_args()
 
@@ -247,6 +248,9 @@ def cpu_baseline(shape, dtype, batch, ctx, n_layers):
 
 def main():
     args = parse()
+    if os.environ.get("HX_BENCH_WATCHDOG"):      # diagnose hangs: periodic stack dumps
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["HX_BENCH_WATCHDOG"]), repeat=True)
     from hydrainfer_amd import parallel
     ctx = parallel.init_from_env()
     world, rank, local_rank = ctx.world_size, ctx.rank, ctx.local_rank
@@ -307,14 +311,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0, dev)
     barrier()
-
-    ttft = None if args.skip_prefill or args.no_ttft else measure_ttft(runner, prompts, shape, dtype, dev, rank)
-    migration = measure_migration(ctx, runner, dev) if world > 1 else None
-
     ms_per_step = elapsed / steps * 1e3
     tokens = args.batch * steps * n_gpus
     value = tokens / elapsed
 
+    ttft = None if args.skip_prefill or args.no_ttft else measure_ttft(runner, prompts, shape, dtype, dev, rank)
     # ---- roofline of the dominant hand-written kernel + whole-step fraction (rank 0)
     out = None
     if rank == 0:
@@ -347,11 +348,28 @@ def main():
                            "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
                            "weight_bytes": model.weight_bytes()},
             "prefill_batch_ms": None if ttft_ms is None else round(ttft_ms, 2),
-            "ttft": ttft, "migration": migration,
+            "ttft": ttft, "migration": None,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(shape, dtype, args.batch, mid_ctx, args.cpu_layers)
+    # ---- optional last leg on every rank (nothing touches the GPU after it)
+    migration, stuck = None, False
+    if world > 1 and not args.no_migration:
+        # optional leg, bounded: a wedged peer mapping must not cost the benchmark line
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.update(r=measure_migration(ctx, runner, dev)), daemon=True)
+        th.start()
+        th.join(timeout=90)
+        stuck = th.is_alive()
+        migration = {"error": "timed out after 90 s"} if stuck else box.get("r")
+
+    if rank == 0:
+        out["migration"] = migration
         print(json.dumps(out), flush=True)
+    if stuck:
+        sys.stdout.flush()
+        os._exit(0)     # a HIP call is wedged in the helper thread: skip collective teardown
     ctx.shutdown()
 
 
