@@ -171,6 +171,19 @@ def measure_migration(ctx, runner, dev, reps=5):
         return {"error": repr(e)[:300]}
 
 
+def measured_traffic(args, model_name):
+    """HBM bytes per attention launch from the committed PMC passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE; profiles/r1_attn_decode_pmc.json).  PMC counters cannot be read
+    from inside the benchmark, so this is reported only when the workload is the one profiled."""
+    path = os.path.join(ROOT, "profiles", "r1_attn_decode_pmc.json")
+    if not (os.path.exists(path) and args.model == "7b" and args.batch == 32 and args.dtype == "bf16"):
+        return None
+    try:
+        return int(json.load(open(path))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(shape, dtype, batch, ctx, n_layers):
     """The oracle (reference's eager-PyTorch CPU path restated) timed on this host's cores:
     one decode step of `n_layers` of the decoder layers + final norm + lm_head at the mid-run
@@ -341,7 +354,7 @@ def main():
                        "parallelism": f"replicas x{n_gpus} (independent requests, no data-path collective)"},
             "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (paged decode attention)",
                          "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, model_name),
                          "avg_launch_us": round(attn_ms * 1e3, 2),
                          "algorithmic_bytes_per_launch": int(attn_bytes)},
             "whole_step": {"algorithmic_bytes": int(step_bytes), "achieved_GBps": round(step_gbs, 1),

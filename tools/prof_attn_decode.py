@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Launches the decode-attention kernel a few times at the BASELINE shape (B=32, H=32, D=128,
+bf16, ctx 832) over distinct layers of a pool larger than the 256 MiB Infinity Cache —
+the target program for `rocprofv3 --pmc ...` counter passes."""
+import math, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+
+dev = torch.device("cuda:0")
+dt = torch.bfloat16
+B, H, D, bs, ctx, L = 32, 32, 128, 16, 832, 6
+nb_seq = (ctx + bs - 1) // bs
+n_blocks = B * nb_seq
+g = torch.Generator(device=dev).manual_seed(0)
+pool = torch.randn((L, 2, n_blocks, bs, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
+perm = torch.randperm(n_blocks, generator=g, device=dev).to(torch.int32)
+cu_b = torch.arange(0, (B + 1) * nb_seq, nb_seq, dtype=torch.int32, device=dev)
+cu_q = torch.arange(0, B + 1, dtype=torch.int32, device=dev)
+cu_k = torch.arange(0, (B + 1) * ctx, ctx, dtype=torch.int32, device=dev)
+q = torch.randn((B, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
+out = torch.empty_like(q)
+for i in range(12):
+    mha_varlen_fwd(out, q, pool[i % L, 0], pool[i % L, 1], cu_q, cu_k, perm, cu_b, None, 1, ctx,
+                   1 / math.sqrt(D), 0.0, -1, 0, 1)
+torch.cuda.synchronize()
+nbytes = 2 * (2 * H * D * ctx * B + 2 * B * H * D) + 4 * B * nb_seq
+print("algorithmic_bytes_per_launch", nbytes)
