@@ -105,3 +105,58 @@ def mha_varlen_fwd(out: Tensor, q: Tensor, k: Tensor, v: Tensor, cu_seqlens_q: T
         a.workspace, a.workspace_bytes = ws.data_ptr(), need
     with torch.cuda.device(q.device):
         _lib.check(l.hx_mha_varlen_fwd(ctypes.byref(a), _lib.current_stream()), "mha_varlen_fwd")
+
+
+def decode_attention_fused(out: Tensor, q: Tensor, k_new: Tensor, v_new: Tensor, key_cache: Tensor,
+                           value_cache: Tensor, positions: Tensor, cos_sin: Tensor,
+                           new_cache_slots: Tensor, cu_seqlens_q: Tensor, cu_seqlens_k: Tensor,
+                           block_table: Tensor, cu_block_lens: Tensor, max_seqlen_k: int,
+                           softmax_scale: float, num_splits: int = 0) -> None:
+    """Extension: apply_rotary_pos_emb(q, k_new) + set_kv_cache(new_cache_slots, k_new, v_new) +
+    mha_varlen_fwd(paged, causal) for an all-decode batch, as ONE launch.  q / k_new / v_new are
+    the un-rotated projections [batch, heads, head_dim]; cu_seqlens_k already counts the new
+    token.  Bit-identical to the three separate ops (q and k_new are NOT modified in place)."""
+    _lib.require_gpu(out, q, k_new, v_new, key_cache, value_cache, positions, cos_sin, new_cache_slots,
+                     cu_seqlens_q, cu_seqlens_k, block_table, cu_block_lens)
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise _lib.HydraHipError("FlashAttention only support fp16 and bf16 data type")
+    for t in (k_new, v_new, key_cache, value_cache, cos_sin, out):
+        if t.dtype != q.dtype:
+            raise _lib.HydraHipError("decode_attention_fused: dtype mismatch")
+    for t, name in ((positions, "positions"), (new_cache_slots, "new_cache_slots"), (cu_seqlens_q, "cu_seqlens_q"),
+                    (cu_seqlens_k, "cu_seqlens_k"), (block_table, "block_table"), (cu_block_lens, "cu_block_lens")):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise _lib.HydraHipError(f"{name} must be contiguous int32")
+    if q.dim() != 3 or k_new.dim() != 3 or v_new.dim() != 3 or key_cache.dim() != 4:
+        raise _lib.HydraHipError("decode_attention_fused: q/k_new/v_new [B, heads, D], caches 4-D")
+    for t in (q, k_new, v_new, out):
+        if t.stride(-1) != 1 or t.stride(-2) != t.size(-1):
+            raise _lib.HydraHipError("decode_attention_fused: last two dims must be contiguous")
+    batch, n_heads, head_dim = q.shape
+    if cu_seqlens_q.numel() != batch + 1:
+        raise _lib.HydraHipError("decode_attention_fused needs exactly one query token per sequence")
+    k, v = key_cache, value_cache
+    a = _lib.hx_attn_args()
+    a.out, a.q, a.k, a.v = out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr()
+    a.cu_seqlens_q, a.cu_seqlens_k = cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr()
+    a.block_table, a.cu_block_lens = block_table.data_ptr(), cu_block_lens.data_ptr()
+    a.batch, a.n_heads, a.n_kv_heads, a.head_dim = batch, n_heads, k.size(2), head_dim
+    a.block_size, a.max_seqlen_q, a.max_seqlen_k, a.total_q = k.size(1), 1, int(max_seqlen_k), batch
+    a.q_row_stride, a.o_row_stride = q.stride(0), out.stride(0)
+    a.k_block_stride, a.k_row_stride, a.k_head_stride = k.stride(0), k.stride(1), k.stride(2)
+    a.v_block_stride, a.v_row_stride, a.v_head_stride = v.stride(0), v.stride(1), v.stride(2)
+    a.softmax_scale, a.causal, a.dtype, a.num_splits = float(softmax_scale), 1, _lib.dtype_code(q), int(num_splits)
+    a.workspace, a.workspace_bytes = None, 0
+    fz = _lib.hx_fused_decode_args()
+    fz.k_new, fz.v_new = k_new.data_ptr(), v_new.data_ptr()
+    fz.k_new_row_stride, fz.v_new_row_stride = k_new.stride(0), v_new.stride(0)
+    fz.positions, fz.cos_sin, fz.new_cache_slots = positions.data_ptr(), cos_sin.data_ptr(), new_cache_slots.data_ptr()
+    fz.rotary_dim, fz.interleaved = head_dim, 0
+    l = _lib.lib()
+    need = l.hx_mha_varlen_fwd_workspace_bytes(ctypes.byref(a))
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    with torch.cuda.device(q.device):
+        _lib.check(l.hx_decode_attention_fused(ctypes.byref(a), ctypes.byref(fz), _lib.current_stream()),
+                   "decode_attention_fused")

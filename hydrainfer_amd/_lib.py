@@ -41,6 +41,14 @@ class hx_attn_args(ctypes.Structure):
     ]
 
 
+class hx_fused_decode_args(ctypes.Structure):
+    _fields_ = [
+        ("k_new", c_void_p), ("v_new", c_void_p), ("k_new_row_stride", c_int64),
+        ("v_new_row_stride", c_int64), ("positions", c_void_p), ("cos_sin", c_void_p),
+        ("new_cache_slots", c_void_p), ("rotary_dim", c_int32), ("interleaved", c_int32),
+    ]
+
+
 _SIGNATURES = {
     "hx_abi_version": (c_int, []),
     "hx_strerror": (c_char_p, [c_int]),
@@ -54,8 +62,11 @@ _SIGNATURES = {
     "hx_rope_set_kv_cache": (c_int, [c_void_p] * 8 + [c_int64] * 11 + [c_int, c_void_p]),
     "hx_silu": (c_int, [c_void_p] * 2 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_silu_and_mul": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_void_p]),
+    "hx_linear_decode_workspace_bytes": (c_int64, [c_int64] * 3),
+    "hx_linear_decode": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_void_p, c_int64, c_int, c_void_p]),
     "hx_mha_varlen_fwd_workspace_bytes": (c_int64, [POINTER(hx_attn_args)]),
     "hx_mha_varlen_fwd": (c_int, [POINTER(hx_attn_args), c_void_p]),
+    "hx_decode_attention_fused": (c_int, [POINTER(hx_attn_args), POINTER(hx_fused_decode_args), c_void_p]),
     "hx_ipc_get_mem_handle": (c_int, [c_void_p, c_void_p, POINTER(c_int64)]),
     "hx_ipc_open_mem_handle": (c_int, [c_void_p, POINTER(c_void_p)]),
     "hx_ipc_close_all": (c_int, []),

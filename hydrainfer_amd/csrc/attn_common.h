@@ -44,6 +44,13 @@ struct AttnParams {
   int32_t n_splits;
   float* ws_o;              // [batch, n_heads, n_splits, D] unnormalised partial outputs
   float* ws_ml;             // [batch, n_heads, n_splits, 2] (max, sum)
+  // fused RoPE + cache append (decode only; all null/0 otherwise)
+  const void* k_new;        // [batch, n_kv_heads, D] un-rotated key of the new token
+  const void* v_new;        // [batch, n_kv_heads, D]
+  int64_t kn_row_stride, vn_row_stride;
+  const int32_t* positions; // [batch] rotary position of the new token
+  const void* cos_sin;      // [max_pos, 2, D/2] in T
+  const int32_t* new_slots; // [batch] cache slot of the new token
 };
 
 }  // namespace hx

@@ -77,6 +77,38 @@ __device__ __forceinline__ void load_tile(KVTile<D>& buf, const AttnParams& p, c
   }
 }
 
+// T-arithmetic rotation of one (x, y) pair, identical to norm_rope_act.hip::rotate_pair
+template <typename T>
+__device__ __forceinline__ void rope_pair(float x, float y, float c, float s, float& xo, float& yo) {
+#pragma clang fp contract(off)
+  const float xc = round_to<T>(x * c), ys = round_to<T>(y * s);
+  const float xs = round_to<T>(x * s), yc = round_to<T>(y * c);
+  xo = round_to<T>(xc - ys);
+  yo = round_to<T>(xs + yc);
+}
+
+// NeoX rotation of the fragment set f[s] (lane holds dims 32s+8g+j): the partner of dim d is
+// d +- D/2, i.e. fragment s +- NS/2 of the SAME lane.  cs points at cos_sin[pos] ([2][D/2]).
+template <typename T, int D>
+__device__ __forceinline__ void rope_frags(u16x8 (&f)[D / 32], const u16* cs, int g) {
+  constexpr int NS = D / 32, HS = NS / 2;
+#pragma unroll
+  for (int s = 0; s < HS; ++s) {
+    const u16x8 c = *reinterpret_cast<const u16x8*>(cs + 32 * s + 8 * g);
+    const u16x8 sn = *reinterpret_cast<const u16x8*>(cs + D / 2 + 32 * s + 8 * g);
+    u16x8 x = f[s], y = f[s + HS];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float xo, yo;
+      rope_pair<T>(T::to_float(x[j]), T::to_float(y[j]), T::to_float(c[j]), T::to_float(sn[j]), xo, yo);
+      x[j] = T::from_float(xo);
+      y[j] = T::from_float(yo);
+    }
+    f[s] = x;
+    f[s + HS] = y;
+  }
+}
+
 template <typename T, int D>
 __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (&qf)[D / 32],
                                              int valid, float scale_log2, int lane, float& m,
@@ -114,7 +146,7 @@ __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (
     }
 }
 
-template <typename T, int D, int NW, bool NT>
+template <typename T, int D, int NW, bool NT, bool FUSE>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p) {
   constexpr int OE = D / 16;  // fp32 partial-output elements per lane
   constexpr int NP = NW * 4;  // partial softmax states per workgroup
@@ -148,6 +180,57 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p
     for (int s = 0; s < D / 32; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 32 * s);
   }
 
+  // FUSE: q and the new token's k arrive un-rotated and the cache does not hold the new token
+  // yet.  Rotate both in registers (T arithmetic, same rounding as apply_rotary_pos_emb), use
+  // k/v of the new token from registers in its tile, and append them to the cache once.
+  u16x8 kn[D / 32];
+  typename VRow<D>::type vn[VRow<D>::NV];
+  const int t_new = (kv_len - 1) >> 4, r_new = (kv_len - 1) & 15;
+  if (FUSE) {
+    const u16* cs = reinterpret_cast<const u16*>(p.cos_sin) + (int64_t)p.positions[b] * D;
+    const u16* kp = reinterpret_cast<const u16*>(p.k_new) + (int64_t)b * p.kn_row_stride +
+                    (int64_t)hk * D + 8 * g;
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) kn[s] = *reinterpret_cast<const u16x8*>(kp + 32 * s);
+    const u16* vp = reinterpret_cast<const u16*>(p.v_new) + (int64_t)b * p.vn_row_stride +
+                    (int64_t)hk * D + VRow<D>::E * c;
+#pragma unroll
+    for (int n = 0; n < VRow<D>::NV; ++n)
+      vn[n] = *reinterpret_cast<const typename VRow<D>::type*>(vp + 128 * n);
+    rope_frags<T, D>(qf, cs, g);
+    rope_frags<T, D>(kn, cs, g);
+    // one writer per kv head and per split set: the first q head of the group, split 0, wave 0
+    if (h == hk * p.group && split == 0 && w == 0) {
+      const int slot = p.new_slots[b];
+      const int64_t blk = slot / p.block_size, off = slot % p.block_size;
+      if (c == 0) {   // lanes (r=0, g): 4 x 16 B per step cover the 2*D-byte key row
+        u16* kd = const_cast<u16*>(kbase) + blk * p.k_block_stride + off * p.k_row_stride + 8 * g;
+#pragma unroll
+        for (int s = 0; s < D / 32; ++s) *reinterpret_cast<u16x8*>(kd + 32 * s) = kn[s];
+      }
+      if (g == 0) {   // lanes (g=0, c): D/16 elements each cover the value row
+        u16* vd = const_cast<u16*>(vbase) + blk * p.v_block_stride + off * p.v_row_stride + VRow<D>::E * c;
+#pragma unroll
+        for (int n = 0; n < VRow<D>::NV; ++n)
+          *reinterpret_cast<typename VRow<D>::type*>(vd + 128 * n) = vn[n];
+      }
+    }
+  }
+  auto patch = [&](KVTile<D>& buf, int t) {
+    if (FUSE && t == t_new) {     // wave-uniform
+      if ((lane & 15) == r_new) {
+#pragma unroll
+        for (int s = 0; s < D / 32; ++s) buf.k[s] = kn[s];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * g + i == r_new) {
+#pragma unroll
+          for (int n = 0; n < VRow<D>::NV; ++n) buf.v[i][n] = vn[n];
+        }
+    }
+  };
+
   float m = HX_NEG_BIG, l = 0.f;
   float o[OE];
 #pragma unroll
@@ -175,6 +258,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p
         load_tile<T, D, NT>(bufB, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
                         (t % tpp) << 4, kv_len - (t << 4), lane);
       }
+      patch(bufA, chunk0 + NW * j);
       compute_tile<T, D>(bufA, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o);
       ++j;
       if (j >= n_my) break;
@@ -183,6 +267,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p
         load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
                         (t % tpp) << 4, kv_len - (t << 4), lane);
       }
+      patch(bufB, chunk0 + NW * j);
       compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o);
       ++j;
     }
@@ -253,12 +338,14 @@ int g_decode_nt = 1;   // K/V are read once: non-temporal loads measured +4 % (p
 template <typename T, int D>
 int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
   dim3 grid(p.n_heads, batch, p.n_splits);
-  if (g_decode_waves == 8) {
-    if (g_decode_nt) attn_decode_kernel<T, D, 8, true><<<grid, 512, 0, stream>>>(p);
-    else attn_decode_kernel<T, D, 8, false><<<grid, 512, 0, stream>>>(p);
+  if (p.k_new) {
+    attn_decode_kernel<T, D, 4, true, true><<<grid, 256, 0, stream>>>(p);
+  } else if (g_decode_waves == 8) {
+    if (g_decode_nt) attn_decode_kernel<T, D, 8, true, false><<<grid, 512, 0, stream>>>(p);
+    else attn_decode_kernel<T, D, 8, false, false><<<grid, 512, 0, stream>>>(p);
   } else {
-    if (g_decode_nt) attn_decode_kernel<T, D, 4, true><<<grid, 256, 0, stream>>>(p);
-    else attn_decode_kernel<T, D, 4, false><<<grid, 256, 0, stream>>>(p);
+    if (g_decode_nt) attn_decode_kernel<T, D, 4, true, false><<<grid, 256, 0, stream>>>(p);
+    else attn_decode_kernel<T, D, 4, false, false><<<grid, 256, 0, stream>>>(p);
   }
   int rc = check_launch();
   if (rc) return rc;

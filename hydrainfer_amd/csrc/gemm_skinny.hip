@@ -1,0 +1,279 @@
+// gemm_skinny.hip — weight-streaming GEMM for decode batches (M <= 64 rows):
+//     partial[s][m][n] = sum_{k in split s} x[m][k] * W[n][k]         (fp32 slabs)
+// i.e. y = x @ W^T for the nn.Linear weights of the decoder layers
+// (hydrainfer/model/llama.py:24-27,48-50) at decode batch sizes, where the library GEMM
+// reaches only 3.5-4.7 TB/s of weight streaming on MI355X (profiles/r1_bench7b_*).
+//
+// HBM-bound design (every weight byte is read exactly once, by one wave):
+//   * grid = (N tiles, K splits); 8 waves per workgroup.  The workgroup's slice of x
+//     ([M_pad][<=1024 k], <= 66 KB) is staged ONCE into LDS (row stride KR*2+32 B: the
+//     ds_read_b128 of the B fragments is bank-conflict free), then never touched again.
+//   * each wave streams whole 16-row groups of W straight HBM -> VGPR in the MFMA A-operand
+//     layout (lane (r,g) <- W[n0+r][k0+8g..+8], 16 B), 8 k-steps (8 KiB) per chunk,
+//     register double-buffered across chunk AND row-group boundaries; non-temporal loads.
+//   * MFMA 16x16x32: A = W fragment, B = x^T fragment from LDS (one per 16 batch rows), so a
+//     weight fragment is used for M/16 MFMAs; the accumulator holds out^T[n][m].
+//   * K is split across workgroups (<= 1024 k each) to have >= 2 workgroups per CU in flight;
+//     partial sums go to fp32 slabs that the consumer kernels (finalize / fused epilogues)
+//     add in a fixed order — deterministic, no atomics.
+#include <cstring>
+#include "attn_common.h"
+
+namespace {
+
+using namespace hx;
+
+struct GemmParams {
+  const void* x;
+  const void* w;
+  float* partial;   // [S][M][N]
+  int64_t ldx, ldw; // row strides in elements
+  int32_t M, N, K;
+  int32_t ks_per_split;  // k-steps (of 32) per split, multiple of 8
+  int32_t n_splits;
+};
+
+constexpr int kChunk = 16;       // k-steps per register buffer (16 KiB of W per wave)
+constexpr int kMaxKs = 32;       // k-steps per split (KR <= 1024) = 2 chunks
+constexpr int kRS = kMaxKs * 64 + 32;   // LDS row stride in bytes
+
+// R = 16-row groups per wave (each 2 chunks); NW = waves per workgroup.  The per-wave work is
+// a compile-time constant so the load/compute schedule below is straight-line code and the
+// compiler's vmcnt counts are exact (a loop makes it fall back to vmcnt(0) and serialises the
+// two buffers).
+template <typename T, int MB, int R, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kThreads = NW * 64;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4, c = lane & 15;
+
+  const int split = blockIdx.y;
+  const int total_ks = p.K >> 5;
+  const int ks0 = split * p.ks_per_split;
+  const int nks = min(p.ks_per_split, total_ks - ks0);   // multiple of 8, <= 32
+  const int KR = nks << 5;
+  const int n_rg_all = p.N >> 4;
+  // wave's row groups: rg0 + j*NW, j < R (groups past the end are clamped for loads and
+  // skipped at the store)
+  const int rg0 = blockIdx.x * (NW * R) + w;
+
+  // ---- 1. x slice -> registers.  The LDS image always spans kMaxKs k-steps; k beyond this
+  // split's range and rows beyond M are zero, so a short last split needs no predication.
+  constexpr int kCpr = kMaxKs * 4;                         // 16-byte chunks per LDS row
+  constexpr int XPT = MB * 16 * kCpr / kThreads;           // chunks per thread
+  u16x8 xr[XPT];
+  {
+    const u16* xb = reinterpret_cast<const u16*>(p.x) + (int64_t)ks0 * 32;
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+      const int i = threadIdx.x + j * kThreads;
+      const int row = i / kCpr, ch = i % kCpr;
+      const bool ok = row < p.M && ch * 8 < KR;
+      // always a valid address; the zero-fill select happens at the LDS write so that no
+      // loaded value is consumed before the weight prefetch has been issued
+      xr[j] = *reinterpret_cast<const u16x8*>(xb + (int64_t)(ok ? row : 0) * p.ldx + (ok ? ch * 8 : 0));
+    }
+  }
+
+  // ---- 2. W prefetch
+  const u16* wb = reinterpret_cast<const u16*>(p.w) + (int64_t)ks0 * 32 + 8 * g;
+  auto load = [&](u16x8 (&buf)[kChunk], int it) {
+    const int rgi = it >> 1, ch = it & 1;
+    const int n0 = min(rg0 + rgi * NW, n_rg_all - 1) << 4;
+    const int last = nks - 1 - ch * kChunk;   // k-steps past the range re-read a valid one
+    const u16* wp = wb + (int64_t)(n0 + r) * p.ldw + ch * (kChunk * 32);
+#pragma unroll
+    for (int s = 0; s < kChunk; ++s)
+      buf[s] = __builtin_nontemporal_load(
+          reinterpret_cast<const u16x8*>(wp + 32 * max(min(s, last), -ch * kChunk)));
+  };
+  u16x8 buf[2][kChunk];
+  load(buf[0], 0);
+  load(buf[1], 1);
+  // keep the 32 KiB weight prefetch in flight UNDER the x staging: without this fence hipcc
+  // sinks the weight loads below the LDS writes (one exposed L2 round trip per workgroup)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- 3. x slice -> LDS
+#pragma unroll
+  for (int j = 0; j < XPT; ++j) {
+    const int i = threadIdx.x + j * kThreads;
+    const int row = i / kCpr, ch = i % kCpr;
+    const bool ok = row < p.M && ch * 8 < KR;
+    *reinterpret_cast<u16x8*>(smem + row * kRS + ch * 16) = ok ? xr[j] : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  __syncthreads();
+
+  const char* xl = smem + c * kRS + g * 16;
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int it = 0; it < 2 * R; ++it) {
+    const int rgi = it >> 1, ch = it & 1;
+    const char* xp = xl + ch * (kChunk * 64);
+#pragma unroll
+    for (int s = 0; s < kChunk; ++s) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const u16x8 xf = *reinterpret_cast<const u16x8*>(xp + mb * 16 * kRS + s * 64);
+        acc[mb] = Mfma<T>::mma(buf[it & 1][s], xf, acc[mb]);
+      }
+    }
+    if (it + 2 < 2 * R) load(buf[it & 1], it + 2);
+    if (ch == 1) {
+      const int rg = rg0 + rgi * NW;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int m = mb * 16 + c;
+        if (m < p.M && rg < n_rg_all)
+          *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g) =
+              acc[mb];
+        acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+}
+
+// out[m][n] = (T) sum_s partial[s][m][n]   (fixed summation order)
+template <typename T>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial,
+                                                          u16* __restrict__ out, int64_t mn,
+                                                          int n_splits, int64_t N, int64_t ldo) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= mn) return;
+  f32x4 a = *reinterpret_cast<const f32x4*>(partial + i4);
+  for (int s = 1; s < n_splits; ++s) a += *reinterpret_cast<const f32x4*>(partial + s * mn + i4);
+  const int64_t m = i4 / N, n = i4 - m * N;
+  u16x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = T::from_float(a[e]);
+  *reinterpret_cast<u16x4*>(out + m * ldo + n) = r;
+}
+
+int g_force_r = 0;       // tuning: 0 = automatic, else row groups per wave
+int g_force_nw = 0;      // tuning: 0 = automatic, else waves per workgroup (4 or 8)
+
+}  // namespace
+
+namespace hx {
+
+int gemm_set_option(const char* name, int value) {
+  if (!strcmp(name, "gemm_rows_per_wave")) { g_force_r = value; return HX_OK; }
+  if (!strcmp(name, "gemm_waves")) { g_force_nw = value; return HX_OK; }
+  return HX_ERR_UNSUPPORTED;
+}
+
+bool gemm_skinny_supported(int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw) {
+  return M >= 1 && M <= 64 && N % 16 == 0 && K % 256 == 0 && ldx % 8 == 0 && ldw % 8 == 0;
+}
+
+int gemm_skinny_splits(int64_t K) {
+  const int total_ks = (int)(K >> 5);
+  return (total_ks + kMaxKs - 1) / kMaxKs;
+}
+
+template <typename T, int MB, int R, int NW>
+int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)MB * 16 * kRS;
+  const int n_rg = p.N >> 4;
+  dim3 grid((unsigned)((n_rg + NW * R - 1) / (NW * R)), (unsigned)p.n_splits);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<T, MB, R, NW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_rc(e);
+  }
+  gemm_skinny_kernel<T, MB, R, NW><<<grid, NW * 64, lds, stream>>>(p);
+  return check_launch();
+}
+
+template <typename T, int MB>
+int launch_gemm_mb(const GemmParams& p, hipStream_t stream) {
+  // pick (waves, row groups per wave) so that the launch has ~256..640 workgroups: all
+  // resident at 2 per CU, every CU busy
+  const int64_t units = (int64_t)(p.N >> 4) * p.n_splits;   // (row group, split) pairs
+  // measured cold-weight on MI355X (profiles/r1_gemm_variants.txt): 4-wave workgroups with one
+  // row group per wave win up to ~1000 workgroups; beyond that two row groups per wave
+  int nw = 4;
+  int rpw = 1;
+  while (rpw < 4 && units / ((int64_t)nw * rpw) > 1024) ++rpw;
+  if (g_force_nw == 4 || g_force_nw == 8) nw = g_force_nw;
+  if (g_force_r >= 1 && g_force_r <= 4) rpw = g_force_r;
+  if (nw == 4) {
+    switch (rpw) {
+      case 1: return launch_gemm_cfg<T, MB, 1, 4>(p, stream);
+      case 2: return launch_gemm_cfg<T, MB, 2, 4>(p, stream);
+      case 3: return launch_gemm_cfg<T, MB, 3, 4>(p, stream);
+      default: return launch_gemm_cfg<T, MB, 4, 4>(p, stream);
+    }
+  }
+  switch (rpw) {
+    case 1: return launch_gemm_cfg<T, MB, 1, 8>(p, stream);
+    case 2: return launch_gemm_cfg<T, MB, 2, 8>(p, stream);
+    case 3: return launch_gemm_cfg<T, MB, 3, 8>(p, stream);
+    default: return launch_gemm_cfg<T, MB, 4, 8>(p, stream);
+  }
+}
+
+// partial must hold splits*M*N floats
+int launch_gemm_skinny(const void* x, const void* w, float* partial, int64_t M, int64_t N,
+                       int64_t K, int64_t ldx, int64_t ldw, int dtype, hipStream_t stream) {
+  if (!gemm_skinny_supported(M, N, K, ldx, ldw)) return HX_ERR_SHAPE;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(partial)) return HX_ERR_STRIDE;
+  GemmParams p;
+  p.x = x; p.w = w; p.partial = partial; p.ldx = ldx; p.ldw = ldw;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.ks_per_split = kMaxKs;
+  p.n_splits = gemm_skinny_splits(K);
+  const int MB = (int)((M + 15) / 16);
+  if (dtype == HX_F16) {
+    if (MB == 1) return launch_gemm_mb<F16, 1>(p, stream);
+    if (MB == 2) return launch_gemm_mb<F16, 2>(p, stream);
+    return launch_gemm_mb<F16, 4>(p, stream);
+  }
+  if (dtype == HX_BF16) {
+    if (MB == 1) return launch_gemm_mb<BF16, 1>(p, stream);
+    if (MB == 2) return launch_gemm_mb<BF16, 2>(p, stream);
+    return launch_gemm_mb<BF16, 4>(p, stream);
+  }
+  return HX_ERR_DTYPE;
+}
+
+int launch_slab_reduce(const float* partial, void* out, int64_t M, int64_t N, int64_t ldo,
+                       int n_splits, int dtype, hipStream_t stream) {
+  const int64_t mn = M * N;
+  const unsigned blocks = (unsigned)((mn / 4 + 255) / 256);
+  if (dtype == HX_F16)
+    slab_reduce_kernel<F16><<<blocks, 256, 0, stream>>>(partial, (u16*)out, mn, n_splits, N, ldo);
+  else if (dtype == HX_BF16)
+    slab_reduce_kernel<BF16><<<blocks, 256, 0, stream>>>(partial, (u16*)out, mn, n_splits, N, ldo);
+  else
+    return HX_ERR_DTYPE;
+  return check_launch();
+}
+
+}  // namespace hx
+
+using namespace hx;
+
+extern "C" int64_t hx_linear_decode_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (int64_t)gemm_skinny_splits(K) * M * N * (int64_t)sizeof(float);
+}
+
+extern "C" int hx_linear_decode(void* out, const void* x, const void* weight, int64_t M,
+                                int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldo,
+                                void* workspace, int64_t workspace_bytes, int dtype,
+                                hx_stream stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return HX_ERR_SHAPE;
+  if (!out || !x || !weight || !workspace) return HX_ERR_NULL;
+  if (!gemm_skinny_supported(M, N, K, ldx, ldw) || ldo % 4 != 0) return HX_ERR_SHAPE;
+  if (workspace_bytes < hx_linear_decode_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_gemm_skinny(x, weight, (float*)workspace, M, N, K, ldx, ldw, dtype, s);
+  if (rc) return rc;
+  return launch_slab_reduce((const float*)workspace, out, M, N, ldo, gemm_skinny_splits(K), dtype, s);
+}

@@ -12,6 +12,7 @@ int& last_hip_error() {
 
 bool decode_supported(int head_dim);
 int decode_set_option(const char* name, int value);
+int gemm_set_option(const char* name, int value);
 bool fwd_supported(int head_dim);
 int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested);
 int launch_attn_decode(const AttnParams& p, int batch, int head_dim, int dtype,
@@ -29,7 +30,9 @@ extern "C" int hx_last_hip_error(void) { return last_hip_error(); }
 
 extern "C" int hx_debug_set_option(const char* name, int value) {
   if (!name) return HX_ERR_NULL;
-  return decode_set_option(name, value);
+  int rc = decode_set_option(name, value);
+  if (rc == HX_ERR_UNSUPPORTED) rc = gemm_set_option(name, value);
+  return rc;
 }
 
 extern "C" const char* hx_strerror(int status) {
@@ -94,7 +97,27 @@ extern "C" int64_t hx_mha_varlen_fwd_workspace_bytes(const hx_attn_args* a) {
   return (int64_t)a->batch * a->n_heads * splits * (a->head_dim + 2) * (int64_t)sizeof(float);
 }
 
+static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fused, hx_stream stream);
+
 extern "C" int hx_mha_varlen_fwd(const hx_attn_args* a, hx_stream stream) {
+  return attn_dispatch(a, nullptr, stream);
+}
+
+extern "C" int hx_decode_attention_fused(const hx_attn_args* a, const hx_fused_decode_args* f,
+                                         hx_stream stream) {
+  if (!a || !f) return HX_ERR_NULL;
+  if (!f->k_new || !f->v_new || !f->positions || !f->cos_sin || !f->new_cache_slots)
+    return HX_ERR_NULL;
+  if (!use_decode(a)) return HX_ERR_SHAPE;           // q_len == 1 per sequence, paged cache
+  if (f->rotary_dim != a->head_dim || f->interleaved) return HX_ERR_UNSUPPORTED;
+  if (f->k_new_row_stride % 8 || f->v_new_row_stride % 8 || !aligned16(f->k_new) ||
+      !aligned16(f->v_new) || !aligned16(f->cos_sin))
+    return HX_ERR_STRIDE;
+  if (a->k_head_stride != a->head_dim || a->v_head_stride != a->head_dim) return HX_ERR_STRIDE;
+  return attn_dispatch(a, f, stream);
+}
+
+static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fused, hx_stream stream) {
   int rc = validate(a);
   if (rc) return rc;
   if (a->total_q == 0) return HX_OK;
@@ -124,6 +147,21 @@ extern "C" int hx_mha_varlen_fwd(const hx_attn_args* a, hx_stream stream) {
   p.n_splits = 1;
   p.ws_o = nullptr;
   p.ws_ml = nullptr;
+  p.k_new = nullptr;
+  p.v_new = nullptr;
+  p.kn_row_stride = p.vn_row_stride = 0;
+  p.positions = nullptr;
+  p.cos_sin = nullptr;
+  p.new_slots = nullptr;
+  if (fused) {
+    p.k_new = fused->k_new;
+    p.v_new = fused->v_new;
+    p.kn_row_stride = fused->k_new_row_stride;
+    p.vn_row_stride = fused->v_new_row_stride;
+    p.positions = fused->positions;
+    p.cos_sin = fused->cos_sin;
+    p.new_slots = fused->new_cache_slots;
+  }
 
   hipStream_t s = (hipStream_t)stream;
   if (use_decode(a)) {

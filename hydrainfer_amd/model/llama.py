@@ -21,7 +21,8 @@ from hydrainfer_amd._C.kernel.activation import silu_and_mul
 from hydrainfer_amd._C.kernel.norm import add_rms_norm, rms_norm
 from hydrainfer_amd._C.kernel.position_embedding import rope_set_kv_cache
 from hydrainfer_amd.layer.causal_attention import AttentionParameters
-from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
+from hydrainfer_amd._C.kernel import gemm as hip_gemm
 
 
 @dataclass
@@ -69,6 +70,16 @@ class LlamaForCausalLM:
         self.cos_sin = build_cos_sin(shape, dtype, self.device)
         self.q_size = shape.num_attention_heads * shape.head_dim
         self.kv_size = shape.num_key_value_heads * shape.head_dim
+        # decode batches (<= 64 rows) stream the weights through the HIP kernel; larger
+        # batches (prefill) use the library GEMM
+        self.use_hip_gemm = False
+        # decode steps: RoPE + cache append + attention as one launch
+        self.fuse_decode_attention = shape.head_dim in (64, 128, 256)
+
+    def linear(self, x: Tensor, w: Tensor) -> Tensor:
+        if self.use_hip_gemm and x.shape[0] <= 64 and hip_gemm.supported(x, w):
+            return hip_gemm.linear_decode(x, w)
+        return torch.matmul(x, w.t())
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -161,18 +172,24 @@ class LlamaForCausalLM:
         rms_norm(x, h, st["l0.norm1"], eps)
         for l in range(L):
             ap = model_params.attention_params[l]
-            qkv = torch.matmul(x, st[f"l{l}.wqkv"].t())
+            qkv = self.linear(x, st[f"l{l}.wqkv"])
             q = qkv[:, :q_size].view(n, H, D)
             k = qkv[:, q_size:q_size + kv_size].view(n, HK, D)
             v = qkv[:, q_size + kv_size:].view(n, HK, D)
             kc, vc = ap.kv_cache.get_kv_cache()
-            # RoPE in place + append k/v to the paged cache, one launch
-            rope_set_kv_cache(q, k, v, position_ids, self.cos_sin, D, ap.new_cache_slots, kc, vc)
             o = torch.empty((n, H, D), dtype=h.dtype, device=h.device)
-            mha_varlen_fwd(o, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
-                           ap.cu_blocks_lens, None, ap.q_max_seq_len, ap.kv_max_seq_len,
-                           D ** -0.5, 0, -1, 0, 0)
-            a = torch.matmul(o.view(n, q_size), st[f"l{l}.wo"].t())
+            if model_params.all_sequences_decode and self.fuse_decode_attention:
+                # RoPE + cache append + paged attention, one launch
+                decode_attention_fused(o, q, k, v, kc, vc, position_ids, self.cos_sin,
+                                       ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens,
+                                       ap.block_tables, ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5)
+            else:
+                # RoPE in place + append k/v to the paged cache, one launch; then attention
+                rope_set_kv_cache(q, k, v, position_ids, self.cos_sin, D, ap.new_cache_slots, kc, vc)
+                mha_varlen_fwd(o, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
+                               ap.cu_blocks_lens, None, ap.q_max_seq_len, ap.kv_max_seq_len,
+                               D ** -0.5, 0, -1, 0, 0)
+            a = self.linear(o.view(n, q_size), st[f"l{l}.wo"])
             # h += a ; x = norm2(h)
             add_rms_norm(x, h, a, st[f"l{l}.norm2"], eps)
             if (not model_params.all_sequences_decode) and l == L - 1 \
@@ -180,9 +197,9 @@ class LlamaForCausalLM:
                 # last layer of a prefill: only sampled tokens go through the MLP
                 h = h[model_params.selected_token_ids].contiguous()
                 x = x[model_params.selected_token_ids].contiguous()
-            gu = torch.matmul(x, st[f"l{l}.wgu"].t())
+            gu = self.linear(x, st[f"l{l}.wgu"])
             act = silu_and_mul(gu[:, :inter], gu[:, inter:])
-            m = torch.matmul(act, st[f"l{l}.wdown"].t())
+            m = self.linear(act, st[f"l{l}.wdown"])
             nxt = st[f"l{l + 1}.norm1"] if l + 1 < L else st["norm"]
             if x.shape != h.shape:
                 x = torch.empty_like(h)
@@ -190,8 +207,8 @@ class LlamaForCausalLM:
         return x
 
     def forward_logits(self, input_ids_or_embeds, position_ids, model_params) -> Tensor:
-        return torch.matmul(self.forward_hidden(input_ids_or_embeds, position_ids, model_params),
-                            self.state["lm_head"].t())
+        return self.linear(self.forward_hidden(input_ids_or_embeds, position_ids, model_params),
+                           self.state["lm_head"])
 
     def forward(self, input_ids_or_embeds, position_ids, model_params) -> Tensor:
         """Returns sampled token ids (greedy), like the reference model."""

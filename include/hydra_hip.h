@@ -131,6 +131,18 @@ int hx_silu_and_mul(void* out, const void* gate, const void* up, int64_t rows, i
                     int64_t gate_stride, int64_t up_stride, int dtype, hx_stream stream);
 
 /* ------------------------------------------------------------------------
+ * Extension: decode-batch linear layer  out[M,N] = x[M,K] @ weight[N,K]^T  (M <= 64) as a
+ * weight-streaming HIP kernel — the nn.Linear calls of hydrainfer/model/llama.py:24-27,48-50
+ * at decode batch sizes.  fp32 accumulation, split-K partials summed in a fixed order.
+ * Constraints: N % 16 == 0, K % 256 == 0, f16/bf16.  workspace >=
+ * hx_linear_decode_workspace_bytes(M, N, K).  Strides in elements.
+ * ---------------------------------------------------------------------- */
+int64_t hx_linear_decode_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int hx_linear_decode(void* out, const void* x, const void* weight, int64_t M, int64_t N,
+                     int64_t K, int64_t ldx, int64_t ldw, int64_t ldo, void* workspace,
+                     int64_t workspace_bytes, int dtype, hx_stream stream);
+
+/* ------------------------------------------------------------------------
  * Variable-length attention forward, dense or paged.
  * replaces: csrc/kernel/flash_attn/flash_api.cpp:216-355 (mha_varlen_fwd)
  *           hydrainfer/_C/kernel/flash_attn/__init__.pyi:23-40
@@ -181,6 +193,28 @@ typedef struct hx_attn_args {
 
 int64_t hx_mha_varlen_fwd_workspace_bytes(const hx_attn_args* args);
 int hx_mha_varlen_fwd(const hx_attn_args* args, hx_stream stream);
+
+/* Extension (SURVEY §8f-2 taken to the end): one launch for the three consecutive steps of a
+ * decode layer — apply_rotary_pos_emb(q, k) (NeoX, rotary_dim == head_dim), set_kv_cache(slots,
+ * k, v) and the paged attention itself (hydrainfer/model/model_forward.py:78-84 +
+ * hydrainfer/layer/causal_attention.py:401-406).  `args` is an all-decode batch (q_len 1) whose
+ * cu_seqlens_k already counts the new token; args->q, k_new, v_new are UN-rotated; the kernel
+ * rotates in registers (same T-arithmetic rounding), attends with the new token taken from
+ * registers and appends its rotated key / value to the cache at new_cache_slots.
+ * Results are bit-identical to the three separate ops. */
+typedef struct hx_fused_decode_args {
+  const void* k_new;          /* [batch, n_kv_heads, head_dim] */
+  const void* v_new;          /* [batch, n_kv_heads, head_dim] */
+  int64_t k_new_row_stride;
+  int64_t v_new_row_stride;
+  const int32_t* positions;   /* [batch] */
+  const void* cos_sin;        /* [max_pos, 2, head_dim/2] in the tensors' dtype */
+  const int32_t* new_cache_slots; /* [batch] */
+  int32_t rotary_dim;
+  int32_t interleaved;
+} hx_fused_decode_args;
+int hx_decode_attention_fused(const hx_attn_args* args, const hx_fused_decode_args* fused,
+                              hx_stream stream);
 
 /* ------------------------------------------------------------------------
  * Cache-block migration between GPUs / processes.

@@ -229,3 +229,43 @@ def test_argument_errors_raise():
         mha_varlen_fwd(out, q, kc[:, :8], kc[:, :8], cu, cuk, bt, cub, None, 1, 5, 0.1, 0.0, -1, 0, 0)
     with pytest.raises(HydraHipError):  # heads not divisible (flash_api.cpp:283)
         mha_varlen_fwd(out, q, kc[:, :, :3], kc[:, :, :3], cu, cuk, bt, cub, None, 1, 5, 0.1, 0.0, -1, 0, 0)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("heads", [(8, 8), (8, 2)])
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_fused_rope_cache_decode_attention_is_bit_identical(dt, heads, D):
+    """decode_attention_fused == apply_rotary_pos_emb + set_kv_cache + mha_varlen_fwd: same
+    output bits, same cache bits, q/k inputs untouched."""
+    from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
+    from hydrainfer_amd._C.kernel.position_embedding import rope_set_kv_cache
+    from oracle import ops
+    H, HK = heads
+    bs = 16
+    kv_lens = [1, 16, 17, 100, 255, 256, 33, 704]
+    B = len(kv_lens)
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(B, H, HK, D, kv_lens, [1] * B, dt, seed=D + H)
+    g = torch.Generator().manual_seed(4)
+    k_new = torch.randn((B, HK, D), generator=g).to(dt)
+    v_new = torch.randn((B, HK, D), generator=g).to(dt)
+    pos = torch.tensor([l - 1 for l in kv_lens], dtype=torch.int32)
+    cs = ops.build_cos_sin_cache(D, 4096, 1e4, dt)
+    slots = torch.tensor([int(bt[int(cu_b[i]) + (l - 1) // bs]) * bs + (l - 1) % bs
+                          for i, l in enumerate(kv_lens)], dtype=torch.int32)
+    dev = lambda t: t.to(DEV)
+    for splits in (0, 1, 3):
+        # reference sequence of three ops (in place on copies)
+        qa, ka, va, kca, vca = dev(q).clone(), dev(k_new).clone(), dev(v_new).clone(), dev(kc).clone(), dev(vc).clone()
+        rope_set_kv_cache(qa, ka, va, dev(pos), dev(cs), D, dev(slots), kca, vca)
+        oa = torch.empty_like(qa)
+        mha_varlen_fwd(oa, qa, kca, vca, dev(cu_q), dev(cu_k), dev(bt), dev(cu_b), None, 1, max(kv_lens),
+                       1 / math.sqrt(D), 0.0, -1, 0, splits)
+        # fused
+        qb, kb, vb, kcb, vcb = dev(q).clone(), dev(k_new).clone(), dev(v_new).clone(), dev(kc).clone(), dev(vc).clone()
+        ob = torch.empty_like(qb)
+        decode_attention_fused(ob, qb, kb, vb, kcb, vcb, dev(pos), dev(cs), dev(slots), dev(cu_q), dev(cu_k),
+                               dev(bt), dev(cu_b), max(kv_lens), 1 / math.sqrt(D), splits)
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob), f"output differs (splits={splits})"
+        assert torch.equal(kca, kcb) and torch.equal(vca, vcb), "cache differs"
+        assert torch.equal(qb, dev(q)) and torch.equal(kb, dev(k_new))
