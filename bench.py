@@ -72,13 +72,17 @@ def image_token_id(vocab):
 
 
 def time_attention_kernel(runner, start_len, steps):
-    """Average duration of the decode-attention launch over the same context sequence as the
-    timed region, HIP events on the launch stream (torch's current stream)."""
+    """Average duration of the decode-attention launch (the variant the decode graph runs:
+    fused RoPE + cache append + attention) over the same context sequence as the timed region,
+    HIP events on the launch stream (torch's current stream)."""
     import math
-    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
     sh = runner.model.shape
     B = runner.cfg.batch
-    q = torch.randn((B, sh.num_attention_heads, sh.head_dim), device=runner.dev).to(runner.model.dtype)
+    H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
+    g = torch.Generator(device=runner.dev).manual_seed(5)
+    rnd = lambda *s: torch.randn(s, device=runner.dev, generator=g).to(runner.model.dtype)
+    q, k_new, v_new = rnd(B, H, D), rnd(B, HK, D), rnd(B, HK, D)
     out = torch.empty_like(q)
     ap = runner.decode_params.attention_params[0]
     kc, vc = ap.kv_cache.get_kv_cache()
@@ -86,13 +90,19 @@ def time_attention_kernel(runner, start_len, steps):
     runner.positions.fill_(start_len - 1)
     runner.kv_lens.fill_(start_len)
     evs = []
-    scale = 1.0 / math.sqrt(sh.head_dim)
+    scale = 1.0 / math.sqrt(D)
+    fused = runner.model.fuse_decode_attention
     for s in range(steps + 2):
         runner._advance()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        mha_varlen_fwd(out, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
-                       ap.cu_blocks_lens, None, 1, runner.max_len, scale, 0.0, -1, 0, 0)
+        if fused:
+            decode_attention_fused(out, q, k_new, v_new, kc, vc, runner.positions, runner.model.cos_sin,
+                                   ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens,
+                                   ap.block_tables, ap.cu_blocks_lens, runner.max_len, scale)
+        else:
+            mha_varlen_fwd(out, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
+                           ap.cu_blocks_lens, None, 1, runner.max_len, scale, 0.0, -1, 0, 0)
         e1.record()
         if s >= 2:
             evs.append((e0, e1))
@@ -358,7 +368,9 @@ def main():
                        "global_batch": args.batch * n_gpus, "prompt_tokens": prompt_len,
                        "generated_tokens": n_generate, "hip_graph": cfg.use_graph,
                        "parallelism": f"replicas x{n_gpus} (independent requests, no data-path collective)"},
-            "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (paged decode attention)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "attn_decode_kernel<BF16,128,4,nt,fused> (RoPE + cache append + paged decode attention)"
+                                   if model.fuse_decode_attention else "attn_decode_kernel (paged decode attention)",
                          "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, model_name),
                          "avg_launch_us": round(attn_ms * 1e3, 2),

@@ -17,6 +17,9 @@ from hydrainfer_amd import _lib
 
 cudaMemoryIpcHandle = List[int]
 _registered: List[int] = []
+# handles exported by THIS process -> local base pointer: HIP refuses to open a handle in the
+# process that created it, and a same-process "migration" (EPD node, tests) needs no mapping
+_exported: dict = {}
 
 
 def get_ipc_mem_handle(tensor: Tensor) -> cudaMemoryIpcHandle:
@@ -26,6 +29,7 @@ def get_ipc_mem_handle(tensor: Tensor) -> cudaMemoryIpcHandle:
     with torch.cuda.device(tensor.device):
         _lib.check(_lib.lib().hx_ipc_get_mem_handle(tensor.data_ptr(), buf, ctypes.byref(off)),
                    "get_ipc_mem_handle")
+    _exported[bytes(buf)] = tensor.data_ptr() - int(off.value)
     return list(buf) + list(int(off.value).to_bytes(8, "little"))
 
 
@@ -34,6 +38,9 @@ def _open(handle: cudaMemoryIpcHandle) -> int:
         raise _lib.HydraHipError("IPC handle must be 64 (+8 offset) byte values")
     buf = (ctypes.c_uint8 * _lib.HX_IPC_HANDLE_BYTES)(*handle[:_lib.HX_IPC_HANDLE_BYTES])
     off = int.from_bytes(bytes(handle[_lib.HX_IPC_HANDLE_BYTES:]), "little") if len(handle) > 64 else 0
+    local = _exported.get(bytes(buf))
+    if local is not None:
+        return local + off
     ptr = ctypes.c_void_p(0)
     _lib.check(_lib.lib().hx_ipc_open_mem_handle(buf, ctypes.byref(ptr)), "open ipc handle")
     return int(ptr.value) + off

@@ -120,3 +120,39 @@ def test_decode_advance_matches_builder():
     assert kvl.tolist() == [l + 1 for l in lens]
     assert pos.tolist() == lens
     assert cu_k.tolist() == [0] + torch.tensor([l + 1 for l in lens]).cumsum(0).tolist()
+
+
+def test_token_cache_block_manager_end_to_end():
+    """TokenCacheBlockManager (hydrainfer/memory/token_cache_manger.py:51-179 mirror): pool
+    layout, allocation, v2p, per-layer caches feeding set_kv_cache, and a same-process P->D
+    migration through the manager's IPC backend (handle bytes -> cached mapping -> one gather
+    kernel on the migrate stream)."""
+    from hydrainfer_amd.memory import (KVCache, TokenCacheBlockManager, TokenCacheBlockManagerConfig,
+                                       TokenCacheBlockManagerContext)
+    cfg = dict(n_layers=3, n_tokens=2, block_size=16, n_heads=4, head_size=64, dtype="fp16", device=DEV)
+    ctx = TokenCacheBlockManagerContext(rank=0, rank2host={0: "h", 1: "h"})
+    p_mgr = TokenCacheBlockManager(TokenCacheBlockManagerConfig(n_blocks=12, **cfg), ctx)
+    d_mgr = TokenCacheBlockManager(TokenCacheBlockManagerConfig(n_blocks=9, **cfg),
+                                   TokenCacheBlockManagerContext(rank=1, rank2host={0: "h", 1: "h"}))
+    assert p_mgr.cache_tensor.shape == (3, 2, 12, 16, 4, 64) and len(p_mgr.memory_handle) == 72
+    src = p_mgr.allocate_virtual_cache()
+    p_mgr.realloc(src, 40)
+    assert src.block_table == [2, 1, 0] and p_mgr.v2p(src, [0, 17, 39]) == [32, 17, 7]
+    # prefill-side: write 40 tokens into every layer through KVCache views of the pool
+    slots = torch.tensor(p_mgr.v2p(src, list(range(40))), dtype=torch.int32, device=DEV)
+    for l in range(3):
+        kv = KVCache.from_token_cache(p_mgr.get_layer_cache(l))
+        k = torch.randn((40, 4, 64), device=DEV).half()
+        kv.set_kv_cache(slots, k, -k)
+    dst = d_mgr.allocate_virtual_cache()
+    d_mgr.realloc(dst, 40)
+    dst_before = d_mgr.cache_tensor.clone()
+    d_mgr.migrate_blocks(src, dst, is_send=False)       # pull model: receiver moves the data
+    p_mgr.migrate_blocks(src, dst, is_send=True)        # sender side is a no-op for ipc
+    d_mgr.synchronize()
+    for s, d in zip(src.block_table, dst.block_table):
+        assert torch.equal(d_mgr.cache_tensor[:, :, d], p_mgr.cache_tensor[:, :, s])
+    rest = [b for b in range(9) if b not in dst.block_table]
+    assert torch.equal(d_mgr.cache_tensor[:, :, rest], dst_before[:, :, rest])
+    d_mgr.realloc(dst, 10)
+    assert len(dst.block_table) == 1 and d_mgr.get_num_avaiable_blocks() == 8

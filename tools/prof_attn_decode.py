@@ -5,7 +5,8 @@ the target program for `rocprofv3 --pmc ...` counter passes."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused
+from oracle import ops
 
 dev = torch.device("cuda:0")
 dt = torch.bfloat16
@@ -20,9 +21,15 @@ cu_q = torch.arange(0, B + 1, dtype=torch.int32, device=dev)
 cu_k = torch.arange(0, (B + 1) * ctx, ctx, dtype=torch.int32, device=dev)
 q = torch.randn((B, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
 out = torch.empty_like(q)
+k_new = torch.randn((B, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
+v_new = torch.randn((B, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
+pos = torch.full((B,), ctx - 1, dtype=torch.int32, device=dev)
+cs = ops.build_cos_sin_cache(D, 4096, 1e4, dt).to(dev)
+slots = (perm[cu_b[:-1].long() + (ctx - 1) // bs] * bs + (ctx - 1) % bs).to(torch.int32)
 for i in range(12):
-    mha_varlen_fwd(out, q, pool[i % L, 0], pool[i % L, 1], cu_q, cu_k, perm, cu_b, None, 1, ctx,
-                   1 / math.sqrt(D), 0.0, -1, 0, 1)
+    # the variant the decode graph runs: fused RoPE + cache append + attention
+    decode_attention_fused(out, q, k_new, v_new, pool[i % L, 0], pool[i % L, 1], pos, cs, slots, cu_q, cu_k,
+                           perm, cu_b, ctx, 1 / math.sqrt(D), 1)
 torch.cuda.synchronize()
 nbytes = 2 * (2 * H * D * ctx * B + 2 * B * H * D) + 4 * B * nb_seq
 print("algorithmic_bytes_per_launch", nbytes)
