@@ -41,8 +41,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ttft", action="store_true")
     p.add_argument("--no-migration", action="store_true")
-    p.add_argument("--hip-gemm", action="store_true",
-                   help="decode GEMMs on the weight-streaming HIP kernel instead of the library")
+    p.add_argument("--lib-gemm", action="store_true",
+                   help="library GEMMs (hipBLASLt) for decode too, instead of the weight-streaming HIP kernel")
     p.add_argument("--no-fused-attention", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=2)
     return p.parse_args()
@@ -298,7 +298,7 @@ def main():
     cfg = RunnerConfig(batch=args.batch, prompt_len=prompt_len, n_generate=n_generate,
                        use_graph=not args.no_graph)
     model = LlamaForCausalLM.random_init(shape, dtype, dev, seed=0)
-    model.use_hip_gemm = args.hip_gemm
+    model.use_hip_gemm = not args.lib_gemm
     if args.no_fused_attention:
         model.fuse_decode_attention = False
     runner = DecodeRunner(model, cfg, seed=rank)

@@ -30,3 +30,18 @@ def silu_and_mul(gate: Tensor, up: Tensor) -> Tensor:
         out.data_ptr(), gate.data_ptr(), up.data_ptr(), gate.size(0), gate.size(1),
         gate.stride(0), up.stride(0), _lib.dtype_code(gate), _lib.current_stream()), "silu_and_mul")
     return out
+
+
+def silu_and_mul_slabs(partial: Tensor, n_splits: int, rows: int, inter: int, dtype: torch.dtype) -> Tensor:
+    """Extension: gate|up = (T) sum of the fp32 slabs [n_splits, rows, 2*inter]; returns
+    (T)silu(gate) * up.  Bit-identical to reduce + silu_and_mul."""
+    _lib.require_gpu(partial)
+    if partial.dtype != torch.float32 or partial.numel() < n_splits * rows * 2 * inter:
+        raise _lib.HydraHipError("silu_and_mul_slabs: partial must be float32 [n_splits, rows, 2*inter]")
+    out = torch.empty((rows, inter), dtype=dtype, device=partial.device)
+    code = {torch.float16: _lib.HX_F16, torch.bfloat16: _lib.HX_BF16}.get(dtype)
+    if code is None:
+        raise _lib.HydraHipError("silu_and_mul_slabs: fp16 / bf16 only")
+    _lib.check(_lib.lib().hx_silu_and_mul_slabs(out.data_ptr(), partial.data_ptr(), int(n_splits), rows, inter,
+                                                code, _lib.current_stream()), "silu_and_mul_slabs")
+    return out

@@ -111,7 +111,8 @@ def decode_attention_fused(out: Tensor, q: Tensor, k_new: Tensor, v_new: Tensor,
                            value_cache: Tensor, positions: Tensor, cos_sin: Tensor,
                            new_cache_slots: Tensor, cu_seqlens_q: Tensor, cu_seqlens_k: Tensor,
                            block_table: Tensor, cu_block_lens: Tensor, max_seqlen_k: int,
-                           softmax_scale: float, num_splits: int = 0) -> None:
+                           softmax_scale: float, num_splits: int = 0,
+                           qkv_partial: Optional[Tensor] = None, qkv_splits: int = 0) -> None:
     """Extension: apply_rotary_pos_emb(q, k_new) + set_kv_cache(new_cache_slots, k_new, v_new) +
     mha_varlen_fwd(paged, causal) for an all-decode batch, as ONE launch.  q / k_new / v_new are
     the un-rotated projections [batch, heads, head_dim]; cu_seqlens_k already counts the new
@@ -152,6 +153,14 @@ def decode_attention_fused(out: Tensor, q: Tensor, k_new: Tensor, v_new: Tensor,
     fz.k_new_row_stride, fz.v_new_row_stride = k_new.stride(0), v_new.stride(0)
     fz.positions, fz.cos_sin, fz.new_cache_slots = positions.data_ptr(), cos_sin.data_ptr(), new_cache_slots.data_ptr()
     fz.rotary_dim, fz.interleaved = head_dim, 0
+    if qkv_partial is not None:
+        # q / k_new / v_new are then only shape carriers: the kernel reads the fp32 slabs
+        n_kv = k.size(2)
+        if qkv_partial.dtype != torch.float32 or qkv_partial.numel() < qkv_splits * batch * (n_heads + 2 * n_kv) * head_dim:
+            raise _lib.HydraHipError("decode_attention_fused: qkv_partial must be float32 [splits, batch, (H+2HK)*D]")
+        fz.qkv_partial, fz.qkv_splits = qkv_partial.data_ptr(), int(qkv_splits)
+    else:
+        fz.qkv_partial, fz.qkv_splits = None, 0
     l = _lib.lib()
     need = l.hx_mha_varlen_fwd_workspace_bytes(ctypes.byref(a))
     if need > 0:

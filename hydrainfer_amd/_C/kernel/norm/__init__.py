@@ -2,6 +2,7 @@
 (reference stub: hydrainfer/_C/kernel/norm/__init__.pyi:4-9;
 CUDA original: csrc/kernel/norm/rms_norm.cu:43-63).  bf16 is accepted (extension: the
 reference dispatch, csrc/kernel/dispatch.h:12-28, is fp32/fp16 only)."""
+import torch
 from torch import Tensor
 
 from hydrainfer_amd import _lib
@@ -33,3 +34,20 @@ def add_rms_norm(out: Tensor, residual: Tensor, x: Tensor, weight: Tensor, epsil
     _lib.check(_lib.lib().hx_add_rms_norm(
         out.data_ptr(), residual.data_ptr(), x.data_ptr(), weight.data_ptr(), float(epsilon),
         x.size(0), x.size(1), _lib.dtype_code(x), _lib.current_stream()), "add_rms_norm")
+
+
+def add_rms_norm_slabs(out: Tensor, residual: Tensor, partial: Tensor, n_splits: int, weight: Tensor,
+                       epsilon: float) -> None:
+    """Extension: x = (T) sum of the n_splits fp32 slabs in `partial` ([n_splits, rows, hidden]);
+    residual += x (in place); out = rms_norm(residual).  Bit-identical to reduce + add_rms_norm."""
+    _lib.require_gpu(out, residual, partial, weight)
+    rows, hidden = residual.shape
+    if partial.dtype != torch.float32 or partial.numel() < n_splits * rows * hidden:
+        raise _lib.HydraHipError("add_rms_norm_slabs: partial must be float32 [n_splits, rows, hidden]")
+    for t in (out, residual, weight):
+        if not t.is_contiguous() or t.dtype != residual.dtype:
+            raise _lib.HydraHipError("add_rms_norm_slabs: tensors must be contiguous and of one dtype")
+    _lib.check(_lib.lib().hx_add_rms_norm_slabs(out.data_ptr(), residual.data_ptr(), partial.data_ptr(),
+                                                int(n_splits), weight.data_ptr(), float(epsilon), rows,
+                                                hidden, _lib.dtype_code(residual), _lib.current_stream()),
+               "add_rms_norm_slabs")

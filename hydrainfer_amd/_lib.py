@@ -46,6 +46,7 @@ class hx_fused_decode_args(ctypes.Structure):
         ("k_new", c_void_p), ("v_new", c_void_p), ("k_new_row_stride", c_int64),
         ("v_new_row_stride", c_int64), ("positions", c_void_p), ("cos_sin", c_void_p),
         ("new_cache_slots", c_void_p), ("rotary_dim", c_int32), ("interleaved", c_int32),
+        ("qkv_partial", c_void_p), ("qkv_splits", c_int32),
     ]
 
 
@@ -64,6 +65,9 @@ _SIGNATURES = {
     "hx_silu_and_mul": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_void_p]),
     "hx_linear_decode_workspace_bytes": (c_int64, [c_int64] * 3),
     "hx_linear_decode": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_void_p, c_int64, c_int, c_void_p]),
+    "hx_linear_decode_partial": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_int, c_void_p]),
+    "hx_add_rms_norm_slabs": (c_int, [c_void_p] * 3 + [c_int32, c_void_p, c_float, c_int64, c_int64, c_int, c_void_p]),
+    "hx_silu_and_mul_slabs": (c_int, [c_void_p] * 2 + [c_int32, c_int64, c_int64, c_int, c_void_p]),
     "hx_mha_varlen_fwd_workspace_bytes": (c_int64, [POINTER(hx_attn_args)]),
     "hx_mha_varlen_fwd": (c_int, [POINTER(hx_attn_args), c_void_p]),
     "hx_decode_attention_fused": (c_int, [POINTER(hx_attn_args), POINTER(hx_fused_decode_args), c_void_p]),

@@ -51,6 +51,11 @@ struct AttnParams {
   const int32_t* positions; // [batch] rotary position of the new token
   const void* cos_sin;      // [max_pos, 2, D/2] in T
   const int32_t* new_slots; // [batch] cache slot of the new token
+  // optional: q / k_new / v_new arrive as split-K fp32 slabs of the fused qkv projection
+  const float* qkv_partial; // [n_splits][batch][(n_heads + 2*n_kv_heads) * D]
+  int32_t qkv_splits;
+  int64_t qkv_slab_stride;  // batch * row length
+  int64_t qkv_row;          // (n_heads + 2*n_kv_heads) * D
 };
 
 }  // namespace hx

@@ -44,9 +44,14 @@ template <> struct VRow<256> {
 
 template <int D>
 struct KVTile {
-  u16x8 k[D / 32];                         // A-operand fragments, one per 32-dim step
-  typename VRow<D>::type v[4][VRow<D>::NV];  // keys 4g+i, i = 0..3
+  typename VRow<D>::type k[4][VRow<D>::NV];  // keys 4g+i, i = 0..3: dims [c*D/16, (c+1)*D/16)
+  typename VRow<D>::type v[4][VRow<D>::NV];  // same layout for values
 };
+
+// LDS image of one K tile: [16 keys][2*D bytes + 32] — the +32 makes both the row-wise
+// ds_write (16 lanes x 16 B contiguous) and the A-operand ds_read_b128 (lane (r,g) <- key r,
+// bytes 64s+16g) bank-conflict free.
+template <int D> struct KLds { static constexpr int RS = 2 * D + 32, BYTES = 16 * RS; };
 
 template <bool NT, typename V>
 __device__ __forceinline__ V ld(const V* p) {
@@ -59,13 +64,19 @@ __device__ __forceinline__ void load_tile(KVTile<D>& buf, const AttnParams& p, c
                                           const u16* vbase, int page, int row0, int valid,
                                           int lane) {
   // valid = number of in-range keys in this tile (>= 1; may exceed 16)
-  const int r = lane & 15, g = lane >> 4, c = lane & 15;
-  const int r_eff = min(r, valid - 1);
-  const u16* kp = kbase + (int64_t)page * p.k_block_stride + (int64_t)(row0 + r_eff) * p.k_row_stride +
-                  8 * g;
-#pragma unroll
-  for (int s = 0; s < D / 32; ++s) buf.k[s] = ld<NT>(reinterpret_cast<const u16x8*>(kp + 32 * s));
+  const int g = lane >> 4, c = lane & 15;
   constexpr int E = VRow<D>::E;
+  // every load instruction covers 4 whole key (value) rows of 2*D contiguous bytes: full
+  // cache lines, half the line requests of a fragment-shaped (16 rows x 64 B) load
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tok = min(4 * g + i, valid - 1);
+    const u16* kp = kbase + (int64_t)page * p.k_block_stride + (int64_t)(row0 + tok) * p.k_row_stride +
+                    E * c;
+#pragma unroll
+    for (int n = 0; n < VRow<D>::NV; ++n)
+      buf.k[i][n] = ld<NT>(reinterpret_cast<const typename VRow<D>::type*>(kp + 128 * n));
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int tok = min(4 * g + i, valid - 1);
@@ -112,11 +123,25 @@ __device__ __forceinline__ void rope_frags(u16x8 (&f)[D / 32], const u16* cs, in
 template <typename T, int D>
 __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (&qf)[D / 32],
                                              int valid, float scale_log2, int lane, float& m,
-                                             float& l, float (&o)[D / 16]) {
-  const int g = lane >> 4;
+                                             float& l, float (&o)[D / 16], char* klds) {
+  const int g = lane >> 4, c = lane & 15;
+  constexpr int RS = KLds<D>::RS;
+  // K rows -> wave-private LDS -> MFMA A fragments (key r = lane&15, dims 32s+8g..+8).
+  // DS operations of one wave execute in order, so no barrier is needed.
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int n = 0; n < VRow<D>::NV; ++n)
+      *reinterpret_cast<typename VRow<D>::type*>(klds + (4 * g + i) * RS + 256 * n + 2 * VRow<D>::E * c) =
+          buf.k[i][n];
+  __builtin_amdgcn_wave_barrier();
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int st = 0; st < D / 32; ++st) s = Mfma<T>::mma(buf.k[st], qf[st], s);
+  for (int st = 0; st < D / 32; ++st) {
+    const u16x8 kf = *reinterpret_cast<const u16x8*>(klds + c * RS + 64 * st + 16 * g);
+    s = Mfma<T>::mma(kf, qf[st], s);
+  }
+  __builtin_amdgcn_wave_barrier();
   float x[4];
   float mx = m;
 #pragma unroll
@@ -146,12 +171,16 @@ __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (
     }
 }
 
+// launch bound: 4 workgroups of 4 waves (or 2 of 8) per CU => <= 128 VGPRs for D <= 128; the
+// D = 256 instantiation needs more registers and runs at half that occupancy.
 template <typename T, int D, int NW, bool NT, bool FUSE>
-__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kernel(const AttnParams p) {
   constexpr int OE = D / 16;  // fp32 partial-output elements per lane
   constexpr int NP = NW * 4;  // partial softmax states per workgroup
   __shared__ float s_m[NP], s_l[NP];
   __shared__ float s_o[NP][D];
+  __shared__ __attribute__((aligned(16))) char s_k[NW][KLds<D>::BYTES];
+  __shared__ __attribute__((aligned(16))) u16 s_qkv[FUSE ? 3 : 1][FUSE ? D : 8];
 
   const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
   const int lane = threadIdx.x & 63;
@@ -173,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p
 
   // q as the MFMA B operand, identical in all 16 columns
   u16x8 qf[D / 32];
-  {
+  if (!(FUSE && p.qkv_partial)) {
     const u16* qp = reinterpret_cast<const u16*>(p.q) + (int64_t)q_row * p.q_row_stride +
                     (int64_t)h * D + 8 * g;
 #pragma unroll
@@ -183,11 +212,39 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p
   // FUSE: q and the new token's k arrive un-rotated and the cache does not hold the new token
   // yet.  Rotate both in registers (T arithmetic, same rounding as apply_rotary_pos_emb), use
   // k/v of the new token from registers in its tile, and append them to the cache once.
-  u16x8 kn[D / 32];
+  u16x8 kn[D / 32];                              // rotated new key, fragment layout (RoPE is lane-local there)
+  typename VRow<D>::type knr[VRow<D>::NV];       // the same row in the row layout of KVTile
   typename VRow<D>::type vn[VRow<D>::NV];
   const int t_new = (kv_len - 1) >> 4, r_new = (kv_len - 1) & 15;
   if (FUSE) {
     const u16* cs = reinterpret_cast<const u16*>(p.cos_sin) + (int64_t)p.positions[b] * D;
+    if (p.qkv_partial) {
+      // q, k, v of this token/head straight from the qkv GEMM's split-K slabs: thread d < D adds
+      // the splits of column d in order and rounds once to T (the projection's output
+      // rounding); the three rows are shared through LDS so every slab element is read once
+      // per workgroup.
+      const float* row = p.qkv_partial + (int64_t)b * p.qkv_row;
+      const int64_t col0[3] = {(int64_t)h * D, (int64_t)p.n_heads * D + (int64_t)hk * D,
+                               (int64_t)p.n_heads * D + (int64_t)(p.n_heads / p.group) * D + (int64_t)hk * D};
+      if (threadIdx.x < D) {
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+          const float* src = row + col0[which] + threadIdx.x;
+          float acc = src[0];
+          for (int s = 1; s < p.qkv_splits; ++s) acc += src[s * p.qkv_slab_stride];
+          s_qkv[which][threadIdx.x] = T::from_float(acc);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < D / 32; ++s) {
+        qf[s] = *reinterpret_cast<const u16x8*>(&s_qkv[0][32 * s + 8 * g]);
+        kn[s] = *reinterpret_cast<const u16x8*>(&s_qkv[1][32 * s + 8 * g]);
+      }
+#pragma unroll
+      for (int n = 0; n < VRow<D>::NV; ++n)
+        vn[n] = *reinterpret_cast<const typename VRow<D>::type*>(&s_qkv[2][128 * n + VRow<D>::E * c]);
+    } else {
     const u16* kp = reinterpret_cast<const u16*>(p.k_new) + (int64_t)b * p.kn_row_stride +
                     (int64_t)hk * D + 8 * g;
 #pragma unroll
@@ -197,8 +254,19 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p
 #pragma unroll
     for (int n = 0; n < VRow<D>::NV; ++n)
       vn[n] = *reinterpret_cast<const typename VRow<D>::type*>(vp + 128 * n);
+    }
     rope_frags<T, D>(qf, cs, g);
     rope_frags<T, D>(kn, cs, g);
+    // fragment layout -> row layout through one row of this wave's LDS region
+    if (c == 0) {
+#pragma unroll
+      for (int s = 0; s < D / 32; ++s) *reinterpret_cast<u16x8*>(s_k[w] + 64 * s + 16 * g) = kn[s];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int n = 0; n < VRow<D>::NV; ++n)
+      knr[n] = *reinterpret_cast<const typename VRow<D>::type*>(s_k[w] + 256 * n + 2 * VRow<D>::E * c);
+    __builtin_amdgcn_wave_barrier();
     // one writer per kv head and per split set: the first q head of the group, split 0, wave 0
     if (h == hk * p.group && split == 0 && w == 0) {
       const int slot = p.new_slots[b];
@@ -218,15 +286,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p
   }
   auto patch = [&](KVTile<D>& buf, int t) {
     if (FUSE && t == t_new) {     // wave-uniform
-      if ((lane & 15) == r_new) {
-#pragma unroll
-        for (int s = 0; s < D / 32; ++s) buf.k[s] = kn[s];
-      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (4 * g + i == r_new) {
 #pragma unroll
-          for (int n = 0; n < VRow<D>::NV; ++n) buf.v[i][n] = vn[n];
+          for (int n = 0; n < VRow<D>::NV; ++n) {
+            buf.k[i][n] = knr[n];
+            buf.v[i][n] = vn[n];
+          }
         }
     }
   };
@@ -259,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p
                         (t % tpp) << 4, kv_len - (t << 4), lane);
       }
       patch(bufA, chunk0 + NW * j);
-      compute_tile<T, D>(bufA, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o);
+      compute_tile<T, D>(bufA, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o, s_k[w]);
       ++j;
       if (j >= n_my) break;
       if (j + 1 < n_my) {
@@ -268,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const AttnParams p
                         (t % tpp) << 4, kv_len - (t << 4), lane);
       }
       patch(bufB, chunk0 + NW * j);
-      compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o);
+      compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o, s_k[w]);
       ++j;
     }
   }
@@ -338,7 +405,7 @@ int g_decode_nt = 1;   // K/V are read once: non-temporal loads measured +4 % (p
 template <typename T, int D>
 int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
   dim3 grid(p.n_heads, batch, p.n_splits);
-  if (p.k_new) {
+  if (p.k_new || p.qkv_partial) {
     attn_decode_kernel<T, D, 4, true, true><<<grid, 256, 0, stream>>>(p);
   } else if (g_decode_waves == 8) {
     if (g_decode_nt) attn_decode_kernel<T, D, 8, true, false><<<grid, 512, 0, stream>>>(p);

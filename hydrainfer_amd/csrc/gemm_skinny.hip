@@ -8,9 +8,11 @@
 //   * grid = (N tiles, K splits); 8 waves per workgroup.  The workgroup's slice of x
 //     ([M_pad][<=1024 k], <= 66 KB) is staged ONCE into LDS (row stride KR*2+32 B: the
 //     ds_read_b128 of the B fragments is bank-conflict free), then never touched again.
-//   * each wave streams whole 16-row groups of W straight HBM -> VGPR in the MFMA A-operand
-//     layout (lane (r,g) <- W[n0+r][k0+8g..+8], 16 B), 8 k-steps (8 KiB) per chunk,
-//     register double-buffered across chunk AND row-group boundaries; non-temporal loads.
+//   * each wave streams whole 16-row groups of W HBM -> VGPR with FULL-LINE loads (one
+//     instruction = 8 rows x 128 B; a fragment-shaped 16 rows x 64 B load issues twice the line
+//     requests and measured ~20 % slower), 16 k-steps (16 KiB) per register buffer, two buffers
+//     in flight, non-temporal.  Each 2-k-step column block is transposed into the MFMA
+//     A-operand layout through a 2 KiB wave-private, XOR-swizzled LDS image.
 //   * MFMA 16x16x32: A = W fragment, B = x^T fragment from LDS (one per 16 batch rows), so a
 //     weight fragment is used for M/16 MFMAs; the accumulator holds out^T[n][m].
 //   * K is split across workgroups (<= 1024 k each) to have >= 2 workgroups per CU in flight;
@@ -77,17 +79,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
     }
   }
 
-  // ---- 2. W prefetch
-  const u16* wb = reinterpret_cast<const u16*>(p.w) + (int64_t)ks0 * 32 + 8 * g;
+  // ---- 2. W prefetch.  Load layout: instruction j of a chunk covers rows 8*(j&1) + (lane>>3)
+  // and the 128-byte column block j>>1 (2 k-steps); lane&7 selects the 16-byte piece.
+  const int lrow = lane >> 3, lpiece = lane & 7;
+  const u16* wb = reinterpret_cast<const u16*>(p.w) + (int64_t)ks0 * 32 + 8 * lpiece;
   auto load = [&](u16x8 (&buf)[kChunk], int it) {
     const int rgi = it >> 1, ch = it & 1;
     const int n0 = min(rg0 + rgi * NW, n_rg_all - 1) << 4;
-    const int last = nks - 1 - ch * kChunk;   // k-steps past the range re-read a valid one
-    const u16* wp = wb + (int64_t)(n0 + r) * p.ldw + ch * (kChunk * 32);
+    const int last_cb = ((nks - ch * kChunk) >> 1) - 1;   // column blocks past the range re-read a valid one
+    const u16* wp = wb + (int64_t)(n0 + lrow) * p.ldw + ch * (kChunk * 32);
 #pragma unroll
-    for (int s = 0; s < kChunk; ++s)
-      buf[s] = __builtin_nontemporal_load(
-          reinterpret_cast<const u16x8*>(wp + 32 * max(min(s, last), -ch * kChunk)));
+    for (int j = 0; j < kChunk; ++j) {
+      const int cb = max(min(j >> 1, last_cb), -ch * (kChunk / 2));
+      buf[j] = __builtin_nontemporal_load(
+          reinterpret_cast<const u16x8*>(wp + (int64_t)(8 * (j & 1)) * p.ldw + 64 * cb));
+    }
   };
   u16x8 buf[2][kChunk];
   load(buf[0], 0);
@@ -106,6 +112,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
   }
   __syncthreads();
 
+  // wave-private transpose image: [16 rows][128 B], 16-byte slot s of row r stored at slot
+  // s ^ ((r >> 1) & 7): row writes (8 lanes x 16 B per row, two rows per 16-lane group) and
+  // A-fragment reads (lane (r,g) <- row r, slot 4*st+g) are both bank-conflict free.
+  char* tl = smem + MB * 16 * kRS + w * 2048;
+  const int wr_off0 = lrow * 128 + 16 * (lpiece ^ ((lrow >> 1) & 7));
+  const int wr_off1 = (lrow + 8) * 128 + 16 * (lpiece ^ (((lrow + 8) >> 1) & 7));
   const char* xl = smem + c * kRS + g * 16;
   f32x4 acc[MB];
 #pragma unroll
@@ -116,12 +128,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
     const int rgi = it >> 1, ch = it & 1;
     const char* xp = xl + ch * (kChunk * 64);
 #pragma unroll
-    for (int s = 0; s < kChunk; ++s) {
+    for (int cb = 0; cb < kChunk / 2; ++cb) {
+      *reinterpret_cast<u16x8*>(tl + wr_off0) = buf[it & 1][2 * cb];
+      *reinterpret_cast<u16x8*>(tl + wr_off1) = buf[it & 1][2 * cb + 1];
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const u16x8 xf = *reinterpret_cast<const u16x8*>(xp + mb * 16 * kRS + s * 64);
-        acc[mb] = Mfma<T>::mma(buf[it & 1][s], xf, acc[mb]);
+      for (int st = 0; st < 2; ++st) {
+        const u16x8 af = *reinterpret_cast<const u16x8*>(tl + r * 128 + 16 * ((4 * st + g) ^ ((r >> 1) & 7)));
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const u16x8 xf = *reinterpret_cast<const u16x8*>(xp + mb * 16 * kRS + (2 * cb + st) * 64);
+          acc[mb] = Mfma<T>::mma(af, xf, acc[mb]);
+        }
       }
+      __builtin_amdgcn_wave_barrier();
     }
     if (it + 2 < 2 * R) load(buf[it & 1], it + 2);
     if (ch == 1) {
@@ -178,7 +198,7 @@ int gemm_skinny_splits(int64_t K) {
 
 template <typename T, int MB, int R, int NW>
 int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)MB * 16 * kRS;
+  const size_t lds = (size_t)MB * 16 * kRS + (size_t)NW * 2048;   // x slice + per-wave transpose images
   const int n_rg = p.N >> 4;
   dim3 grid((unsigned)((n_rg + NW * R - 1) / (NW * R)), (unsigned)p.n_splits);
   if (lds > 48 * 1024) {
@@ -276,4 +296,19 @@ extern "C" int hx_linear_decode(void* out, const void* x, const void* weight, in
   int rc = launch_gemm_skinny(x, weight, (float*)workspace, M, N, K, ldx, ldw, dtype, s);
   if (rc) return rc;
   return launch_slab_reduce((const float*)workspace, out, M, N, ldo, gemm_skinny_splits(K), dtype, s);
+}
+
+// GEMM only: leaves the split-K slabs for a fused consumer (hx_add_rms_norm_slabs,
+// hx_silu_and_mul_slabs, hx_decode_attention_fused).  Returns the number of slabs (>= 1) or a
+// negative status.
+extern "C" int hx_linear_decode_partial(float* partial, const void* x, const void* weight,
+                                        int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                                        int64_t partial_bytes, int dtype, hx_stream stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return HX_ERR_SHAPE;
+  if (!partial || !x || !weight) return HX_ERR_NULL;
+  if (!gemm_skinny_supported(M, N, K, ldx, ldw)) return HX_ERR_SHAPE;
+  if (partial_bytes < hx_linear_decode_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
+  int rc = launch_gemm_skinny(x, weight, partial, M, N, K, ldx, ldw, dtype, (hipStream_t)stream);
+  if (rc) return rc;
+  return gemm_skinny_splits(K);
 }

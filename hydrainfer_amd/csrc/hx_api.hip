@@ -106,12 +106,18 @@ extern "C" int hx_mha_varlen_fwd(const hx_attn_args* a, hx_stream stream) {
 extern "C" int hx_decode_attention_fused(const hx_attn_args* a, const hx_fused_decode_args* f,
                                          hx_stream stream) {
   if (!a || !f) return HX_ERR_NULL;
-  if (!f->k_new || !f->v_new || !f->positions || !f->cos_sin || !f->new_cache_slots)
+  if (!f->positions || !f->cos_sin || !f->new_cache_slots) return HX_ERR_NULL;
+  if (f->qkv_partial) {
+    if (f->qkv_splits < 1 || !aligned16(f->qkv_partial)) return HX_ERR_SHAPE;
+    if (a->total_q != a->batch) return HX_ERR_SHAPE;   // slab row b belongs to sequence b
+  } else if (!f->k_new || !f->v_new) {
     return HX_ERR_NULL;
+  }
   if (!use_decode(a)) return HX_ERR_SHAPE;           // q_len == 1 per sequence, paged cache
   if (f->rotary_dim != a->head_dim || f->interleaved) return HX_ERR_UNSUPPORTED;
-  if (f->k_new_row_stride % 8 || f->v_new_row_stride % 8 || !aligned16(f->k_new) ||
-      !aligned16(f->v_new) || !aligned16(f->cos_sin))
+  if (!aligned16(f->cos_sin)) return HX_ERR_STRIDE;
+  if (!f->qkv_partial && (f->k_new_row_stride % 8 || f->v_new_row_stride % 8 ||
+                          !aligned16(f->k_new) || !aligned16(f->v_new)))
     return HX_ERR_STRIDE;
   if (a->k_head_stride != a->head_dim || a->v_head_stride != a->head_dim) return HX_ERR_STRIDE;
   return attn_dispatch(a, f, stream);
@@ -153,7 +159,16 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.positions = nullptr;
   p.cos_sin = nullptr;
   p.new_slots = nullptr;
+  p.qkv_partial = nullptr;
+  p.qkv_splits = 0;
+  p.qkv_slab_stride = p.qkv_row = 0;
   if (fused) {
+    if (fused->qkv_partial) {
+      p.qkv_partial = fused->qkv_partial;
+      p.qkv_splits = fused->qkv_splits;
+      p.qkv_row = (int64_t)(a->n_heads + 2 * a->n_kv_heads) * a->head_dim;
+      p.qkv_slab_stride = (int64_t)a->batch * p.qkv_row;
+    }
     p.k_new = fused->k_new;
     p.v_new = fused->v_new;
     p.kn_row_stride = fused->k_new_row_stride;

@@ -367,6 +367,100 @@ __global__ __launch_bounds__(256) void silu_elem_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Split-K slab consumers (SURVEY.md §8f-2 + csrc/gemm_skinny.hip): the decode GEMM leaves
+// fp32 partial sums partial[s][row][col]; these kernels add the splits in a fixed order,
+// round ONCE to T (= the GEMM's output rounding) and continue exactly like their plain
+// counterparts — so results are bit-identical to "reduce, then op".
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void slab_sum8(const float* __restrict__ p, int n_splits,
+                                          int64_t slab_stride, float (&acc)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  for (int s = 1; s < n_splits; ++s) {
+    a += *reinterpret_cast<const f32x4*>(p + s * slab_stride);
+    b += *reinterpret_cast<const f32x4*>(p + s * slab_stride + 4);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    acc[e] = round_to<T>(a[e]);
+    acc[4 + e] = round_to<T>(b[e]);
+  }
+}
+
+template <typename T, int MAXV, int NT>
+__global__ __launch_bounds__(NT) void add_rms_norm_slab_kernel(
+    u16* __restrict__ out, u16* __restrict__ residual, const float* __restrict__ partial,
+    int n_splits, int64_t slab_stride, const u16* __restrict__ weight, float eps, int32_t hidden) {
+  __shared__ float red[NT / 64];
+  const int64_t row = blockIdx.x;
+  const int nvec = hidden / 8;
+  u16x8* res_v = reinterpret_cast<u16x8*>(residual + row * hidden);
+  u16x8* out_v = reinterpret_cast<u16x8*>(out + row * hidden);
+  const u16x8* w_v = reinterpret_cast<const u16x8*>(weight);
+  float x[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = threadIdx.x + j * NT;
+    if (i < nvec) {
+      float a[8];
+      slab_sum8<T>(partial + row * hidden + i * 8, n_splits, slab_stride, a);
+      const u16x8 r = res_v[i];
+      u16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sum = round_to<T>(a[e] + T::to_float(r[e]));
+        x[j][e] = sum;
+        h[e] = T::from_float(sum);
+        ss += sum * sum;
+      }
+      res_v[i] = h;
+    }
+  }
+  // block reduction over NT threads
+  float tsum = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tsum;
+  __syncthreads();
+  float total = 0.f;
+#pragma unroll
+  for (int k = 0; k < NT / 64; ++k) total += red[k];
+  const float inv = rsqrtf(total / (float)hidden + eps);
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = threadIdx.x + j * NT;
+    if (i < nvec) {
+      const u16x8 w = w_v[i];
+      u16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = T::from_float(round_to<T>(x[j][e] * inv) * T::to_float(w[e]));
+      out_v[i] = o;
+    }
+  }
+}
+
+// out[row][i] = (T)silu(gate) * up, gate = col i, up = col inter + i of the [rows, 2*inter] slabs
+template <typename T>
+__global__ __launch_bounds__(256) void silu_mul_slab_kernel(u16* __restrict__ out,
+                                                            const float* __restrict__ partial,
+                                                            int n_splits, int64_t slab_stride,
+                                                            int32_t inter) {
+  const int64_t row = blockIdx.y;
+  const int nvec = inter / 8;
+  const float* base = partial + row * 2 * inter;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+    float gte[8], up[8];
+    slab_sum8<T>(base + i * 8, n_splits, slab_stride, gte);
+    slab_sum8<T>(base + inter + i * 8, n_splits, slab_stride, up);
+    u16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = T::from_float(round_to<T>(silu_f32(gte[e])) * up[e]);
+    *reinterpret_cast<u16x8*>(out + row * inter + i * 8) = r;
+  }
+}
+
 template <typename T, bool MUL>
 int launch_silu(void* out, const void* gate, const void* up, int64_t rows, int64_t n,
                 int64_t gate_stride, int64_t up_stride, hipStream_t stream) {
@@ -529,5 +623,56 @@ extern "C" int hx_rope_set_kv_cache(void* query, void* key, const void* value,
     default: return HX_ERR_DTYPE;
   }
 #undef HX_RC
+  return check_launch();
+}
+
+extern "C" int hx_add_rms_norm_slabs(void* out, void* residual, const float* partial,
+                                     int32_t n_splits, const void* weight, float epsilon,
+                                     int64_t rows, int64_t hidden, int dtype, hx_stream stream) {
+  if (rows < 0 || hidden <= 0 || n_splits < 1) return HX_ERR_SHAPE;
+  if (rows == 0) return HX_OK;
+  if (!out || !residual || !partial || !weight) return HX_ERR_NULL;
+  if (hidden % 8 || hidden / 8 > 2048) return HX_ERR_SHAPE;
+  if (!aligned16(out) || !aligned16(residual) || !aligned16(partial) || !aligned16(weight))
+    return HX_ERR_STRIDE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t stride = rows * hidden;
+  dim3 grid((unsigned)rows);
+  // 512 threads: one 8-element vector (and its n_splits fp32 slab pieces) per thread up to
+  // hidden = 4096 — the kernel is latency-bound on 32 rows, so more loads in flight per row win
+#define HX_L(TT, MV)                                                                             \
+  add_rms_norm_slab_kernel<TT, MV, 512><<<grid, 512, 0, s>>>((u16*)out, (u16*)residual, partial, \
+                                                            n_splits, stride, (const u16*)weight, \
+                                                            epsilon, (int)hidden)
+  const int mv = (int)((hidden / 8 + 511) / 512);
+  if (dtype == HX_F16) {
+    if (mv <= 1) HX_L(F16, 1); else if (mv <= 2) HX_L(F16, 2); else HX_L(F16, 4);
+  } else if (dtype == HX_BF16) {
+    if (mv <= 1) HX_L(BF16, 1); else if (mv <= 2) HX_L(BF16, 2); else HX_L(BF16, 4);
+  } else {
+    return HX_ERR_DTYPE;
+  }
+#undef HX_L
+  return check_launch();
+}
+
+extern "C" int hx_silu_and_mul_slabs(void* out, const float* partial, int32_t n_splits,
+                                     int64_t rows, int64_t inter, int dtype, hx_stream stream) {
+  if (rows < 0 || inter <= 0 || n_splits < 1) return HX_ERR_SHAPE;
+  if (rows == 0) return HX_OK;
+  if (!out || !partial) return HX_ERR_NULL;
+  if (inter % 8 || rows > 65535) return HX_ERR_SHAPE;
+  if (!aligned16(out) || !aligned16(partial)) return HX_ERR_STRIDE;
+  hipStream_t s = (hipStream_t)stream;
+  int gx = (int)((inter / 8 + 255) / 256);
+  if (gx > 64) gx = 64;
+  dim3 grid(gx, (unsigned)rows);
+  const int64_t stride = rows * 2 * inter;
+  if (dtype == HX_F16)
+    silu_mul_slab_kernel<F16><<<grid, 256, 0, s>>>((u16*)out, partial, n_splits, stride, (int)inter);
+  else if (dtype == HX_BF16)
+    silu_mul_slab_kernel<BF16><<<grid, 256, 0, s>>>((u16*)out, partial, n_splits, stride, (int)inter);
+  else
+    return HX_ERR_DTYPE;
   return check_launch();
 }

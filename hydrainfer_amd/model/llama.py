@@ -17,8 +17,8 @@ from typing import Dict, List, Optional
 import torch
 from torch import Tensor
 
-from hydrainfer_amd._C.kernel.activation import silu_and_mul
-from hydrainfer_amd._C.kernel.norm import add_rms_norm, rms_norm
+from hydrainfer_amd._C.kernel.activation import silu_and_mul, silu_and_mul_slabs
+from hydrainfer_amd._C.kernel.norm import add_rms_norm, add_rms_norm_slabs, rms_norm
 from hydrainfer_amd._C.kernel.position_embedding import rope_set_kv_cache
 from hydrainfer_amd.layer.causal_attention import AttentionParameters
 from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
@@ -72,7 +72,7 @@ class LlamaForCausalLM:
         self.kv_size = shape.num_key_value_heads * shape.head_dim
         # decode batches (<= 64 rows) stream the weights through the HIP kernel; larger
         # batches (prefill) use the library GEMM
-        self.use_hip_gemm = False
+        self.use_hip_gemm = True
         # decode steps: RoPE + cache append + attention as one launch
         self.fuse_decode_attention = shape.head_dim in (64, 128, 256)
 
@@ -153,6 +153,40 @@ class LlamaForCausalLM:
     def embed(self, input_ids: Tensor) -> Tensor:
         return torch.nn.functional.embedding(input_ids, self.state["embed"])
 
+    def _decode_hidden_hip_gemm(self, h: Tensor, position_ids: Tensor,
+                                model_params: LanguageModelParameters) -> Tensor:
+        """All-decode step with the weight-streaming HIP GEMMs and fused slab consumers: 8
+        launches per layer — qkv GEMM, [slab reduce + RoPE + cache append + attention], o GEMM,
+        [slab reduce + residual add + RMSNorm], gate|up GEMM, [slab reduce + silu*mul], down GEMM,
+        [slab reduce + residual add + RMSNorm].  Same rounding points as the unfused path."""
+        sh, st = self.shape, self.state
+        n = h.shape[0]
+        H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
+        q_size, kv_size, inter, hid = self.q_size, self.kv_size, sh.intermediate_size, sh.hidden_size
+        eps, L = sh.rms_norm_eps, sh.num_hidden_layers
+        ws_n = max(hip_gemm.workspace_floats(n, q_size + 2 * kv_size, hid), hip_gemm.workspace_floats(n, hid, q_size),
+                   hip_gemm.workspace_floats(n, 2 * inter, hid), hip_gemm.workspace_floats(n, hid, inter))
+        ws = torch.empty(ws_n, dtype=torch.float32, device=h.device)
+        x = torch.empty_like(h)
+        rms_norm(x, h, st["l0.norm1"], eps)
+        for l in range(L):
+            ap = model_params.attention_params[l]
+            kc, vc = ap.kv_cache.get_kv_cache()
+            s_qkv = hip_gemm.linear_decode_partial(x, st[f"l{l}.wqkv"], ws)
+            o = torch.empty((n, H, D), dtype=h.dtype, device=h.device)
+            # q / k_new / v_new arguments are shape carriers here: the kernel reads the slabs
+            decode_attention_fused(o, o, o[:, :HK], o[:, :HK], kc, vc, position_ids, self.cos_sin,
+                                   ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
+                                   ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws, s_qkv)
+            s_o = hip_gemm.linear_decode_partial(o.view(n, q_size), st[f"l{l}.wo"], ws)
+            add_rms_norm_slabs(x, h, ws, s_o, st[f"l{l}.norm2"], eps)
+            s_gu = hip_gemm.linear_decode_partial(x, st[f"l{l}.wgu"], ws)
+            act = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype)
+            s_dn = hip_gemm.linear_decode_partial(act, st[f"l{l}.wdown"], ws)
+            nxt = st[f"l{l + 1}.norm1"] if l + 1 < L else st["norm"]
+            add_rms_norm_slabs(x, h, ws, s_dn, nxt, eps)
+        return x
+
     def forward_hidden(self, input_ids_or_embeds: Tensor, position_ids: Tensor,
                        model_params: LanguageModelParameters) -> Tensor:
         sh, st = self.shape, self.state
@@ -163,6 +197,10 @@ class LlamaForCausalLM:
         if not h.is_contiguous():
             h = h.contiguous()
         n = h.shape[0]
+        if (self.use_hip_gemm and model_params.all_sequences_decode and self.fuse_decode_attention
+                and n <= 64 and h.dtype in (torch.float16, torch.bfloat16)
+                and sh.hidden_size % 256 == 0 and sh.intermediate_size % 256 == 0):
+            return self._decode_hidden_hip_gemm(h, position_ids, model_params)
         H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
         q_size, kv_size, inter = self.q_size, self.kv_size, sh.intermediate_size
         eps = sh.rms_norm_eps
@@ -207,8 +245,8 @@ class LlamaForCausalLM:
         return x
 
     def forward_logits(self, input_ids_or_embeds, position_ids, model_params) -> Tensor:
-        return self.linear(self.forward_hidden(input_ids_or_embeds, position_ids, model_params),
-                           self.state["lm_head"])
+        return torch.matmul(self.forward_hidden(input_ids_or_embeds, position_ids, model_params),
+                            self.state["lm_head"].t())
 
     def forward(self, input_ids_or_embeds, position_ids, model_params) -> Tensor:
         """Returns sampled token ids (greedy), like the reference model."""

@@ -141,6 +141,19 @@ int64_t hx_linear_decode_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int hx_linear_decode(void* out, const void* x, const void* weight, int64_t M, int64_t N,
                      int64_t K, int64_t ldx, int64_t ldw, int64_t ldo, void* workspace,
                      int64_t workspace_bytes, int dtype, hx_stream stream);
+/* Same GEMM, but the fp32 split-K slabs partial[s][M][N] are left for a fused consumer.
+ * Returns the number of slabs (>= 1) or a negative hx_status. */
+int hx_linear_decode_partial(float* partial, const void* x, const void* weight, int64_t M,
+                             int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                             int64_t partial_bytes, int dtype, hx_stream stream);
+/* Slab consumers: sum the n_splits slabs in order, round once to T (the projection's output
+ * rounding), then behave exactly like hx_add_rms_norm / hx_silu_and_mul on that tensor.
+ * partial: [n_splits][rows][hidden] resp. [n_splits][rows][2*inter] (gate | up columns). */
+int hx_add_rms_norm_slabs(void* out, void* residual, const float* partial, int32_t n_splits,
+                          const void* weight, float epsilon, int64_t rows, int64_t hidden,
+                          int dtype, hx_stream stream);
+int hx_silu_and_mul_slabs(void* out, const float* partial, int32_t n_splits, int64_t rows,
+                          int64_t inter, int dtype, hx_stream stream);
 
 /* ------------------------------------------------------------------------
  * Variable-length attention forward, dense or paged.
@@ -212,6 +225,11 @@ typedef struct hx_fused_decode_args {
   const int32_t* new_cache_slots; /* [batch] */
   int32_t rotary_dim;
   int32_t interleaved;
+  /* optional: take q / k_new / v_new from the split-K slabs of the fused qkv projection
+   * ([qkv_splits][batch][(n_heads + 2*n_kv_heads) * head_dim] fp32, hx_linear_decode_partial);
+   * args->q, k_new, v_new are then ignored */
+  const float* qkv_partial;
+  int32_t qkv_splits;
 } hx_fused_decode_args;
 int hx_decode_attention_fused(const hx_attn_args* args, const hx_fused_decode_args* fused,
                               hx_stream stream);

@@ -269,3 +269,39 @@ def test_fused_rope_cache_decode_attention_is_bit_identical(dt, heads, D):
         assert torch.equal(oa, ob), f"output differs (splits={splits})"
         assert torch.equal(kca, kcb) and torch.equal(vca, vcb), "cache differs"
         assert torch.equal(qb, dev(q)) and torch.equal(kb, dev(k_new))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_fused_attention_from_qkv_slabs_is_bit_identical(dt):
+    """decode_attention_fused reading q/k/v from the qkv GEMM's split-K slabs == reducing the
+    slabs to T first and calling it with tensors."""
+    from hydrainfer_amd._C.kernel import gemm
+    from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused
+    from oracle import ops
+    H = HK = 8
+    D, hid, bs = 128, 1024, 16
+    kv_lens = [5, 16, 17, 300, 64, 1]
+    B = len(kv_lens)
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(B, H, HK, D, kv_lens, [1] * B, dt, seed=21)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((B, hid), generator=g).to(dt).to(DEV)
+    wqkv = (torch.randn(((H + 2 * HK) * D, hid), generator=g) * 0.05).to(dt).to(DEV)
+    pos = torch.tensor([l - 1 for l in kv_lens], dtype=torch.int32, device=DEV)
+    cs = ops.build_cos_sin_cache(D, 4096, 1e4, dt).to(DEV)
+    slots = torch.tensor([int(bt[int(cu_b[i]) + (l - 1) // bs]) * bs + (l - 1) % bs
+                          for i, l in enumerate(kv_lens)], dtype=torch.int32, device=DEV)
+    dev = lambda t: t.to(DEV)
+    qkv = gemm.linear_decode(x, wqkv)
+    qa = qkv[:, :H * D].view(B, H, D); ka = qkv[:, H * D:(H + HK) * D].view(B, HK, D); va = qkv[:, (H + HK) * D:].view(B, HK, D)
+    kca, vca = dev(kc).clone(), dev(vc).clone()
+    oa = torch.empty((B, H, D), dtype=dt, device=DEV)
+    decode_attention_fused(oa, qa, ka, va, kca, vca, pos, cs, slots, dev(cu_q), dev(cu_k), dev(bt), dev(cu_b),
+                           max(kv_lens), 1 / math.sqrt(D))
+    ws = torch.empty(gemm.workspace_floats(B, (H + 2 * HK) * D, hid), dtype=torch.float32, device=DEV)
+    s = gemm.linear_decode_partial(x, wqkv, ws)
+    kcb, vcb = dev(kc).clone(), dev(vc).clone()
+    ob = torch.empty_like(oa)
+    decode_attention_fused(ob, ob, ob[:, :HK], ob[:, :HK], kcb, vcb, pos, cs, slots, dev(cu_q), dev(cu_k), dev(bt),
+                           dev(cu_b), max(kv_lens), 1 / math.sqrt(D), 0, ws, s)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob) and torch.equal(kca, kcb) and torch.equal(vca, vcb)

@@ -189,3 +189,51 @@ def test_rope_set_kv_cache_equals_two_ops():
         qb, kb, vb = view(b)
         pe.rope_set_kv_cache(qb, kb, vb, pos, cs, D, slots, kc2, vc2)
         assert torch.equal(a, b) and torch.equal(kc, kc2) and torch.equal(vc, vc2)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 7, 32, 33, 64])
+def test_linear_decode_matches_fp32_reference(dt, M):
+    """Weight-streaming decode GEMM vs an fp32 matmul of the same T inputs (fp32 accumulation in
+    both; only the summation order differs): within 1 ulp of T almost everywhere."""
+    from hydrainfer_amd._C.kernel.gemm import linear_decode
+    for (N, K) in ((4096, 4096), (12288, 4096), (4096, 11008), (22016, 4096), (48, 256), (5120 * 3, 5120)):
+        g = torch.Generator().manual_seed(N + K + M)
+        x = torch.randn((M, K), generator=g).to(dt)
+        w = (torch.randn((N, K), generator=g) * 0.02).to(dt)
+        got = linear_decode(x.to(DEV), w.to(DEV)).cpu()
+        ref = (x.double() @ w.double().t())
+        err = (got.double() - ref).abs()
+        tol = (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * ref.abs().clamp_min(0.05)
+        assert (err <= tol).all(), f"N={N} K={K} M={M} {dt}: max err {err.max()}"
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_slab_consumers_equal_reduce_then_op(dt):
+    """add_rms_norm_slabs / silu_and_mul_slabs == (linear_decode -> T) followed by the plain op."""
+    from hydrainfer_amd._C.kernel import activation, gemm, norm
+    M, hid, inter = 32, 4096, 11008
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((M, hid), generator=g).to(dt).to(DEV)
+    res = torch.randn((M, hid), generator=g).to(dt).to(DEV)
+    w_o = (torch.randn((hid, hid), generator=g) * 0.02).to(dt).to(DEV)
+    w_gu = (torch.randn((2 * inter, hid), generator=g) * 0.02).to(dt).to(DEV)
+    w_n = (1 + 0.1 * torch.randn(hid, generator=g)).to(dt).to(DEV)
+    ws = torch.empty(gemm.workspace_floats(M, 2 * inter, hid), dtype=torch.float32, device=DEV)
+    # o-projection -> residual add + norm
+    a = gemm.linear_decode(x, w_o)
+    want_res = res.clone(); want = torch.empty_like(a)
+    norm.add_rms_norm(want, want_res, a, w_n, 1e-5)
+    s = gemm.linear_decode_partial(x, w_o, ws)
+    got_res = res.clone(); got = torch.empty_like(a)
+    norm.add_rms_norm_slabs(got, got_res, ws, s, w_n, 1e-5)
+    assert torch.equal(got_res, want_res)          # residual stream: bit-identical
+    # the row statistic is reduced by 512 threads instead of 256 (different fp32 summation
+    # order): the normalised output may differ in the last place of T on a few elements
+    assert_ulp_close(got.cpu(), want.cpu(), max_ulp=1, min_exact_frac=0.99, what="add_rms_norm_slabs")
+    # gate|up projection -> silu * mul
+    gu = gemm.linear_decode(x, w_gu)
+    want = activation.silu_and_mul(gu[:, :inter], gu[:, inter:])
+    s = gemm.linear_decode_partial(x, w_gu, ws)
+    got = activation.silu_and_mul_slabs(ws, s, M, inter, dt)
+    assert torch.equal(got, want)
