@@ -3,9 +3,11 @@
 
 A "step" = one batched decode step of a LLaVA-1.5-7B-shaped language model (random weights,
 SURVEY.md §8d) for 32 concurrent requests (576 image + 128 text prompt tokens each) on ONE
-MI355X: embed -> 32 x [rms_norm, qkv GEMM, RoPE, set_kv_cache, paged decode attention,
-o GEMM, add+rms_norm, gate|up GEMM, silu*mul, down GEMM] -> norm -> lm_head -> argmax.
-GEMMs are library GEMMs (hipBLASLt via torch); every other op is libhydra_hip.  The KV
+MI355X: embed -> 32 x [qkv GEMM, (RoPE + set_kv_cache + paged decode attention), o GEMM,
+(residual add + rms_norm), gate|up GEMM, silu*mul, down GEMM, (residual add + rms_norm)]
+-> lm_head -> argmax.  Every per-layer launch is libhydra_hip (decode GEMMs: the
+weight-streaming HIP kernel; --lib-gemm switches them to hipBLASLt); prefill GEMMs and lm_head
+are library GEMMs.  The KV
 context starts at the prompt (704 cached tokens) and grows by one per step exactly as in a
 real generation, so K steps cover contexts 705..704+K (K=255 = the whole 256-token
 generation).  Inputs (weights, KV cache, metadata) are resident in HBM before the timed region.
@@ -92,6 +94,14 @@ def time_attention_kernel(runner, start_len, steps):
     evs = []
     scale = 1.0 / math.sqrt(D)
     fused = runner.model.fuse_decode_attention
+    # with the HIP decode GEMMs the graph runs the variant that also reduces the qkv split-K slabs
+    slabs, n_slabs = None, 0
+    if fused and runner.model.use_hip_gemm and B <= 64:
+        from hydrainfer_amd._C.kernel import gemm as hip_gemm
+        x = rnd(B, sh.hidden_size)
+        slabs = torch.empty(hip_gemm.workspace_floats(B, (H + 2 * HK) * D, sh.hidden_size),
+                            dtype=torch.float32, device=runner.dev)
+        n_slabs = hip_gemm.linear_decode_partial(x, runner.model.state["l0.wqkv"], slabs)
     for s in range(steps + 2):
         runner._advance()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -99,7 +109,7 @@ def time_attention_kernel(runner, start_len, steps):
         if fused:
             decode_attention_fused(out, q, k_new, v_new, kc, vc, runner.positions, runner.model.cos_sin,
                                    ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens,
-                                   ap.block_tables, ap.cu_blocks_lens, runner.max_len, scale)
+                                   ap.block_tables, ap.cu_blocks_lens, runner.max_len, scale, 0, slabs, n_slabs)
         else:
             mha_varlen_fwd(out, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
                            ap.cu_blocks_lens, None, 1, runner.max_len, scale, 0.0, -1, 0, 0)
@@ -369,8 +379,9 @@ def main():
                        "generated_tokens": n_generate, "hip_graph": cfg.use_graph,
                        "parallelism": f"replicas x{n_gpus} (independent requests, no data-path collective)"},
             "roofline": {"bound": "hbm",
-                         "kernel": "attn_decode_kernel<BF16,128,4,nt,fused> (RoPE + cache append + paged decode attention)"
-                                   if model.fuse_decode_attention else "attn_decode_kernel (paged decode attention)",
+                         "kernel": "attn_decode_kernel<BF16,128,4,nt,fused> (qkv split-K reduce + RoPE + cache append "
+                                   "+ paged decode attention)" if model.fuse_decode_attention else
+                                   "attn_decode_kernel (paged decode attention)",
                          "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, model_name),
                          "avg_launch_us": round(attn_ms * 1e3, 2),

@@ -200,6 +200,20 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
   const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
 
+  // Start the HBM stream first: page ids of this wave's first chunk and its first K/V tile are
+  // requested before the q / RoPE / slab prologue, which then runs under their latency.
+  KVTile<D> bufA, bufB;
+  int my_page = 0, n_my = 0;
+  int chunk0 = t_begin + w;
+  auto begin_chunk = [&]() {
+    const int tj = chunk0 + NW * lane;
+    my_page = (tj < t_end) ? bt[tj / tpp] : 0;
+    n_my = min(64, (t_end - chunk0 + NW - 1) / NW);  // wave-uniform
+    load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
+                        (chunk0 % tpp) << 4, kv_len - (chunk0 << 4), lane);
+  };
+  if (chunk0 < t_end) begin_chunk();
+
   // q as the MFMA B operand, identical in all 16 columns
   u16x8 qf[D / 32];
   if (!(FUSE && p.qkv_partial)) {
@@ -304,21 +318,9 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   for (int e = 0; e < OE; ++e) o[e] = 0.f;
 
   // my tiles: t_begin + w + NW*j.  Chunks of 64 tiles per wave share one page-id vector.
-  for (int chunk0 = t_begin + w; chunk0 < t_end; chunk0 += NW * 64) {
-    int my_page = 0;
-    {
-      const int tj = chunk0 + NW * lane;
-      if (tj < t_end) my_page = bt[tj / tpp];
-    }
-    const int n_my = min(64, (t_end - chunk0 + NW - 1) / NW);  // wave-uniform
-
-    KVTile<D> bufA, bufB;
+  for (bool first = true; chunk0 < t_end; chunk0 += NW * 64, first = false) {
+    if (!first) begin_chunk();
     int j = 0;
-    {
-      const int t = chunk0;
-      load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
-                      (t % tpp) << 4, kv_len - (t << 4), lane);
-    }
     while (j < n_my) {
       if (j + 1 < n_my) {
         const int t = chunk0 + NW * (j + 1);
