@@ -18,6 +18,8 @@
 //   * K is split across workgroups (<= 1024 k each) to have >= 2 workgroups per CU in flight;
 //     partial sums go to fp32 slabs that the consumer kernels (finalize / fused epilogues)
 //     add in a fixed order — deterministic, no atomics.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "attn_common.h"
 
@@ -220,6 +222,26 @@ int launch_gemm_mb(const GemmParams& p, hipStream_t stream) {
   int nw = 4;
   int rpw = 1;
   while (rpw < 4 && units / ((int64_t)nw * rpw) > 1024) ++rpw;
+  // in-pipeline sweep on the 7B shapes (HX_GEMM_CFG, 96 decode steps each): the widest
+  // projection (gate|up, 5504 units) and the many-split one (down, 11 K splits) prefer 8-wave
+  // workgroups with 3 resp. 2 row groups per wave; qkv / o keep 4 waves x 1
+  if (units > 4096) { nw = 8; rpw = 3; }
+  else if (p.n_splits >= 8) { nw = 8; rpw = 2; }
+  // per-shape override for tuning runs: HX_GEMM_CFG="N:K:R:NW;N:K:R:NW;..."
+  static const char* cfg = getenv("HX_GEMM_CFG");
+  if (cfg) {
+    const char* q = cfg;
+    while (*q) {
+      long n = 0, k = 0, r = 0, w = 0;
+      if (sscanf(q, "%ld:%ld:%ld:%ld", &n, &k, &r, &w) == 4 && n == p.N && k == p.K) {
+        if (r >= 1 && r <= 4) rpw = (int)r;
+        if (w == 4 || w == 8) nw = (int)w;
+      }
+      const char* semi = strchr(q, ';');
+      if (!semi) break;
+      q = semi + 1;
+    }
+  }
   if (g_force_nw == 4 || g_force_nw == 8) nw = g_force_nw;
   if (g_force_r >= 1 && g_force_r <= 4) rpw = g_force_r;
   if (nw == 4) {
