@@ -286,3 +286,24 @@ def tiny_clip_pixels(n_images: int = 2) -> torch.Tensor:
     std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
     x = (img / 255.0 - mean) / std
     return torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------ G10 tiny LLaVA end-to-end
+TINY_IMAGE_TOKEN_ID = TINY_LLAMA["vocab_size"] - 1
+TINY_LLAVA_TEXT = (10, 7)      # text tokens after the 16 image tokens of each request
+
+
+def tiny_llava_prompt(req: int) -> List[int]:
+    n_img = (TINY_CLIP["image_size"] // TINY_CLIP["patch_size"]) ** 2
+    g = torch.Generator().manual_seed(900 + req)
+    text = torch.randint(0, TINY_IMAGE_TOKEN_ID, (TINY_LLAVA_TEXT[req],), generator=g).tolist()
+    return [TINY_IMAGE_TOKEN_ID] * n_img + text
+
+
+def tiny_llava_block_tables() -> List[List[int]]:
+    tables, nxt = [], TINY_BLOCKS - 1
+    for r in range(2):
+        n = (len(tiny_llava_prompt(r)) + TINY_DECODE_STEPS + TINY_BLOCK_SIZE - 1) // TINY_BLOCK_SIZE
+        tables.append([nxt - j for j in range(n)][::-1])
+        nxt -= n
+    return tables

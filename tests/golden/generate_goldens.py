@@ -308,6 +308,84 @@ def gen_tiny_clip(out):
     out["clip_pixels_chk"] = np.array(C.checksum(pixels))
 
 
+def gen_tiny_llava(out):
+    """G10: image -> reference CLIP tower + projector -> features overwrite the image-token rows of
+    the reference Llama's input embeddings (the four lines of hydrainfer/model/llava.py:132-136,
+    whose class needs a checkpoint directory) -> reference LlamaForCausalLM prefill + greedy decode."""
+    from transformers import CLIPVisionConfig, LlamaConfig
+    from hydrainfer.layer.causal_attention import AttentionParametersBuilder
+    from hydrainfer.memory.kv_cache import KVCache
+    from hydrainfer.model.clip import CLIPVisionModel
+    from hydrainfer.model.llama import LlamaForCausalLM
+    from hydrainfer.model.llava import LlavaMultiModalProjector
+    from hydrainfer.model.parameters import LanguageModelParameters, VisionModelParameters
+    from hydrainfer_amd.model.clip import ClipShape, random_state_dict
+    t, tc, bs = C.TINY_LLAMA, C.TINY_CLIP, C.TINY_BLOCK_SIZE
+    vcfg = CLIPVisionConfig(hidden_size=tc["hidden_size"], intermediate_size=tc["intermediate_size"],
+                            num_hidden_layers=tc["num_hidden_layers"], num_attention_heads=tc["num_attention_heads"],
+                            image_size=tc["image_size"], patch_size=tc["patch_size"], layer_norm_eps=tc["layer_norm_eps"])
+
+    class _Cfg:
+        vision_config = vcfg
+        text_config = type("T", (), {"hidden_size": tc["projector_hidden_size"]})()
+    sd32 = random_state_dict(ClipShape(**tc), seed=3, std=0.05)
+    pixels = C.tiny_clip_pixels(2)
+    for dname in ("fp16", "bf16"):
+        dt = C.DTYPES[dname]
+        tower, proj = CLIPVisionModel(vcfg), LlavaMultiModalProjector(_Cfg)
+        tower.load_state_dict({k[len("vision_tower."):]: v for k, v in sd32.items() if k.startswith("vision_tower.")}, strict=False)
+        proj.load_state_dict({k[len("multi_modal_projector."):]: v for k, v in sd32.items() if k.startswith("multi_modal_projector.")})
+        tower.to(dt).eval(); proj.to(dt).eval()
+        cfg = LlamaConfig(hidden_size=t["hidden_size"], intermediate_size=t["intermediate_size"],
+                          num_hidden_layers=t["num_hidden_layers"], num_attention_heads=t["num_attention_heads"],
+                          num_key_value_heads=t["num_key_value_heads"], vocab_size=t["vocab_size"],
+                          rms_norm_eps=t["rms_norm_eps"], max_position_embeddings=t["max_position_embeddings"])
+        cfg.head_dim, cfg.rope_theta = t["head_dim"], t["rope_theta"]
+        lm = LlamaForCausalLM(cfg)
+        lm.load_state_dict(C.tiny_llama_state_dict(dt), strict=False)
+        lm.to(dt).eval()
+        logits_log = []
+        lm.lm_head.register_forward_hook(lambda m, i, o: logits_log.append(o.detach().float().clone()))
+        L, HK, D = t["num_hidden_layers"], t["num_key_value_heads"], t["head_dim"]
+        pool = torch.randn((L, 2, C.TINY_BLOCKS, bs, HK, D), generator=torch.Generator().manual_seed(77)).to(dt)
+        tables, lens, tokens = C.tiny_llava_block_tables(), [0, 0], []
+        with torch.inference_mode():
+            h, _ = tower(pixels, tc["vision_feature_layer"], VisionModelParameters())
+            feats = proj(h[:, 1:])                                     # [2, 16, 256]
+
+        def run(ids_per_req, image_features):
+            b = AttentionParametersBuilder(t["num_attention_heads"], HK, D, bs, torch.device("cpu"))
+            ids, pos, sel, n = [], [], [], 0
+            for r, new in enumerate(ids_per_req):
+                slots = [tables[r][p // bs] * bs + p % bs for p in range(lens[r], lens[r] + len(new))]
+                pos += list(range(lens[r], lens[r] + len(new)))
+                lens[r] += len(new)
+                b.add_request(len(new), lens[r], slots, tables[r][: (lens[r] + bs - 1) // bs])
+                ids += new
+                n += len(new)
+                sel.append(n - 1)
+            for l in range(L):
+                b.add_kv_cache(KVCache(pool[l, 0], pool[l, 1]))
+            params = LanguageModelParameters(
+                input_ids_or_input_embeds=None, position_ids=None, image_features=None, image_overwrite_mask=None,
+                attention_params=b.build_attention_parameters(),
+                all_sequences_decode=all(len(x) == 1 for x in ids_per_req), selected_token_ids=sel)
+            with torch.inference_mode():
+                input_ids = torch.tensor(ids, dtype=torch.int)
+                embeds = lm.model.embed_tokens(input_ids)
+                if image_features is not None:
+                    embeds[input_ids == C.TINY_IMAGE_TOKEN_ID, :] = image_features.view(-1, embeds.shape[-1])
+                return lm(embeds, torch.tensor(pos, dtype=torch.int), params)
+
+        nxt = run([C.tiny_llava_prompt(0), C.tiny_llava_prompt(1)], feats)
+        tokens.append(nxt.tolist())
+        for _ in range(C.TINY_DECODE_STEPS - 1):
+            nxt = run([[int(nxt[0])], [int(nxt[1])]], None)
+            tokens.append(nxt.tolist())
+        out[f"llava_{dname}_tokens"] = np.array(tokens, dtype=np.int64)
+        out[f"llava_{dname}_logits"] = torch.stack(logits_log).numpy()
+
+
 def main():
     import_reference()
     torch.manual_seed(0)
@@ -321,6 +399,7 @@ def main():
         "g7_trace": gen_trace,
         "g8_tiny_llama": gen_tiny_llama,
         "g9_tiny_clip": gen_tiny_clip,
+        "g10_tiny_llava": gen_tiny_llava,
     }
     only = sys.argv[1:]
     for name, fn in sets.items():

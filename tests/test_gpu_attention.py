@@ -305,3 +305,46 @@ def test_fused_attention_from_qkv_slabs_is_bit_identical(dt):
                            dev(cu_b), max(kv_lens), 1 / math.sqrt(D), 0, ws, s)
     torch.cuda.synchronize()
     assert torch.equal(oa, ob) and torch.equal(kca, kcb) and torch.equal(vca, vcb)
+
+
+def test_edge_cases_empty_and_degenerate_sequences():
+    """Edge cases of the varlen interface: a sequence with no query tokens inside a batch, kv
+    lengths that are exact multiples of the page size, a single key, and head_dim 32 / 96."""
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    from oracle import ops
+    dt = torch.float16
+    # (a) q_len = 0 for the middle sequence (chunked prefill leaves such holes)
+    q_lens, kv_lens = [5, 0, 1, 32], [21, 16, 48, 32]
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(4, 4, 2, 128, kv_lens, q_lens, dt, seed=31)
+    ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+    out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
+    assert_close_t(out, ref, 1e-3, 1e-3, what="q_len=0 inside batch")
+    # (b) head dims only the general kernel takes, paged and causal
+    for D in (32, 96):
+        q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(3, 4, 4, D, [1, 40, 100], [1, 40, 7], dt, seed=D)
+        ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+        out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, 40, 100)
+        assert_close_t(out, ref, 1e-3, 1e-3, what=f"D={D}")
+    # (c) unsupported head_dim is an error, not a wrong answer
+    from hydrainfer_amd._lib import HydraHipError
+    q = torch.randn((2, 2, 80), device=DEV, dtype=dt)
+    kc = torch.randn((4, 16, 2, 80), device=DEV, dtype=dt)
+    cu = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV)
+    with pytest.raises(HydraHipError):
+        mha_varlen_fwd(torch.empty_like(q), q, kc, kc, cu, torch.tensor([0, 5, 9], dtype=torch.int32, device=DEV),
+                       torch.tensor([0, 1], dtype=torch.int32, device=DEV), cu, None, 1, 5, 0.1, 0.0, -1, 0, 0)
+
+
+def test_zero_token_calls_are_noops():
+    from hydrainfer_amd._C.kernel import activation, cache_kernels, norm, position_embedding as pe
+    dt = torch.float16
+    e2 = torch.empty((0, 64), dtype=dt, device=DEV)
+    assert activation.silu(e2).shape == (0, 64)
+    norm.rms_norm(torch.empty_like(e2), e2, torch.ones(64, dtype=dt, device=DEV), 1e-5)
+    e3 = torch.empty((0, 2, 64), dtype=dt, device=DEV)
+    cache = torch.ones((2, 16, 2, 64), dtype=dt, device=DEV)
+    cache_kernels.set_image_cache(torch.empty(0, dtype=torch.int32, device=DEV), e3, cache)
+    pe.apply_rotary_pos_emb(e3, e3.clone(), torch.empty(0, dtype=torch.int32, device=DEV),
+                            torch.zeros((16, 2, 32), dtype=dt, device=DEV), 64, False)
+    torch.cuda.synchronize()
+    assert float(cache.float().min()) == 1.0
