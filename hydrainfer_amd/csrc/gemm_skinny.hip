@@ -46,7 +46,7 @@ constexpr int kRS = kMaxKs * 64 + 32;   // LDS row stride in bytes
 // compiler's vmcnt counts are exact (a loop makes it fall back to vmcnt(0) and serialises the
 // two buffers).
 template <typename T, int MB, int R, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p, const int g_nt_store) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kThreads = NW * 64;
   const int lane = threadIdx.x & 63;
@@ -151,9 +151,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int m = mb * 16 + c;
-        if (m < p.M && rg < n_rg_all)
-          *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g) =
-              acc[mb];
+        if (m < p.M && rg < n_rg_all) {
+          f32x4* dst = reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g);
+          if (g_nt_store) __builtin_nontemporal_store(acc[mb], dst);
+          else *dst = acc[mb];
+        }
         acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   *reinterpret_cast<u16x4*>(out + m * ldo + n) = r;
 }
 
+int g_slab_nt = 0;       // tuning: non-temporal slab stores
 int g_force_r = 0;       // tuning: 0 = automatic, else row groups per wave
 int g_force_nw = 0;      // tuning: 0 = automatic, else waves per workgroup (4 or 8)
 
@@ -186,6 +189,7 @@ namespace hx {
 int gemm_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_rows_per_wave")) { g_force_r = value; return HX_OK; }
   if (!strcmp(name, "gemm_waves")) { g_force_nw = value; return HX_OK; }
+  if (!strcmp(name, "gemm_slab_nt")) { g_slab_nt = value; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 
@@ -208,7 +212,7 @@ int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  gemm_skinny_kernel<T, MB, R, NW><<<grid, NW * 64, lds, stream>>>(p);
+  gemm_skinny_kernel<T, MB, R, NW><<<grid, NW * 64, lds, stream>>>(p, g_slab_nt);
   return check_launch();
 }
 
@@ -228,6 +232,8 @@ int launch_gemm_mb(const GemmParams& p, hipStream_t stream) {
   if (units > 4096) { nw = 8; rpw = 3; }
   else if (p.n_splits >= 8) { nw = 8; rpw = 2; }
   // per-shape override for tuning runs: HX_GEMM_CFG="N:K:R:NW;N:K:R:NW;..."
+  static const char* nt_env = getenv("HX_GEMM_SLAB_NT");
+  if (nt_env) g_slab_nt = atoi(nt_env);
   static const char* cfg = getenv("HX_GEMM_CFG");
   if (cfg) {
     const char* q = cfg;

@@ -139,6 +139,46 @@ class DecodeRunner:
         self.tokens = [first.clone()]
         return first
 
+    def capture_prefill(self, request: int, image_token_id: int = 32000):
+        """hipGraph of the prefill of ONE request (fixed prompt length, this request's blocks):
+        the ~290 eager launches of a 704-token prefill cost several ms of host time, which is
+        what bounds TTFT on an idle replica.  Returns (graph, static_ids, static_features,
+        static_first_token)."""
+        cfg, sh, bs = self.cfg, self.model.shape, self.cfg.block_size
+        P = cfg.prompt_len
+        n_prompt_blocks = (P + bs - 1) // bs
+        b = AttentionParametersBuilder(sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim, bs, self.dev)
+        t = self.tables[request][:n_prompt_blocks]
+        b.add_request(P, P, [t[p // bs] * bs + p % bs for p in range(P)], t)
+        for kc in self.kv_caches:
+            b.add_kv_cache(kc)
+        params = LanguageModelParameters(attention_params=b.build_attention_parameters(),
+                                         all_sequences_decode=False,
+                                         selected_token_ids=torch.tensor([P - 1], device=self.dev))
+        ids = torch.zeros(P, dtype=torch.int64, device=self.dev)
+        feats = torch.zeros((576, sh.hidden_size), dtype=self.model.dtype, device=self.dev)
+        pos = torch.arange(P, dtype=torch.int32, device=self.dev)
+        first = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        n_img = 576
+
+        def body():
+            embeds = self.model.embed(ids)
+            # image-token rows are the first 576 of the synthetic prompt (llava.py:132-135 with a
+            # static mask, so the graph has no data-dependent shapes)
+            embeds[:n_img] = feats
+            first.copy_(self.model(embeds, pos, params))
+
+        torch.cuda.synchronize(self.dev)
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            body()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        return graph, ids, feats, first
+
     def set_state(self, kv_len: int, input_ids: Optional[Tensor] = None) -> None:
         """Position the decode state at `kv_len` cached tokens per sequence without running a
         prefill (the cache then holds its randn fill — used by kernel-only measurements)."""

@@ -138,3 +138,62 @@ def test_hip_model_matches_reference(dname):
         assert (toks[s] == ref_toks[s]).all(), f"greedy token mismatch at step {s}"
     else:
         assert (toks == ref_toks).all()
+
+
+@pytest.mark.gpu
+def test_7b_shaped_two_layer_model_matches_oracle():
+    """BASELINE layer shapes (hidden 4096, 32 heads x 128, inter 11008, vocab 32064) with 2
+    layers: prefill + 4 greedy decode steps on the HIP path (decode GEMMs on the weight-streaming
+    kernel, fused attention) against the CPU oracle model on the same weights."""
+    from hydrainfer_amd.layer.causal_attention import AttentionParametersBuilder
+    from hydrainfer_amd.memory.kv_cache import KVCache
+    from hydrainfer_amd.model.llama import LanguageModelParameters, LlamaForCausalLM, LlamaShape
+    from oracle.model import OracleAttnMeta, OracleLlama
+    dt, dev = torch.float16, torch.device("cuda:0")
+    shape = LlamaShape(4096, 11008, 2, 32, 32, 128, 32064)
+    model = LlamaForCausalLM.random_init(shape, dt, dev, seed=3, std=0.02)
+    sd = model.to_reference_state_dict()
+    oracle = OracleLlama(shape, sd, dt)
+    bs, n_blocks = 16, 16
+    gen = torch.Generator().manual_seed(5)
+    pool = torch.randn((2, 2, n_blocks, bs, 32, 128), generator=gen).to(dt)
+    pool_d = pool.to(dev)
+    prompts = [torch.randint(0, 32000, (50,), generator=gen).tolist(), torch.randint(0, 32000, (33,), generator=gen).tolist()]
+    tables = [[15, 14, 13, 12], [11, 10, 9]]
+    lens = [0, 0]
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)
+    new = prompts
+    n_checked = 0
+    for step in range(5):
+        ids, pos, sel, slots, bt, cu_q, cu_k, cu_b = [], [], [], [], [], [0], [0], [0]
+        b = AttentionParametersBuilder(32, 32, 128, bs, dev)
+        for r, x in enumerate(new):
+            sl = [tables[r][p // bs] * bs + p % bs for p in range(lens[r], lens[r] + len(x))]
+            pos += list(range(lens[r], lens[r] + len(x)))
+            lens[r] += len(x)
+            tb = tables[r][: (lens[r] + bs - 1) // bs]
+            b.add_request(len(x), lens[r], sl, tb)
+            slots += sl; bt += tb; ids += x
+            cu_q.append(cu_q[-1] + len(x)); cu_k.append(cu_k[-1] + lens[r]); cu_b.append(cu_b[-1] + len(tb))
+            sel.append(cu_q[-1] - 1)
+        for l in range(2):
+            b.add_kv_cache(KVCache(pool_d[l, 0], pool_d[l, 1]))
+        prefill = step == 0
+        params = LanguageModelParameters(attention_params=b.build_attention_parameters(),
+                                         all_sequences_decode=not prefill,
+                                         selected_token_ids=torch.tensor(sel, device=dev) if prefill else None)
+        got = model.forward_logits(torch.tensor(ids, dtype=torch.int64, device=dev),
+                                   torch.tensor(pos, dtype=torch.int32, device=dev), params).float().cpu()
+        meta = OracleAttnMeta(i32(cu_q), i32(cu_k), i32(slots), i32(bt), i32(cu_b))
+        ref = oracle.forward_logits(i32(ids), i32(pos), meta, [(pool[l, 0], pool[l, 1]) for l in range(2)],
+                                    torch.tensor(sel) if prefill else None).float()
+        err = (got - ref).abs().max().item()
+        assert err <= 3e-2, f"step {step}: logits max abs err {err}"       # stated tolerance (fp16)
+        srt = ref.sort(dim=-1).values
+        margin_ok = (srt[:, -1] - srt[:, -2]) > 6e-2
+        gt, rt = got.argmax(-1), ref.argmax(-1)
+        assert (gt[margin_ok] == rt[margin_ok]).all(), f"step {step}: greedy token differs despite a clear margin"
+        n_checked += int(margin_ok.sum())
+        new = [[int(rt[0])], [int(rt[1])]]          # both sides follow the oracle's tokens
+    # the KV pool written by the HIP path equals the oracle's up to T round-off of the projections
+    assert (pool_d.cpu().float() - pool.float()).abs().max().item() <= 2e-2
