@@ -5,15 +5,17 @@
 // mask.h:130-211 (bottom-right aligned causal).
 //
 // Design (gfx950, MFMA 16x16x32, "swapped" products so no P transpose is needed):
-//   * workgroup = 4 independent waves; wave w owns 16 query rows; grid =
-//     (ceil(max_q/64), head, sequence).
-//   * S^T[key][query] = K . Q^T : A = K tile loaded HBM->VGPR directly in the A-operand
-//     lane layout (16 keys x 32 dims per step), B = Q^T fragments kept in registers.
+//   * workgroup = 4 waves x 16 query rows; grid = (ceil(max_q/64), head, sequence).  The
+//     32-key K and V tiles are staged ONCE per workgroup (coalesced 16-byte loads of whole
+//     rows, register prefetch of tile t+1 under tile t's MFMAs, double-buffered LDS images,
+//     one barrier per tile) and shared by the four waves.
+//   * S^T[key][query] = K . Q^T : A = K fragments read from the LDS image (row stride 2D+32 B:
+//     conflict free), B = Q^T fragments kept in registers.
 //     The accumulator leaves lane (g=l>>4, c=l&15) with query c, keys 4g..4g+3 of each
 //     16-key sub-tile: row statistics need only two cross-group shuffles (xor 16, 32).
 //   * O^T[dim][query] += V^T . P^T : P^T is used as the B operand straight from the
 //     softmax registers (k-slot j of lane group g <-> key 16*(j>>2)+4g+(j&3)); V^T is the
-//     A operand, read with ds_read_b64_tr_b16 from a wave-private LDS image of the V tile
+//     A operand, read with ds_read_b64_tr_b16 from the shared LDS image of the V tile
 //     [32 keys][D] (row stride 2D+32 bytes => conflict-free transposed reads).
 //   * P is rounded to T before P.V exactly like the reference kernel
 //     (flash_fwd_kernel.h:878); accumulation is fp32.
@@ -36,10 +38,12 @@ template <typename T, int D, bool PAGED>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   constexpr int NS = D / 32;       // QK k-steps
   constexpr int NDB = D / 16;      // 16-dim output blocks
-  constexpr int RS = 2 * D + 32;   // LDS row stride in bytes
-  constexpr int LPR = D / 8;       // lanes per V row when staging (16 B per lane)
-  constexpr int NVI = D / 16;      // staging instructions per 32-key tile (32*LPR/64)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = 2 * D + 32;   // LDS row stride in bytes (K and V images)
+  constexpr int LPR = D / 8;       // 16-byte chunks per key row
+  constexpr int TILE_CHUNKS = 32 * LPR;
+  constexpr int NL = (TILE_CHUNKS + 255) / 256;   // chunks per thread per tile
+  constexpr int TILE_BYTES = 32 * RS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2][32][RS] | V[2][32][RS]
 
   const int mblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63;
@@ -51,11 +55,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int q_len = p.cu_q[b + 1] - q_start;
   const int k_start = p.cu_k[b];
   const int kv_len = p.cu_k[b + 1] - k_start;
-  const int q_row0 = mblk * 64 + w * 16;
-  if (q_row0 >= q_len) return;  // wave-uniform; kernel uses no workgroup barrier
+  const int q_row0_wg = mblk * 64;
+  if (q_row0_wg >= q_len) return;            // workgroup-uniform
+  const int q_row0 = q_row0_wg + w * 16;     // may exceed q_len for the last workgroup's waves:
+                                             // those waves still load / synchronise, never store
 
-  char* vlds = smem + w * (32 * RS);
-
+  char* kbuf = smem;
+  char* vbuf = smem + 2 * TILE_BYTES;
   const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
   const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
   const int32_t* bt = PAGED ? p.block_table + p.cu_block_lens[b] : nullptr;
@@ -70,118 +76,125 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 32 * s);
   }
 
-  // visible keys for query column c: key <= limit_c
   const int shift = kv_len - q_len;
   const int limit_c = p.causal ? min(kv_len - 1, q_row0 + c + shift) : kv_len - 1;
-  int last_key = p.causal ? min(kv_len - 1, q_row0 + 15 + shift) : kv_len - 1;  // wave-uniform
-  const int n_tiles = (last_key >= 0) ? (last_key >> 5) + 1 : 0;
+  const int last_key_wave = p.causal ? min(kv_len - 1, q_row0 + 15 + shift) : kv_len - 1;
+  const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + 63, q_len - 1) + shift) : kv_len - 1;
+  const int n_tiles = (last_key_wg >= 0) ? (last_key_wg >> 5) + 1 : 0;   // workgroup-uniform
+
+  // ---- cooperative tile staging: thread owns chunks idx = tid + 256*j of the [32][D] tile
+  int my_row[NL], my_chunk[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int idx = threadIdx.x + 256 * j;
+    my_row[j] = idx / LPR;
+    my_chunk[j] = idx % LPR;
+  }
+  auto key_offset = [&](int key, bool is_v) -> int64_t {   // element offset of key row `key`
+    key = min(key, kv_len - 1);
+    if (PAGED) {
+      const int page = bt[key / p.block_size];
+      const int row = key % p.block_size;
+      return is_v ? (int64_t)page * p.v_block_stride + (int64_t)row * p.v_row_stride
+                  : (int64_t)page * p.k_block_stride + (int64_t)row * p.k_row_stride;
+    }
+    return (int64_t)(k_start + key) * (is_v ? p.v_row_stride : p.k_row_stride);
+  };
+  u16x8 kreg[NL], vreg[NL];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      if (TILE_CHUNKS % 256 == 0 || threadIdx.x + 256 * j < TILE_CHUNKS) {
+        const int key = t * 32 + my_row[j];
+        kreg[j] = *reinterpret_cast<const u16x8*>(kbase + key_offset(key, false) + 8 * my_chunk[j]);
+        vreg[j] = *reinterpret_cast<const u16x8*>(vbase + key_offset(key, true) + 8 * my_chunk[j]);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      if (TILE_CHUNKS % 256 == 0 || threadIdx.x + 256 * j < TILE_CHUNKS) {
+        const int off = buf * TILE_BYTES + my_row[j] * RS + my_chunk[j] * 16;
+        *reinterpret_cast<u16x8*>(kbuf + off) = kreg[j];
+        *reinterpret_cast<u16x8*>(vbuf + off) = vreg[j];
+      }
+    }
+  };
 
   f32x4 acc[NDB];
 #pragma unroll
   for (int i = 0; i < NDB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = HX_NEG_BIG, l = 0.f;
 
+  if (n_tiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  const int q4 = c >> 2, p4 = c & 3;
   for (int t = 0; t < n_tiles; ++t) {
-    // ---- sub-tile bases (wave-uniform); fully out-of-range sub-tiles alias the last valid
-    int tok0[2];
-    int64_t kro[2], vro[2];
+    const int cur = t & 1;
+    if (t + 1 < n_tiles) load_tile(t + 1);       // in flight under this tile's MFMAs
+
+    if (t * 32 <= last_key_wave) {               // wave-uniform: tiles past this wave's diagonal
+      const char* kt = kbuf + cur * TILE_BYTES;
+      const char* vt = vbuf + cur * TILE_BYTES;
+      // ---- S^T = K . Q^T for the two 16-key sub-tiles (A fragments from the shared K image)
+      f32x4 s[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      int t0 = t * 32 + u * 16;
-      if (t0 >= kv_len) t0 = ((kv_len - 1) >> 4) << 4;
-      tok0[u] = t0;
-      if (PAGED) {
-        const int page = bt[t0 / p.block_size];
-        const int row0 = t0 % p.block_size;
-        kro[u] = (int64_t)page * p.k_block_stride + (int64_t)row0 * p.k_row_stride;
-        vro[u] = (int64_t)page * p.v_block_stride + (int64_t)row0 * p.v_row_stride;
-      } else {
-        kro[u] = (int64_t)(k_start + t0) * p.k_row_stride;
-        vro[u] = (int64_t)(k_start + t0) * p.v_row_stride;
+      for (int u = 0; u < 2; ++u) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          const u16x8 kf = *reinterpret_cast<const u16x8*>(kt + (16 * u + c) * RS + 64 * st + 16 * g);
+          a = Mfma<T>::mma(kf, qf[st], a);
+        }
+        s[u] = a;
+      }
+      // ---- mask + online softmax (per query column c; state replicated over g)
+      float x[8];
+      float mx = HX_NEG_BIG;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = t * 32 + u * 16 + 4 * g + i;
+          const float v = (key <= limit_c) ? s[u][i] * p.scale_log2 : -INFINITY;
+          x[u * 4 + i] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx);
+      const float alpha = fast_exp2(m - m_new);
+      m = m_new;
+      u16x8 pf;
+      float ps = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = fast_exp2(x[j] - m_new);
+        ps += e;
+        pf[j] = T::from_float(e);
+      }
+      l = l * alpha + ps;
+#pragma unroll
+      for (int i = 0; i < NDB; ++i) acc[i] *= alpha;
+      // ---- O^T += V^T . P^T (V^T fragments by transposed LDS reads of the shared V image)
+      const char* vrd = vt + (4 * g + q4) * RS + p4 * 8;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const u16x4 lo = lds_tr_read(vrd + db * 32);
+        const u16x4 hi = lds_tr_read(vrd + 16 * RS + db * 32);
+        u16x8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+        acc[db] = Mfma<T>::mma(vf, pf, acc[db]);
       }
     }
-
-    // ---- issue V global loads early (consumed after the softmax)
-    u16x8 vst[NVI];
-#pragma unroll
-    for (int n = 0; n < NVI; ++n) {
-      const int idx = n * 64 + lane;
-      const int row = idx / LPR;        // 0..31 within the tile
-      const int chunk = idx % LPR;
-      const int u = row >> 4;
-      const int rr = min(row & 15, kv_len - 1 - tok0[u]);
-      vst[n] = *reinterpret_cast<const u16x8*>(vbase + vro[u] + (int64_t)rr * p.v_row_stride +
-                                               8 * chunk);
-    }
-
-    // ---- S^T = K . Q^T for the two 16-key sub-tiles
-    f32x4 s[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int rr = min(c, kv_len - 1 - tok0[u]);  // A-operand row = key (lane & 15)
-      const u16* kp = kbase + kro[u] + (int64_t)rr * p.k_row_stride + 8 * g;
-      u16x8 kf[NS];
-#pragma unroll
-      for (int st = 0; st < NS; ++st) kf[st] = *reinterpret_cast<const u16x8*>(kp + 32 * st);
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int st = 0; st < NS; ++st) a = Mfma<T>::mma(kf[st], qf[st], a);
-      s[u] = a;
-    }
-
-    // ---- mask + online softmax (per query column c; state replicated over g)
-    float x[8];
-    float mx = HX_NEG_BIG;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int key = t * 32 + u * 16 + 4 * g + i;
-        const float v = (key <= limit_c) ? s[u][i] * p.scale_log2 : -INFINITY;
-        x[u * 4 + i] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = fast_exp2(m - m_new);
-    m = m_new;
-    u16x8 pf;
-    float ps = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float e = fast_exp2(x[j] - m_new);
-      ps += e;
-      pf[j] = T::from_float(e);
-    }
-    l = l * alpha + ps;
-#pragma unroll
-    for (int i = 0; i < NDB; ++i) acc[i] *= alpha;
-
-    // ---- stage V tile into the wave-private LDS image
-#pragma unroll
-    for (int n = 0; n < NVI; ++n) {
-      const int idx = n * 64 + lane;
-      const int row = idx / LPR;
-      const int chunk = idx % LPR;
-      *reinterpret_cast<u16x8*>(vlds + row * RS + chunk * 16) = vst[n];
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-
-    // ---- O^T += V^T . P^T
-    const int q4 = c >> 2, p4 = c & 3;
-    const char* vrd = vlds + (4 * g + q4) * RS + p4 * 8;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-      const u16x4 lo = lds_tr_read(vrd + db * 32);
-      const u16x4 hi = lds_tr_read(vrd + 16 * RS + db * 32);
-      u16x8 vf;
-      vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-      vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-      acc[db] = Mfma<T>::mma(vf, pf, acc[db]);
-    }
-    __builtin_amdgcn_wave_barrier();
+    if (t + 1 < n_tiles) store_tile(cur ^ 1);
+    __syncthreads();    // tile t+1 visible; everyone is done with tile t's image
   }
 
   // ---- epilogue: O[q c][dim 16db + 4g + i] = acc[db][i] / L
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 template <typename T, int D>
 int launch_fwd(const AttnParams& p, int batch, int max_seqlen_q, bool paged, hipStream_t stream) {
   constexpr int RS = 2 * D + 32;
-  const size_t lds = 4 * 32 * RS;
+  const size_t lds = 4 * 32 * RS;   // K[2][32][RS] + V[2][32][RS]
   dim3 grid((max_seqlen_q + 63) / 64, p.n_heads, batch);
   if (grid.x == 0) return HX_OK;
   if (paged) {
