@@ -184,7 +184,7 @@ def measure_ttft(runner, prompts, shape, dtype, dev, rank, reps=7):
             "reps": reps}
 
 
-def measure_migration(ctx, runner, dev, reps=5):
+def measure_migration(ctx, runner, dev, peer, reps=5):
     """P->D KV migration of one 704-token request between neighbouring ranks (rank r pulls from
     r-1) through the IPC-mapped peer pool over xGMI: one gather-copy kernel per transfer."""
     try:
@@ -192,10 +192,6 @@ def measure_migration(ctx, runner, dev, reps=5):
         from hydrainfer_amd import parallel
         bs, P = runner.cfg.block_size, runner.cfg.prompt_len
         n_blk = (P + bs - 1) // bs
-        handle = bm.get_ipc_mem_handle(runner.pool)
-        infos = ctx.all_gather_object({"handle": handle, "table": runner.tables[0][:n_blk],
-                                       "n_blocks": runner.pool.shape[2]})
-        peer = infos[parallel.migration_peer(ctx.rank, ctx.world_size)]
         # destination: the blocks of local request 1 (rewritten by nothing afterwards)
         dst_table = runner.tables[1][:n_blk]
         nbytes = runner.pool[:, :, :n_blk].numel() * runner.pool.element_size()
@@ -337,6 +333,28 @@ def main():
         model.fuse_decode_attention = False
     runner = DecodeRunner(model, cfg, seed=rank)
 
+    # multi-GPU: exchange IPC handles and map the neighbour's pool NOW — before any hipGraph is
+    # captured (mapping a peer allocation after graphs were instantiated wedged in a 2-process
+    # test) — bounded by a watchdog so a driver problem cannot cost the benchmark line
+    peer_info, ipc_stuck = None, False
+    if world > 1 and not args.no_migration:
+        import threading
+        box = {}
+
+        def _exchange():
+            from hydrainfer_amd._C.data_transfer import block_migration as bm
+            n_blk = (prompt_len + cfg.block_size - 1) // cfg.block_size
+            infos = ctx.all_gather_object({"handle": bm.get_ipc_mem_handle(runner.pool),
+                                           "table": runner.tables[0][:n_blk], "n_blocks": runner.pool.shape[2]})
+            peer = infos[parallel.migration_peer(ctx.rank, ctx.world_size)]
+            bm._open(peer["handle"])          # cached mapping; later calls are lookups
+            box["peer"] = peer
+        th = threading.Thread(target=_exchange, daemon=True)
+        th.start()
+        th.join(timeout=60)
+        ipc_stuck = th.is_alive()
+        peer_info = box.get("peer")
+
     prompts = synth_prompts(args.batch, prompt_len, shape.vocab_size, dev)
     ttft_ms = None
     if args.skip_prefill:
@@ -419,16 +437,19 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(shape, dtype, args.batch, mid_ctx, args.cpu_layers)
     # ---- optional last leg on every rank (nothing touches the GPU after it)
-    migration, stuck = None, False
+    migration, stuck = None, ipc_stuck
     if world > 1 and not args.no_migration:
-        # optional leg, bounded: a wedged peer mapping must not cost the benchmark line
-        import threading
-        box = {}
-        th = threading.Thread(target=lambda: box.update(r=measure_migration(ctx, runner, dev)), daemon=True)
-        th.start()
-        th.join(timeout=90)
-        stuck = th.is_alive()
-        migration = {"error": "timed out after 90 s"} if stuck else box.get("r")
+        if ipc_stuck or peer_info is None:
+            migration = {"error": "mapping the neighbour's pool (hipIpcOpenMemHandle) did not return within 60 s"}
+        else:
+            import threading
+            box = {}
+            th = threading.Thread(target=lambda: box.update(r=measure_migration(ctx, runner, dev, peer_info)),
+                                  daemon=True)
+            th.start()
+            th.join(timeout=90)
+            stuck = th.is_alive()
+            migration = {"error": "timed out after 90 s"} if stuck else box.get("r")
 
     if rank == 0:
         out["migration"] = migration

@@ -66,6 +66,9 @@ class TokenCacheBlockManager:
         self.n_blocks, self.block_size = config.n_blocks, config.block_size
         self.n_heads, self.head_size = config.n_heads, config.head_size
         self.dtype = _DTYPES[config.dtype]
+        itemsize = torch.empty((), dtype=self.dtype).element_size()
+        self.n_blocks = ipc_safe_n_blocks(self.n_blocks, self.n_layers * self.n_tokens * self.block_size *
+                                          self.n_heads * self.head_size * itemsize)
         self.device = torch.device(config.device)
         self.rank = context.rank
 
@@ -140,6 +143,21 @@ class TokenCacheBlockManager:
 
 
 # --- pure host logic, usable (and tested) without a GPU --------------------------------
+def ipc_safe_n_blocks(n_blocks: int, bytes_per_block: int) -> int:
+    """Smallest block count >= n_blocks whose pool size is not in [7/8 * 2^k, 2^k).
+    Observed on this MI355X / ROCm 7.2 pool (tools/ipc_probe2.py): hipIpcOpenMemHandle of an
+    allocation of 14, 14.65, 15, 15.5, 30 or 31 GiB never returns, while 8.5, 12, 13, 16, 17, 20
+    and 24 GiB map in 1 ms.  Pools that other processes map are therefore sized past the window."""
+    size = n_blocks * bytes_per_block
+    if size <= 0:
+        return n_blocks
+    p2 = 1 << (size - 1).bit_length()          # next power of two >= size
+    if size < p2 and size * 8 >= p2 * 7:
+        return -(-p2 // bytes_per_block)
+    return n_blocks
+
+
+
 def v2p(block_table: List[int], virtual_cache_ids: List[int], block_size: int) -> List[int]:
     """slot = table[id // bs] * bs + id % bs  (token_cache_manger.py:126-133)."""
     return [block_table[i // block_size] * block_size + i % block_size for i in virtual_cache_ids]

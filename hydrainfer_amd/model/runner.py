@@ -67,6 +67,11 @@ class DecodeRunner:
         self.blocks_per_seq = (self.max_len - 1 + bs - 1) // bs  # last sampled token is never cached
         n_blocks = B * self.blocks_per_seq
         self.tables = plan_block_tables(B, cfg.prompt_len, cfg.n_generate, bs, n_blocks)
+        # the pool may be mapped by a neighbour process (migration): keep its size out of the
+        # window in which hipIpcOpenMemHandle was seen to hang (token_cache_manger.ipc_safe_n_blocks)
+        from hydrainfer_amd.memory.token_cache_manger import ipc_safe_n_blocks
+        n_blocks = ipc_safe_n_blocks(n_blocks, sh.num_hidden_layers * 2 * bs * sh.num_key_value_heads *
+                                     sh.head_dim * torch.empty((), dtype=dt).element_size())
         # 6-D pool (token_cache_manger.py:65); randn = "garbage but finite"
         g = torch.Generator(device=dev).manual_seed(seed + 1)
         self.pool = torch.empty((sh.num_hidden_layers, 2, n_blocks, bs, sh.num_key_value_heads,

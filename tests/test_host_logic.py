@@ -103,3 +103,13 @@ def test_realloc_shrink_and_prefix_match():
     tcm.realloc(alloc, shared, vc, 16, bs)
     assert vc.block_table == [2] and shared.get_num_avaiable_blocks() == 7
     assert tcm.v2p([5, 9], [0, 15, 16, 31], bs) == [80, 95, 144, 159]
+
+
+def test_ipc_safe_pool_sizing():
+    blk = 8 << 20                                    # 7B: 8 MiB per block across layers and k/v
+    f = tcm.ipc_safe_n_blocks
+    assert f(1920, blk) == 2048                      # 15.0 GiB -> 16 GiB (window [14, 16) GiB)
+    assert f(1536, blk) == 1536                      # 12 GiB is fine
+    assert f(2048, blk) == 2048 and f(2049, blk) == 2049
+    assert f(3840, blk) == 4096                      # 30 GiB -> 32 GiB
+    assert f(1, 4096) == 1 and f(7, 4096) == 8       # generic: 7/8 of the next power of two
