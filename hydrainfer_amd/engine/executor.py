@@ -1,0 +1,131 @@
+"""Instruction executors — mirror of hydrainfer/engine/executor.py:82-299.
+
+BatchFillExecutor: publish finished blocks to the prefix cache, build the step's inputs, run the
+language model on the HIP path, hand each sampled token to its request.
+BatchImageEmbedExecutor: run the vision tower + projector and scatter the embeddings into the
+image cache.  Both run on the current stream; `InstructionExecutor` can put the vision side on
+its own stream (executor.py:247-249)."""
+import time
+from typing import List, Optional
+
+import torch
+
+from hydrainfer_amd.engine.isa import Fill
+from hydrainfer_amd.engine.parameters_builder import LanguageModelParametersBuilder
+from hydrainfer_amd.engine.rcb import BatchRequest
+from hydrainfer_amd.model.llama import LanguageModelParameters
+
+
+class BatchFillExecutor:
+    def __init__(self, language_model, kv_cache_block_manager, image_cache_block_manager,
+                 dtype: torch.dtype, device: torch.device):
+        self.language_model = language_model            # LlavaLanguageModel
+        lm = language_model.language_model
+        self.shape = lm.shape
+        self.kv_manager, self.image_manager = kv_cache_block_manager, image_cache_block_manager
+        self.dtype, self.device = dtype, device
+
+    def _publish_prefix_blocks(self, batch: BatchRequest) -> None:
+        """A block's hash enters the prefix cache in the step that computes its last token
+        (executor.py:111-127); decode tokens are never published."""
+        bs = self.kv_manager.block_size
+        for rcb, inst in batch:
+            if inst.hashes is None:
+                continue
+            vblocks = [c // bs for c in inst.cache_ids if c % bs == bs - 1 and c // bs < len(inst.hashes)]
+            self.kv_manager.set_blocks(rcb.virtual_kv_cache, vblocks, [inst.hashes[v] for v in vblocks])
+
+    def execute(self, batch: BatchRequest) -> None:
+        if len(batch) == 0:
+            return
+        self._publish_prefix_blocks(batch)
+        sh = self.shape
+        builder = LanguageModelParametersBuilder(
+            self.image_manager, self.kv_manager, sh.num_hidden_layers, sh.num_attention_heads,
+            sh.num_key_value_heads, sh.head_dim, self.language_model.image_token_id, self.dtype, self.device)
+        builder.add_batch(batch)
+        inputs = builder.build_language_model_parameters()
+        params = LanguageModelParameters(inputs.attention_params, inputs.all_sequences_decode,
+                                         inputs.selected_token_ids_tensor)
+        if not inputs.selected_token_ids:
+            # nothing samples: the forward still has to run for its cache writes
+            self.language_model.language_model.forward_hidden(
+                self.language_model.embed(inputs.input_ids, inputs.image_features), inputs.position_ids, params)
+            batch.step()
+            return
+        sampled = self.language_model.forward(inputs.input_ids, inputs.image_features, inputs.position_ids,
+                                              params)
+        if inputs.all_sequences_decode and sampled.numel() != len(inputs.selected_token_ids):
+            sampled = sampled[inputs.selected_token_ids_tensor]
+        sampled = sampled.tolist()                      # the step's only device sync
+
+        now = time.perf_counter()
+        i = 0
+        for rcb, inst in batch:
+            if not isinstance(inst, Fill) or not inst.sample:
+                continue
+            token = sampled[i]
+            i += 1
+            if not inst.is_chunked:
+                rcb.metric.token_times.append(now)
+                rcb.output_token_ids.append(token)
+            if inst.sample_dst is not None:
+                inst.sample_dst.token_ids = [token]
+            if not inst.is_chunked:
+                last = rcb.is_finished()
+                for p in rcb.output_token_processors:
+                    p.append_token_id(token, last)
+        batch.step()
+
+
+class BatchImageEmbedExecutor:
+    def __init__(self, vision_model, image_cache_block_manager, n_qo_heads: int, head_dim: int,
+                 dtype: torch.dtype, device: torch.device):
+        self.vision_model = vision_model
+        self.manager = image_cache_block_manager
+        self.n_qo_heads, self.head_dim = n_qo_heads, head_dim
+        self.dtype, self.device = dtype, device
+
+    def execute(self, batch: BatchRequest) -> None:
+        if len(batch) == 0:
+            return
+        slots: List[int] = []
+        pixels = []
+        for rcb, inst in batch:
+            pixels.append(inst.pixel_values.to(device=self.device, dtype=self.dtype))
+            inst.pixel_values = None
+            slots += self.manager.v2p(rcb.virtual_image_cache, inst.cache_ids)
+        feats = self.vision_model.forward(torch.cat(pixels, dim=0))      # (n_img, 576, hidden)
+        tokens = feats.reshape(-1, self.n_qo_heads, self.head_dim)
+        slot_t = torch.tensor(slots, dtype=torch.int32)
+        if self.device.type == "cuda":
+            slot_t = slot_t.pin_memory().to(self.device, non_blocking=True)
+        self.manager.get_layer_cache(layer_id=0).set_caches(slot_t, [tokens])
+        batch.step()
+
+
+class InstructionExecutor:
+    def __init__(self, fill_executor: Optional[BatchFillExecutor],
+                 image_embed_executor: Optional[BatchImageEmbedExecutor], multi_streams_forward: bool = False):
+        self.fill_executor = fill_executor
+        self.image_embed_executor = image_embed_executor
+        self.vision_stream = torch.cuda.Stream() if multi_streams_forward else None
+
+    def execute_fill(self, batch: BatchRequest) -> None:
+        if len(batch):
+            self.fill_executor.execute(batch)
+
+    def execute_image_embed(self, batch: BatchRequest) -> None:
+        if len(batch) == 0:
+            return
+        if self.vision_stream is None:
+            self.image_embed_executor.execute(batch)
+            return
+        self.vision_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.vision_stream):
+            self.image_embed_executor.execute(batch)
+        # the image cache is read by a later step's prefill on the main stream
+        torch.cuda.current_stream().wait_stream(self.vision_stream)
+
+    def execute_empty(self, batch: BatchRequest) -> None:
+        batch.step()

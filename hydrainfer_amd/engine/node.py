@@ -1,0 +1,254 @@
+"""E/P/D node step loop — mirror of hydrainfer/cluster/epdnode.py:238-447 (AsyncEPDNode.step and
+the four-phase migrate protocol) and hydrainfer/cluster/migrate.py:5-24 (NodeType), without the
+Ray/asyncio control plane: nodes of one `LocalCluster` live in one process and call each other
+directly, which keeps the protocol order (1 sender announces, 2 receiver queues a PullCache,
+3 receiver allocates + pulls, 4 sender frees) and lets it run under test.
+
+Data path of a pull = TokenCacheBlockManager.migrate_blocks -> hx_migrate_blocks (one gather
+kernel over the peer pool); the control plane moves block tables only."""
+import copy
+import time
+from typing import Dict, List, Optional
+
+from hydrainfer_amd.engine.executor import InstructionExecutor
+from hydrainfer_amd.engine.isa import (EmptyInstruction, EPMigrate, Fill, ImageEmbed, MigrateRequest,
+                                       PullCache)
+from hydrainfer_amd.engine.rcb import BatchRequest, RequestControlBlock, ScenarioType
+from hydrainfer_amd.engine.scheduler import BatchScheduler
+
+
+class NodeType:
+    def __init__(self, node_type: str = "EPD"):
+        assert node_type in ("E", "P", "D", "EP", "ED", "PD", "EPD"), f"invalid node type {node_type}"
+        self.node_type = node_type
+        self.enable_encode = "E" in node_type
+        self.enable_prefill = "P" in node_type
+        self.enable_decode = "D" in node_type
+        self.has_kv_cache = self.has_language_model = "P" in node_type or "D" in node_type
+        self.has_image_cache = "E" in node_type or "P" in node_type
+        self.has_vision_model = "E" in node_type
+
+    def __eq__(self, other):
+        return self.node_type == (other.node_type if isinstance(other, NodeType) else other)
+
+
+class RoundRobin:
+    """LoadBalancer(policy='round') keyed by scenario with fall-through to any non-empty key
+    (cluster/loadbalancer.py:14-68)."""
+
+    def __init__(self):
+        self.workers: Dict[int, list] = {int(s): [] for s in ScenarioType}
+        self.cursor: Dict[int, int] = {int(s): 0 for s in ScenarioType}
+
+    def register_worker(self, key, worker) -> None:
+        self.workers[int(key)].append(worker)
+
+    def _choice(self, key: int):
+        ws = self.workers[key]
+        if not ws:
+            return None
+        w = ws[self.cursor[key]]
+        self.cursor[key] = (self.cursor[key] + 1) % len(ws)
+        return w
+
+    def choice(self, key):
+        w = self._choice(int(key))
+        if w is not None:
+            return w
+        for k in self.workers:
+            w = self._choice(k)
+            if w is not None:
+                return w
+        return None
+
+
+class EPDNode:
+    def __init__(self, name: str, node_type: NodeType, scheduler: BatchScheduler,
+                 executor: InstructionExecutor, kv_cache_block_manager, image_cache_block_manager,
+                 tpot_slo: float = 0.4):
+        self.name, self.node_type, self.tpot_slo = name, node_type, tpot_slo
+        self.batch_scheduler = scheduler
+        self.executor = executor
+        self.kv_cache_block_manager = kv_cache_block_manager
+        self.image_cache_block_manager = image_cache_block_manager
+        self.ep_loadbalancer, self.pd_loadbalancer = RoundRobin(), RoundRobin()
+        self.finished: List[RequestControlBlock] = []
+
+    # ---- migrate graph (epdnode.py:60-75): strict traffic only to nodes with a tight TPOT SLO
+    def connect(self, ep_targets: List["EPDNode"], pd_targets: List["EPDNode"]) -> None:
+        for targets, lb in ((ep_targets, self.ep_loadbalancer), (pd_targets, self.pd_loadbalancer)):
+            for node in targets:
+                if node.tpot_slo < 0.05:
+                    lb.register_worker(ScenarioType.Strict, node)
+                lb.register_worker(ScenarioType.Relaxed, node)
+
+    def add_request(self, rcb: RequestControlBlock) -> None:
+        rcb.metric.arrival_time = time.perf_counter()
+        self.batch_scheduler.schedule_new(rcb)
+
+    def idle(self) -> bool:
+        s = self.batch_scheduler
+        return not s.waiting and not s.running
+
+    # ---- one engine step (epdnode.py:238-337)
+    def step(self) -> int:
+        batch = self.batch_scheduler.step()
+        if len(batch) == 0:
+            return 0
+        fill, embed, empty, migrate, pull = (BatchRequest() for _ in range(5))
+        for rcb, inst in batch:
+            if isinstance(inst, Fill):
+                fill.append(rcb)
+            elif isinstance(inst, EmptyInstruction):
+                empty.append(rcb)
+            elif isinstance(inst, ImageEmbed):
+                embed.append(rcb)
+            elif isinstance(inst, MigrateRequest):
+                migrate.append(rcb)
+            elif isinstance(inst, PullCache):
+                pull.append(rcb)
+            else:
+                raise RuntimeError(f"unsupported instruction {type(inst)}")
+
+        now = time.perf_counter()
+        for rcb, inst in fill:
+            phase = rcb.metric.prefill_execute if len(inst.token_ids) > 1 else rcb.metric.decode_execute
+            if not phase:
+                phase.append(now)
+        for rcb, _ in embed:
+            rcb.metric.encode_execute.append(now)
+
+        self.executor.execute_image_embed(embed)
+        self.executor.execute_fill(fill)
+        self.executor.execute_empty(empty)
+
+        now = time.perf_counter()
+        for rcb, _ in embed:
+            rcb.metric.encode_execute.append(now)
+        for group in (embed, fill, empty, pull):
+            for rcb in group.rcbs:
+                if rcb.is_finished():
+                    rcb.metric.finished_time = now
+                    self._free_cache(rcb)
+                    self.finished.append(rcb)
+                else:
+                    self.batch_scheduler.schedule_running(rcb)
+        # The reference runs the two migrate handlers as asyncio tasks that only get the loop once
+        # step() has returned (epdnode.py:286-297,345-347), i.e. AFTER the re-queue above: a request
+        # that stays on this node re-enters `running` behind this step's other requests, and a
+        # pulled request is already re-queued when its PullCache completes.  Same order here.
+        self._execute_batch_migrate(migrate)
+        self._execute_pull_cache(pull)
+        for m in (self.kv_cache_block_manager, self.image_cache_block_manager):
+            if m is not None:
+                m.synchronize()
+        return len(batch)
+
+    # ---- 1. sender: hand the request (with its block tables) to the next stage
+    def _execute_batch_migrate(self, batch: BatchRequest) -> None:
+        for rcb, inst in batch:
+            rcb.step()
+            assert isinstance(rcb.current_instruction(), PullCache)
+            lb = self.ep_loadbalancer if isinstance(inst, EPMigrate) else self.pd_loadbalancer
+            node = lb.choice(rcb.scenario_type)
+            if node is None or node is self:
+                rcb.step()                          # stays here: skip the pull as well
+                self.batch_scheduler.schedule_running(rcb)
+                continue
+            self.batch_scheduler.migrating_acquire()
+            self._drain_compute()                   # the peer reads these blocks on another stream
+            node.migrate(self, rcb)
+
+    def _drain_compute(self) -> None:
+        for m in (self.kv_cache_block_manager, self.image_cache_block_manager):
+            device = getattr(m, "device", None)
+            if device is not None and device.type == "cuda":
+                import torch
+                torch.cuda.current_stream(device).synchronize()
+                return
+
+    # ---- 2. receiver: queue the request; its PullCache runs when the scheduler admits it
+    def migrate(self, src_node: "EPDNode", rcb: RequestControlBlock) -> None:
+        rcb.current_instruction().src_node = src_node
+        self.batch_scheduler.schedule_new(rcb)
+
+    # ---- 3. receiver: allocate local blocks, pull, then tell the sender to free
+    def _migrate_virtual_cache(self, src_cache, manager):
+        dst = manager.allocate_virtual_cache()
+        manager.realloc(dst, src_cache.n_cache_tokens)
+        manager.migrate_blocks(src_cache, dst, is_send=False)
+        return dst
+
+    def _execute_pull_cache(self, batch: BatchRequest) -> None:
+        for rcb, inst in batch:
+            m = rcb.metric       # (text-only requests log their P->D pull under ep_transfer, as upstream)
+            (m.ep_transfer if len(m.ep_transfer) == 0 else m.pd_transfer).append(time.perf_counter())
+            old = copy.copy(rcb)
+            if rcb.virtual_kv_cache is not None and self.node_type.has_kv_cache:
+                rcb.virtual_kv_cache = self._migrate_virtual_cache(rcb.virtual_kv_cache, self.kv_cache_block_manager)
+            else:
+                rcb.virtual_kv_cache = None
+            if rcb.virtual_image_cache is not None and self.node_type.has_image_cache:
+                rcb.virtual_image_cache = self._migrate_virtual_cache(rcb.virtual_image_cache,
+                                                                      self.image_cache_block_manager)
+            else:
+                rcb.virtual_image_cache = None
+            # the sender may only free once the copy has been issued AND completed
+            for manager in (self.kv_cache_block_manager, self.image_cache_block_manager):
+                if manager is not None:
+                    manager.synchronize()
+            inst.src_node.free_migrate_request(old)
+            rcb.step()
+            (m.ep_transfer if len(m.ep_transfer) == 1 else m.pd_transfer).append(time.perf_counter())
+
+    # ---- 4. sender: release the blocks of a request that has been pulled
+    def free_migrate_request(self, rcb: RequestControlBlock) -> None:
+        self._free_cache(rcb)
+        self.batch_scheduler.migrating_release()
+
+    def _free_cache(self, rcb: RequestControlBlock) -> None:
+        if rcb.virtual_kv_cache is not None and self.kv_cache_block_manager is not None:
+            self.kv_cache_block_manager.realloc(rcb.virtual_kv_cache, 0)
+        if rcb.virtual_image_cache is not None and self.image_cache_block_manager is not None:
+            self.image_cache_block_manager.realloc(rcb.virtual_image_cache, 0)
+
+
+class LocalCluster:
+    """Nodes + routing: new requests go round-robin to the E nodes (text-only ones to the P
+    nodes), cluster.py:178-184; every E node may hand over to every P node and every P node to
+    every D node (MigrateGraphBuilder.build_graph, migrate.py:96-119)."""
+
+    def __init__(self, nodes: List[EPDNode]):
+        self.nodes = nodes
+        e = [n for n in nodes if n.node_type.enable_encode]
+        p = [n for n in nodes if n.node_type.enable_prefill]
+        d = [n for n in nodes if n.node_type.enable_decode]
+        for n in nodes:
+            n.connect(p if n.node_type.enable_encode else [], d if n.node_type.enable_prefill else [])
+        self._entry_image, self._entry_text = e, p
+        self._next_image = self._next_text = 0
+
+    def add_request(self, rcb: RequestControlBlock) -> None:
+        if isinstance(rcb.current_instruction(), ImageEmbed):
+            node = self._entry_image[self._next_image % len(self._entry_image)]
+            self._next_image += 1
+        else:
+            node = self._entry_text[self._next_text % len(self._entry_text)]
+            self._next_text += 1
+        node.add_request(rcb)
+
+    def step(self) -> int:
+        return sum(node.step() for node in self.nodes)
+
+    def idle(self) -> bool:
+        return all(n.idle() for n in self.nodes)
+
+    def run_until_idle(self, max_steps: int = 1 << 20) -> int:
+        steps = 0
+        while not self.idle() and steps < max_steps:
+            self.step()
+            steps += 1
+        return steps
+
+    def finished(self) -> List[RequestControlBlock]:
+        return [r for n in self.nodes for r in n.finished]

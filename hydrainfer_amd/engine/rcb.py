@@ -1,0 +1,115 @@
+"""Request control block and batch — mirror of hydrainfer/engine/rcb.py:8-71,
+hydrainfer/request/request.py:6-39, hydrainfer/engine/metric.py:5-19 and
+hydrainfer/engine/scenario.py:3-16."""
+from dataclasses import dataclass, field
+from enum import IntEnum
+from typing import List, Optional, Tuple
+
+from hydrainfer_amd.engine.isa import Instruction, InstructionList
+from hydrainfer_amd.memory.token_cache import VirtualTokenCache
+
+
+@dataclass
+class SamplingParameters:
+    max_tokens: int = 50
+    eos_token_ids: List[int] = field(default_factory=list)
+
+
+@dataclass
+class RequestMetaData:
+    n_images: int
+    n_prompt_tokens: int
+    n_text_tokens: int
+    n_image_tokens: int
+
+
+@dataclass
+class RequestMetric:
+    arrival_time: float = 0.0
+    token_times: List[float] = field(default_factory=list)
+    finished_time: float = 0.0
+    # latency breakdown: [begin, end] stamps per phase
+    encode_queueing: List[float] = field(default_factory=list)
+    encode_execute: List[float] = field(default_factory=list)
+    ep_transfer: List[float] = field(default_factory=list)
+    prefill_queueing: List[float] = field(default_factory=list)
+    prefill_execute: List[float] = field(default_factory=list)
+    pd_transfer: List[float] = field(default_factory=list)
+    decode_queueing: List[float] = field(default_factory=list)
+    decode_execute: List[float] = field(default_factory=list)
+
+
+class ScenarioType(IntEnum):
+    Relaxed = 0
+    Strict = 1
+
+
+class ScenarioClassifier:
+    def classify(self, n_text_tokens: int, n_output_tokens: int) -> ScenarioType:
+        strict = n_text_tokens < 100 and n_output_tokens < 100
+        return ScenarioType.Strict if strict else ScenarioType.Relaxed
+
+
+class OutputTokenProcessor:
+    def append_token_id(self, token_id: int, is_last_token: bool = False) -> None:
+        raise NotImplementedError
+
+
+class LogOutputTokenProcessor(OutputTokenProcessor):
+    def __init__(self):
+        self.token_ids: List[int] = []
+
+    def append_token_id(self, token_id: int, is_last_token: bool = False) -> None:
+        self.token_ids.append(token_id)
+
+
+class RequestControlBlock:
+    def __init__(self):
+        self.request_id = None
+        self.sampling_params: Optional[SamplingParameters] = None
+        self.request_metadata: Optional[RequestMetaData] = None
+        self.instructions: Optional[InstructionList] = None
+        self.virtual_kv_cache: Optional[VirtualTokenCache] = None
+        self.virtual_image_cache: Optional[VirtualTokenCache] = None
+        self.sid: int = -1
+        self.output_token_processors: List[OutputTokenProcessor] = []
+        self.output_token_ids: List[int] = []
+        self.scenario_type: Optional[ScenarioType] = None
+        self.metric = RequestMetric()
+
+    def current_instruction(self) -> Instruction:
+        return self.instructions.curr
+
+    def step(self) -> None:
+        self.instructions.curr = self.instructions.curr.next
+
+    def is_finished(self) -> bool:
+        if self.instructions.curr is None:
+            return True
+        if len(self.output_token_ids) == self.sampling_params.max_tokens:
+            return True
+        return bool(self.output_token_ids) and self.output_token_ids[-1] in self.sampling_params.eos_token_ids
+
+    def register_output_token_processor(self, p: OutputTokenProcessor) -> None:
+        self.output_token_processors.append(p)
+
+    def __repr__(self):
+        return f"rcb(sid={self.sid}, {self.instructions})"
+
+
+class BatchRequest:
+    def __init__(self, rcbs: Optional[List[RequestControlBlock]] = None):
+        self.rcbs = rcbs if rcbs is not None else []
+
+    def __len__(self):
+        return len(self.rcbs)
+
+    def __getitem__(self, idx: int) -> Tuple[RequestControlBlock, Instruction]:
+        return self.rcbs[idx], self.rcbs[idx].instructions.curr
+
+    def append(self, rcb: RequestControlBlock) -> None:
+        self.rcbs.append(rcb)
+
+    def step(self) -> None:
+        for rcb in self.rcbs:
+            rcb.step()

@@ -1,0 +1,181 @@
+"""Continuous-batching scheduler — mirror of hydrainfer/engine/scheduler.py:16-200.
+
+Every step: admit waiting requests up to `max_running_requests` (requests that arrive to pull a
+migrated cache may overshoot by `max_overload_requests`, which breaks the E<->P pull deadlock the
+reference describes at :110-114), grow each running request's block table for the tokens of its
+current instruction, then pack one batch: image encodes up to `image_budgets`, fills up to
+`token_budgets` tokens in priority order with the last prefill chunked to fit.  Requests that do
+not fit stay in `running` for the next step; the caller re-queues executed ones through
+`schedule_running`.
+
+The reference derives the two budgets by timing the executor against a TPOT SLO
+(engine/profiler.py:182-210); here they are plain config fields, and
+`hydrainfer_amd.engine.profiler.BatchSchedulerProfiler` fills them in on a GPU."""
+import time
+from collections import deque
+from dataclasses import dataclass
+from typing import Deque, List, Optional
+
+from hydrainfer_amd.engine.isa import Fill, ImageEmbed, ImageEmbedFill, PullCache, TextFill
+from hydrainfer_amd.engine.rcb import BatchRequest, RequestControlBlock
+from hydrainfer_amd.memory.token_cache_manger import BlockTableManager
+
+
+@dataclass
+class BatchSchedulerMetrics:
+    n_running_requests: int
+    n_requests_waiting_migrate: int
+
+
+@dataclass
+class BatchSchedulerConfig:
+    priority: str = "prefill"          # 'prefill' | 'decode'
+    max_running_requests: int = 15
+    chunked_prefill: bool = True
+    token_budgets: int = 2048
+    image_budgets: int = 8
+    debug: bool = False
+
+
+@dataclass
+class BatchSchedulerContext:
+    kv_cache_block_manager: Optional[BlockTableManager]
+    image_cache_block_manager: Optional[BlockTableManager]
+
+
+class BatchScheduler:
+    def __init__(self, config: BatchSchedulerConfig, context: BatchSchedulerContext):
+        self.config = config
+        self.context = context
+        self.token_budgets = config.token_budgets
+        self.image_budgets = config.image_budgets
+        self.waiting: Deque[RequestControlBlock] = deque()
+        self.running: List[RequestControlBlock] = []
+        self.step_cnt = 0
+        self.next_sid = 1
+        self.max_overload_requests = config.max_running_requests
+        self.running_cnt = 0
+        self.migrating_cnt = 0
+
+    # -- requests handed to a downstream node but not pulled yet still hold their blocks here
+    def migrating_acquire(self) -> None:
+        assert self.migrating_cnt < self.config.max_running_requests + self.max_overload_requests, \
+            "invalid acquire"
+        self.migrating_cnt += 1
+
+    def migrating_release(self) -> None:
+        assert self.migrating_cnt > 0, "invalid release"
+        self.migrating_cnt -= 1
+
+    # -- queueing-time stamps (scheduler.py:64-86): first open phase gets the begin stamp,
+    #    first phase with exactly one stamp gets the end stamp
+    @staticmethod
+    def _stamp_begin(rcb: RequestControlBlock) -> None:
+        m, now = rcb.metric, time.perf_counter()
+        if isinstance(rcb.current_instruction(), ImageEmbed):
+            m.encode_queueing.append(now)
+        elif not m.prefill_queueing:
+            m.prefill_queueing.append(now)
+        elif not m.decode_queueing:
+            m.decode_queueing.append(now)
+
+    @staticmethod
+    def _stamp_end(rcb: RequestControlBlock) -> None:
+        m, now = rcb.metric, time.perf_counter()
+        for phase in (m.encode_queueing, m.prefill_queueing, m.decode_queueing):
+            if len(phase) == 1:
+                phase.append(now)
+                return
+
+    def schedule_new(self, rcb: RequestControlBlock) -> None:
+        rcb.sid = self.next_sid
+        self.next_sid += 1
+        if isinstance(rcb.current_instruction(), PullCache):
+            self.waiting.appendleft(rcb)     # migrated-in requests jump the queue
+        else:
+            self.waiting.append(rcb)
+        self._stamp_begin(rcb)
+
+    def schedule_running(self, rcb: RequestControlBlock) -> None:
+        self.running.append(rcb)
+        self._stamp_end(rcb)
+
+    def _admit(self) -> None:
+        cap = self.config.max_running_requests - self.migrating_cnt
+        while len(self.running) < cap and self.waiting:
+            self.schedule_running(self.waiting.popleft())
+        while (len(self.running) < cap + self.max_overload_requests and self.waiting
+               and isinstance(self.waiting[0].current_instruction(), PullCache)):
+            self.schedule_running(self.waiting.popleft())
+
+    def _grow_caches(self) -> None:
+        kv, img = self.context.kv_cache_block_manager, self.context.image_cache_block_manager
+        for rcb in self.running:
+            inst = rcb.current_instruction()
+            if isinstance(inst, Fill):
+                if rcb.virtual_kv_cache is None:
+                    rcb.virtual_kv_cache = kv.allocate_virtual_cache(inst.hashes)
+                    n_hit = rcb.virtual_kv_cache.n_cache_tokens
+                    if n_hit > 0:
+                        # prefix-cache hit: split the matched tokens off and skip them
+                        assert n_hit <= len(inst.token_ids)
+                        if n_hit < len(inst.token_ids):
+                            inst.chunk_prefill(chunk_size=n_hit)
+                        rcb.step()
+                inst = rcb.current_instruction()
+                if isinstance(inst, Fill):
+                    kv.realloc(rcb.virtual_kv_cache,
+                               max(rcb.virtual_kv_cache.n_cache_tokens, max(inst.cache_ids) + 1))
+            elif isinstance(inst, ImageEmbed):
+                if rcb.virtual_image_cache is None:
+                    rcb.virtual_image_cache = img.allocate_virtual_cache()
+                img.realloc(rcb.virtual_image_cache,
+                            max(rcb.virtual_image_cache.n_cache_tokens, max(inst.cache_ids) + 1))
+
+    def step(self) -> BatchRequest:
+        self.step_cnt += 1
+        self._admit()
+        self.running_cnt = len(self.running)
+        if not self.running:
+            return BatchRequest()
+        self._grow_caches()
+
+        embeds, prefills, decodes = [], [], []
+        this_step: List[RequestControlBlock] = []
+        next_step: List[RequestControlBlock] = []
+        for rcb in self.running:
+            inst = rcb.current_instruction()
+            if isinstance(inst, Fill):
+                (decodes if len(inst.token_ids) == 1 else prefills).append(rcb)
+            elif isinstance(inst, ImageEmbed):
+                embeds.append(rcb)
+            else:
+                this_step.append(rcb)      # Empty / Migrate / PullCache cost no budget
+
+        this_step += embeds[: self.image_budgets]      # one image per request
+        next_step += embeds[self.image_budgets:]
+
+        n_tok, budget = 0, self.token_budgets
+        fills = prefills + decodes if self.config.priority == "prefill" else decodes + prefills
+        for rcb in fills:
+            inst = rcb.current_instruction()
+            n = len(inst.token_ids)
+            if n_tok + n <= budget:
+                this_step.append(rcb)
+                n_tok += n
+            elif (n_tok < budget and n > 1 and self.config.chunked_prefill
+                  and isinstance(inst, (TextFill, ImageEmbedFill))):
+                inst.chunk_prefill(budget - n_tok)
+                this_step.append(rcb)
+                n_tok = budget
+            elif n_tok == 0:               # a fill larger than the whole budget must still run
+                this_step.append(rcb)
+                n_tok += n
+            else:
+                next_step.append(rcb)
+
+        self.running = next_step
+        return BatchRequest(this_step)
+
+    def get_metrics(self) -> BatchSchedulerMetrics:
+        return BatchSchedulerMetrics(self.running_cnt, self.migrating_cnt)

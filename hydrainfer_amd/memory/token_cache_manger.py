@@ -58,36 +58,23 @@ class _IncreasingAllocator:
         return v
 
 
-class TokenCacheBlockManager:
-    def __init__(self, config: TokenCacheBlockManagerConfig, context: TokenCacheBlockManagerContext):
-        self.config = config
-        self.context = context
-        self.n_layers, self.n_tokens = config.n_layers, config.n_tokens
-        self.n_blocks, self.block_size = config.n_blocks, config.block_size
-        self.n_heads, self.head_size = config.n_heads, config.head_size
-        self.dtype = _DTYPES[config.dtype]
-        itemsize = torch.empty((), dtype=self.dtype).element_size()
-        self.n_blocks = ipc_safe_n_blocks(self.n_blocks, self.n_layers * self.n_tokens * self.block_size *
-                                          self.n_heads * self.head_size * itemsize)
-        self.device = torch.device(config.device)
-        self.rank = context.rank
+class BlockTableManager:
+    """The host-only half of the block manager: free list, prefix-hash table, virtual caches and
+    their block tables (token_cache_manger.py:97-153 of the reference).  The scheduler and the
+    parameter builders need nothing else, so they run (and are tested) without a GPU."""
 
-        # reference fills the pool with randn ("garbage but finite", token_cache_manger.py:65)
-        self.cache_tensor = torch.randn(
-            size=(self.n_layers, self.n_tokens, self.n_blocks, self.block_size, self.n_heads,
-                  self.head_size), dtype=self.dtype, device=self.device)
-        self.memory_handle: List[int] = get_ipc_mem_handle(self.cache_tensor)
+    def __init__(self, n_blocks: int, block_size: int, rank: int = 0,
+                 memory_handle: Optional[List[int]] = None):
+        self.n_blocks, self.block_size, self.rank = n_blocks, block_size, rank
+        self.memory_handle: List[int] = memory_handle if memory_handle is not None else []
         self.block_allocator = BlockAllocator(self.n_blocks)
         self.vid_allocator = _IncreasingAllocator(first_value=1)
-        self.migrate_stream = torch.cuda.Stream(device=self.device)
-        self.migrate_manager = CommunicationBackendManager(
-            config.communication_backend_manager_config,
-            CommunicationBackendManagerContext(migrate_stream=self.migrate_stream,
-                                               cache=self.cache_tensor, n_blocks=self.n_blocks,
-                                               rank2host=context.rank2host))
         self.shared_cache = SharedCache(SharedCacheConfig(n_blocks=self.n_blocks))
         self.total_block_queried = 0.0
         self.total_block_matched = 0.0
+
+    def synchronize(self) -> None:
+        pass
 
     def get_num_avaiable_blocks(self) -> int:
         return self.block_allocator.get_num_avaiable_blocks() + self.shared_cache.get_num_avaiable_blocks()
@@ -121,6 +108,35 @@ class TokenCacheBlockManager:
     def realloc(self, virtual_cache: VirtualTokenCache, n_tokens: int) -> None:
         realloc(self.block_allocator, self.shared_cache, virtual_cache, n_tokens, self.block_size)
 
+    def get_metrics(self) -> TokenCacheManagerMetrics:
+        rate = self.total_block_matched / self.total_block_queried if self.total_block_queried else 0.0
+        return TokenCacheManagerMetrics(self.block_allocator.get_metrics(), rate)
+
+
+class TokenCacheBlockManager(BlockTableManager):
+    def __init__(self, config: TokenCacheBlockManagerConfig, context: TokenCacheBlockManagerContext):
+        self.config = config
+        self.context = context
+        self.n_layers, self.n_tokens = config.n_layers, config.n_tokens
+        self.n_heads, self.head_size = config.n_heads, config.head_size
+        self.dtype = _DTYPES[config.dtype]
+        itemsize = torch.empty((), dtype=self.dtype).element_size()
+        n_blocks = ipc_safe_n_blocks(config.n_blocks, self.n_layers * self.n_tokens * config.block_size *
+                                     self.n_heads * self.head_size * itemsize)
+        self.device = torch.device(config.device)
+
+        # reference fills the pool with randn ("garbage but finite", token_cache_manger.py:65)
+        self.cache_tensor = torch.randn(
+            size=(self.n_layers, self.n_tokens, n_blocks, config.block_size, self.n_heads,
+                  self.head_size), dtype=self.dtype, device=self.device)
+        super().__init__(n_blocks, config.block_size, context.rank, get_ipc_mem_handle(self.cache_tensor))
+        self.migrate_stream = torch.cuda.Stream(device=self.device)
+        self.migrate_manager = CommunicationBackendManager(
+            config.communication_backend_manager_config,
+            CommunicationBackendManagerContext(migrate_stream=self.migrate_stream,
+                                               cache=self.cache_tensor, n_blocks=self.n_blocks,
+                                               rank2host=context.rank2host))
+
     def get_layer_cache(self, layer_id: int) -> TokenCache:
         return TokenCache([self.cache_tensor[layer_id, t] for t in range(self.n_tokens)])
 
@@ -136,10 +152,6 @@ class TokenCacheBlockManager:
         itemsize = torch.empty((), dtype=_DTYPES[config.dtype]).element_size()
         return memory // (config.n_layers * config.n_tokens * config.block_size * config.n_heads *
                           config.head_size * itemsize)
-
-    def get_metrics(self) -> TokenCacheManagerMetrics:
-        rate = self.total_block_matched / self.total_block_queried if self.total_block_queried else 0.0
-        return TokenCacheManagerMetrics(self.block_allocator.get_metrics(), rate)
 
 
 # --- pure host logic, usable (and tested) without a GPU --------------------------------
@@ -165,12 +177,18 @@ def v2p(block_table: List[int], virtual_cache_ids: List[int], block_size: int) -
 
 def allocate_new_blocks(block_allocator: BlockAllocator, shared_cache: SharedCache,
                         n_blocks: int) -> List[int]:
-    """token_cache_manger.py:93-99: free list first, then evict unpinned shared blocks."""
+    """token_cache_manger.py:93-99: free list first, then evict unpinned shared blocks.
+    Where the free list holds some but not all of the blocks the reference evicts `n_blocks` more
+    (not the shortfall) and then fails its own length assert; here the free-list blocks are pinned
+    first (they sit in the eviction set until then, shared_cache.py:26) and only the shortfall is
+    evicted.  Identical results whenever the reference does not assert."""
     block_ids = block_allocator.allocate(n_blocks)
-    if len(block_ids) < n_blocks:
-        block_ids += shared_cache.allocate(n_blocks)
-    assert len(block_ids) == n_blocks, "not enough blocks"
     shared_cache.pin(block_ids)
+    if len(block_ids) < n_blocks:
+        evicted = shared_cache.allocate(n_blocks - len(block_ids))
+        shared_cache.pin(evicted)
+        block_ids += evicted
+    assert len(block_ids) == n_blocks, "not enough blocks"
     return block_ids
 
 

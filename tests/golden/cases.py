@@ -307,3 +307,77 @@ def tiny_llava_block_tables() -> List[List[int]]:
         tables.append([nxt - j for j in range(n)][::-1])
         nxt -= n
     return tables
+
+
+# ---- G11: engine trace (scheduler + parameter builder + executor bookkeeping) -----------------
+@dataclass
+class EngineTraceConfig:
+    tag: str
+    priority: str
+    chunked_prefill: bool
+    token_budgets: int
+    image_budgets: int
+    max_running_requests: int
+    kv_blocks: int
+    image_blocks: int
+    n_image_tokens: int = 40     # per image; also the image cache block size
+    block_size: int = 16
+    n_layers: int = 2
+    n_heads: int = 1
+    head_dim: int = 8
+    image_token_id: int = 32000
+
+
+@dataclass
+class EngineTraceRequest:
+    arrival_step: int
+    token_ids: List[int]         # one image_token_id per image
+    image_seed: int              # -1: text only
+    max_tokens: int
+
+
+ENGINE_TRACES = [
+    EngineTraceConfig("A", "prefill", True, 48, 2, 5, 36, 8),
+    EngineTraceConfig("B", "decode", False, 80, 1, 6, 31, 6),
+]
+
+
+def engine_trace_requests(cfg: EngineTraceConfig) -> List[EngineTraceRequest]:
+    g = torch.Generator().manual_seed(77 + ord(cfg.tag))
+    reqs: List[EngineTraceRequest] = []
+
+    def text(n):
+        return torch.randint(1000, 31999, (n,), generator=g).tolist()
+
+    if cfg.tag == "A":   # image requests only; 4, 9 and 12 repeat request 0 -> prefix-cache hits
+        lens = [21, 7, 30, 12, 21, 5, 26, 18, 9, 21, 14, 28, 21, 11]
+        arrive = [0, 0, 0, 1, 9, 9, 10, 14, 14, 22, 22, 23, 40, 40]
+        first = None
+        for i, (n, a) in enumerate(zip(lens, arrive)):
+            ids = [1] + [cfg.image_token_id] + text(n)
+            seed = 500 + i
+            if i == 0:
+                first = ids
+            if i in (4, 9, 12):
+                ids, seed = list(first), 500
+            reqs.append(EngineTraceRequest(a, ids, seed, 3 + (i * 5) % 7))
+    else:                # text-only and image requests mixed, distinct prompts
+        lens = [33, 12, 50, 8, 27, 41, 16, 22, 10, 36, 19, 45]
+        arrive = [0, 0, 1, 1, 2, 6, 6, 11, 11, 12, 20, 20]
+        for i, (n, a) in enumerate(zip(lens, arrive)):
+            img = i % 3 == 1
+            ids = [1] + ([cfg.image_token_id] if img else []) + text(n)
+            reqs.append(EngineTraceRequest(a, ids, 700 + i if img else -1, 2 + (i * 3) % 8))
+    return reqs
+
+
+def engine_trace_image(seed: int):
+    """8x8 RGB uint8 image of request `seed` (content only matters through its xxh64)."""
+    rng = np.random.RandomState(seed)
+    return rng.randint(0, 256, (8, 8, 3), dtype=np.uint8)
+
+
+def engine_trace_sample(input_id: int, position_id: int) -> int:
+    """Stand-in for the language model in the engine trace: the token sampled at a row is a fixed
+    function of that row's input id and position."""
+    return (position_id * 131 + input_id * 7 + 13) % 30000 + 100

@@ -38,6 +38,11 @@ def import_reference():
     sys.modules["ray"].remote = lambda *a, **k: (lambda f: f)
     sys.modules["ray.actor"].ActorHandle = object
     sys.modules["zmq.sugar.socket"].Socket = object
+    sys.modules["zmq.asyncio"].Socket = object
+    sys.modules["zmq"].sugar = sys.modules["zmq.sugar"]
+    sys.modules["zmq"].asyncio = sys.modules["zmq.asyncio"]
+    sys.modules["zmq.sugar"].socket = sys.modules["zmq.sugar.socket"]
+    sys.modules["ray"].actor = sys.modules["ray.actor"]
     sys.path.insert(0, REFERENCE)
     import hydrainfer  # noqa: F401
     return hydrainfer
@@ -386,6 +391,206 @@ def gen_tiny_llava(out):
         out[f"llava_{dname}_logits"] = torch.stack(logits_log).numpy()
 
 
+class Ragged:
+    """Accumulates variable-length integer rows; saved as <name>_flat + <name>_off."""
+
+    def __init__(self):
+        self.rows = {}
+
+    def add(self, name, values):
+        self.rows.setdefault(name, []).append(np.asarray(values, dtype=np.int64).reshape(-1))
+
+    def save(self, out, prefix):
+        for name, rows in self.rows.items():
+            out[f"{prefix}_{name}_flat"] = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+            out[f"{prefix}_{name}_off"] = np.cumsum([0] + [len(r) for r in rows]).astype(np.int64)
+
+
+INST_CODES = {"EM": 0, "TF": 1, "EF": 2, "IE": 3, "EPMR": 4, "PDMR": 5, "PR": 6}
+
+
+def gen_engine_trace(out):
+    """G11: the reference's own InstructionCreator.process, BatchScheduler.step, BatchFillExecutor /
+    BatchImageEmbedExecutor.execute (hence LanguageModelParametersBuilder and
+    AttentionParametersBuilder) and AsyncEPDNode.step, run unmodified on CPU for one collocated EPD
+    node over a scripted arrival trace.  Only the things that cannot exist here are stood in for:
+    tokenizer / image processor / model factory (token ids and pixel tensors are given), the two
+    models (the sampled token is tests.golden.cases.engine_trace_sample of the row; the image
+    embedding rows carry request*1000 + index), ray actor identity, IPC handle and CUDA stream."""
+    import asyncio
+    from PIL import Image
+    import hydrainfer.memory.token_cache_manger as tcm
+    from hydrainfer.memory import TokenCacheBlockManager, TokenCacheBlockManagerConfig, TokenCacheBlockManagerContext
+    from hydrainfer.engine import (BatchScheduler, RequestControlBlock, RequestProcessParameters, Fill)
+    from hydrainfer.engine.scheduler import BatchSchedulerConfig, BatchSchedulerContext
+    from hydrainfer.engine.request_processor import InstructionCreator
+    from hydrainfer.engine.executor import (BatchFillExecutor, BatchImageEmbedExecutor, InstructionExecutor,
+                                            ExecutorContext)
+    from hydrainfer.engine.output_token_processor import OutputTokenParams
+    from hydrainfer.engine.scenario import ScenarioClassifier
+    from hydrainfer.model.parameters import LanguageModelOutput, VisionModelOutput
+    from hydrainfer.request import Request, SamplingParameters
+    from hydrainfer.cluster.epdnode import AsyncEPDNode, NodeContext
+    from hydrainfer.cluster import MigrateGraph, MigrateNode, NodeType
+    from types import SimpleNamespace as NS
+
+    tcm.get_ipc_mem_handle = lambda t: [0] * 64
+    tcm.CommunicationBackendManager = lambda *a, **k: None
+    real_stream = torch.cuda.Stream
+    torch.cuda.Stream = lambda *a, **k: NS(synchronize=lambda: None)
+    try:
+        for cfg in C.ENGINE_TRACES:
+            _engine_trace_one(cfg, out, locals())
+    finally:
+        torch.cuda.Stream = real_stream
+
+
+def _engine_trace_one(cfg, out, L):
+    import asyncio
+    from PIL import Image
+    from types import SimpleNamespace as NS
+    reqs = C.engine_trace_requests(cfg)
+    rag = Ragged()
+    dev = torch.device("cpu")
+
+    def manager(n_layers, n_tokens, n_blocks, block_size, heads):
+        c = L["TokenCacheBlockManagerConfig"](communication_backend_manager_config=None, n_layers=n_layers,
+                                              n_tokens=n_tokens, n_blocks=n_blocks, block_size=block_size,
+                                              n_heads=heads, head_size=cfg.head_dim, dtype="fp32", device="cpu")
+        return L["TokenCacheBlockManager"](c, L["TokenCacheBlockManagerContext"](rank=0, rank2host={0: "h"}))
+
+    kv = manager(cfg.n_layers, 2, cfg.kv_blocks, cfg.block_size, cfg.n_heads)
+    img = manager(1, 1, cfg.image_blocks, cfg.n_image_tokens, cfg.n_heads)
+    lm_cfg = NS(n_layers=cfg.n_layers, n_qo_heads=cfg.n_heads, n_kv_heads=cfg.n_heads, head_dim=cfg.head_dim)
+    vis_cfg = NS(image_token_id=cfg.image_token_id)
+
+    class Worker:   # stands in for both models
+        def execute_language_model(self, input_ids, image_features, position_ids, p):
+            ap = p.attention_params[0]
+            rag.add("input_ids", input_ids)
+            rag.add("position_ids", position_ids)
+            rag.add("selected", p.selected_token_ids)
+            rag.add("image_rows", [] if image_features is None else image_features[:, 0].round().long())
+            rag.add("q_cu", ap.q_cu_seq_lens)
+            rag.add("kv_cu_reference", ap.kv_cu_seq_lens)
+            rag.add("new_cache_slots", ap.new_cache_slots)
+            rag.add("block_tables", ap.block_tables)
+            rag.add("cu_blocks_lens", ap.cu_blocks_lens)
+            rag.add("fill_scalars", [ap.num_sequences, int(ap.all_sequences_decode), ap.q_max_seq_len])
+            ids, pos = input_ids.tolist(), position_ids.tolist()
+            toks = [C.engine_trace_sample(ids[j], pos[j]) for j in p.selected_token_ids]
+            return L["LanguageModelOutput"](sample_token_ids=torch.tensor(toks, dtype=torch.int))
+
+        def execute_vision_model(self, pixel_values, params):
+            feats = []
+            for pv in pixel_values:     # pv[0,0,0,0] carries the request index
+                r = int(pv.flatten()[0].item())
+                f = torch.zeros(1, cfg.n_image_tokens, cfg.n_heads * cfg.head_dim)
+                f[0, :, 0] = r * 1000 + torch.arange(cfg.n_image_tokens)
+                feats.append(f)
+            rag.add("encode_requests", [int(pv.flatten()[0].item()) for pv in pixel_values])
+            return L["VisionModelOutput"](image_features=torch.cat(feats, dim=0))
+
+    worker = Worker()
+    fill = object.__new__(L["BatchFillExecutor"])
+    fill.config = NS(use_flash_infer=False)
+    fill.context = NS(kv_cache_block_manager=kv, image_cache_block_manager=img, worker=worker, zmq_send=None)
+    fill.worker, fill.vision_model_config, fill.language_model_config = worker, vis_cfg, lm_cfg
+    fill.tokenizer, fill.dtype, fill.device = None, torch.float32, dev
+    fill.block_mangaer, fill.image_block_manager = kv, img
+    fill.batch_prefill_with_paged_kvcache_wrapper = fill.batch_decode_with_paged_kvcache_wrapper = None
+    fill.print_text_output_token_processor = None
+    emb = object.__new__(L["BatchImageEmbedExecutor"])
+    emb.worker, emb.block_manager, emb.language_model_config = worker, img, lm_cfg
+    emb.n_qo_heads, emb.head_dim, emb.dtype, emb.device = cfg.n_heads, cfg.head_dim, torch.float32, dev
+    executor = object.__new__(L["InstructionExecutor"])
+    executor.image_embed_executor, executor.fill_executor = emb, fill
+
+    profiler = NS(profile_image_budgets=lambda: cfg.image_budgets, profile_token_budgets=lambda: cfg.token_budgets)
+    sched = L["BatchScheduler"](
+        L["BatchSchedulerConfig"](priority=cfg.priority, max_running_requests=cfg.max_running_requests,
+                                  chunked_prefill=cfg.chunked_prefill),
+        L["BatchSchedulerContext"](profiler=profiler, kv_cache_block_manager=kv, image_cache_block_manager=img))
+    real_step = sched.step
+
+    def recording_step():
+        batch = real_step()
+        rows = [(rcb.sid, INST_CODES[repr(inst)], len(inst.token_ids) if isinstance(inst, L["Fill"]) else 0)
+                for rcb, inst in batch] if len(batch) else []
+        rag.add("batch_sid", [r[0] for r in rows])
+        rag.add("batch_inst", [r[1] for r in rows])
+        rag.add("batch_ntok", [r[2] for r in rows])
+        return batch
+    sched.step = recording_step
+
+    creator = object.__new__(L["InstructionCreator"])
+    creator.config = NS(debug=False)
+    creator.image_token_id, creator.block_size = cfg.image_token_id, cfg.block_size
+    creator.image_token_caculator = NS(get_num_image_tokens=lambda image_size: cfg.n_image_tokens)
+    prompts = {}
+    creator.tokenizer = NS(encode=lambda prompt: list(prompts[prompt]))
+    creator.processor = NS(process=lambda image: torch.full((1, 3, 2, 2), float(image.info["request"])))
+
+    node = object.__new__(L["AsyncEPDNode"])
+    node.actor_id, node.actor_handle, node.name = "self", None, "EPD"
+    node.config = NS(log_latency_breakdown=False)
+    me = L["MigrateNode"](id="self", tpot_slo=0.4, actor=None)
+    node.context = L["NodeContext"](rank=0, world_size=1, node_type=L["NodeType"]("EPD"),
+                                    migrate_graph=L["MigrateGraph"](ep_table={"self": [me]}, pd_table={"self": [me]}))
+    node._update_migrate_graph(node.context)
+    node.batch_scheduler, node.executor = sched, executor
+    node.kv_cache_block_manager, node.image_cache_block_manager, node.zmq_send = kv, img, None
+
+    rcbs = []
+    classifier = L["ScenarioClassifier"]()
+
+    def admit(i, r):
+        prompts[f"p{i}"] = r.token_ids
+        image = None
+        if r.image_seed >= 0:
+            image = Image.fromarray(C.engine_trace_image(r.image_seed))
+            image.info["request"] = i
+        request = L["Request"](request_id=i, prompt=f"p{i}", image=image,
+                               sampling_params=L["SamplingParameters"](max_tokens=r.max_tokens))
+        rcb = L["RequestControlBlock"]()
+        rcb.sampling_params = request.sampling_params          # SamplingParamsProcess, ignore_eos=True
+        rcb = creator.process(request, rcb, L["RequestProcessParameters"]())
+        rcb.scenario_type = classifier.classify(n_text_tokens=rcb.request_metadata.n_text_tokens,
+                                                n_output_tokens=r.max_tokens)
+        rcb.request_id = i
+        rcb.output_token_params = L["OutputTokenParams"](print_output_text=False, zmq_output=False)
+        first = rcb.instructions.head.next
+        if first.hashes is not None and r.image_seed >= 0:
+            rag.add("image_hash", np.array(first.hashes[:1], dtype=np.uint64).view(np.int64))
+        fillinst = first if isinstance(first, L["Fill"]) else first.next.next.next
+        rag.add("prefix_hashes", np.array(fillinst.hashes, dtype=np.uint64).view(np.int64))
+        rcbs.append(rcb)
+        sched.schedule_new(rcb)
+
+    async def drive():
+        step = 0
+        while True:
+            for i, r in enumerate(reqs):
+                if r.arrival_step == step:
+                    admit(i, r)
+            await node.step()
+            await asyncio.sleep(0.001)       # lets the migrate tasks of this step run (epdnode.py:347)
+            rag.add("free_blocks", [kv.get_num_avaiable_blocks(), img.get_num_avaiable_blocks(),
+                                    len(kv.block_allocator.free_blocks), len(sched.running), len(sched.waiting)])
+            step += 1
+            if step > max(r.arrival_step for r in reqs) and not sched.running and not sched.waiting:
+                return step
+            assert step < 2000
+
+    n_steps = asyncio.run(drive())
+    for rcb in rcbs:
+        rag.add("output_token_ids", rcb.output_token_ids)
+    rag.save(out, f"engine{cfg.tag}")
+    out[f"engine{cfg.tag}_n_steps"] = np.array([n_steps])
+    print(f"engine trace {cfg.tag}: {n_steps} steps, {len(rag.rows['input_ids'])} fill batches, "
+          f"kv hit rate {kv.get_metrics().cache_hit_rate:.3f}, allocator left {len(kv.block_allocator.free_blocks)}")
+
+
 def main():
     import_reference()
     torch.manual_seed(0)
@@ -400,6 +605,7 @@ def main():
         "g8_tiny_llama": gen_tiny_llama,
         "g9_tiny_clip": gen_tiny_clip,
         "g10_tiny_llava": gen_tiny_llava,
+        "g11_engine_trace": gen_engine_trace,
     }
     only = sys.argv[1:]
     for name, fn in sets.items():
