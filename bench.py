@@ -42,6 +42,7 @@ def parse():
                    help="decode against the randn-filled cache instead of a real prefill")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ttft", action="store_true")
+    p.add_argument("--no-serving", action="store_true", help="skip the continuous-batching engine leg")
     p.add_argument("--no-migration", action="store_true")
     p.add_argument("--lib-gemm", action="store_true",
                    help="library GEMMs (hipBLASLt) for decode too, instead of the weight-streaming HIP kernel")
@@ -121,9 +122,9 @@ def time_attention_kernel(runner, start_len, steps):
     return sum(a.elapsed_time(b) for a, b in evs) / len(evs)   # ms
 
 
-def measure_ttft(runner, prompts, shape, dtype, dev, rank, reps=7):
-    """p50 time-to-first-token of ONE image+text request on an idle replica: CLIP ViT-L/14-336
-    encode (23 layers, dense HIP attention) + projector + 704-token prefill + greedy sample."""
+def make_vision(shape, dtype, dev):
+    """CLIP ViT-L/14-336 + projector with random weights, and the reference's synthetic image
+    (hydrainfer/utils/image_utils.py:4-7) after CLIP preprocessing."""
     from hydrainfer_amd.model.clip import CLIP_VIT_L_14_336, ClipShape, LlavaVisionModel
     import dataclasses
     import numpy as np
@@ -134,11 +135,48 @@ def measure_ttft(runner, prompts, shape, dtype, dev, rank, reps=7):
     else:
         cshape = dataclasses.replace(CLIP_VIT_L_14_336, projector_hidden_size=shape.hidden_size)
     vision = LlavaVisionModel.random_init(cshape, dtype, dev, seed=1)
-    rng = np.random.RandomState(0)     # hydrainfer/utils/image_utils.py:4-7
+    rng = np.random.RandomState(0)
     img = rng.randint(0, 256, (336, 336, 3)).astype(np.float32) / 255.0
     mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
     std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
-    pixels = torch.from_numpy((img - mean) / std).permute(2, 0, 1)[None].to(dev)
+    pixels = torch.from_numpy((img - mean) / std).permute(2, 0, 1)[None]
+    return vision, pixels
+
+
+def measure_serving(model, vision, pixels, shape, dtype, dev, batch, n_text, max_tokens):
+    """The whole serving path on this GPU (BASELINE configs[1]/[2]): `batch` image+text requests
+    admitted together to the continuous-batching engine (hydrainfer_amd/engine: scheduler with
+    chunked prefill, CLIP encode -> image cache -> prefill -> decode steps replayed from hipGraphs
+    with one step of look-ahead), until every request has its max_tokens."""
+    from hydrainfer_amd.engine.node import LocalCluster
+    from hydrainfer_amd.engine.request_processor import InstructionCreator
+    from hydrainfer_amd.engine.scheduler import BatchSchedulerConfig
+    from hydrainfer_amd.engine.serve import build_node, replay, synthetic_requests
+    from hydrainfer_amd.model.llava import LlavaLanguageModel
+    itid = image_token_id(shape.vocab_size)
+    lm = LlavaLanguageModel(model, image_token_id=itid)
+    per_req = (576 + n_text + max_tokens + 15) // 16 + 1
+    sched = BatchSchedulerConfig(priority="prefill", max_running_requests=batch, chunked_prefill=True,
+                                 token_budgets=2048, image_budgets=8)
+    node = build_node("EPD0", "EPD", lm, vision, shape, dtype, dev, per_req * (batch + 2), batch + 2, 576, sched,
+                      max_blocks_per_seq=per_req)
+    node.executor.fill_executor.graph_decoder.warmup(list(range(4, batch + 1, 4)), kv_max=1024)
+    cluster = LocalCluster([node])
+    creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16)
+    text_hi = min(31999, itid - 1)
+    replay(cluster, creator, synthetic_requests(2, n_text, 4, itid, pixels, (min(1000, text_hi - 1), text_hi), 99),
+           [0.0, 0.0], dev)
+    reqs = synthetic_requests(batch, n_text, max_tokens, itid, pixels, (min(1000, text_hi - 1), text_hi), 1)
+    res = replay(cluster, creator, reqs, [0.0] * batch, dev)
+    res["what"] = (f"{batch} requests (1 image + {n_text} text tokens, {max_tokens} generated) admitted at t=0 to one "
+                   "collocated EPD engine: continuous batching, chunked prefill (2048-token budget), hipGraph decode")
+    return res
+
+
+def measure_ttft(runner, prompts, shape, dtype, dev, rank, vision, pixels, reps=7):
+    """p50 time-to-first-token of ONE image+text request on an idle replica: CLIP ViT-L/14-336
+    encode (23 layers, dense HIP attention) + projector + 704-token prefill + greedy sample."""
+    pixels = pixels.to(dev)
     times, enc_times = [], []
     use_graph = runner.cfg.use_graph and shape.vocab_size > 32000
     if use_graph:
@@ -396,7 +434,14 @@ def main():
     tokens = args.batch * steps * n_gpus
     value = tokens / elapsed
 
-    ttft = None if args.skip_prefill or args.no_ttft else measure_ttft(runner, prompts, shape, dtype, dev, rank)
+    vision = pixels = None
+    if not (args.skip_prefill or (args.no_ttft and args.no_serving)):
+        vision, pixels = make_vision(shape, dtype, dev)
+    ttft = None if args.skip_prefill or args.no_ttft else measure_ttft(runner, prompts, shape, dtype, dev, rank,
+                                                                         vision, pixels)
+    serving = None
+    if rank == 0 and world == 1 and vision is not None and not args.no_serving:
+        serving = measure_serving(model, vision, pixels, shape, dtype, dev, args.batch, prompt_len - 576, n_generate)
     # ---- roofline of the dominant hand-written kernel + whole-step fraction (rank 0)
     out = None
     if rank == 0:
@@ -432,7 +477,7 @@ def main():
                            "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
                            "weight_bytes": model.weight_bytes()},
             "prefill_batch_ms": None if ttft_ms is None else round(ttft_ms, 2),
-            "ttft": ttft, "migration": None,
+            "ttft": ttft, "serving": serving, "migration": None,
         }
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(shape, dtype, args.batch, mid_ctx, args.cpu_layers)

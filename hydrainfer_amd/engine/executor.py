@@ -16,14 +16,110 @@ from hydrainfer_amd.engine.rcb import BatchRequest
 from hydrainfer_amd.model.llama import LanguageModelParameters
 
 
+class PendingToken:
+    """Placeholder for a token that has been sampled on the device but not read back yet
+    (graph decode look-ahead): row `row` of decode launch `launch`."""
+    __slots__ = ("launch", "row")
+
+    def __init__(self, launch: int, row: int):
+        self.launch, self.row = launch, row
+
+    def __repr__(self):
+        return f"<pending {self.launch}:{self.row}>"
+
+
 class BatchFillExecutor:
     def __init__(self, language_model, kv_cache_block_manager, image_cache_block_manager,
-                 dtype: torch.dtype, device: torch.device):
+                 dtype: torch.dtype, device: torch.device, graph_decoder=None):
         self.language_model = language_model            # LlavaLanguageModel
         lm = language_model.language_model
         self.shape = lm.shape
         self.kv_manager, self.image_manager = kv_cache_block_manager, image_cache_block_manager
         self.dtype, self.device = dtype, device
+        self.graph_decoder = graph_decoder              # engine.graph_decode.GraphedDecoder or None
+        self.pending = None        # (launch id, [(rcb, inst, index into rcb.output_token_ids)])
+
+    def _decode_rows(self, batch: BatchRequest):
+        """(token, position, slot, kv_len, block_table) per request if the whole batch is decode.
+        A token still on the device is encoded as -(row + 1) of the pending launch."""
+        rows, n_blocks = [], 0
+        for rcb, inst in batch:
+            if len(inst.token_ids) != 1 or not inst.sample:
+                return None
+            token = inst.token_ids[0]
+            if isinstance(token, PendingToken):
+                if self.pending is None or token.launch != self.pending[0]:
+                    return None
+                token = -(token.row + 1)
+            vc = rcb.virtual_kv_cache
+            c = inst.cache_ids[0]
+            rows.append((token, inst.position_ids[0], self.kv_manager.v2p(vc, [c])[0], c + 1, vc.block_table))
+            n_blocks += len(vc.block_table)
+        return rows if self.graph_decoder.fits(len(rows), n_blocks) else None
+
+    def _launch_decode(self, batch: BatchRequest, rows) -> None:
+        """Enqueue the step, hand every request a placeholder for its new token, THEN read the
+        previous step's tokens: the GPU already has the next step queued while the host catches up."""
+        launch = self.graph_decoder.launch(rows)
+        entries = []
+        for row, (rcb, inst) in enumerate(batch):
+            placeholder = PendingToken(launch, row)
+            entries.append((rcb, inst, len(rcb.output_token_ids), placeholder))
+            if rcb.eos_hit:
+                continue                       # ended by a late-read token; this row's sample is dropped
+            rcb.output_token_ids.append(placeholder)
+            if inst.sample_dst is not None:
+                inst.sample_dst.token_ids = [placeholder]
+        batch.step()
+        previous, self.pending = self.pending, (launch, entries)
+        if previous is not None:
+            self._resolve(previous)
+
+    def _resolve(self, pending) -> None:
+        launch, entries = pending
+        tokens = self.graph_decoder.fetch(launch)
+        now = time.perf_counter()
+        for (rcb, inst, index, placeholder), token in zip(entries, tokens):
+            if rcb.eos_hit:
+                continue                       # a step that ran past an end-of-sequence token
+            rcb.output_token_ids[index] = token
+            dst = inst.sample_dst
+            if dst is not None and dst.token_ids and dst.token_ids[0] is placeholder:
+                dst.token_ids = [token]
+            rcb.metric.token_times.append(now)
+            if token in rcb.sampling_params.eos_token_ids:
+                del rcb.output_token_ids[index + 1:]   # whatever ran past it is discarded
+                rcb.eos_hit = True
+            last = rcb.eos_hit or index + 1 == rcb.sampling_params.max_tokens
+            for p in rcb.output_token_processors:
+                p.append_token_id(token, last)
+
+    def resolve_pending(self) -> None:
+        """Read back the tokens of the decode step that is still in flight (if any)."""
+        if self.pending is not None:
+            pending, self.pending = self.pending, None
+            self._resolve(pending)
+
+    def _deliver(self, batch: BatchRequest, sampled: List[int]) -> None:
+        now = time.perf_counter()
+        i = 0
+        for rcb, inst in batch:
+            if not isinstance(inst, Fill) or not inst.sample:
+                continue
+            token = sampled[i]
+            i += 1
+            if rcb.eos_hit:
+                continue                       # already ended by a token that was read back late
+            if not inst.is_chunked:
+                rcb.metric.token_times.append(now)
+                rcb.output_token_ids.append(token)
+            if inst.sample_dst is not None:
+                inst.sample_dst.token_ids = [token]
+            if not inst.is_chunked:
+                last = rcb.is_finished()
+                for p in rcb.output_token_processors:
+                    p.append_token_id(token, last)
+        batch.step()
 
     def _publish_prefix_blocks(self, batch: BatchRequest) -> None:
         """A block's hash enters the prefix cache in the step that computes its last token
@@ -39,6 +135,12 @@ class BatchFillExecutor:
         if len(batch) == 0:
             return
         self._publish_prefix_blocks(batch)
+        if self.graph_decoder is not None:
+            rows = self._decode_rows(batch)
+            if rows is not None:
+                self._launch_decode(batch, rows)
+                return
+            self.resolve_pending()             # the eager path needs every token on the host
         sh = self.shape
         builder = LanguageModelParametersBuilder(
             self.image_manager, self.kv_manager, sh.num_hidden_layers, sh.num_attention_heads,
@@ -59,23 +161,7 @@ class BatchFillExecutor:
             sampled = sampled[inputs.selected_token_ids_tensor]
         sampled = sampled.tolist()                      # the step's only device sync
 
-        now = time.perf_counter()
-        i = 0
-        for rcb, inst in batch:
-            if not isinstance(inst, Fill) or not inst.sample:
-                continue
-            token = sampled[i]
-            i += 1
-            if not inst.is_chunked:
-                rcb.metric.token_times.append(now)
-                rcb.output_token_ids.append(token)
-            if inst.sample_dst is not None:
-                inst.sample_dst.token_ids = [token]
-            if not inst.is_chunked:
-                last = rcb.is_finished()
-                for p in rcb.output_token_processors:
-                    p.append_token_id(token, last)
-        batch.step()
+        self._deliver(batch, sampled)
 
 
 class BatchImageEmbedExecutor:
@@ -129,3 +215,7 @@ class InstructionExecutor:
 
     def execute_empty(self, batch: BatchRequest) -> None:
         batch.step()
+
+    def resolve_pending(self) -> None:
+        if self.fill_executor is not None:
+            self.fill_executor.resolve_pending()

@@ -1,0 +1,170 @@
+"""hipGraph replay of decode-only fill batches inside the engine (the
+reference's unfinished attempt is hydrainfer/model_runner/cuda_graph_model_runner.py:1-72).
+
+A decode step of a 7B model is ~260 launches of 5-70 us kernels; issued eagerly the host cannot
+keep ahead of the GPU.  Here the step's integer inputs live in ONE static device buffer
+
+    [ input_ids | positions | new_cache_slots | kv_cu | cu_blocks_lens | block_tables ... ]
+
+filled by one pinned H2D copy per step, and the forward over views of that buffer is captured
+once per padded batch size.  Batches are padded to a multiple of `pad_to` rows; padding rows are
+1-token sequences that write into a scratch block reserved from the pool, so they never touch a
+live request.  The attention kernel reads each sequence's true length from kv_cu, so one graph
+serves every context length (the captured max length only seeds the split heuristic).
+
+One step of look-ahead: the token a request sampled in launch N is its input in launch N+1, and
+only the DEVICE needs it for that.  The graph therefore starts by taking each row's input id either
+from the host-written id or from `prev_tokens[src_row]` (the previous launch's samples, kept in a
+static buffer the graph itself updates at its end), so the host can build and enqueue launch N+1
+while launch N is still running and read N's tokens afterwards (`launch` / `fetch`).  The host work
+of a step (scheduler, tables, staging) no longer leaves the GPU idle."""
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from hydrainfer_amd.layer.causal_attention import AttentionParameters
+from hydrainfer_amd.memory.kv_cache import KVCache
+from hydrainfer_amd.model.llama import LanguageModelParameters
+
+
+class GraphedDecoder:
+    def __init__(self, language_model, kv_cache_block_manager, max_batch: int = 64,
+                 max_blocks_per_seq: int = 256, pad_to: int = 4):
+        self.lm = language_model                       # LlavaLanguageModel
+        self.model = language_model.language_model     # LlamaForCausalLM
+        self.kv = kv_cache_block_manager
+        self.dev = self.kv.device
+        self.pad_to = pad_to
+        self.max_batch = (max_batch + pad_to - 1) // pad_to * pad_to
+        self.table_cap = self.max_batch * max_blocks_per_seq
+        B = self.max_batch
+        self.off = {"ids": 0, "pos": B, "slots": 2 * B, "src": 3 * B, "kv_cu": 4 * B, "cu_blocks": 5 * B + 1,
+                    "tables": 6 * B + 2}
+        total = self.off["tables"] + self.table_cap
+        self.static = torch.zeros(total, dtype=torch.int32, device=self.dev)
+        self.staging = torch.zeros(total, dtype=torch.int32).pin_memory()
+        self.stage = self.staging.numpy()
+        self.q_cu = torch.arange(0, B + 1, dtype=torch.int32, device=self.dev)
+        self.prev_tokens = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.host_tokens = [torch.zeros(B, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.launches = 0                  # id of the most recent launch (1-based)
+        self.launch_rows = {}              # launch id -> number of live rows
+        n_layers = self.model.shape.num_hidden_layers
+        self.kv_caches = [KVCache.from_token_cache(self.kv.get_layer_cache(l)) for l in range(n_layers)]
+        # scratch block for padding rows
+        self.pad_cache = self.kv.allocate_virtual_cache()
+        self.kv.realloc(self.pad_cache, 1)
+        self.pad_block = self.pad_cache.block_table[0]
+        self.graphs: Dict[Tuple[int, int], Tuple[torch.cuda.CUDAGraph, torch.Tensor]] = {}
+
+    def fits(self, n_seqs: int, n_blocks: int) -> bool:
+        padded = (n_seqs + self.pad_to - 1) // self.pad_to * self.pad_to
+        return padded <= self.max_batch and n_blocks + (padded - n_seqs) <= self.table_cap
+
+    def _views(self, B: int):
+        o, s = self.off, self.static
+        return (s[o["ids"]:o["ids"] + B], s[o["pos"]:o["pos"] + B], s[o["slots"]:o["slots"] + B],
+                s[o["kv_cu"]:o["kv_cu"] + B + 1], s[o["cu_blocks"]:o["cu_blocks"] + B + 1],
+                s[o["tables"]:], s[o["src"]:o["src"] + B])
+
+    def _kv_bucket(self, B: int, kv_max: int) -> int:
+        if B * self.model.shape.num_attention_heads >= 768:
+            return 0                       # one split whatever the length (attn_decode.hip heuristic)
+        b = 256
+        while b < kv_max:
+            b *= 2
+        return b
+
+    def _params(self, B: int, kv_max: int) -> LanguageModelParameters:
+        ids, pos, slots, kv_cu, cu_blocks, tables, _ = self._views(B)
+        attn = [AttentionParameters(kv_cache=kc, q_cu_seq_lens=self.q_cu[:B + 1], kv_cu_seq_lens=kv_cu,
+                                    new_cache_slots=slots, block_tables=tables, cu_blocks_lens=cu_blocks,
+                                    num_sequences=B, all_sequences_decode=True, q_max_seq_len=1,
+                                    kv_max_seq_len=kv_max) for kc in self.kv_caches]
+        return LanguageModelParameters(attention_params=attn, all_sequences_decode=True)
+
+    def _body(self, B: int, params):
+        ids, pos = self._views(B)[:2]
+        src = self._views(B)[6]
+        fed = self.prev_tokens[src.clamp_min(0).long()]
+        out = self.model(torch.where(src >= 0, fed, ids), pos, params)
+        self.prev_tokens[:B].copy_(out)
+        return out
+
+    def _capture(self, B: int, bucket: int):
+        params = self._params(B, bucket if bucket else 4096)
+        saved = self.prev_tokens.clone()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):             # warm-up outside capture: workspace growth, lazy init
+                self.prev_tokens.copy_(saved)
+                self._body(B, params)
+            self.prev_tokens.copy_(saved)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._body(B, params)
+        return graph, out
+
+    def _fill(self, rows: List[Tuple[int, int, int, int, List[int]]], B: int) -> int:
+        """rows: (token, position, slot, kv_len, block_table) per live sequence; a token < 0 means
+        "the sample of row -(token + 1) of the previous launch"."""
+        o, st = self.off, self.stage
+        n = len(rows)
+        bs = self.kv.block_size
+        pad = (0, 0, self.pad_block * bs, 1, [self.pad_block])
+        rows = rows + [pad] * (B - n)
+        st[o["ids"]:o["ids"] + B] = [max(r[0], 0) for r in rows]
+        st[o["src"]:o["src"] + B] = [-(r[0] + 1) if r[0] < 0 else -1 for r in rows]
+        st[o["pos"]:o["pos"] + B] = [r[1] for r in rows]
+        st[o["slots"]:o["slots"] + B] = [r[2] for r in rows]
+        st[o["kv_cu"]] = 0
+        st[o["kv_cu"] + 1:o["kv_cu"] + B + 1] = np.cumsum([r[3] for r in rows])
+        lens = [len(r[4]) for r in rows]
+        st[o["cu_blocks"]] = 0
+        st[o["cu_blocks"] + 1:o["cu_blocks"] + B + 1] = np.cumsum(lens)
+        flat = [b for r in rows for b in r[4]]
+        st[o["tables"]:o["tables"] + len(flat)] = flat
+        used = o["tables"] + len(flat)
+        self.static[:used].copy_(self.staging[:used], non_blocking=True)
+        return max(r[3] for r in rows)
+
+    def warmup(self, batch_sizes: List[int], kv_max: int = 1024) -> None:
+        rows = [(1, 0, self.pad_block * self.kv.block_size, 1, [self.pad_block])]
+        for n in batch_sizes:
+            B = (n + self.pad_to - 1) // self.pad_to * self.pad_to
+            key = (B, self._kv_bucket(B, kv_max))
+            if key not in self.graphs:
+                self._fill(rows, B)
+                self.graphs[key] = self._capture(*key)
+        torch.cuda.synchronize(self.dev)
+
+    def launch(self, rows: List[Tuple[int, int, int, int, List[int]]]) -> int:
+        """Enqueue one decode step; returns a launch id for `fetch`.  Does not wait for the GPU."""
+        n = len(rows)
+        B = (n + self.pad_to - 1) // self.pad_to * self.pad_to
+        kv_max = self._fill(rows, B)
+        key = (B, self._kv_bucket(B, kv_max))
+        if key not in self.graphs:
+            self.graphs[key] = self._capture(*key)
+        graph, out = self.graphs[key]
+        graph.replay()
+        self.launches += 1
+        slot = self.launches % 2
+        self.host_tokens[slot][:n].copy_(out[:n], non_blocking=True)
+        self.events[slot].record()
+        self.launch_rows[self.launches] = n
+        return self.launches
+
+    def fetch(self, launch_id: int) -> List[int]:
+        """Tokens sampled by a launch (waits for it).  Only the two most recent launches are kept."""
+        assert launch_id > self.launches - 2, "tokens of an older launch have been overwritten"
+        slot = launch_id % 2
+        self.events[slot].synchronize()
+        return self.host_tokens[slot][: self.launch_rows.pop(launch_id)].tolist()
+
+    def run(self, rows: List[Tuple[int, int, int, int, List[int]]]) -> List[int]:
+        return self.fetch(self.launch(rows))

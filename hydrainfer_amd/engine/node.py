@@ -128,6 +128,9 @@ class EPDNode:
         for group in (embed, fill, empty, pull):
             for rcb in group.rcbs:
                 if rcb.is_finished():
+                    # its last tokens may still be in flight (decode look-ahead); they must be on
+                    # the host, and the step that wrote its blocks done, before the blocks go back
+                    self.executor.resolve_pending()
                     rcb.metric.finished_time = now
                     self._free_cache(rcb)
                     self.finished.append(rcb)
@@ -156,6 +159,7 @@ class EPDNode:
                 self.batch_scheduler.schedule_running(rcb)
                 continue
             self.batch_scheduler.migrating_acquire()
+            self.executor.resolve_pending()
             self._drain_compute()                   # the peer reads these blocks on another stream
             node.migrate(self, rcb)
 

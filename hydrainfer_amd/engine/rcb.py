@@ -76,6 +76,7 @@ class RequestControlBlock:
         self.output_token_ids: List[int] = []
         self.scenario_type: Optional[ScenarioType] = None
         self.metric = RequestMetric()
+        self.eos_hit = False      # set when a token read back late (decode look-ahead) was end-of-sequence
 
     def current_instruction(self) -> Instruction:
         return self.instructions.curr
@@ -84,7 +85,7 @@ class RequestControlBlock:
         self.instructions.curr = self.instructions.curr.next
 
     def is_finished(self) -> bool:
-        if self.instructions.curr is None:
+        if self.instructions.curr is None or self.eos_hit:
             return True
         if len(self.output_token_ids) == self.sampling_params.max_tokens:
             return True

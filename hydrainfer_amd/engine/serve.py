@@ -1,0 +1,104 @@
+"""Build a serving node (pools + models + scheduler + executors) and replay an arrival trace on it.
+Used by bench.py's `serving` leg and tools/bench_engine.py; mirrors what
+hydrainfer/cluster/epdnode.py:_update_engine assembles and what benchmark/benchmark.py drives."""
+import dataclasses
+import time
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from hydrainfer_amd.engine.executor import BatchFillExecutor, BatchImageEmbedExecutor, InstructionExecutor
+from hydrainfer_amd.engine.node import EPDNode, LocalCluster, NodeType
+from hydrainfer_amd.engine.rcb import SamplingParameters
+from hydrainfer_amd.engine.request_processor import InstructionCreator, TokenRequest
+from hydrainfer_amd.engine.scheduler import BatchScheduler, BatchSchedulerConfig, BatchSchedulerContext
+from hydrainfer_amd.memory.token_cache_manger import (TokenCacheBlockManager, TokenCacheBlockManagerConfig,
+                                                      TokenCacheBlockManagerContext)
+
+_DTYPE_NAMES = {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "fp32"}
+
+
+def build_node(name: str, node_type: str, language_model, vision_model, lm_shape, dtype: torch.dtype,
+               device: torch.device, kv_blocks: int, image_blocks: int, n_image_tokens: int,
+               sched: BatchSchedulerConfig, rank: int = 0, graph_decode: bool = True,
+               max_blocks_per_seq: int = 256) -> EPDNode:
+    nt = NodeType(node_type)
+    ctx = TokenCacheBlockManagerContext(rank=rank, rank2host={rank: "localhost"})
+    kv = img = None
+    if nt.has_kv_cache:
+        kv = TokenCacheBlockManager(TokenCacheBlockManagerConfig(
+            n_layers=lm_shape.num_hidden_layers, n_tokens=2, n_blocks=kv_blocks, block_size=16,
+            n_heads=lm_shape.num_key_value_heads, head_size=lm_shape.head_dim, dtype=_DTYPE_NAMES[dtype],
+            device=str(device)), ctx)
+    if nt.has_image_cache:
+        img = TokenCacheBlockManager(TokenCacheBlockManagerConfig(
+            n_layers=1, n_tokens=1, n_blocks=image_blocks, block_size=n_image_tokens,
+            n_heads=lm_shape.num_attention_heads, head_size=lm_shape.head_dim, dtype=_DTYPE_NAMES[dtype],
+            device=str(device)), ctx)
+    fill = None
+    if nt.has_language_model:
+        decoder = None
+        if graph_decode and nt.enable_decode:
+            from hydrainfer_amd.engine.graph_decode import GraphedDecoder
+            decoder = GraphedDecoder(language_model, kv, max_batch=sched.max_running_requests,
+                                     max_blocks_per_seq=max_blocks_per_seq)
+        fill = BatchFillExecutor(language_model, kv, img, dtype, device, graph_decoder=decoder)
+    emb = BatchImageEmbedExecutor(vision_model, img, lm_shape.num_attention_heads, lm_shape.head_dim, dtype,
+                                  device) if nt.has_vision_model else None
+    scheduler = BatchScheduler(sched, BatchSchedulerContext(kv, img))
+    return EPDNode(name, nt, scheduler, InstructionExecutor(fill, emb), kv, img)
+
+
+def synthetic_requests(n: int, n_text: int, max_tokens: int, image_token_id: int, pixels: Optional[torch.Tensor],
+                       vocab_text: Tuple[int, int] = (1000, 31999), seed: int = 0) -> List[TokenRequest]:
+    """The benchmark request of SURVEY.md §8(d): one image + n_text random text ids, distinct per request."""
+    out = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(seed * 100003 + i)
+        text = torch.randint(vocab_text[0], vocab_text[1], (n_text,), generator=g).tolist()
+        ids = ([image_token_id] if pixels is not None else []) + text
+        out.append(TokenRequest(request_id=i, token_ids=ids, pixel_values=pixels, image_size=(336, 336),
+                                image_hash=(seed << 20) + i,       # distinct images: no prefix sharing
+                                sampling_params=SamplingParameters(max_tokens=max_tokens)))
+    return out
+
+
+def poisson_arrivals(n: int, rate: float, seed: int = 0) -> List[float]:
+    """benchmark/timestamp.py:9-16 with the seeding of benchmark/benchmark.py:136-137."""
+    rng = np.random.RandomState(seed)
+    gaps = rng.exponential(1.0 / rate, n)
+    return np.cumsum(gaps).tolist()
+
+
+def replay(cluster: LocalCluster, creator: InstructionCreator, requests: List[TokenRequest],
+           arrivals: List[float], device: torch.device) -> dict:
+    """Wall-clock replay: a request enters at its arrival time (0 = all at once).  Returns the
+    serving metrics of benchmark/metric.py: output tokens/s, TTFT and TPOT percentiles."""
+    order = sorted(range(len(requests)), key=lambda i: arrivals[i])
+    rcbs = [None] * len(requests)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    nxt, steps = 0, 0
+    while nxt < len(order) or not cluster.idle():
+        now = time.perf_counter() - t0
+        while nxt < len(order) and arrivals[order[nxt]] <= now:
+            i = order[nxt]
+            rcbs[i] = creator.process(requests[i])
+            cluster.add_request(rcbs[i])
+            rcbs[i].metric.arrival_time = t0 + arrivals[i]
+            nxt += 1
+        if cluster.step() == 0 and nxt < len(order):
+            time.sleep(max(0.0, min(0.001, arrivals[order[nxt]] - (time.perf_counter() - t0))))
+        steps += 1
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    ttft = sorted(r.metric.token_times[0] - r.metric.arrival_time for r in rcbs)
+    tpot = sorted((r.metric.token_times[-1] - r.metric.token_times[0]) / max(1, len(r.metric.token_times) - 1)
+                  for r in rcbs)
+    n_out = sum(len(r.output_token_ids) for r in rcbs)
+    pct = lambda xs, p: xs[min(len(xs) - 1, int(p * len(xs)))]
+    return {"requests": len(rcbs), "output_tokens": n_out, "wall_s": round(wall, 3),
+            "output_tok_s": round(n_out / wall, 1), "steps": steps,
+            "ttft_p50_ms": round(pct(ttft, 0.5) * 1e3, 2), "ttft_p99_ms": round(pct(ttft, 0.99) * 1e3, 2),
+            "tpot_p50_ms": round(pct(tpot, 0.5) * 1e3, 3), "tpot_p99_ms": round(pct(tpot, 0.99) * 1e3, 3)}

@@ -101,9 +101,14 @@ class LogitsTap:
 
 
 def make_node(name, node_type, lm, vision, kv, img, lm_shape, dtype, device, sched_cfg: BatchSchedulerConfig,
-              batch_log=None):
+              batch_log=None, graph_decode=False):
     nt = NodeType(node_type)
-    fill = BatchFillExecutor(lm, kv, img, dtype, device) if nt.has_language_model else None
+    decoder = None
+    if graph_decode and nt.enable_decode:
+        from hydrainfer_amd.engine.graph_decode import GraphedDecoder
+        decoder = GraphedDecoder(getattr(lm, "lm", lm), kv, max_batch=sched_cfg.max_running_requests,
+                                 max_blocks_per_seq=8)
+    fill = BatchFillExecutor(lm, kv, img, dtype, device, graph_decoder=decoder) if nt.has_language_model else None
     emb = BatchImageEmbedExecutor(vision, img, lm_shape.num_attention_heads, lm_shape.head_dim, dtype,
                                   device) if nt.has_vision_model else None
     if fill is not None and batch_log is not None:

@@ -76,7 +76,7 @@ def oracle_cluster(dt, topology, chunked):
     return LocalCluster(nodes), lm, rows
 
 
-def hip_cluster(dt, dname, topology, chunked):
+def hip_cluster(dt, dname, topology, chunked, graph_decode=False):
     from hydrainfer_amd.memory.token_cache_manger import (TokenCacheBlockManager, TokenCacheBlockManagerConfig,
                                                           TokenCacheBlockManagerContext)
     from hydrainfer_amd.model.clip import LlavaVisionModel
@@ -97,7 +97,8 @@ def hip_cluster(dt, dname, topology, chunked):
         img = TokenCacheBlockManager(TokenCacheBlockManagerConfig(
             n_layers=1, n_tokens=1, n_blocks=6, block_size=N_IMG_TOK, n_heads=lshape.num_attention_heads,
             head_size=lshape.head_dim, dtype=dname, device="cuda:0"), ctx)
-        nodes.append(make_node(f"{t}{k}", t, lm, vision, kv, img, lshape, dt, dev, sched_cfg(chunked), rows))
+        nodes.append(make_node(f"{t}{k}", t, lm, vision, kv, img, lshape, dt, dev, sched_cfg(chunked), rows,
+                               graph_decode=graph_decode))
     return LocalCluster(nodes), lm, rows
 
 
@@ -185,3 +186,23 @@ def test_hip_engine_matches_oracle_engine(dname, topology, chunked):
     torch.cuda.synchronize()
     drained(cluster)
     compare(base, (rcbs, rows, lm.logits), reqs, tol=1.5e-1 if dname == "bf16" else 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dname", ["fp16", "bf16"])
+@pytest.mark.parametrize("topology", [["EPD"], ["EP", "D"]], ids="-".join)
+def test_hip_engine_graph_decode_equals_eager(dname, topology):
+    """Decode-only batches replayed from hipGraphs (padded batch, static metadata buffer) generate
+    exactly the tokens of the eager engine."""
+    dt = C.DTYPES[dname]
+    reqs = trace_requests()
+    eager_cluster, _, _ = hip_cluster(dt, dname, topology, True)
+    eager = run_trace(eager_cluster, creator(), reqs)
+    graph_cluster, _, _ = hip_cluster(dt, dname, topology, True, graph_decode=True)
+    graphed = run_trace(graph_cluster, creator(), reqs)
+    torch.cuda.synchronize()
+    decoders = [n.executor.fill_executor.graph_decoder for n in graph_cluster.nodes
+                if n.executor.fill_executor is not None and n.executor.fill_executor.graph_decoder is not None]
+    assert decoders and sum(len(d.graphs) for d in decoders) > 0, "no decode batch went through a graph"
+    for i in range(len(reqs)):
+        assert graphed[i].output_token_ids == eager[i].output_token_ids, f"request {i}"

@@ -155,3 +155,72 @@ def test_engine_trace_matches_reference(cfg):
     for i, rcb in enumerate(rcbs):
         assert rcb.output_token_ids == gold.rows("output_token_ids")[i].tolist(), f"tokens of request {i}"
         assert len(rcb.output_token_ids) == reqs[i].max_tokens
+
+
+class FakeGraphDecoder:
+    """CPU stand-in with GraphedDecoder's launch/fetch contract (tokens stay 'on the device' until
+    fetched; a negative token means 'row -(t+1) of the previous launch')."""
+
+    def __init__(self):
+        self.launches, self.tokens, self.n_launch_ahead = 0, {}, 0
+
+    def fits(self, n_seqs, n_blocks):
+        return True
+
+    def launch(self, rows):
+        prev = self.tokens.get(self.launches, [])
+        out = []
+        for token, pos, slot, kv_len, table in rows:
+            if token < 0:
+                token = prev[-(token + 1)]
+                self.n_launch_ahead += 1
+            assert kv_len == pos + 1 and slot == table[pos // 16] * 16 + pos % 16
+            out.append(C.engine_trace_sample(token, pos))
+        self.launches += 1
+        self.tokens[self.launches] = out
+        return self.launches
+
+    def fetch(self, launch_id):
+        assert launch_id > self.launches - 2
+        return list(self.tokens[launch_id])
+
+
+def _run_plain(cfg, eos, decoder):
+    reqs = C.engine_trace_requests(cfg)
+    node, sched, kv, img = build_node(cfg, None, [])
+    node.executor.fill_executor.graph_decoder = decoder
+    cluster = LocalCluster([node])
+    creator = InstructionCreator(image_token_id=cfg.image_token_id, n_image_tokens_per_image=cfg.n_image_tokens,
+                                 block_size=cfg.block_size, ignore_eos=eos is None,
+                                 eos_token_id=eos if eos is not None else 2)
+    rcbs, step = [None] * len(reqs), 0
+    while step <= max(r.arrival_step for r in reqs) or not cluster.idle():
+        for i, r in enumerate(reqs):
+            if r.arrival_step == step:
+                px = torch.full((1, 3, 2, 2), float(i)) if r.image_seed >= 0 else None
+                rcbs[i] = creator.process(TokenRequest(i, r.token_ids, px, (8, 8), 100 + r.image_seed,
+                                                       SamplingParameters(max_tokens=r.max_tokens)))
+                cluster.add_request(rcbs[i])
+        cluster.step()
+        step += 1
+        assert step < 500
+    for m in (kv, img):
+        assert len(m.shared_cache.to_be_evicted) == m.n_blocks
+    return [r.output_token_ids for r in rcbs], [len(r.metric.token_times) for r in rcbs]
+
+
+@pytest.mark.parametrize("cfg", C.ENGINE_TRACES, ids=lambda c: c.tag)
+def test_decode_lookahead_is_invisible(cfg):
+    """Launching decode step N+1 before reading step N's tokens changes no request's output,
+    with and without an end-of-sequence token cutting requests short."""
+    plain, _ = _run_plain(cfg, None, None)
+    dec = FakeGraphDecoder()
+    ahead, n_times = _run_plain(cfg, None, dec)
+    assert ahead == plain and dec.n_launch_ahead > 10
+    assert n_times == [len(t) for t in plain]
+    # pick an end-of-sequence id that really occurs mid-request
+    eos = next(t[2] for t in plain if len(t) >= 6)
+    plain_eos, _ = _run_plain(cfg, eos, None)
+    ahead_eos, n_times = _run_plain(cfg, eos, FakeGraphDecoder())
+    assert plain_eos == ahead_eos and n_times == [len(t) for t in plain_eos]
+    assert any(len(a) < len(b) and a[-1] == eos for a, b in zip(plain_eos, plain))
