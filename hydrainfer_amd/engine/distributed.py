@@ -1,0 +1,213 @@
+"""One engine node per process (one process per GPU), E/P/D roles by rank
+(parallel.epd_roles), migration by IPC peer reads — the multi-GPU form of engine.node.
+
+What the reference does with Ray actor RPCs (epdnode.py:362-447: `migrate.remote`,
+`pull_virtual_cache.remote`, `free_migrate_request.remote`) is done here with one small
+all-gather of pickled control messages per engine step over a gloo group: block tables and
+request state travel on the host, KV / image blocks never do — the receiver reads them out of
+the sender's pool with hx_migrate_blocks (xGMI peer reads through the IPC mapping).  The
+exchange is a few hundred microseconds of host time per step and, with the decode look-ahead,
+overlaps the GPU's work."""
+import dataclasses
+import time
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from hydrainfer_amd.engine.isa import (EmptyInstruction, EPMigrate, Fill, ImageEmbedFill, InstructionListBuilder,
+                                       PDMigrate, PullCache, TextFill)
+from hydrainfer_amd.engine.node import EPDNode, NodeType
+from hydrainfer_amd.engine.rcb import (RequestControlBlock, RequestMetaData, RequestMetric, SamplingParameters,
+                                       ScenarioType)
+from hydrainfer_amd.memory.token_cache import VirtualTokenCache
+
+
+# ---------------------------------------------------------------- request state on the wire
+def _cache_to_wire(vc: Optional[VirtualTokenCache]):
+    return None if vc is None else dataclasses.asdict(vc)
+
+
+def _cache_from_wire(d) -> Optional[VirtualTokenCache]:
+    return None if d is None else VirtualTokenCache(**d)
+
+
+def rcb_to_wire(rcb: RequestControlBlock) -> dict:
+    """Everything the next stage needs: the instructions from the current one on (a flat list —
+    the linked chain would pickle recursively), the block tables + IPC handles of the caches, the
+    tokens so far and the timing stamps (CLOCK_MONOTONIC is shared by the processes of a node)."""
+    insts = []
+    inst = rcb.current_instruction()
+    while inst is not None and inst.next is not None:          # stop at the tail sentinel
+        if isinstance(inst, ImageEmbedFill):
+            insts.append(("EF", inst.image_token_cache_ids, inst.image_token_mask, inst.token_ids,
+                          inst.position_ids, inst.cache_ids, inst.sample, inst.hashes, inst.is_chunked))
+        elif isinstance(inst, TextFill):
+            insts.append(("TF", inst.token_ids, inst.position_ids, inst.cache_ids, inst.sample, inst.hashes,
+                          inst.is_chunked))
+        elif isinstance(inst, PullCache):
+            insts.append(("PR",))
+        elif isinstance(inst, EPMigrate):
+            insts.append(("EPMR",))
+        elif isinstance(inst, PDMigrate):
+            insts.append(("PDMR",))
+        elif isinstance(inst, EmptyInstruction):
+            insts.append(("EM",))
+        else:
+            raise RuntimeError(f"{inst!r} cannot migrate")
+        inst = inst.next
+    md = rcb.request_metadata
+    return {"request_id": rcb.request_id, "instructions": insts,
+            "sampling": (rcb.sampling_params.max_tokens, list(rcb.sampling_params.eos_token_ids)),
+            "metadata": None if md is None else dataclasses.astuple(md),
+            "kv": _cache_to_wire(rcb.virtual_kv_cache), "image": _cache_to_wire(rcb.virtual_image_cache),
+            "output_token_ids": list(rcb.output_token_ids), "scenario": int(rcb.scenario_type or 0),
+            "metric": dataclasses.asdict(rcb.metric)}
+
+
+def rcb_from_wire(w: dict) -> RequestControlBlock:
+    rcb = RequestControlBlock()
+    rcb.request_id = w["request_id"]
+    rcb.sampling_params = SamplingParameters(w["sampling"][0], list(w["sampling"][1]))
+    if w["metadata"] is not None:
+        rcb.request_metadata = RequestMetaData(*w["metadata"])
+    rcb.virtual_kv_cache, rcb.virtual_image_cache = _cache_from_wire(w["kv"]), _cache_from_wire(w["image"])
+    rcb.output_token_ids = list(w["output_token_ids"])
+    rcb.scenario_type = ScenarioType(w["scenario"])
+    rcb.metric = RequestMetric(**w["metric"])
+    b = InstructionListBuilder()
+    fills: List[Fill] = []
+    for rec in w["instructions"]:
+        kind = rec[0]
+        if kind == "EF":
+            inst = ImageEmbedFill(rec[1], rec[2], rec[3], rec[4], rec[5], rec[6], None, rec[7])
+            inst.is_chunked = rec[8]
+        elif kind == "TF":
+            inst = TextFill(rec[1], rec[2], rec[3], rec[4], None, rec[5])
+            inst.is_chunked = rec[6]
+        else:
+            inst = {"PR": PullCache, "EPMR": EPMigrate, "PDMR": PDMigrate, "EM": EmptyInstruction}[kind]()
+        if isinstance(inst, Fill):
+            fills.append(inst)
+        b.append(inst)
+    for cur, nxt in zip(fills, fills[1:] + [None]):
+        # a chunk head's sample is thrown away (isa.py); every other fill feeds the next one
+        cur.sample_dst = EmptyInstruction() if cur.is_chunked else nxt
+    rcb.instructions = b.build_instruction_list()
+    return rcb
+
+
+# ---------------------------------------------------------------- peers
+class RemoteNode:
+    """What an EPDNode sees of a node that lives in another process."""
+
+    def __init__(self, rank: int, node_type: str, engine: "RankEngine", tpot_slo: float = 0.4):
+        self.rank, self.node_type, self.engine, self.tpot_slo = rank, NodeType(node_type), engine, tpot_slo
+        self.name = f"{node_type}@{rank}"
+
+    # sender side, phase 1 (epdnode.py:412-441)
+    def migrate(self, src_node: EPDNode, rcb: RequestControlBlock) -> None:
+        self.engine.held[rcb.request_id] = rcb                   # blocks stay pinned until FREE
+        self.engine.outbox.append((self.rank, "migrate", rcb_to_wire(rcb)))
+
+    # receiver side, phase 4 (epdnode.py:443-446) — addressed to the sender
+    def free_migrate_request(self, rcb: RequestControlBlock) -> None:
+        self.engine.outbox.append((self.rank, "free", rcb.request_id))
+
+
+class RankEngine:
+    """The node of this rank + its mailbox."""
+
+    def __init__(self, rank: int, roles: List[str], node: EPDNode, group=None):
+        self.rank, self.roles, self.node, self.group = rank, roles, node, group
+        self.world = len(roles)
+        self.outbox: List[Tuple[int, str, object]] = []
+        self.held: Dict[object, RequestControlBlock] = {}
+        self.peers = {r: (node if r == rank else RemoteNode(r, t, self)) for r, t in enumerate(roles)}
+        nt = node.node_type
+        p_nodes = [self.peers[r] for r, t in enumerate(roles) if "P" in t]
+        d_nodes = [self.peers[r] for r, t in enumerate(roles) if "D" in t]
+        node.connect(p_nodes if nt.enable_encode else [], d_nodes if nt.enable_prefill else [])
+        self.remote_finished = 0
+        self.n_exchanges = 0
+
+    def _deliver(self, src_rank: int, kind: str, payload) -> None:
+        if kind == "migrate":
+            rcb = rcb_from_wire(payload)
+            self.node.migrate(self.peers[src_rank], rcb)
+        elif kind == "free":
+            self.node.free_migrate_request(self.held.pop(payload))
+        else:
+            raise RuntimeError(kind)
+
+    def exchange(self) -> int:
+        """All-gather the outboxes; returns the number of requests finished cluster-wide."""
+        mine = (self.outbox, len(self.node.finished))
+        self.outbox = []
+        if self.world == 1:
+            boxes = [mine]
+        else:
+            boxes = [None] * self.world
+            dist.all_gather_object(boxes, mine, group=self.group)
+        self.n_exchanges += 1
+        for src, (msgs, _) in enumerate(boxes):
+            for dst, kind, payload in msgs:
+                if dst == self.rank:
+                    self._deliver(src, kind, payload)
+        return sum(n for _, n in boxes)
+
+    def step(self) -> int:
+        self.node.step()
+        return self.exchange()
+
+
+def entry_rank(request_index: int, roles: List[str], has_image: bool) -> int:
+    """cluster.py:178-184: image requests round-robin over the E nodes, text-only over the P nodes."""
+    ranks = [r for r, t in enumerate(roles) if ("E" if has_image else "P") in t]
+    return ranks[request_index % len(ranks)]
+
+
+def replay_distributed(engine: RankEngine, creator, requests, arrivals: List[float], t0: float,
+                       device: Optional[torch.device] = None, deadline_s: float = 600.0) -> dict:
+    """Every rank runs this with the same request list; a request enters at the rank
+    `entry_rank` names.  Returns this rank's finished requests' metrics."""
+    mine = sorted((i for i, r in enumerate(requests)
+                   if entry_rank(i, engine.roles, r.pixel_values is not None) == engine.rank),
+                  key=lambda i: arrivals[i])
+    nxt, total = 0, len(requests)
+    while True:
+        now = time.perf_counter() - t0
+        while nxt < len(mine) and arrivals[mine[nxt]] <= now:
+            i = mine[nxt]
+            rcb = creator.process(requests[i])
+            engine.node.add_request(rcb)
+            rcb.metric.arrival_time = t0 + arrivals[i]
+            nxt += 1
+        if engine.step() >= total:
+            break
+        if now > deadline_s:
+            raise TimeoutError(f"rank {engine.rank}: trace not drained after {deadline_s} s")
+        if engine.node.idle():
+            time.sleep(0.0002)
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    return {r.request_id: {"arrival": r.metric.arrival_time, "token_times": list(r.metric.token_times),
+                           "tokens": list(r.output_token_ids), "ep_transfer": list(r.metric.ep_transfer),
+                           "pd_transfer": list(r.metric.pd_transfer)}
+            for r in engine.node.finished}
+
+
+def summarize(per_request: Dict[int, dict], t0: float) -> dict:
+    rs = list(per_request.values())
+    end = max(r["token_times"][-1] for r in rs)
+    n_out = sum(len(r["tokens"]) for r in rs)
+    ttft = sorted(r["token_times"][0] - r["arrival"] for r in rs)
+    tpot = sorted((r["token_times"][-1] - r["token_times"][0]) / max(1, len(r["token_times"]) - 1) for r in rs)
+    hop = lambda key: sorted(r[key][1] - r[key][0] for r in rs if len(r[key]) == 2)
+    pct = lambda xs, p: xs[min(len(xs) - 1, int(p * len(xs)))] if xs else None
+    ms = lambda v: None if v is None else round(v * 1e3, 3)
+    return {"requests": len(rs), "output_tokens": n_out, "wall_s": round(end - t0, 3),
+            "output_tok_s": round(n_out / (end - t0), 1),
+            "ttft_p50_ms": ms(pct(ttft, 0.5)), "ttft_p99_ms": ms(pct(ttft, 0.99)),
+            "tpot_p50_ms": ms(pct(tpot, 0.5)), "tpot_p99_ms": ms(pct(tpot, 0.99)),
+            "ep_pull_p50_ms": ms(pct(hop("ep_transfer"), 0.5)), "pd_pull_p50_ms": ms(pct(hop("pd_transfer"), 0.5))}

@@ -1,0 +1,171 @@
+"""One engine node per process over gloo (engine/distributed.py): request state on the wire and
+the migrate / pull / free protocol between E, P and D ranks.  CPU only: the models are the
+deterministic stand-in of tests.golden.cases.engine_trace_sample, so every request's tokens are
+known in closed form whatever the interleaving; the pools are CPU tensors whose cross-process
+pull is a no-op (the GPU pull is covered by tests/test_gpu_migration.py and the single-GPU
+multi-rank run of tests/test_gpu_distributed_engine.py)."""
+import os
+import socket
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.golden import cases as C
+
+N_IMG, BS, IMAGE_TOKEN = 40, 16, 32000
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _requests():
+    from hydrainfer_amd.engine import SamplingParameters, TokenRequest
+    g = torch.Generator().manual_seed(31)
+    reqs = []
+    for i in range(14):
+        text = torch.randint(1000, 31999, (5 + (i * 7) % 40,), generator=g).tolist()
+        has_image = i % 5 != 4
+        reqs.append(TokenRequest(i, ([IMAGE_TOKEN] if has_image else []) + text,
+                                 torch.full((1, 3, 2, 2), float(i)) if has_image else None, (8, 8), 4000 + i,
+                                 SamplingParameters(max_tokens=2 + (i * 3) % 9)))
+    return reqs
+
+
+def expected_tokens(req):
+    """Closed form of the stand-in model: the prompt's last token samples f(id, pos), and so on."""
+    ids = []
+    for t in req.token_ids:
+        ids += [IMAGE_TOKEN] * N_IMG if t == IMAGE_TOKEN else [t]
+    out, last, pos = [], ids[-1], len(ids) - 1
+    for _ in range(req.sampling_params.max_tokens):
+        last = C.engine_trace_sample(last, pos)
+        out.append(last)
+        pos += 1
+    return out
+
+
+def _build_engine(rank, roles, group):
+    from hydrainfer_amd.engine import BatchSchedulerConfig
+    from hydrainfer_amd.engine.distributed import RankEngine
+    from tests.engine_util import CpuPoolManager, make_node
+
+    class Pool(CpuPoolManager):
+        def migrate_blocks(self, src, dst, is_send=False):
+            assert len(src.block_table) == len(dst.block_table) and src.memory_handle
+            self.pulled = getattr(self, "pulled", 0) + len(src.block_table)
+
+    shape = NS(num_hidden_layers=1, num_attention_heads=1, num_key_value_heads=1, head_dim=8)
+
+    class LM:
+        image_token_id = IMAGE_TOKEN
+        language_model = NS(shape=shape)
+
+        def forward(self, ids, feats, pos, params):
+            i, p = ids.tolist(), pos.tolist()
+            return torch.tensor([C.engine_trace_sample(i[j], p[j]) for j in params.selected_token_ids.tolist()])
+
+    class Vision:
+        def forward(self, px):
+            return torch.zeros(px.shape[0], N_IMG, 8)
+
+    kv, img = Pool(1, 2, 64, BS, 1, 8), Pool(1, 1, 10, N_IMG, 1, 8)
+    cfg = BatchSchedulerConfig(max_running_requests=4, token_budgets=64, image_budgets=2)
+    node = make_node(f"{roles[rank]}{rank}", roles[rank], LM(), Vision(), kv, img, shape, torch.float32,
+                     torch.device("cpu"), cfg)
+    return RankEngine(rank, roles, node, group), kv, img
+
+
+def _worker(rank, roles, port, q):
+    try:
+        import time
+        import torch.distributed as dist
+        from hydrainfer_amd.engine import InstructionCreator
+        from hydrainfer_amd.engine.distributed import replay_distributed, summarize
+        world = len(roles)
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+        engine, kv, img = _build_engine(rank, roles, None)
+        reqs = _requests()
+        arrivals = [0.002 * i for i in range(len(reqs))]
+        box = [time.perf_counter() + 0.05]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        creator = InstructionCreator(IMAGE_TOKEN, N_IMG, BS)
+        mine = replay_distributed(engine, creator, reqs, arrivals, box[0], deadline_s=120)
+        # every block of every pool is free again and nothing is waiting for a FREE
+        for m in (engine.node.kv_cache_block_manager, engine.node.image_cache_block_manager):
+            if m is not None:
+                assert len(m.shared_cache.to_be_evicted) == m.n_blocks
+        assert not engine.held and engine.node.batch_scheduler.migrating_cnt == 0
+        allr = [None] * world
+        if world > 1:
+            dist.all_gather_object(allr, (mine, getattr(kv, "pulled", 0), getattr(img, "pulled", 0)))
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            allr = [(mine, 0, 0)]
+        if rank == 0:
+            merged = {}
+            for m, _, _ in allr:
+                merged.update(m)
+            assert sorted(merged) == list(range(len(reqs)))
+            for i, r in enumerate(reqs):
+                assert merged[i]["tokens"] == expected_tokens(r), f"request {i}"
+            s = summarize(merged, box[0])
+            assert s["requests"] == len(reqs) and s["output_tokens"] == sum(r.sampling_params.max_tokens for r in reqs)
+            d_ranks = [r for r, t in enumerate(roles) if "D" in t]
+            for r in range(world):           # requests finish on D ranks only
+                assert (len(allr[r][0]) > 0) == (r in d_ranks), f"rank {r} finished {len(allr[r][0])}"
+            if world > 1:
+                assert sum(a[1] for a in allr) > 0          # KV blocks were pulled P -> D
+                if "E" in roles:
+                    assert sum(a[2] for a in allr) > 0      # image blocks were pulled E -> P
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_rcb_wire_round_trip():
+    from hydrainfer_amd.engine import InstructionCreator
+    from hydrainfer_amd.engine.distributed import rcb_from_wire, rcb_to_wire
+    import pickle
+    creator = InstructionCreator(IMAGE_TOKEN, N_IMG, BS)
+    rcb = creator.process(_requests()[0])
+    first = rcb.current_instruction()
+    rcb.step(); rcb.step()                      # ImageEmbed, EPMigrate done -> at PullCache
+    fill = rcb.current_instruction().next
+    fill.chunk_prefill(17)                      # a chunked prefill must survive the trip
+    rcb.output_token_ids = [5]
+    back = rcb_from_wire(pickle.loads(pickle.dumps(rcb_to_wire(rcb))))
+    a, b = list(rcb.instructions)[3:], list(back.instructions)[1:]   # from the current instruction on
+    assert [repr(x) for x in a] == [repr(x) for x in b]
+    for x, y in zip(a, b):
+        for f in ("token_ids", "position_ids", "cache_ids", "sample", "hashes", "is_chunked",
+                  "image_token_cache_ids", "image_token_mask"):
+            assert getattr(x, f, None) == getattr(y, f, None), f
+    fills = [x for x in b if hasattr(x, "token_ids")]
+    assert repr(fills[0].sample_dst) == "EM" and fills[1].sample_dst is fills[2] and fills[-1].sample_dst is None
+    assert repr(back.current_instruction()) == "PR" and back.output_token_ids == [5]
+    assert back.sampling_params.max_tokens == rcb.sampling_params.max_tokens and first is not None
+
+
+@pytest.mark.parametrize("roles", [["EPD"], ["EP", "D"], ["E", "P", "D"], ["E", "P", "D", "D"]], ids="-".join)
+def test_distributed_engine_protocol(roles):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, roles, port, q)) for r in range(len(roles))]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, "ok") for r in range(len(roles))], results
