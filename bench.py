@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ttft", action="store_true")
     p.add_argument("--no-serving", action="store_true", help="skip the continuous-batching engine leg")
+    p.add_argument("--no-disaggregated", action="store_true", help="N>1: skip the E/P/D engine leg")
     p.add_argument("--no-migration", action="store_true")
     p.add_argument("--lib-gemm", action="store_true",
                    help="library GEMMs (hipBLASLt) for decode too, instead of the weight-streaming HIP kernel")
@@ -170,6 +171,77 @@ def measure_serving(model, vision, pixels, shape, dtype, dev, batch, n_text, max
     res = replay(cluster, creator, reqs, [0.0] * batch, dev)
     res["what"] = (f"{batch} requests (1 image + {n_text} text tokens, {max_tokens} generated) admitted at t=0 to one "
                    "collocated EPD engine: continuous batching, chunked prefill (2048-token budget), hipGraph decode")
+    return res
+
+
+def build_rank_engine(ctx, model, vision, shape, dtype, dev, batch, n_text, max_tokens):
+    """This rank's E / P / D node (parallel.epd_roles) with its own cache pools, for the
+    disaggregated leg.  Pools are created (and, by the caller, IPC-mapped by their peers) before
+    any hipGraph exists."""
+    import torch.distributed as dist
+    from hydrainfer_amd import parallel
+    from hydrainfer_amd.engine.distributed import RankEngine
+    from hydrainfer_amd.engine.scheduler import BatchSchedulerConfig
+    from hydrainfer_amd.engine.serve import build_node
+    from hydrainfer_amd.model.llava import LlavaLanguageModel
+    roles = parallel.epd_roles(ctx.world_size)
+    role = roles[ctx.rank]
+    n_d = sum("D" in r for r in roles)
+    n_p = sum("P" in r for r in roles)
+    per_req = (576 + n_text + max_tokens + 15) // 16 + 1
+    # a P node keeps a prefilled request's blocks until a D node has pulled them
+    live = batch + 2 if "D" in role else (batch * n_d + n_p - 1) // n_p + 2
+    sched = BatchSchedulerConfig(priority="prefill", max_running_requests=batch, chunked_prefill=True,
+                                 token_budgets=2048, image_budgets=8)
+    lm = LlavaLanguageModel(model, image_token_id=image_token_id(shape.vocab_size))
+    node = build_node(f"{role}{ctx.rank}", role, lm, vision, shape, dtype, dev, per_req * live, 2 * batch + 2, 576,
+                      sched, rank=ctx.rank, max_blocks_per_seq=per_req, world_size=ctx.world_size)
+    group = None if ctx.backend == "gloo" else dist.new_group(backend="gloo")
+    return RankEngine(ctx.rank, roles, node, group)
+
+
+def measure_disaggregated(ctx, engine, shape, dev, pixels, batch, n_text, max_tokens):
+    """BASELINE configs[3]/[4]: one E / P / D node per GPU, requests enter at the E ranks, image
+    blocks are pulled E->P and KV blocks P->D over the IPC-mapped peer pools (hx_migrate_blocks),
+    control messages over gloo.  32 requests per D rank, all admitted at t=0."""
+    import torch.distributed as dist
+    from hydrainfer_amd.engine.distributed import replay_distributed, summarize
+    from hydrainfer_amd.engine.request_processor import InstructionCreator
+    from hydrainfer_amd.engine.serve import synthetic_requests
+    torch.cuda.set_device(dev)
+    itid = image_token_id(shape.vocab_size)
+    roles = engine.roles
+    n_d = sum("D" in r for r in roles)
+    fe = engine.node.executor.fill_executor
+    if fe is not None and fe.graph_decoder is not None:
+        fe.graph_decoder.warmup(list(range(4, batch + 1, 4)), kv_max=1024)
+    creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16)
+    hi = min(31999, itid - 1)
+    vocab_text = (min(1000, hi - 1), hi)
+
+    def run(n, gen, seed):
+        reqs = synthetic_requests(n, n_text, gen, itid, pixels, vocab_text, seed)
+        engine.open_mailbox(f"disagg{seed}")
+        box = [time.perf_counter() + 0.2]
+        dist.broadcast_object_list(box, src=0, group=engine.group)
+        mine = replay_distributed(engine, creator, reqs, [0.0] * n, box[0], dev, deadline_s=150)
+        allr = [None] * ctx.world_size
+        dist.all_gather_object(allr, mine, group=engine.group)
+        merged = {}
+        for m in allr:
+            merged.update(m)
+        return merged, box[0]
+
+    run(2 * len(roles), 4, 99)                     # warm-up through every hop
+    merged, t0 = run(batch * n_d, max_tokens, 1)
+    res = summarize(merged, t0)
+    kv_bytes = (576 + n_text) * 2 * shape.num_hidden_layers * shape.num_key_value_heads * shape.head_dim * 2
+    if res["pd_pull_p50_ms"]:
+        res["pd_pull_GBps"] = round(kv_bytes / res["pd_pull_p50_ms"] / 1e6, 1)
+    res["kv_bytes_per_request"] = kv_bytes
+    res["roles"] = roles
+    res["what"] = (f"{batch * n_d} requests (1 image + {n_text} text tokens, {max_tokens} generated) at t=0; "
+                   "one E/P/D engine node per GPU, pulls over IPC-mapped peer pools, control over gloo")
     return res
 
 
@@ -375,6 +447,11 @@ def main():
     # captured (mapping a peer allocation after graphs were instantiated wedged in a 2-process
     # test) — bounded by a watchdog so a driver problem cannot cost the benchmark line
     peer_info, ipc_stuck = None, False
+    vision = pixels = engine = None
+    if not (args.skip_prefill or (args.no_ttft and args.no_serving and (world == 1 or args.no_disaggregated))):
+        vision, pixels = make_vision(shape, dtype, dev)
+    if world > 1 and not args.no_disaggregated and vision is not None and not args.no_migration:
+        engine = build_rank_engine(ctx, model, vision, shape, dtype, dev, args.batch, prompt_len - 576, n_generate)
     if world > 1 and not args.no_migration:
         import threading
         box = {}
@@ -387,6 +464,18 @@ def main():
             peer = infos[parallel.migration_peer(ctx.rank, ctx.world_size)]
             bm._open(peer["handle"])          # cached mapping; later calls are lookups
             box["peer"] = peer
+            if engine is not None:            # pools this rank will pull from: E image pools for P, P kv pools for D
+                node = engine.node
+                mine = {"kv": node.kv_cache_block_manager.memory_handle if node.kv_cache_block_manager else None,
+                        "image": node.image_cache_block_manager.memory_handle if node.image_cache_block_manager else None}
+                pools = ctx.all_gather_object(mine)
+                for r, role in enumerate(engine.roles):
+                    if r == ctx.rank:
+                        continue
+                    if node.node_type.enable_prefill and "E" in role and pools[r]["image"]:
+                        bm._open(pools[r]["image"])
+                    if node.node_type.enable_decode and "P" in role and pools[r]["kv"]:
+                        bm._open(pools[r]["kv"])
         th = threading.Thread(target=_exchange, daemon=True)
         th.start()
         th.join(timeout=60)
@@ -434,9 +523,6 @@ def main():
     tokens = args.batch * steps * n_gpus
     value = tokens / elapsed
 
-    vision = pixels = None
-    if not (args.skip_prefill or (args.no_ttft and args.no_serving)):
-        vision, pixels = make_vision(shape, dtype, dev)
     ttft = None if args.skip_prefill or args.no_ttft else measure_ttft(runner, prompts, shape, dtype, dev, rank,
                                                                          vision, pixels)
     serving = None
@@ -496,8 +582,26 @@ def main():
             stuck = th.is_alive()
             migration = {"error": "timed out after 90 s"} if stuck else box.get("r")
 
+    disagg = None
+    if engine is not None and not stuck:
+        import threading
+        box = {}
+
+        def _leg():
+            try:
+                box["r"] = measure_disaggregated(ctx, engine, shape, dev, pixels, args.batch, prompt_len - 576,
+                                                 n_generate)
+            except Exception as e:      # never let the optional leg break the benchmark line
+                box["r"] = {"error": repr(e)[:300]}
+        th = threading.Thread(target=_leg, daemon=True)
+        th.start()
+        th.join(timeout=240)
+        stuck = th.is_alive()
+        disagg = {"error": "timed out after 240 s"} if stuck else box.get("r")
+
     if rank == 0:
         out["migration"] = migration
+        out["disaggregated"] = disagg
         print(json.dumps(out), flush=True)
     if stuck:
         sys.stdout.flush()

@@ -2,13 +2,15 @@
 (parallel.epd_roles), migration by IPC peer reads — the multi-GPU form of engine.node.
 
 What the reference does with Ray actor RPCs (epdnode.py:362-447: `migrate.remote`,
-`pull_virtual_cache.remote`, `free_migrate_request.remote`) is done here with one small
-all-gather of pickled control messages per engine step over a gloo group: block tables and
-request state travel on the host, KV / image blocks never do — the receiver reads them out of
-the sender's pool with hx_migrate_blocks (xGMI peer reads through the IPC mapping).  The
-exchange is a few hundred microseconds of host time per step and, with the decode look-ahead,
-overlaps the GPU's work."""
+`pull_virtual_cache.remote`, `free_migrate_request.remote`) is done here with a mailbox on the
+process group's key-value store (the TCPStore torch.distributed already runs): a sender numbers
+and posts a pickled message, a receiver polls its own slots once per engine step.  Nodes are
+never in lock-step — a D rank's 6 ms decode steps do not wait for a P rank's 40 ms prefill step.
+Block tables and request state travel on the host; KV / image blocks never do — the receiver
+reads them out of the sender's pool with hx_migrate_blocks (xGMI peer reads through the IPC
+mapping).  The two store round trips per step are host time that the decode look-ahead hides."""
 import dataclasses
+import pickle
 import time
 from typing import Dict, List, Optional, Tuple
 
@@ -115,6 +117,45 @@ class RemoteNode:
         self.engine.outbox.append((self.rank, "free", rcb.request_id))
 
 
+class StoreMailbox:
+    """Numbered per-destination slots on a torch.distributed store.  `epoch` separates runs."""
+
+    def __init__(self, store, rank: int, epoch: str):
+        self.store, self.rank, self.epoch = store, rank, epoch
+        self.next_slot = 1
+
+    def send(self, dst: int, kind: str, payload) -> None:
+        n = self.store.add(f"{self.epoch}/n/{dst}", 1)
+        self.store.set(f"{self.epoch}/m/{dst}/{n}", pickle.dumps((self.rank, kind, payload)))
+
+    def poll(self) -> List[Tuple[int, str, object]]:
+        out = []
+        while self.store.check([f"{self.epoch}/m/{self.rank}/{self.next_slot}"]):
+            out.append(pickle.loads(self.store.get(f"{self.epoch}/m/{self.rank}/{self.next_slot}")))
+            self.next_slot += 1
+        return out
+
+    def add_finished(self, k: int) -> int:
+        return self.store.add(f"{self.epoch}/finished", k)
+
+
+class LocalMailbox:
+    """world_size 1."""
+
+    def __init__(self):
+        self.finished = 0
+
+    def send(self, dst, kind, payload):
+        raise RuntimeError("a single node has nobody to write to")
+
+    def poll(self):
+        return []
+
+    def add_finished(self, k: int) -> int:
+        self.finished += k
+        return self.finished
+
+
 class RankEngine:
     """The node of this rank + its mailbox."""
 
@@ -128,8 +169,16 @@ class RankEngine:
         p_nodes = [self.peers[r] for r, t in enumerate(roles) if "P" in t]
         d_nodes = [self.peers[r] for r, t in enumerate(roles) if "D" in t]
         node.connect(p_nodes if nt.enable_encode else [], d_nodes if nt.enable_prefill else [])
-        self.remote_finished = 0
-        self.n_exchanges = 0
+        self.mailbox = LocalMailbox()
+        self.reported = 0
+
+    def open_mailbox(self, epoch: str) -> None:
+        """Call on every rank before a run (same epoch everywhere)."""
+        if self.world > 1:
+            self.mailbox = StoreMailbox(dist.distributed_c10d._get_default_store(), self.rank, epoch)
+        else:
+            self.mailbox = LocalMailbox()
+        self.reported = len(self.node.finished)
 
     def _deliver(self, src_rank: int, kind: str, payload) -> None:
         if kind == "migrate":
@@ -141,20 +190,16 @@ class RankEngine:
             raise RuntimeError(kind)
 
     def exchange(self) -> int:
-        """All-gather the outboxes; returns the number of requests finished cluster-wide."""
-        mine = (self.outbox, len(self.node.finished))
+        """Post what this step produced, take what has arrived; returns the number of requests
+        finished cluster-wide in this run."""
+        for dst, kind, payload in self.outbox:
+            self.mailbox.send(dst, kind, payload)
         self.outbox = []
-        if self.world == 1:
-            boxes = [mine]
-        else:
-            boxes = [None] * self.world
-            dist.all_gather_object(boxes, mine, group=self.group)
-        self.n_exchanges += 1
-        for src, (msgs, _) in enumerate(boxes):
-            for dst, kind, payload in msgs:
-                if dst == self.rank:
-                    self._deliver(src, kind, payload)
-        return sum(n for _, n in boxes)
+        for src, kind, payload in self.mailbox.poll():
+            self._deliver(src, kind, payload)
+        done = len(self.node.finished) - self.reported
+        self.reported += done
+        return self.mailbox.add_finished(done)
 
     def step(self) -> int:
         self.node.step()
@@ -175,6 +220,7 @@ def replay_distributed(engine: RankEngine, creator, requests, arrivals: List[flo
                    if entry_rank(i, engine.roles, r.pixel_values is not None) == engine.rank),
                   key=lambda i: arrivals[i])
     nxt, total = 0, len(requests)
+    first_finished = len(engine.node.finished)
     while True:
         now = time.perf_counter() - t0
         while nxt < len(mine) and arrivals[mine[nxt]] <= now:
@@ -189,12 +235,16 @@ def replay_distributed(engine: RankEngine, creator, requests, arrivals: List[flo
             raise TimeoutError(f"rank {engine.rank}: trace not drained after {deadline_s} s")
         if engine.node.idle():
             time.sleep(0.0002)
+    t_wait = time.perf_counter()
+    while engine.held and time.perf_counter() - t_wait < 10.0:     # FREEs still on their way
+        engine.exchange()
+        time.sleep(0.0005)
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)
     return {r.request_id: {"arrival": r.metric.arrival_time, "token_times": list(r.metric.token_times),
                            "tokens": list(r.output_token_ids), "ep_transfer": list(r.metric.ep_transfer),
                            "pd_transfer": list(r.metric.pd_transfer)}
-            for r in engine.node.finished}
+            for r in engine.node.finished[first_finished:]}
 
 
 def summarize(per_request: Dict[int, dict], t0: float) -> dict:

@@ -183,8 +183,23 @@ class EPDNode:
         manager.migrate_blocks(src_cache, dst, is_send=False)
         return dst
 
+    def _can_pull(self, rcb: RequestControlBlock) -> bool:
+        """Room for the caches of a request that wants to move in?  (The reference allocates
+        blindly and dies on its 'not enough blocks' assert; here the request keeps waiting at its
+        PullCache and is retried next step — its blocks stay pinned at the sender meanwhile.)"""
+        for vc, manager, wanted in ((rcb.virtual_kv_cache, self.kv_cache_block_manager, self.node_type.has_kv_cache),
+                                    (rcb.virtual_image_cache, self.image_cache_block_manager,
+                                     self.node_type.has_image_cache)):
+            if vc is not None and wanted:
+                need = (vc.n_cache_tokens + manager.block_size - 1) // manager.block_size
+                if need > len(manager.shared_cache.to_be_evicted):
+                    return False
+        return True
+
     def _execute_pull_cache(self, batch: BatchRequest) -> None:
         for rcb, inst in batch:
+            if not self._can_pull(rcb):
+                continue
             m = rcb.metric       # (text-only requests log their P->D pull under ep_transfer, as upstream)
             (m.ep_transfer if len(m.ep_transfer) == 0 else m.pd_transfer).append(time.perf_counter())
             old = copy.copy(rcb)

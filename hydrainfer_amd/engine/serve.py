@@ -22,9 +22,10 @@ _DTYPE_NAMES = {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "f
 def build_node(name: str, node_type: str, language_model, vision_model, lm_shape, dtype: torch.dtype,
                device: torch.device, kv_blocks: int, image_blocks: int, n_image_tokens: int,
                sched: BatchSchedulerConfig, rank: int = 0, graph_decode: bool = True,
-               max_blocks_per_seq: int = 256) -> EPDNode:
+               max_blocks_per_seq: int = 256, world_size: int = 1) -> EPDNode:
     nt = NodeType(node_type)
-    ctx = TokenCacheBlockManagerContext(rank=rank, rank2host={rank: "localhost"})
+    # one node of MI355Xs: every rank is a same-host peer, so pulls take the IPC path
+    ctx = TokenCacheBlockManagerContext(rank=rank, rank2host={r: "localhost" for r in range(max(world_size, rank + 1))})
     kv = img = None
     if nt.has_kv_cache:
         kv = TokenCacheBlockManager(TokenCacheBlockManagerConfig(

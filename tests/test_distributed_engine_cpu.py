@@ -98,6 +98,9 @@ def _worker(rank, roles, port, q):
         if world > 1:
             dist.broadcast_object_list(box, src=0)
         creator = InstructionCreator(IMAGE_TOKEN, N_IMG, BS)
+        engine.open_mailbox("run0")
+        if world > 1:
+            dist.barrier()
         mine = replay_distributed(engine, creator, reqs, arrivals, box[0], deadline_s=120)
         # every block of every pool is free again and nothing is waiting for a FREE
         for m in (engine.node.kv_cache_block_manager, engine.node.image_cache_block_manager):

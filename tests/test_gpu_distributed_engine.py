@@ -1,0 +1,123 @@
+"""E / P / D engine nodes in separate processes sharing one GPU: request state over the store
+mailbox, image and KV blocks pulled through the IPC-mapped peer pools by hx_migrate_blocks, decode
+replayed from hipGraphs — the multi-GPU serving path with every GPU standing in as cuda:0."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.golden import cases as C
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, roles, port, q):
+    try:
+        import time
+        import torch.distributed as dist
+        from hydrainfer_amd._C.data_transfer import block_migration as bm
+        from hydrainfer_amd.engine.distributed import RankEngine, replay_distributed
+        from hydrainfer_amd.engine.node import LocalCluster
+        from hydrainfer_amd.engine.scheduler import BatchSchedulerConfig
+        from hydrainfer_amd.engine.serve import build_node
+        from hydrainfer_amd.model.clip import ClipShape, LlavaVisionModel, random_state_dict
+        from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
+        from hydrainfer_amd.model.llava import LlavaLanguageModel
+        from tests.engine_util import run_trace
+        from tests.test_engine_e2e import N_IMG_TOK, creator, trace_requests
+        world = len(roles)
+        if os.environ.get("HX_TEST_STACKS"):     # debugging aid: dump all stacks of a stuck rank
+            import faulthandler
+            faulthandler.dump_traceback_later(60, file=open(f"{os.environ['HX_TEST_STACKS']}_{rank}.txt", "w"))
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+        dev, dt = torch.device("cuda:0"), torch.float16
+        torch.cuda.set_device(dev)
+        lshape, cshape = LlamaShape(**C.TINY_LLAMA), ClipShape(**C.TINY_CLIP)
+        lm = LlavaLanguageModel(LlamaForCausalLM.from_reference_state_dict(lshape, C.tiny_llama_state_dict(dt), dt, dev),
+                                image_token_id=C.TINY_IMAGE_TOKEN_ID)
+        vision = LlavaVisionModel(cshape, dt, dev, {k: v.to(dt).to(dev) for k, v in
+                                                    random_state_dict(cshape, seed=3, std=0.05).items()})
+        sched = BatchSchedulerConfig(priority="prefill", max_running_requests=6, chunked_prefill=True,
+                                     token_budgets=40, image_budgets=2)
+
+        def node(role, r, graph):
+            return build_node(f"{role}{r}", role, lm, vision, lshape, dt, dev, 96, 14, N_IMG_TOK, sched, rank=r,
+                              graph_decode=graph, max_blocks_per_seq=8, world_size=world)
+
+        engine = RankEngine(rank, roles, node(roles[rank], rank, True), None)
+        n = engine.node
+        pools = [None] * world
+        dist.all_gather_object(pools, {
+            "kv": n.kv_cache_block_manager.memory_handle if n.kv_cache_block_manager else None,
+            "image": n.image_cache_block_manager.memory_handle if n.image_cache_block_manager else None})
+        for r, role in enumerate(roles):          # map peers' pools before any graph exists
+            if r != rank and n.node_type.enable_prefill and "E" in role:
+                bm._open(pools[r]["image"])
+            if r != rank and n.node_type.enable_decode and "P" in role:
+                bm._open(pools[r]["kv"])
+        reqs = [r for _, r in trace_requests()]
+        box = [time.perf_counter() + 0.1]
+        dist.broadcast_object_list(box, src=0)
+        engine.open_mailbox("t")
+        dist.barrier()
+        mine = replay_distributed(engine, creator(), reqs, [0.01 * i for i in range(len(reqs))], box[0], dev,
+                                  deadline_s=120)
+        for m in (n.kv_cache_block_manager, n.image_cache_block_manager):
+            if m is not None:
+                pinned = m.n_blocks - len(m.shared_cache.to_be_evicted)
+                assert pinned == (1 if m is n.kv_cache_block_manager and n.node_type.enable_decode else 0)
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        if rank == 0:
+            merged = {}
+            for m in allr:
+                merged.update(m)
+            # the same trace through ONE process (same kernels, other batch compositions)
+            single = run_trace(LocalCluster([node("EPD", 0, False)]), creator(), trace_requests())
+            total = same = first_same = 0
+            for i, r in enumerate(reqs):
+                got, want = merged[i]["tokens"], single[i].output_token_ids
+                assert len(got) == len(want) == r.sampling_params.max_tokens
+                assert len(merged[i]["pd_transfer"]) == 2 or len(merged[i]["ep_transfer"]) == 2
+                first_same += got[0] == want[0]
+                for a, b in zip(got, want):
+                    total += 1
+                    same += a == b
+            assert first_same >= len(reqs) - 1, f"{first_same} of {len(reqs)} first tokens agree"
+            assert same >= 0.75 * total, f"{same}/{total} tokens agree with the single-process run"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        if os.environ.get("HX_TEST_STACKS"):
+            open(f"{os.environ['HX_TEST_STACKS']}_exc_{rank}.txt", "w").write(traceback.format_exc())
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("roles", [["EP", "D"], ["E", "P", "D"]], ids="-".join)
+def test_engine_nodes_in_processes_share_one_gpu(roles):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, roles, port, q)) for r in range(len(roles))]
+    for p in procs:
+        p.start()
+    try:
+        results = [q.get(timeout=300) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    bad = [f"rank {r}: {msg[-1500:]}" for r, msg in results if msg != "ok"]
+    assert not bad, "\n".join(bad)
