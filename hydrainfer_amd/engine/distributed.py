@@ -48,7 +48,7 @@ def rcb_to_wire(rcb: RequestControlBlock) -> dict:
             insts.append(("TF", inst.token_ids, inst.position_ids, inst.cache_ids, inst.sample, inst.hashes,
                           inst.is_chunked))
         elif isinstance(inst, PullCache):
-            insts.append(("PR",))
+            insts.append(("PR", inst.hop))
         elif isinstance(inst, EPMigrate):
             insts.append(("EPMR",))
         elif isinstance(inst, PDMigrate):
@@ -87,8 +87,11 @@ def rcb_from_wire(w: dict) -> RequestControlBlock:
         elif kind == "TF":
             inst = TextFill(rec[1], rec[2], rec[3], rec[4], None, rec[5])
             inst.is_chunked = rec[6]
+        elif kind == "PR":
+            inst = PullCache()
+            inst.hop = rec[1]
         else:
-            inst = {"PR": PullCache, "EPMR": EPMigrate, "PDMR": PDMigrate, "EM": EmptyInstruction}[kind]()
+            inst = {"EPMR": EPMigrate, "PDMR": PDMigrate, "EM": EmptyInstruction}[kind]()
         if isinstance(inst, Fill):
             fills.append(inst)
         b.append(inst)
@@ -170,7 +173,7 @@ class RankEngine:
         d_nodes = [self.peers[r] for r, t in enumerate(roles) if "D" in t]
         node.connect(p_nodes if nt.enable_encode else [], d_nodes if nt.enable_prefill else [])
         self.mailbox = LocalMailbox()
-        self.reported = 0
+        self.reported = self.n_exchanges = self.total_finished = 0
 
     def open_mailbox(self, epoch: str) -> None:
         """Call on every rank before a run (same epoch everywhere)."""
@@ -179,6 +182,7 @@ class RankEngine:
         else:
             self.mailbox = LocalMailbox()
         self.reported = len(self.node.finished)
+        self.n_exchanges = self.total_finished = 0
 
     def _deliver(self, src_rank: int, kind: str, payload) -> None:
         if kind == "migrate":
@@ -199,7 +203,10 @@ class RankEngine:
             self._deliver(src, kind, payload)
         done = len(self.node.finished) - self.reported
         self.reported += done
-        return self.mailbox.add_finished(done)
+        self.n_exchanges += 1
+        if done or self.n_exchanges % 8 == 0:          # the end-of-run test is not latency critical
+            self.total_finished = self.mailbox.add_finished(done)
+        return self.total_finished
 
     def step(self) -> int:
         self.node.step()
@@ -234,7 +241,7 @@ def replay_distributed(engine: RankEngine, creator, requests, arrivals: List[flo
         if now > deadline_s:
             raise TimeoutError(f"rank {engine.rank}: trace not drained after {deadline_s} s")
         if engine.node.idle():
-            time.sleep(0.0002)
+            time.sleep(0.001)       # an idle rank polls its mailbox about 1000 times a second
     t_wait = time.perf_counter()
     while engine.held and time.perf_counter() - t_wait < 10.0:     # FREEs still on their way
         engine.exchange()

@@ -119,6 +119,7 @@ class PDMigrate(MigrateRequest):
 
 class PullCache(Instruction):
     src_node = None   # set by the receiving node (epdnode.py:407-410, `src_node_actor_handle`)
+    hop = None        # 'ep' | 'pd': which migrate instruction this pull answers (set by the sender)
 
     def __repr__(self):
         return "PR"

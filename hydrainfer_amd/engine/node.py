@@ -152,6 +152,7 @@ class EPDNode:
         for rcb, inst in batch:
             rcb.step()
             assert isinstance(rcb.current_instruction(), PullCache)
+            rcb.current_instruction().hop = "ep" if isinstance(inst, EPMigrate) else "pd"
             lb = self.ep_loadbalancer if isinstance(inst, EPMigrate) else self.pd_loadbalancer
             node = lb.choice(rcb.scenario_type)
             if node is None or node is self:
@@ -200,8 +201,11 @@ class EPDNode:
         for rcb, inst in batch:
             if not self._can_pull(rcb):
                 continue
-            m = rcb.metric       # (text-only requests log their P->D pull under ep_transfer, as upstream)
-            (m.ep_transfer if len(m.ep_transfer) == 0 else m.pd_transfer).append(time.perf_counter())
+            # upstream stamps "first pull = ep, second = pd" (epdnode.py:384-387), which files a
+            # text-only or EP-node request's P->D pull under ep_transfer; the hop is known here
+            m = rcb.metric
+            stamps = m.ep_transfer if inst.hop == "ep" else m.pd_transfer
+            stamps.append(time.perf_counter())
             old = copy.copy(rcb)
             if rcb.virtual_kv_cache is not None and self.node_type.has_kv_cache:
                 rcb.virtual_kv_cache = self._migrate_virtual_cache(rcb.virtual_kv_cache, self.kv_cache_block_manager)
@@ -218,7 +222,7 @@ class EPDNode:
                     manager.synchronize()
             inst.src_node.free_migrate_request(old)
             rcb.step()
-            (m.ep_transfer if len(m.ep_transfer) == 1 else m.pd_transfer).append(time.perf_counter())
+            stamps.append(time.perf_counter())
 
     # ---- 4. sender: release the blocks of a request that has been pulled
     def free_migrate_request(self, rcb: RequestControlBlock) -> None:
