@@ -75,6 +75,24 @@ def image_token_id(vocab):
     return 32000 if vocab > 32000 else vocab - 1
 
 
+def copy_ceiling_gbs(dev, nbytes=1 << 30, reps=5):
+    """Measured streaming-copy rate of this GPU in this run (read + write bytes / time): the
+    practical HBM ceiling SURVEY.md §8(d) asks to be reported beside the 8 TB/s vendor peak."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(reps):
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        best = min(best, e0.elapsed_time(e1))
+    del src, dst
+    return 2 * nbytes / (best * 1e-3) / 1e9
+
+
 def time_attention_kernel(runner, start_len, steps):
     """Average duration of the decode-attention launch (the variant the decode graph runs:
     fused RoPE + cache append + attention) over the same context sequence as the timed region,
@@ -558,6 +576,7 @@ def main():
                          "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, model_name),
                          "avg_launch_us": round(attn_ms * 1e3, 2),
+                         "measured_copy_ceiling_GBps": round(copy_ceiling_gbs(dev), 1),
                          "algorithmic_bytes_per_launch": int(attn_bytes)},
             "whole_step": {"algorithmic_bytes": int(step_bytes), "achieved_GBps": round(step_gbs, 1),
                            "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),

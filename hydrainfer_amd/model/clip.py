@@ -73,8 +73,13 @@ class LlavaVisionModel:
         s, sh = self.state, self.shape
         pre = "vision_tower.vision_model."
         n = pixel_values.shape[0]
-        patches = F.conv2d(pixel_values.to(self.dtype), s[pre + "embeddings.patch_embedding.weight"],
-                           stride=sh.patch_size).flatten(2).transpose(1, 2)
+        # The patch embedding is a stride == kernel convolution (clip.py:33-40 of the reference), i.e.
+        # one GEMM over non-overlapping patches.  MIOpen runs the bf16 convolution on a naive kernel
+        # (1.8 ms for 8 images, profiles/r1_serving7b_summary.md); the GEMM takes microseconds.
+        w = s[pre + "embeddings.patch_embedding.weight"]
+        ps, g = sh.patch_size, pixel_values.shape[-1] // sh.patch_size
+        x = pixel_values.to(self.dtype).reshape(n, w.shape[1], g, ps, g, ps).permute(0, 2, 4, 1, 3, 5)
+        patches = torch.matmul(x.reshape(n, g * g, -1), w.reshape(w.shape[0], -1).t())
         cls_tok = s[pre + "embeddings.class_embedding"].expand(n, 1, -1)
         h = torch.cat([cls_tok, patches], dim=1) + s[pre + "embeddings.position_embedding.weight"][None]
         h = F.layer_norm(h, (sh.hidden_size,), s[pre + "pre_layrnorm.weight"], s[pre + "pre_layrnorm.bias"],
