@@ -398,7 +398,7 @@ def cpu_baseline(shape, dtype, batch, ctx, n_layers):
     model = OracleLlama(shape, sd, dtype, n_layers=n_layers)
     bs = 16
     nb_seq = (ctx + bs - 1) // bs
-    n_blocks = batch * nb_seq
+    n_blocks = max(batch * nb_seq, (608 + 16 + bs - 1) // bs)
     caches = [(torch.randn((n_blocks, bs, shape.num_key_value_heads, shape.head_dim), generator=g).to(dtype),
                torch.randn((n_blocks, bs, shape.num_key_value_heads, shape.head_dim), generator=g).to(dtype))
               for _ in range(n_layers)]
@@ -421,8 +421,38 @@ def cpu_baseline(shape, dtype, batch, ctx, n_layers):
     t_head = min(run(0) for _ in range(2))       # embed + final norm + lm_head only
     per_layer = (t_full - t_head) / n_layers
     step_s = t_head + per_layer * shape.num_hidden_layers
+
+    # BASELINE configs[0] on the same cores: ONE request, 576 image + 32 text tokens prefilled
+    # (608 tokens, 38 blocks), then single-sequence decode steps — the reference's eager CPU path
+    n_p = 608
+    nb_p = (n_p + 16 + bs - 1) // bs
+    meta_p = OracleAttnMeta(i32([0, n_p]), i32([0, n_p]), i32(list(range(n_p))), i32(list(range(nb_p))),
+                            i32([0, nb_p]))
+    ids_p = torch.randint(0, 32000, (n_p,), generator=g, dtype=torch.int64)
+    pos_p = torch.arange(n_p, dtype=torch.int32)
+    meta_d = OracleAttnMeta(i32([0, 1]), i32([0, n_p + 1]), i32([n_p]), i32(list(range(nb_p))), i32([0, nb_p]))
+
+    def run1(nl, prefill):
+        model.n_layers = nl
+        t0 = time.perf_counter()
+        with torch.inference_mode():
+            if prefill:
+                model.forward(ids_p, pos_p, meta_p, caches)
+            else:
+                model.forward(ids_p[:1], i32([n_p]), meta_d, caches)
+        return time.perf_counter() - t0
+    run1(n_layers, True)
+    # layers over all 608 rows; embedding + final norm + lm_head only for the one sampled row
+    pf = min(run1(n_layers, True) for _ in range(2)) - min(run1(0, True) for _ in range(2))
+    prefill_s = min(run1(0, False) for _ in range(2)) + pf / n_layers * shape.num_hidden_layers
+    run1(n_layers, False)
+    dc = min(run1(n_layers, False) for _ in range(2)) - (h1 := min(run1(0, False) for _ in range(2)))
+    decode1_s = h1 + dc / n_layers * shape.num_hidden_layers
     return {"value": round(batch / step_s, 3), "unit": "tokens/s", "cores": n_threads,
             "kind": "port",
+            "config0": {"what": "BASELINE configs[0]: 1 request, 608-token prefill then batch-1 decode, language "
+                                "model only (vision tower not timed), same extrapolation",
+                        "prefill_s": round(prefill_s, 2), "decode_tokens_per_s": round(1.0 / decode1_s, 3)},
             "sample": f"one decode step, batch {batch}, ctx {ctx}: {n_layers} of "
                       f"{shape.num_hidden_layers} decoder layers + lm_head timed with torch CPU "
                       f"({str(dtype).split('.')[-1]} weights, fp32 attention as the reference's torch "

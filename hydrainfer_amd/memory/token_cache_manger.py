@@ -182,6 +182,8 @@ def allocate_new_blocks(block_allocator: BlockAllocator, shared_cache: SharedCac
     (not the shortfall) and then fails its own length assert; here the free-list blocks are pinned
     first (they sit in the eviction set until then, shared_cache.py:26) and only the shortfall is
     evicted.  Identical results whenever the reference does not assert."""
+    # every unpinned block (free-list ones included) sits in the eviction set: fail before taking any
+    assert n_blocks <= len(shared_cache.to_be_evicted), "not enough blocks"
     block_ids = block_allocator.allocate(n_blocks)
     shared_cache.pin(block_ids)
     if len(block_ids) < n_blocks:

@@ -381,3 +381,10 @@ def engine_trace_sample(input_id: int, position_id: int) -> int:
     """Stand-in for the language model in the engine trace: the token sampled at a row is a fixed
     function of that row's input id and position."""
     return (position_id * 131 + input_id * 7 + 13) % 30000 + 100
+
+
+def profiler_weird_criterion(n: int) -> bool:
+    """Non-monotonic and sometimes failing, like a real latency measurement near an OOM."""
+    if n % 7 == 0:
+        raise RuntimeError("out of memory")
+    return (n * 37) % 11 < 6

@@ -443,6 +443,15 @@ def gen_engine_trace(out):
             _engine_trace_one(cfg, out, locals())
     finally:
         torch.cuda.Stream = real_stream
+    # the budget search of BatchSchedulerProfiler (profiler.py:118-133) on threshold criteria and on
+    # the non-monotonic / raising criterion of tests.golden.cases.profiler_weird_criterion
+    from hydrainfer.engine.profiler import BatchSchedulerProfiler
+    prof = object.__new__(BatchSchedulerProfiler)
+    prof.config = NS(debug=False)
+    for hi in (8, 2048):
+        out[f"profiler_search_{hi}"] = np.array(
+            [prof._binary_search_max_batch_size(1, hi, lambda n, T=T: n <= T) for T in range(hi + 3)] +
+            [prof._binary_search_max_batch_size(1, hi, C.profiler_weird_criterion)])
 
 
 def _engine_trace_one(cfg, out, L):

@@ -224,3 +224,29 @@ def test_decode_lookahead_is_invisible(cfg):
     ahead_eos, n_times = _run_plain(cfg, eos, FakeGraphDecoder())
     assert plain_eos == ahead_eos and n_times == [len(t) for t in plain_eos]
     assert any(len(a) < len(b) and a[-1] == eos for a, b in zip(plain_eos, plain))
+
+
+def test_profiler_budget_search_matches_reference():
+    from hydrainfer_amd.engine.profiler import binary_search_max_batch_size
+    z = np.load(GOLD)
+    for hi in (8, 2048):
+        want = z[f"profiler_search_{hi}"]
+        got = [binary_search_max_batch_size(1, hi, lambda n, T=T: n <= T) for T in range(hi + 3)]
+        got.append(binary_search_max_batch_size(1, hi, C.profiler_weird_criterion))
+        assert got == want.tolist()
+
+
+def test_profiler_runs_the_executors_and_frees_its_blocks():
+    """Budgets come out of timing real executor calls on synthetic batches (CPU stand-ins here)."""
+    from hydrainfer_amd.engine.profiler import BatchSchedulerProfiler, BatchSchedulerProfilerConfig
+    cfg = C.ENGINE_TRACES[0]
+    log = []
+    node, sched, kv, img = build_node(cfg, None, log)
+    prof = BatchSchedulerProfiler(BatchSchedulerProfilerConfig(tpot_slo=10.0, n_warmup_iter=1, n_profile_iter=1),
+                                  node.executor, kv, img, pixel_values=torch.zeros(1, 3, 2, 2),
+                                  n_image_tokens=cfg.n_image_tokens)
+    assert prof.profile_image_budgets() == 8          # everything meets a 10 s SLO -> the upper bound
+    n_fill_calls = len([e for e in log if "input_ids" in e])
+    assert prof.profile_token_budgets() >= 16 and len([e for e in log if "input_ids" in e]) > n_fill_calls
+    for m in (kv, img):
+        assert len(m.shared_cache.to_be_evicted) == m.n_blocks
