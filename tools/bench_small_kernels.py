@@ -4,7 +4,7 @@ import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hydrainfer_amd._C.kernel import norm, activation, position_embedding as pe
-from oracle import ops
+from hydrainfer_amd.model.llama import LLAVA_1_5_7B, build_cos_sin
 
 dev = torch.device("cuda:0"); dt = torch.bfloat16
 B, H, D, hid, inter = 32, 32, 128, 4096, 11008
@@ -13,7 +13,7 @@ w = torch.ones(hid, device=dev, dtype=dt); out = torch.empty_like(x)
 gu = torch.randn((B, 2 * inter), device=dev).to(dt)
 qkv = torch.randn((B, 3 * hid), device=dev).to(dt)
 pos = torch.arange(700, 700 + B, dtype=torch.int32, device=dev)
-cs = ops.build_cos_sin_cache(D, 4096, 1e4, dt).to(dev)
+cs = build_cos_sin(LLAVA_1_5_7B, dt, dev)
 kc = torch.zeros((64, 16, H, D), dtype=dt, device=dev); vc = torch.zeros_like(kc)
 slots = torch.arange(B, dtype=torch.int32, device=dev) * 16
 e = torch.empty(1, device=dev)

@@ -6,7 +6,7 @@ import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused
-from oracle import ops
+from hydrainfer_amd.model.llama import LLAVA_1_5_7B, build_cos_sin
 
 dev = torch.device("cuda:0")
 dt = torch.bfloat16
@@ -24,7 +24,7 @@ out = torch.empty_like(q)
 k_new = torch.randn((B, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
 v_new = torch.randn((B, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
 pos = torch.full((B,), ctx - 1, dtype=torch.int32, device=dev)
-cs = ops.build_cos_sin_cache(D, 4096, 1e4, dt).to(dev)
+cs = build_cos_sin(LLAVA_1_5_7B, dt, dev)
 slots = (perm[cu_b[:-1].long() + (ctx - 1) // bs] * bs + (ctx - 1) % bs).to(torch.int32)
 for i in range(12):
     # the variant the decode graph runs: fused RoPE + cache append + attention
