@@ -5,10 +5,13 @@
 // mask.h:130-211 (bottom-right aligned causal).
 //
 // Design (gfx950, MFMA 16x16x32, "swapped" products so no P transpose is needed):
-//   * workgroup = 4 waves x 16 query rows; grid = (ceil(max_q/64), head, sequence).  The
-//     32-key K and V tiles are staged ONCE per workgroup (coalesced 16-byte loads of whole
-//     rows, register prefetch of tile t+1 under tile t's MFMAs, double-buffered LDS images,
-//     one barrier per tile) and shared by the four waves.
+//   * workgroup = 4 waves x QR x 16 query rows (QR = 2 for query runs of >= 1024 tokens: every
+//     K / V fragment read from LDS then feeds two MFMAs, halving the LDS traffic per flop);
+//     grid = (ceil(max_q/(64 QR)), head, sequence), longest causal tiles launched first.  The 32-key K and V tiles are staged ONCE per workgroup (coalesced
+//     16-byte loads of whole rows, register prefetch of tile t+1 under tile t's MFMAs,
+//     double-buffered LDS images, one barrier per tile) and shared by the four waves.
+//   * the running output is rescaled only when some row's maximum moved (wave-uniform test):
+//     after the first tiles it rarely does, and multiplying by exactly 1 is the identity.
 //   * S^T[key][query] = K . Q^T : A = K fragments read from the LDS image (row stride 2D+32 B:
 //     conflict free), B = Q^T fragments kept in registers.
 //     The accumulator leaves lane (g=l>>4, c=l&15) with query c, keys 4g..4g+3 of each
@@ -19,6 +22,7 @@
 //     [32 keys][D] (row stride 2D+32 bytes => conflict-free transposed reads).
 //   * P is rounded to T before P.V exactly like the reference kernel
 //     (flash_fwd_kernel.h:878); accumulation is fp32.
+#include <cstring>
 #include "attn_common.h"
 
 namespace {
@@ -34,7 +38,7 @@ __device__ __forceinline__ u16x4 lds_tr_read(const char* lds_ptr) {
   return __builtin_bit_cast(u16x4, r);
 }
 
-template <typename T, int D, bool PAGED>
+template <typename T, int D, bool PAGED, int QR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   constexpr int NS = D / 32;       // QK k-steps
   constexpr int NDB = D / 16;      // 16-dim output blocks
@@ -45,7 +49,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   constexpr int TILE_BYTES = 32 * RS;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2][32][RS] | V[2][32][RS]
 
-  const int mblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // causal tiles get longer with the row index: launch the long ones first
+  const int mblk = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
@@ -55,9 +60,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int q_len = p.cu_q[b + 1] - q_start;
   const int k_start = p.cu_k[b];
   const int kv_len = p.cu_k[b + 1] - k_start;
-  const int q_row0_wg = mblk * 64;
+  constexpr int WROWS = 16 * QR;             // query rows per wave
+  const int q_row0_wg = mblk * (4 * WROWS);
   if (q_row0_wg >= q_len) return;            // workgroup-uniform
-  const int q_row0 = q_row0_wg + w * 16;     // may exceed q_len for the last workgroup's waves:
+  const int q_row0 = q_row0_wg + w * WROWS;  // may exceed q_len for the last workgroup's waves:
                                              // those waves still load / synchronise, never store
 
   char* kbuf = smem;
@@ -66,20 +72,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
   const int32_t* bt = PAGED ? p.block_table + p.cu_block_lens[b] : nullptr;
 
-  // Q^T fragments (B operand): lane (c,g) holds Q[row c][32s + 8g + j]
-  u16x8 qf[NS];
-  {
-    const int qr = min(q_row0 + c, q_len - 1);
+  // Q^T fragments (B operand): lane (c,g) holds Q[row 16 rb + c][32s + 8g + j]
+  u16x8 qf[QR][NS];
+#pragma unroll
+  for (int rb = 0; rb < QR; ++rb) {
+    const int qr = min(q_row0 + 16 * rb + c, q_len - 1);
     const u16* qp = reinterpret_cast<const u16*>(p.q) + (int64_t)(q_start + qr) * p.q_row_stride +
                     (int64_t)h * D + 8 * g;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 32 * s);
+    for (int s = 0; s < NS; ++s) qf[rb][s] = *reinterpret_cast<const u16x8*>(qp + 32 * s);
   }
 
   const int shift = kv_len - q_len;
-  const int limit_c = p.causal ? min(kv_len - 1, q_row0 + c + shift) : kv_len - 1;
-  const int last_key_wave = p.causal ? min(kv_len - 1, q_row0 + 15 + shift) : kv_len - 1;
-  const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + 63, q_len - 1) + shift) : kv_len - 1;
+  int limit_c[QR];
+#pragma unroll
+  for (int rb = 0; rb < QR; ++rb)
+    limit_c[rb] = p.causal ? min(kv_len - 1, q_row0 + 16 * rb + c + shift) : kv_len - 1;
+  const int last_key_wave = p.causal ? min(kv_len - 1, q_row0 + WROWS - 1 + shift) : kv_len - 1;
+  const int last_key_wg =
+      p.causal ? min(kv_len - 1, min(q_row0_wg + 4 * WROWS - 1, q_len - 1) + shift) : kv_len - 1;
   const int n_tiles = (last_key_wg >= 0) ? (last_key_wg >> 5) + 1 : 0;   // workgroup-uniform
 
   // ---- cooperative tile staging: thread owns chunks idx = tid + 256*j of the [32][D] tile
@@ -90,10 +101,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     my_row[j] = idx / LPR;
     my_chunk[j] = idx % LPR;
   }
-  auto key_offset = [&](int key, bool is_v) -> int64_t {   // element offset of key row `key`
+  // element offset of key row `key` given its page (paged) — the page id is looked up ONE TILE
+  // AHEAD of the loads that need it, so a tile's loads are a single round trip, not two
+  auto page_of = [&](int key) -> int {
+    return PAGED ? bt[min(key, kv_len - 1) / p.block_size] : 0;
+  };
+  auto key_offset = [&](int key, int page, bool is_v) -> int64_t {
     key = min(key, kv_len - 1);
     if (PAGED) {
-      const int page = bt[key / p.block_size];
       const int row = key % p.block_size;
       return is_v ? (int64_t)page * p.v_block_stride + (int64_t)row * p.v_row_stride
                   : (int64_t)page * p.k_block_stride + (int64_t)row * p.k_row_stride;
@@ -101,13 +116,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     return (int64_t)(k_start + key) * (is_v ? p.v_row_stride : p.k_row_stride);
   };
   u16x8 kreg[NL], vreg[NL];
+  int page_next[NL];      // pages of the tile that will be loaded next
+  auto lookup_pages = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) page_next[j] = page_of(t * 32 + my_row[j]);
+  };
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       if (TILE_CHUNKS % 256 == 0 || threadIdx.x + 256 * j < TILE_CHUNKS) {
         const int key = t * 32 + my_row[j];
-        kreg[j] = *reinterpret_cast<const u16x8*>(kbase + key_offset(key, false) + 8 * my_chunk[j]);
-        vreg[j] = *reinterpret_cast<const u16x8*>(vbase + key_offset(key, true) + 8 * my_chunk[j]);
+        kreg[j] = *reinterpret_cast<const u16x8*>(kbase + key_offset(key, page_next[j], false) + 8 * my_chunk[j]);
+        vreg[j] = *reinterpret_cast<const u16x8*>(vbase + key_offset(key, page_next[j], true) + 8 * my_chunk[j]);
       }
     }
   };
@@ -122,13 +142,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     }
   };
 
-  f32x4 acc[NDB];
+  f32x4 acc[QR][NDB];
+  float m[QR], l[QR];
 #pragma unroll
-  for (int i = 0; i < NDB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = HX_NEG_BIG, l = 0.f;
+  for (int rb = 0; rb < QR; ++rb) {
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) acc[rb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[rb] = HX_NEG_BIG;
+    l[rb] = 0.f;
+  }
 
   if (n_tiles > 0) {
+    lookup_pages(0);
     load_tile(0);
+    lookup_pages(1);
     store_tile(0);
   }
   __syncthreads();
@@ -136,51 +163,61 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int q4 = c >> 2, p4 = c & 3;
   for (int t = 0; t < n_tiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < n_tiles) load_tile(t + 1);       // in flight under this tile's MFMAs
+    if (t + 1 < n_tiles) {
+      load_tile(t + 1);                          // in flight under this tile's MFMAs
+      lookup_pages(t + 2);                       // (clamped to the last key) for the next iteration
+    }
 
     if (t * 32 <= last_key_wave) {               // wave-uniform: tiles past this wave's diagonal
       const char* kt = kbuf + cur * TILE_BYTES;
       const char* vt = vbuf + cur * TILE_BYTES;
-      // ---- S^T = K . Q^T for the two 16-key sub-tiles (A fragments from the shared K image)
-      f32x4 s[2];
+      // ---- S^T = K . Q^T for the two 16-key sub-tiles (A fragments from the shared K image,
+      //      each used for the QR row blocks of this wave)
+      f32x4 s[QR][2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rb = 0; rb < QR; ++rb) s[rb][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
           const u16x8 kf = *reinterpret_cast<const u16x8*>(kt + (16 * u + c) * RS + 64 * st + 16 * g);
-          a = Mfma<T>::mma(kf, qf[st], a);
+#pragma unroll
+          for (int rb = 0; rb < QR; ++rb) s[rb][u] = Mfma<T>::mma(kf, qf[rb][st], s[rb][u]);
         }
-        s[u] = a;
       }
       // ---- mask + online softmax (per query column c; state replicated over g)
-      float x[8];
-      float mx = HX_NEG_BIG;
+      u16x8 pf[QR];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int rb = 0; rb < QR; ++rb) {
+        float x[8];
+        float mx = HX_NEG_BIG;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int key = t * 32 + u * 16 + 4 * g + i;
-          const float v = (key <= limit_c) ? s[u][i] * p.scale_log2 : -INFINITY;
-          x[u * 4 + i] = v;
-          mx = fmaxf(mx, v);
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int key = t * 32 + u * 16 + 4 * g + i;
+            const float v = (key <= limit_c[rb]) ? s[rb][u][i] * p.scale_log2 : -INFINITY;
+            x[u * 4 + i] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m[rb], mx);
+        const float alpha = fast_exp2(m[rb] - m_new);
+        m[rb] = m_new;
+        float ps = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float e = fast_exp2(x[j] - m_new);
+          ps += e;
+          pf[rb][j] = T::from_float(e);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m, mx);
-      const float alpha = fast_exp2(m - m_new);
-      m = m_new;
-      u16x8 pf;
-      float ps = 0.f;
+        l[rb] = l[rb] * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {   // wave-uniform: some row's maximum moved
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float e = fast_exp2(x[j] - m_new);
-        ps += e;
-        pf[j] = T::from_float(e);
+          for (int i = 0; i < NDB; ++i) acc[rb][i] *= alpha;
+        }
       }
-      l = l * alpha + ps;
-#pragma unroll
-      for (int i = 0; i < NDB; ++i) acc[i] *= alpha;
       // ---- O^T += V^T . P^T (V^T fragments by transposed LDS reads of the shared V image)
       const char* vrd = vt + (4 * g + q4) * RS + p4 * 8;
 #pragma unroll
@@ -190,57 +227,78 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         u16x8 vf;
         vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
         vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-        acc[db] = Mfma<T>::mma(vf, pf, acc[db]);
+#pragma unroll
+        for (int rb = 0; rb < QR; ++rb) acc[rb][db] = Mfma<T>::mma(vf, pf[rb], acc[rb][db]);
       }
     }
     if (t + 1 < n_tiles) store_tile(cur ^ 1);
     __syncthreads();    // tile t+1 visible; everyone is done with tile t's image
   }
 
-  // ---- epilogue: O[q c][dim 16db + 4g + i] = acc[db][i] / L
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
-  if (q_row0 + c < q_len) {
-    u16* op = reinterpret_cast<u16*>(p.out) + (int64_t)(q_start + q_row0 + c) * p.o_row_stride +
-              (int64_t)h * D + 4 * g;
+  // ---- epilogue: O[q 16 rb + c][dim 16db + 4g + i] = acc[rb][db][i] / L
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
-      u16x4 r;
+  for (int rb = 0; rb < QR; ++rb) {
+    float lr = l[rb];
+    lr += __shfl_xor(lr, 16, 64);
+    lr += __shfl_xor(lr, 32, 64);
+    const float inv = (lr > 0.f) ? 1.0f / lr : 0.f;
+    const int row = q_row0 + 16 * rb + c;
+    if (row < q_len) {
+      u16* op = reinterpret_cast<u16*>(p.out) + (int64_t)(q_start + row) * p.o_row_stride +
+                (int64_t)h * D + 4 * g;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r[i] = T::from_float(acc[db][i] * inv);
-      *reinterpret_cast<u16x4*>(op + 16 * db) = r;
+      for (int db = 0; db < NDB; ++db) {
+        u16x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = T::from_float(acc[rb][db][i] * inv);
+        *reinterpret_cast<u16x4*>(op + 16 * db) = r;
+      }
     }
   }
 }
 
-template <typename T, int D>
-int launch_fwd(const AttnParams& p, int batch, int max_seqlen_q, bool paged, hipStream_t stream) {
+template <typename T, int D, bool PAGED, int QR>
+int launch_fwd_cfg(const AttnParams& p, int batch, int max_seqlen_q, hipStream_t stream) {
   constexpr int RS = 2 * D + 32;
   const size_t lds = 4 * 32 * RS;   // K[2][32][RS] + V[2][32][RS]
-  dim3 grid((max_seqlen_q + 63) / 64, p.n_heads, batch);
+  dim3 grid((max_seqlen_q + 64 * QR - 1) / (64 * QR), p.n_heads, batch);
   if (grid.x == 0) return HX_OK;
-  if (paged) {
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return hip_rc(e);
-    }
-    attn_fwd_kernel<T, D, true><<<grid, 256, lds, stream>>>(p);
-  } else {
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return hip_rc(e);
-    }
-    attn_fwd_kernel<T, D, false><<<grid, 256, lds, stream>>>(p);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, PAGED, QR>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_rc(e);
   }
+  attn_fwd_kernel<T, D, PAGED, QR><<<grid, 256, lds, stream>>>(p);
   return check_launch();
+}
+
+int g_fwd_rows = 0;   // tuning: 0 = automatic, 1 / 2 = row blocks per wave
+
+template <typename T, int D>
+int launch_fwd(const AttnParams& p, int batch, int max_seqlen_q, bool paged, hipStream_t stream) {
+  // two row blocks per wave for long query runs (measured on MI355X, tools/bench_attn_prefill.py:
+  // 2048 new tokens 177 -> 141 us; at 704 tokens and for the 577-token CLIP tower one row block
+  // is faster — those launches are short of workgroups, not of LDS bandwidth).  D = 256 keeps
+  // one: its accumulators alone are 128 registers per row block.
+  bool two = D <= 128 && max_seqlen_q >= 1024;
+  if (g_fwd_rows == 1) two = false;
+  if (g_fwd_rows == 2 && D <= 128) two = true;
+  if constexpr (D <= 128) {
+    if (two) return paged ? launch_fwd_cfg<T, D, true, 2>(p, batch, max_seqlen_q, stream)
+                          : launch_fwd_cfg<T, D, false, 2>(p, batch, max_seqlen_q, stream);
+  }
+  return paged ? launch_fwd_cfg<T, D, true, 1>(p, batch, max_seqlen_q, stream)
+               : launch_fwd_cfg<T, D, false, 1>(p, batch, max_seqlen_q, stream);
 }
 
 }  // namespace
 
 namespace hx {
+
+int fwd_set_option(const char* name, int value) {
+  if (!strcmp(name, "fwd_row_blocks")) { g_fwd_rows = value; return HX_OK; }
+  return HX_ERR_UNSUPPORTED;
+}
 
 bool fwd_supported(int head_dim) {
   return head_dim == 32 || head_dim == 64 || head_dim == 96 || head_dim == 128 || head_dim == 256;

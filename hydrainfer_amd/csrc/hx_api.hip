@@ -13,6 +13,7 @@ int& last_hip_error() {
 bool decode_supported(int head_dim);
 int decode_set_option(const char* name, int value);
 int gemm_set_option(const char* name, int value);
+int fwd_set_option(const char* name, int value);
 bool fwd_supported(int head_dim);
 int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested);
 int launch_attn_decode(const AttnParams& p, int batch, int head_dim, int dtype,
@@ -32,6 +33,7 @@ extern "C" int hx_debug_set_option(const char* name, int value) {
   if (!name) return HX_ERR_NULL;
   int rc = decode_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = gemm_set_option(name, value);
+  if (rc == HX_ERR_UNSUPPORTED) rc = fwd_set_option(name, value);
   return rc;
 }
 

@@ -348,3 +348,60 @@ def test_zero_token_calls_are_noops():
                             torch.zeros((16, 2, 32), dtype=dt, device=DEV), 64, False)
     torch.cuda.synchronize()
     assert float(cache.float().min()) == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 2])
+def test_prefill_row_block_variants_vs_oracle(rows):
+    """Both tilings of the prefill kernel (one / two 16-row blocks per wave; the second is what runs
+    automatically for query runs >= 1024 tokens) on ragged paged causal, chunked and dense inputs,
+    and bit-identical to each other on a long run."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    from oracle import ops
+    lib = _lib.lib()
+    try:
+        _lib.check(lib.hx_debug_set_option(b"fwd_row_blocks", rows), "option")
+        for dt in (torch.float16, torch.bfloat16):
+            atol, rtol = ATTN_TOL[dt]
+            q_lens, kv_lens = [1, 129, 64, 200, 31, 128], [77, 129, 300, 200, 31, 1000]
+            for D, heads in ((128, (4, 2)), (64, (4, 4))):
+                q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(len(q_lens), heads[0], heads[1], D, kv_lens, q_lens,
+                                                                dt, seed=rows + D)
+                ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+                out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
+                assert_close_t(out, ref, atol, rtol, what=f"rows={rows} paged D={D} {dt}")
+            gen = torch.Generator().manual_seed(3 + rows)
+            lens = [577, 1, 130]
+            cu = torch.tensor([0, 577, 578, 708], dtype=torch.int32)
+            q, k, v = (torch.randn((708, 4, 64), generator=gen).to(dt) for _ in range(3))
+            out = torch.empty_like(q, device=DEV)
+            mha_varlen_fwd(out, q.to(DEV), k.to(DEV), v.to(DEV), cu.to(DEV), cu.to(DEV), None, None, None,
+                           max(lens), max(lens), 1 / 8.0, 0.0, -1, -1, 0)
+            assert_close_t(out, ops.varlen_attention(q, k, v, cu, cu, causal=False), atol, rtol,
+                           what=f"rows={rows} dense {dt}")
+    finally:
+        lib.hx_debug_set_option(b"fwd_row_blocks", 0)
+
+
+@pytest.mark.gpu
+def test_prefill_long_run_takes_two_row_blocks_and_matches():
+    from hydrainfer_amd import _lib
+    from oracle import ops
+    lib = _lib.lib()
+    dt = torch.bfloat16
+    q_lens, kv_lens = [1100, 1030], [1100, 1500]
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(2, 4, 4, 128, kv_lens, q_lens, dt, seed=9)
+    auto = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))      # automatic: two row blocks
+    try:
+        lib.hx_debug_set_option(b"fwd_row_blocks", 1)
+        one = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
+        lib.hx_debug_set_option(b"fwd_row_blocks", 2)
+        two = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
+    finally:
+        lib.hx_debug_set_option(b"fwd_row_blocks", 0)
+    assert torch.equal(auto, two) and torch.equal(one, two)      # same per-row arithmetic, other tiling
+    sel = torch.cat([torch.arange(0, 1100, 37), torch.arange(1100, 2130, 41)])
+    ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+    atol, rtol = ATTN_TOL[dt]
+    assert_close_t(auto[sel.to(DEV)], ref[sel], atol, rtol, what="long run")
