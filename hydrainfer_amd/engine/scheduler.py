@@ -116,11 +116,16 @@ class BatchScheduler:
                 if rcb.virtual_kv_cache is None:
                     rcb.virtual_kv_cache = kv.allocate_virtual_cache(inst.hashes)
                     n_hit = rcb.virtual_kv_cache.n_cache_tokens
+                    assert n_hit <= len(inst.token_ids)
+                    if n_hit == len(inst.token_ids):
+                        # The whole prompt is cached (its length is a multiple of the block size).
+                        # The reference skips the fill altogether (scheduler.py:128-133) and so
+                        # never samples the first token; here the last block is computed again.
+                        n_hit -= kv.block_size
+                        kv.realloc(rcb.virtual_kv_cache, n_hit)
                     if n_hit > 0:
                         # prefix-cache hit: split the matched tokens off and skip them
-                        assert n_hit <= len(inst.token_ids)
-                        if n_hit < len(inst.token_ids):
-                            inst.chunk_prefill(chunk_size=n_hit)
+                        inst.chunk_prefill(chunk_size=n_hit)
                         rcb.step()
                 inst = rcb.current_instruction()
                 if isinstance(inst, Fill):
