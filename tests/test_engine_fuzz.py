@@ -54,6 +54,56 @@ class LM:
         return torch.tensor([C.engine_trace_sample(i[j], p[j]) for j in params.selected_token_ids.tolist()])
 
 
+class FakeStore:
+    """In-memory stand-in for the torch.distributed store the mailbox runs on."""
+
+    def __init__(self):
+        self.kv = {}
+
+    def add(self, key, n):
+        self.kv[key] = self.kv.get(key, 0) + n
+        return self.kv[key]
+
+    def set(self, key, value):
+        self.kv[key] = value
+
+    def get(self, key):
+        return self.kv[key]
+
+    def check(self, keys):
+        return all(k in self.kv for k in keys)
+
+
+class WireCluster:
+    """The nodes of a topology as RankEngines that talk only through pickled mailbox messages
+    (engine/distributed.py) — stepped round-robin in one process."""
+
+    def __init__(self, nodes, roles):
+        from hydrainfer_amd.engine.distributed import RankEngine, StoreMailbox
+        store = FakeStore()
+        self.engines = [RankEngine(r, roles, n) for r, n in enumerate(nodes)]
+        for e in self.engines:
+            e.mailbox = StoreMailbox(store, e.rank, "fuzz")
+        self.roles = roles
+        self.n_added = [0, 0]
+
+    def add_request(self, rcb):
+        from hydrainfer_amd.engine.distributed import entry_rank
+        from hydrainfer_amd.engine.isa import ImageEmbed
+        has_image = isinstance(rcb.current_instruction(), ImageEmbed)
+        r = entry_rank(self.n_added[has_image], self.roles, has_image)
+        self.n_added[has_image] += 1
+        self.engines[r].node.add_request(rcb)
+
+    def step(self):
+        for e in self.engines:
+            e.step()
+
+    def idle(self):
+        return all(e.node.idle() and not e.held and not e.outbox for e in self.engines) and \
+            all(not e.mailbox.store.check([f"fuzz/m/{e.rank}/{e.mailbox.next_slot}"]) for e in self.engines)
+
+
 class Vision:
     def forward(self, px):
         return torch.zeros(px.shape[0], N_IMG, 8)
@@ -98,7 +148,8 @@ def test_engine_fuzz_closed_form(seed):
         if lookahead and node.executor.fill_executor is not None and node.node_type.enable_decode:
             node.executor.fill_executor.graph_decoder = FakeGraphDecoder()
         nodes.append(node)
-    cluster = LocalCluster(nodes)
+    wire = len(topology) > 1 and rng.random() < 0.5
+    cluster = WireCluster(nodes, topology) if wire else LocalCluster(nodes)
     creator = InstructionCreator(IMAGE_TOKEN, N_IMG, BS, ignore_eos=eos is None, eos_token_id=eos if eos else 2)
     rcbs, step = [None] * n_req, 0
     while step <= max(arrivals) or not cluster.idle():
@@ -109,9 +160,11 @@ def test_engine_fuzz_closed_form(seed):
         cluster.step()
         step += 1
         assert step < 3000, "engine did not drain"
+    done = {r.request_id: r for n in nodes for r in n.finished}      # (over the wire a request is re-created)
     for i, r in enumerate(reqs):
-        assert rcbs[i].output_token_ids == closed_form(r, eos), f"request {i} ({topology}, lookahead={lookahead})"
-        assert len(rcbs[i].metric.token_times) == len(rcbs[i].output_token_ids)
+        assert done[i].output_token_ids == closed_form(r, eos), \
+            f"request {i} ({topology}, lookahead={lookahead}, wire={wire})"
+        assert len(done[i].metric.token_times) == len(done[i].output_token_ids)
     for node in nodes:
         for m in (node.kv_cache_block_manager, node.image_cache_block_manager):
             if m is not None:
