@@ -21,6 +21,16 @@ template <> struct Mfma<BF16> {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// ds_read_b64_tr_b16: lane (g = l>>4, c = l&15) of a [16 rows][16 cols] 2-byte tile whose rows
+// start at lds_ptr(row-group base) receives column-major data suitable as an MFMA A operand of
+// the transposed tile (see attn_fwd.hip for the addressing used with it).
+typedef short hx_s16x4_t __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ u16x4 lds_tr_read(const char* lds_ptr) {
+  typedef __attribute__((address_space(3))) hx_s16x4_t lds_s4;
+  hx_s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)lds_ptr);
+  return __builtin_bit_cast(u16x4, r);
+}
+
 // Finite "minus infinity" for running maxima: keeps exp2(m_old - m_new) == 1 when a
 // lane group has not seen any unmasked key yet (no NaN from inf - inf).
 #define HX_NEG_BIG (-1.0e30f)

@@ -437,6 +437,22 @@ int decode_set_option(const char* name, int value) {
 
 bool decode_supported(int head_dim) { return head_dim == 64 || head_dim == 128 || head_dim == 256; }
 
+// final pass over split-KV partials in AttnParams::ws_o / ws_ml (shared with attn_decode_gqa.hip)
+int launch_decode_combine(const AttnParams& p, int batch, int head_dim, int dtype, hipStream_t stream) {
+  const dim3 grid(p.n_heads, batch);
+#define HX_COMBINE_CASE(TT, DD) \
+  case DD: attn_decode_combine_kernel<TT, DD><<<grid, DD, 0, stream>>>(p); break;
+  if (dtype == HX_F16) {
+    switch (head_dim) { HX_COMBINE_CASE(F16, 64) HX_COMBINE_CASE(F16, 128) HX_COMBINE_CASE(F16, 256) default: return HX_ERR_SHAPE; }
+  } else if (dtype == HX_BF16) {
+    switch (head_dim) { HX_COMBINE_CASE(BF16, 64) HX_COMBINE_CASE(BF16, 128) HX_COMBINE_CASE(BF16, 256) default: return HX_ERR_SHAPE; }
+  } else {
+    return HX_ERR_DTYPE;
+  }
+#undef HX_COMBINE_CASE
+  return check_launch();
+}
+
 int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested) {
   if (requested >= 1) return requested > 128 ? 128 : requested;
   const int64_t base = (int64_t)batch * n_heads;

@@ -29,15 +29,6 @@ namespace {
 
 using namespace hx;
 
-typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
-typedef short s16x4_t __attribute__((__vector_size__(4 * sizeof(short))));
-
-__device__ __forceinline__ u16x4 lds_tr_read(const char* lds_ptr) {
-  typedef __attribute__((address_space(3))) s16x4_t lds_s4;
-  s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)lds_ptr);
-  return __builtin_bit_cast(u16x4, r);
-}
-
 template <typename T, int D, bool PAGED, int QR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   constexpr int NS = D / 32;       // QK k-steps

@@ -1,6 +1,7 @@
 // hx_api.hip — C-ABI entry points that are not tied to one kernel file: status text,
 // argument validation + dispatch of hx_mha_varlen_fwd (error behaviour mirrors the
 // TORCH_CHECKs of csrc/kernel/flash_attn/flash_api.cpp:236-283 of the reference).
+#include <cstring>
 #include "attn_common.h"
 
 namespace hx {
@@ -16,6 +17,9 @@ int gemm_set_option(const char* name, int value);
 int fwd_set_option(const char* name, int value);
 bool fwd_supported(int head_dim);
 int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested);
+bool decode_gqa_supported(int head_dim, int group);
+int decode_gqa_pick_splits(int batch, int n_kv_heads, int max_seqlen_k, int requested);
+int launch_attn_decode_gqa(const AttnParams& p, int batch, int head_dim, int dtype, hipStream_t stream);
 int launch_attn_decode(const AttnParams& p, int batch, int head_dim, int dtype,
                        hipStream_t stream);
 int launch_attn_fwd(const AttnParams& p, int batch, int head_dim, int max_seqlen_q, bool paged,
@@ -29,8 +33,11 @@ extern "C" int hx_abi_version(void) { return HX_ABI_VERSION; }
 
 extern "C" int hx_last_hip_error(void) { return last_hip_error(); }
 
+static int g_decode_gqa = 1;   // tuning: 0 routes grouped-query decode through the per-query-head kernel
+
 extern "C" int hx_debug_set_option(const char* name, int value) {
   if (!name) return HX_ERR_NULL;
+  if (!strcmp(name, "decode_gqa")) { g_decode_gqa = value ? 1 : 0; return HX_OK; }
   int rc = decode_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = gemm_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = fwd_set_option(name, value);
@@ -59,6 +66,16 @@ namespace {
 bool use_decode(const hx_attn_args* a) {
   return a->block_table != nullptr && a->max_seqlen_q == 1 && a->total_q == a->batch &&
          decode_supported(a->head_dim);
+}
+
+
+bool use_gqa(const hx_attn_args* a, bool fused) {
+  return g_decode_gqa && !fused && decode_gqa_supported(a->head_dim, a->n_heads / a->n_kv_heads);
+}
+
+int pick_splits(const hx_attn_args* a, bool fused) {
+  return use_gqa(a, fused) ? decode_gqa_pick_splits(a->batch, a->n_kv_heads, a->max_seqlen_k, a->num_splits)
+                           : decode_pick_splits(a->batch, a->n_heads, a->max_seqlen_k, a->num_splits);
 }
 
 int validate(const hx_attn_args* a) {
@@ -94,7 +111,7 @@ int validate(const hx_attn_args* a) {
 
 extern "C" int64_t hx_mha_varlen_fwd_workspace_bytes(const hx_attn_args* a) {
   if (validate(a) != HX_OK || !use_decode(a)) return 0;
-  const int splits = decode_pick_splits(a->batch, a->n_heads, a->max_seqlen_k, a->num_splits);
+  const int splits = pick_splits(a, false);
   if (splits <= 1) return 0;
   return (int64_t)a->batch * a->n_heads * splits * (a->head_dim + 2) * (int64_t)sizeof(float);
 }
@@ -184,7 +201,8 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   if (use_decode(a)) {
     // with q_len == 1 the causal mask admits every cached key (bottom-right aligned),
     // so causal and non-causal decode coincide.
-    int splits = decode_pick_splits(a->batch, a->n_heads, a->max_seqlen_k, a->num_splits);
+    const bool gqa = use_gqa(a, fused != nullptr);
+    int splits = pick_splits(a, fused != nullptr);
     if (splits > 1) {
       const int64_t need =
           (int64_t)a->batch * a->n_heads * splits * (a->head_dim + 2) * (int64_t)sizeof(float);
@@ -197,6 +215,7 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
       }
     }
     p.n_splits = splits;
+    if (gqa) return launch_attn_decode_gqa(p, a->batch, a->head_dim, a->dtype, s);
     return launch_attn_decode(p, a->batch, a->head_dim, a->dtype, s);
   }
   return launch_attn_fwd(p, a->batch, a->head_dim, a->max_seqlen_q, a->block_table != nullptr,

@@ -236,7 +236,11 @@ def test_argument_errors_raise():
 @pytest.mark.parametrize("D", [64, 128, 256])
 def test_fused_rope_cache_decode_attention_is_bit_identical(dt, heads, D):
     """decode_attention_fused == apply_rotary_pos_emb + set_kv_cache + mha_varlen_fwd: same
-    output bits, same cache bits, q/k inputs untouched."""
+    output bits, same cache bits, q/k inputs untouched.  (The fused kernel is the per-query-head
+    one; for grouped-query shapes the unfused reference is routed through it too — the
+    grouped-query kernel of attn_decode_gqa.hip rounds P to T and is compared by tolerance in
+    test_gqa_decode_kernel_vs_oracle_and_per_head_kernel.)"""
+    from hydrainfer_amd import _lib
     from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
     from hydrainfer_amd._C.kernel.position_embedding import rope_set_kv_cache
     from oracle import ops
@@ -258,8 +262,12 @@ def test_fused_rope_cache_decode_attention_is_bit_identical(dt, heads, D):
         qa, ka, va, kca, vca = dev(q).clone(), dev(k_new).clone(), dev(v_new).clone(), dev(kc).clone(), dev(vc).clone()
         rope_set_kv_cache(qa, ka, va, dev(pos), dev(cs), D, dev(slots), kca, vca)
         oa = torch.empty_like(qa)
-        mha_varlen_fwd(oa, qa, kca, vca, dev(cu_q), dev(cu_k), dev(bt), dev(cu_b), None, 1, max(kv_lens),
-                       1 / math.sqrt(D), 0.0, -1, 0, splits)
+        _lib.lib().hx_debug_set_option(b"decode_gqa", 0)
+        try:
+            mha_varlen_fwd(oa, qa, kca, vca, dev(cu_q), dev(cu_k), dev(bt), dev(cu_b), None, 1, max(kv_lens),
+                           1 / math.sqrt(D), 0.0, -1, 0, splits)
+        finally:
+            _lib.lib().hx_debug_set_option(b"decode_gqa", 1)
         # fused
         qb, kb, vb, kcb, vcb = dev(q).clone(), dev(k_new).clone(), dev(v_new).clone(), dev(kc).clone(), dev(vc).clone()
         ob = torch.empty_like(qb)
@@ -405,3 +413,34 @@ def test_prefill_long_run_takes_two_row_blocks_and_matches():
     ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
     atol, rtol = ATTN_TOL[dt]
     assert_close_t(auto[sel.to(DEV)], ref[sel], atol, rtol, what="long run")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("heads", [(8, 4), (28, 4), (32, 8), (16, 1), (12, 4)])
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_gqa_decode_kernel_vs_oracle_and_per_head_kernel(dt, heads, D):
+    """Grouped-query decode (attn_decode_gqa.hip: one workgroup per KV head, the group's query
+    heads as MFMA columns) against the oracle, with explicit and automatic key splits, ragged
+    lengths around the 32-key tile, and against the per-query-head kernel."""
+    from hydrainfer_amd import _lib
+    from oracle import ops
+    H, HK = heads
+    if D == 256 and H > 16:
+        pytest.skip("covered at smaller head counts")
+    kv_lens = [1, 31, 32, 33, 64, 100, 255, 257, 704, 1500]
+    B = len(kv_lens)
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(B, H, HK, D, kv_lens, [1] * B, dt, seed=H + D)
+    ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
+    atol, rtol = ATTN_TOL[dt]
+    outs = {}
+    for splits in (0, 1, 2, 5):
+        out = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, 1, max(kv_lens), num_splits=splits)
+        assert_close_t(out, ref, atol, rtol, what=f"gqa {heads} D={D} splits={splits} {dt}")
+        outs[splits] = out
+    _lib.lib().hx_debug_set_option(b"decode_gqa", 0)
+    try:
+        old = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, 1, max(kv_lens), num_splits=1)
+    finally:
+        _lib.lib().hx_debug_set_option(b"decode_gqa", 1)
+    assert_close_t(outs[1], old.cpu(), atol, rtol, what="gqa kernel vs per-head kernel")

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=0, help="0 = same as --heads (MHA)")
     ap.add_argument("--ctx", type=int, default=832)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--rounds", type=int, default=7)
@@ -25,12 +26,13 @@ def main():
     dev = torch.device("cuda:0")
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     B, H, D, bs = args.batch, args.heads, 128, 16
+    HK = args.kv_heads or H
     nb_seq = (args.ctx + bs - 1) // bs
     n_blocks = B * nb_seq
     g = torch.Generator(device=dev).manual_seed(0)
     # several layers' worth of cache so successive launches do not hit in the 256 MiB L3
     n_layers = 4
-    pool = torch.randn((n_layers, 2, n_blocks, bs, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
+    pool = torch.randn((n_layers, 2, n_blocks, bs, HK, D), generator=g, device=dev, dtype=torch.float32).to(dt)
     perm = torch.randperm(n_blocks, generator=g, device=dev).to(torch.int32)
     cu_b = torch.arange(0, (B + 1) * nb_seq, nb_seq, dtype=torch.int32, device=dev)
     cu_q = torch.arange(0, B + 1, dtype=torch.int32, device=dev)
@@ -38,7 +40,7 @@ def main():
     q = torch.randn((B, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
     out = torch.empty_like(q)
     scale = 1 / math.sqrt(D)
-    nbytes = 2 * (2 * H * D * args.ctx * B + 2 * B * H * D) + 4 * B * nb_seq
+    nbytes = 2 * (2 * HK * D * args.ctx * B + 2 * B * H * D) + 4 * B * nb_seq
     lib = _lib.lib()
 
     def run(layer, splits):
