@@ -48,7 +48,11 @@ const char* hx_strerror(int status);
 int hx_last_hip_error(void);
 /* Tuning knobs for A/B measurements in one process (not part of the reference surface):
  * "decode_waves" = 4|8 waves per decode-attention workgroup, "decode_nt" = 0|1 non-temporal
- * K/V loads.  Results are identical for every setting. */
+ * K/V loads, "fwd_row_blocks" = 0(auto)|1|2 query row blocks per wave in the prefill kernel,
+ * "gemm_rows_per_wave" / "gemm_waves" / "gemm_slab_nt" for the decode GEMM — results are
+ * identical for every setting of these.  "decode_gqa" = 0|1 selects the per-query-head or the
+ * grouped-query decode kernel for n_heads > n_kv_heads (both within the stated tolerance; the
+ * grouped kernel rounds P to T before P.V like the prefill kernel). */
 int hx_debug_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------
