@@ -111,7 +111,10 @@ int validate(const hx_attn_args* a) {
 
 extern "C" int64_t hx_mha_varlen_fwd_workspace_bytes(const hx_attn_args* a) {
   if (validate(a) != HX_OK || !use_decode(a)) return 0;
-  const int splits = pick_splits(a, false);
+  // the same query serves hx_mha_varlen_fwd and hx_decode_attention_fused, which may pick
+  // different kernels (and split counts) for a grouped-query shape: size for the larger
+  const int s1 = pick_splits(a, false), s2 = pick_splits(a, true);
+  const int splits = s1 > s2 ? s1 : s2;
   if (splits <= 1) return 0;
   return (int64_t)a->batch * a->n_heads * splits * (a->head_dim + 2) * (int64_t)sizeof(float);
 }
