@@ -316,6 +316,7 @@ def measure_migration(ctx, runner, dev, peer, reps=5):
     """P->D KV migration of one 704-token request between neighbouring ranks (rank r pulls from
     r-1) through the IPC-mapped peer pool over xGMI: one gather-copy kernel per transfer."""
     try:
+        torch.cuda.set_device(dev)            # runs in a helper thread: the current device is per thread
         from hydrainfer_amd._C.data_transfer import block_migration as bm
         from hydrainfer_amd import parallel
         bs, P = runner.cfg.block_size, runner.cfg.prompt_len
@@ -505,6 +506,7 @@ def main():
         box = {}
 
         def _exchange():
+            torch.cuda.set_device(dev)        # the current device is per thread; new threads start on 0
             from hydrainfer_amd._C.data_transfer import block_migration as bm
             n_blk = (prompt_len + cfg.block_size - 1) // cfg.block_size
             infos = ctx.all_gather_object({"handle": bm.get_ipc_mem_handle(runner.pool),
