@@ -132,11 +132,23 @@ def dtype_code(t: torch.Tensor) -> int:
 
 def require_gpu(*tensors: torch.Tensor) -> None:
     """The product path is GPU-only; refuse CPU tensors instead of falling back."""
+    current = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise HydraHipError(
                 "hydrainfer_amd ops run only on MI355X device tensors; got a CPU tensor "
                 "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+        # ops launch on the CURRENT device's current stream (like the reference's
+        # at::cuda::getCurrentCUDAStream(), kv_cache_kernels.cu:83); a tensor that lives elsewhere
+        # would be touched from the wrong device's queue — the current device is per thread
+        if current is None:
+            current = torch.cuda.current_device()
+        if t.device.index != current:
+            raise HydraHipError(
+                f"tensor on {t.device} but the calling thread's current device is cuda:{current}; "
+                "call torch.cuda.set_device(...) (or use torch.cuda.device(...)) in this thread first")
 
 
 def current_stream() -> int:
