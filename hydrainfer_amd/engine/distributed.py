@@ -226,22 +226,24 @@ def replay_distributed(engine: RankEngine, creator, requests, arrivals: List[flo
     mine = sorted((i for i, r in enumerate(requests)
                    if entry_rank(i, engine.roles, r.pixel_values is not None) == engine.rank),
                   key=lambda i: arrivals[i])
+    from hydrainfer_amd.engine.serve import quiet_gc
     nxt, total = 0, len(requests)
     first_finished = len(engine.node.finished)
-    while True:
-        now = time.perf_counter() - t0
-        while nxt < len(mine) and arrivals[mine[nxt]] <= now:
-            i = mine[nxt]
-            rcb = creator.process(requests[i])
-            engine.node.add_request(rcb)
-            rcb.metric.arrival_time = t0 + arrivals[i]
-            nxt += 1
-        if engine.step() >= total:
-            break
-        if now > deadline_s:
-            raise TimeoutError(f"rank {engine.rank}: trace not drained after {deadline_s} s")
-        if engine.node.idle():
-            time.sleep(0.001)       # an idle rank polls its mailbox about 1000 times a second
+    with quiet_gc():
+        while True:
+            now = time.perf_counter() - t0
+            while nxt < len(mine) and arrivals[mine[nxt]] <= now:
+                i = mine[nxt]
+                rcb = creator.process(requests[i])
+                engine.node.add_request(rcb)
+                rcb.metric.arrival_time = t0 + arrivals[i]
+                nxt += 1
+            if engine.step() >= total:
+                break
+            if now > deadline_s:
+                raise TimeoutError(f"rank {engine.rank}: trace not drained after {deadline_s} s")
+            if engine.node.idle():
+                time.sleep(0.001)       # an idle rank polls its mailbox about 1000 times a second
     t_wait = time.perf_counter()
     while engine.held and time.perf_counter() - t_wait < 10.0:     # FREEs still on their way
         engine.exchange()

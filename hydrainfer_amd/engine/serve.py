@@ -1,7 +1,9 @@
 """Build a serving node (pools + models + scheduler + executors) and replay an arrival trace on it.
 Used by bench.py's `serving` leg and tools/bench_engine.py; mirrors what
 hydrainfer/cluster/epdnode.py:_update_engine assembles and what benchmark/benchmark.py drives."""
+import contextlib
 import dataclasses
+import gc
 import time
 from typing import List, Optional, Tuple
 
@@ -65,6 +67,24 @@ def synthetic_requests(n: int, n_text: int, max_tokens: int, image_token_id: int
     return out
 
 
+@contextlib.contextmanager
+def quiet_gc():
+    """A full (generation 2) collection walks every live request's instruction chain and lists and
+    was seen to stall a prefill step for 37 ms on a 7B node (tools/prof_engine_host.py).  Serving
+    loops run with the cyclic collector off — nothing the engine allocates per step is cyclic —
+    after moving everything that already exists out of the collector's sight."""
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
+        gc.unfreeze()
+
+
 def poisson_arrivals(n: int, rate: float, seed: int = 0) -> List[float]:
     """benchmark/timestamp.py:9-16 with the seeding of benchmark/benchmark.py:136-137."""
     rng = np.random.RandomState(seed)
@@ -79,21 +99,22 @@ def replay(cluster: LocalCluster, creator: InstructionCreator, requests: List[To
     order = sorted(range(len(requests)), key=lambda i: arrivals[i])
     rcbs = [None] * len(requests)
     torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    nxt, steps = 0, 0
-    while nxt < len(order) or not cluster.idle():
-        now = time.perf_counter() - t0
-        while nxt < len(order) and arrivals[order[nxt]] <= now:
-            i = order[nxt]
-            rcbs[i] = creator.process(requests[i])
-            cluster.add_request(rcbs[i])
-            rcbs[i].metric.arrival_time = t0 + arrivals[i]
-            nxt += 1
-        if cluster.step() == 0 and nxt < len(order):
-            time.sleep(max(0.0, min(0.001, arrivals[order[nxt]] - (time.perf_counter() - t0))))
-        steps += 1
-    torch.cuda.synchronize(device)
-    wall = time.perf_counter() - t0
+    with quiet_gc():
+        t0 = time.perf_counter()
+        nxt, steps = 0, 0
+        while nxt < len(order) or not cluster.idle():
+            now = time.perf_counter() - t0
+            while nxt < len(order) and arrivals[order[nxt]] <= now:
+                i = order[nxt]
+                rcbs[i] = creator.process(requests[i])
+                cluster.add_request(rcbs[i])
+                rcbs[i].metric.arrival_time = t0 + arrivals[i]
+                nxt += 1
+            if cluster.step() == 0 and nxt < len(order):
+                time.sleep(max(0.0, min(0.001, arrivals[order[nxt]] - (time.perf_counter() - t0))))
+            steps += 1
+        torch.cuda.synchronize(device)
+        wall = time.perf_counter() - t0
     ttft = sorted(r.metric.token_times[0] - r.metric.arrival_time for r in rcbs)
     tpot = sorted((r.metric.token_times[-1] - r.metric.token_times[0]) / max(1, len(r.metric.token_times) - 1)
                   for r in rcbs)
