@@ -24,7 +24,7 @@ _DTYPE_NAMES = {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "f
 def build_node(name: str, node_type: str, language_model, vision_model, lm_shape, dtype: torch.dtype,
                device: torch.device, kv_blocks: int, image_blocks: int, n_image_tokens: int,
                sched: BatchSchedulerConfig, rank: int = 0, graph_decode: bool = True,
-               max_blocks_per_seq: int = 256, world_size: int = 1) -> EPDNode:
+               max_blocks_per_seq: int = 256, world_size: int = 1, eager_migrate: bool = True) -> EPDNode:
     nt = NodeType(node_type)
     # one node of MI355Xs: every rank is a same-host peer, so pulls take the IPC path
     ctx = TokenCacheBlockManagerContext(rank=rank, rank2host={r: "localhost" for r in range(max(world_size, rank + 1))})
@@ -50,7 +50,7 @@ def build_node(name: str, node_type: str, language_model, vision_model, lm_shape
     emb = BatchImageEmbedExecutor(vision_model, img, lm_shape.num_attention_heads, lm_shape.head_dim, dtype,
                                   device) if nt.has_vision_model else None
     scheduler = BatchScheduler(sched, BatchSchedulerContext(kv, img))
-    return EPDNode(name, nt, scheduler, InstructionExecutor(fill, emb), kv, img)
+    return EPDNode(name, nt, scheduler, InstructionExecutor(fill, emb), kv, img, eager_migrate=eager_migrate)
 
 
 def synthetic_requests(n: int, n_text: int, max_tokens: int, image_token_id: int, pixels: Optional[torch.Tensor],

@@ -101,7 +101,7 @@ class LogitsTap:
 
 
 def make_node(name, node_type, lm, vision, kv, img, lm_shape, dtype, device, sched_cfg: BatchSchedulerConfig,
-              batch_log=None, graph_decode=False):
+              batch_log=None, graph_decode=False, eager_migrate=False):
     nt = NodeType(node_type)
     decoder = None
     if graph_decode and nt.enable_decode:
@@ -121,7 +121,7 @@ def make_node(name, node_type, lm, vision, kv, img, lm_shape, dtype, device, sch
     sched = BatchScheduler(sched_cfg, BatchSchedulerContext(kv if nt.has_kv_cache else None,
                                                             img if nt.has_image_cache else None))
     return EPDNode(name, nt, sched, InstructionExecutor(fill, emb), kv if nt.has_kv_cache else None,
-                   img if nt.has_image_cache else None)
+                   img if nt.has_image_cache else None, eager_migrate=eager_migrate)
 
 
 def run_trace(cluster: LocalCluster, creator: InstructionCreator, requests, max_steps=4000):

@@ -118,6 +118,7 @@ def test_engine_fuzz_closed_form(seed):
                                chunked_prefill=rng.random() < 0.7, token_budgets=rng.choice([24, 40, 64, 200]),
                                image_budgets=rng.choice([1, 2, 4]))
     lookahead = rng.random() < 0.5
+    eager_migrate = rng.random() < 0.5
     n_req = rng.randint(4, 14)
     g = torch.Generator().manual_seed(seed)
     reqs, arrivals = [], []
@@ -144,7 +145,7 @@ def test_engine_fuzz_closed_form(seed):
         kv = CpuPoolManager(1, 2, worst * (2 * max_running + 2), BS, 1, 8, seed=k)
         img = CpuPoolManager(1, 1, 2 * max_running + 2, N_IMG, 1, 8, seed=100 + k)
         node = make_node(f"{t}{k}", t, LM(), Vision(), kv, img, LM.language_model.shape, torch.float32,
-                         torch.device("cpu"), BatchSchedulerConfig(**vars(cfg)))
+                         torch.device("cpu"), BatchSchedulerConfig(**vars(cfg)), eager_migrate=eager_migrate)
         if lookahead and node.executor.fill_executor is not None and node.node_type.enable_decode:
             node.executor.fill_executor.graph_decoder = FakeGraphDecoder()
         nodes.append(node)
