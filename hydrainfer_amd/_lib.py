@@ -106,6 +106,11 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = argtypes
         if handle.hx_abi_version() != 1:
             raise HydraHipError("libhydra_hip.so ABI version mismatch")
+        # A/B runs of whole programs: HX_DEBUG_OPTIONS="decode_small=0,fwd_row_blocks=1"
+        for item in filter(None, os.environ.get("HX_DEBUG_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            if handle.hx_debug_set_option(name.strip().encode(), int(value)) != 0:
+                raise HydraHipError(f"HX_DEBUG_OPTIONS: unknown option {name!r}")
         _lib = handle
     return _lib
 

@@ -401,15 +401,22 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const AttnParams
       T::from_float(r);
 }
 
+// (sequence, head) pair counts for which one 8-wave workgroup per pair replaces key splits + combine
+int g_decode_small_lo = 160, g_decode_small_hi = 576;
 int g_decode_waves = 4;  // tuning knobs (hx_debug_set_option)
 int g_decode_nt = 1;   // K/V are read once: non-temporal loads measured +4 % (profiles/r1_attn_decode_variants.txt)
 
 template <typename T, int D>
 int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
   dim3 grid(p.n_heads, batch, p.n_splits);
+  // 160..576 (sequence, head) pairs and no key split: 8 waves per workgroup share the keys
+  // (see decode_pick_splits)
+  const int64_t pairs = (int64_t)batch * p.n_heads;
+  const bool wide = pairs >= g_decode_small_lo && pairs <= g_decode_small_hi && p.n_splits == 1;
   if (p.k_new || p.qkv_partial) {
-    attn_decode_kernel<T, D, 4, true, true><<<grid, 256, 0, stream>>>(p);
-  } else if (g_decode_waves == 8) {
+    if (wide) attn_decode_kernel<T, D, 8, true, true><<<grid, 512, 0, stream>>>(p);
+    else attn_decode_kernel<T, D, 4, true, true><<<grid, 256, 0, stream>>>(p);
+  } else if (g_decode_waves == 8 || wide) {
     if (g_decode_nt) attn_decode_kernel<T, D, 8, true, false><<<grid, 512, 0, stream>>>(p);
     else attn_decode_kernel<T, D, 8, false, false><<<grid, 512, 0, stream>>>(p);
   } else {
@@ -432,6 +439,8 @@ namespace hx {
 int decode_set_option(const char* name, int value) {
   if (!strcmp(name, "decode_waves")) { g_decode_waves = (value == 8) ? 8 : 4; return HX_OK; }
   if (!strcmp(name, "decode_nt")) { g_decode_nt = value ? 1 : 0; return HX_OK; }
+  if (!strcmp(name, "decode_small_lo")) { g_decode_small_lo = value; return HX_OK; }
+  if (!strcmp(name, "decode_small_hi")) { g_decode_small_hi = value; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 
@@ -458,6 +467,10 @@ int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested) 
   const int64_t base = (int64_t)batch * n_heads;
   if (base >= 768) return 1;
   const int n_tiles = (max_seqlen_k + 15) / 16;
+  // mid-size batches, context <= 2048 keys: one 8-wave workgroup per (sequence, head) and no
+  // combine launch.  Measured in the 7B decode graph (bench.py --batch N, whole step): batch 6 / 8 /
+  // 12 / 16: -2.5 / -2.0 / -3.4 / -1.9 %; batch <= 4 or >= 20: the split (resp. 4-wave) form wins
+  if (base >= g_decode_small_lo && base <= g_decode_small_hi && n_tiles <= 128) return 1;
   int64_t want = (1024 + base - 1) / base;       // ~4 workgroups per CU
   int64_t cap = n_tiles / 16;                    // >= 16 tiles (4 per wave) per split
   if (cap < 1) cap = 1;

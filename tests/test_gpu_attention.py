@@ -232,7 +232,7 @@ def test_argument_errors_raise():
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("heads", [(8, 8), (8, 2)])
+@pytest.mark.parametrize("heads", [(8, 8), (8, 2), (32, 32)])    # (32, 32) x 8 sequences: the 8-wave no-split form
 @pytest.mark.parametrize("D", [64, 128, 256])
 def test_fused_rope_cache_decode_attention_is_bit_identical(dt, heads, D):
     """decode_attention_fused == apply_rotary_pos_emb + set_kv_cache + mha_varlen_fwd: same
