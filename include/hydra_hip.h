@@ -48,7 +48,9 @@ const char* hx_strerror(int status);
 int hx_last_hip_error(void);
 /* Tuning knobs for A/B measurements in one process (not part of the reference surface):
  * "decode_waves" = 4|8 waves per decode-attention workgroup, "decode_nt" = 0|1 non-temporal
- * K/V loads, "fwd_row_blocks" = 0(auto)|1|2 query row blocks per wave in the prefill kernel,
+ * K/V loads, "decode_small_lo" / "decode_small_hi" = range of (sequence, head) pair counts served
+ * by the 8-wave no-split form, "fwd_row_blocks" = 0(auto)|1|2 query row blocks per wave in the
+ * prefill kernel,
  * "gemm_rows_per_wave" / "gemm_waves" / "gemm_slab_nt" for the decode GEMM — results are
  * identical for every setting of these.  "decode_gqa" = 0|1 selects the per-query-head or the
  * grouped-query decode kernel for n_heads > n_kv_heads (both within the stated tolerance; the
