@@ -226,13 +226,15 @@ def replay_distributed(engine: RankEngine, creator, requests, arrivals: List[flo
     mine = sorted((i for i, r in enumerate(requests)
                    if entry_rank(i, engine.roles, r.pixel_values is not None) == engine.rank),
                   key=lambda i: arrivals[i])
-    from hydrainfer_amd.engine.serve import quiet_gc
+    from hydrainfer_amd.engine.serve import ADMIT_PER_STEP, quiet_gc
     nxt, total = 0, len(requests)
     first_finished = len(engine.node.finished)
     with quiet_gc():
         while True:
             now = time.perf_counter() - t0
-            while nxt < len(mine) and arrivals[mine[nxt]] <= now:
+            admitted = 0
+            while nxt < len(mine) and arrivals[mine[nxt]] <= now and admitted < ADMIT_PER_STEP:
+                admitted += 1
                 i = mine[nxt]
                 rcb = creator.process(requests[i])
                 engine.node.add_request(rcb)
@@ -267,6 +269,7 @@ def summarize(per_request: Dict[int, dict], t0: float) -> dict:
     ms = lambda v: None if v is None else round(v * 1e3, 3)
     return {"requests": len(rs), "output_tokens": n_out, "wall_s": round(end - t0, 3),
             "output_tok_s": round(n_out / (end - t0), 1),
+            "ttft_mean_ms": ms(sum(ttft) / len(ttft)),
             "ttft_p50_ms": ms(pct(ttft, 0.5)), "ttft_p99_ms": ms(pct(ttft, 0.99)),
             "tpot_p50_ms": ms(pct(tpot, 0.5)), "tpot_p99_ms": ms(pct(tpot, 0.99)),
             "ep_pull_p50_ms": ms(pct(hop("ep_transfer"), 0.5)), "pd_pull_p50_ms": ms(pct(hop("pd_transfer"), 0.5))}

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--no-chunk", action="store_true")
     ap.add_argument("--priority", default="prefill")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--repeat", type=int, default=1, help="replay the trace this many times in one process")
     args = ap.parse_args()
 
     from hydrainfer_amd.engine.request_processor import InstructionCreator
@@ -75,6 +76,10 @@ def main():
     replay(cluster, creator, warm, [0.0, 0.0], dev)
     reqs = synthetic_requests(args.requests, args.n_text, args.max_tokens, 32000, pixels, seed=1)
     arrivals = poisson_arrivals(args.requests, args.rate, 0) if args.rate > 0 else [0.0] * args.requests
+    for rep in range(args.repeat - 1):
+        r0 = replay(cluster, creator, synthetic_requests(args.requests, args.n_text, args.max_tokens, 32000, pixels,
+                                                         seed=10 + rep), arrivals, dev)
+        print(json.dumps({k: r0[k] for k in ("wall_s", "output_tok_s", "ttft_p50_ms", "tpot_p50_ms")}), file=sys.stderr)
     res = replay(cluster, creator, reqs, arrivals, dev)
     res.update(model=args.model, topology=args.topology, rate=args.rate, max_running=args.max_running,
                token_budget=args.token_budget, chunked=not args.no_chunk, graph_decode=not args.no_graph)
