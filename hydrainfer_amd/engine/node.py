@@ -15,6 +15,7 @@ from hydrainfer_amd.engine.isa import (EmptyInstruction, EPMigrate, Fill, ImageE
                                        PullCache)
 from hydrainfer_amd.engine.rcb import BatchRequest, RequestControlBlock, ScenarioType
 from hydrainfer_amd.engine.scheduler import BatchScheduler
+from hydrainfer_amd.utils.profiler import profile
 
 
 class NodeType:
@@ -97,7 +98,8 @@ class EPDNode:
 
     # ---- one engine step (epdnode.py:238-337)
     def step(self) -> int:
-        batch = self.batch_scheduler.step()
+        with profile("schedule"):
+            batch = self.batch_scheduler.step()
         if len(batch) == 0:
             return 0
         fill, embed, empty, migrate, pull = (BatchRequest() for _ in range(5))
@@ -123,8 +125,10 @@ class EPDNode:
         for rcb, _ in embed:
             rcb.metric.encode_execute.append(now)
 
-        self.executor.execute_image_embed(embed)
-        self.executor.execute_fill(fill)
+        with profile("encode"):
+            self.executor.execute_image_embed(embed)
+        with profile("fill"):
+            self.executor.execute_fill(fill)
         self.executor.execute_empty(empty)
 
         now = time.perf_counter()
@@ -149,8 +153,9 @@ class EPDNode:
         # step() has returned (epdnode.py:286-297,345-347), i.e. AFTER the re-queue above: a request
         # that stays on this node re-enters `running` behind this step's other requests, and a
         # pulled request is already re-queued when its PullCache completes.  Same order here.
-        self._execute_batch_migrate(migrate)
-        self._execute_pull_cache(pull)
+        with profile("migrate+pull"):
+            self._execute_batch_migrate(migrate)
+            self._execute_pull_cache(pull)
         for m in (self.kv_cache_block_manager, self.image_cache_block_manager):
             if m is not None:
                 m.synchronize()
