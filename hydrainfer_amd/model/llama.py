@@ -73,8 +73,12 @@ class LlamaForCausalLM:
         # decode batches (<= 64 rows) stream the weights through the HIP kernel; larger
         # batches (prefill) use the library GEMM
         self.use_hip_gemm = True
-        # decode steps: RoPE + cache append + attention as one launch
-        self.fuse_decode_attention = shape.head_dim in (64, 128, 256)
+        # decode steps: RoPE + cache append + attention as one launch.  Grouped-query models take
+        # three launches instead (GEMM reduce, RoPE + append, attention): the fused kernel gives
+        # every query head its own workgroup, the unfused entry picks attn_decode_gqa.hip, which
+        # reads each KV head once (3x faster at group 4 and more than pays for the two launches)
+        self.fuse_decode_attention = (shape.head_dim in (64, 128, 256)
+                                      and shape.num_key_value_heads == shape.num_attention_heads)
 
     def linear(self, x: Tensor, w: Tensor) -> Tensor:
         if self.use_hip_gemm and x.shape[0] <= 64 and hip_gemm.supported(x, w):

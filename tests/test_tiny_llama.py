@@ -141,22 +141,26 @@ def test_hip_model_matches_reference(dname):
 
 
 @pytest.mark.gpu
-def test_7b_shaped_two_layer_model_matches_oracle():
+@pytest.mark.parametrize("dims", [(4096, 11008, 32, 32), (2048, 5632, 16, 4)], ids=["7b-mha", "gqa-16q-4kv"])
+def test_7b_shaped_two_layer_model_matches_oracle(dims):
     """BASELINE layer shapes (hidden 4096, 32 heads x 128, inter 11008, vocab 32064) with 2
     layers: prefill + 4 greedy decode steps on the HIP path (decode GEMMs on the weight-streaming
-    kernel, fused attention) against the CPU oracle model on the same weights."""
+    kernel, fused attention) against the CPU oracle model on the same weights; and a grouped-query
+    shape (16 query / 4 KV heads), whose decode steps run the grouped-query attention kernel."""
     from hydrainfer_amd.layer.causal_attention import AttentionParametersBuilder
     from hydrainfer_amd.memory.kv_cache import KVCache
     from hydrainfer_amd.model.llama import LanguageModelParameters, LlamaForCausalLM, LlamaShape
     from oracle.model import OracleAttnMeta, OracleLlama
     dt, dev = torch.float16, torch.device("cuda:0")
-    shape = LlamaShape(4096, 11008, 2, 32, 32, 128, 32064)
+    hidden, inter, H, HK = dims
+    shape = LlamaShape(hidden, inter, 2, H, HK, 128, 32064)
     model = LlamaForCausalLM.random_init(shape, dt, dev, seed=3, std=0.02)
+    assert model.fuse_decode_attention == (H == HK)
     sd = model.to_reference_state_dict()
     oracle = OracleLlama(shape, sd, dt)
     bs, n_blocks = 16, 16
     gen = torch.Generator().manual_seed(5)
-    pool = torch.randn((2, 2, n_blocks, bs, 32, 128), generator=gen).to(dt)
+    pool = torch.randn((2, 2, n_blocks, bs, HK, 128), generator=gen).to(dt)
     pool_d = pool.to(dev)
     prompts = [torch.randint(0, 32000, (50,), generator=gen).tolist(), torch.randint(0, 32000, (33,), generator=gen).tolist()]
     tables = [[15, 14, 13, 12], [11, 10, 9]]
@@ -166,7 +170,7 @@ def test_7b_shaped_two_layer_model_matches_oracle():
     n_checked = 0
     for step in range(5):
         ids, pos, sel, slots, bt, cu_q, cu_k, cu_b = [], [], [], [], [], [0], [0], [0]
-        b = AttentionParametersBuilder(32, 32, 128, bs, dev)
+        b = AttentionParametersBuilder(H, HK, 128, bs, dev)
         for r, x in enumerate(new):
             sl = [tables[r][p // bs] * bs + p % bs for p in range(lens[r], lens[r] + len(x))]
             pos += list(range(lens[r], lens[r] + len(x)))
