@@ -35,6 +35,14 @@ __device__ __forceinline__ u16x4 lds_tr_read(const char* lds_ptr) {
 // lane group has not seen any unmasked key yet (no NaN from inf - inf).
 #define HX_NEG_BIG (-1.0e30f)
 
+// key index -> (page slot in the block table, row inside the page)
+__device__ __forceinline__ int page_slot(int key, int block_size, int block_shift) {
+  return block_shift >= 0 ? key >> block_shift : key / block_size;
+}
+__device__ __forceinline__ int page_row(int key, int block_size, int block_shift) {
+  return block_shift >= 0 ? key & (block_size - 1) : key % block_size;
+}
+
 struct AttnParams {
   void* out;
   const void* q;
@@ -49,6 +57,8 @@ struct AttnParams {
   int64_t v_block_stride, v_row_stride, v_head_stride;
   int32_t n_heads, group;   // group = n_heads / n_kv_heads
   int32_t block_size;       // paged: tokens per page (multiple of 16)
+  int32_t block_shift;      // log2(block_size) when it is a power of two, else -1 (runtime integer
+                            // division costs ~30 VALU instructions; the kernels do two per key row)
   int32_t causal;
   float scale_log2;         // softmax_scale * log2(e)
   int32_t n_splits;

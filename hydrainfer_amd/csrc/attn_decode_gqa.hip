@@ -65,13 +65,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const AttnPara
   int page_next[NL];
   auto lookup_pages = [&](int t) {
 #pragma unroll
-    for (int j = 0; j < NL; ++j) page_next[j] = bt[min(t * 32 + j * RPI + lrow, kv_len - 1) / p.block_size];
+    for (int j = 0; j < NL; ++j)
+      page_next[j] = bt[page_slot(min(t * 32 + j * RPI + lrow, kv_len - 1), p.block_size, p.block_shift)];
   };
   u16x8 kreg[NL], vreg[NL];
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      const int row = min(t * 32 + j * RPI + lrow, kv_len - 1) % p.block_size;
+      const int row = page_row(min(t * 32 + j * RPI + lrow, kv_len - 1), p.block_size, p.block_shift);
       kreg[j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(
           kbase + (int64_t)page_next[j] * p.k_block_stride + (int64_t)row * p.k_row_stride + 8 * lchunk));
       vreg[j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(

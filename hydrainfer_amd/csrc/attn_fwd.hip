@@ -29,16 +29,18 @@ namespace {
 
 using namespace hx;
 
-template <typename T, int D, bool PAGED, int QR>
+template <typename T, int D, bool PAGED, int QR, int KU>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   constexpr int NS = D / 32;       // QK k-steps
   constexpr int NDB = D / 16;      // 16-dim output blocks
   constexpr int RS = 2 * D + 32;   // LDS row stride in bytes (K and V images)
   constexpr int LPR = D / 8;       // 16-byte chunks per key row
-  constexpr int TILE_CHUNKS = 32 * LPR;
+  constexpr int KT = 32 * KU;      // keys per tile (KU = 2: half the barriers and softmax passes, and
+                                   // four independent score sub-tiles per wave to hide MFMA / exp latency)
+  constexpr int TILE_CHUNKS = KT * LPR;
   constexpr int NL = (TILE_CHUNKS + 255) / 256;   // chunks per thread per tile
-  constexpr int TILE_BYTES = 32 * RS;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2][32][RS] | V[2][32][RS]
+  constexpr int TILE_BYTES = KT * RS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2][KT][RS] | V[2][KT][RS]
 
   // causal tiles get longer with the row index: launch the long ones first
   const int mblk = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int last_key_wave = p.causal ? min(kv_len - 1, q_row0 + WROWS - 1 + shift) : kv_len - 1;
   const int last_key_wg =
       p.causal ? min(kv_len - 1, min(q_row0_wg + 4 * WROWS - 1, q_len - 1) + shift) : kv_len - 1;
-  const int n_tiles = (last_key_wg >= 0) ? (last_key_wg >> 5) + 1 : 0;   // workgroup-uniform
+  const int n_tiles = (last_key_wg >= 0) ? last_key_wg / KT + 1 : 0;   // workgroup-uniform
 
   // ---- cooperative tile staging: thread owns chunks idx = tid + 256*j of the [32][D] tile
   int my_row[NL], my_chunk[NL];
@@ -95,12 +97,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   // element offset of key row `key` given its page (paged) — the page id is looked up ONE TILE
   // AHEAD of the loads that need it, so a tile's loads are a single round trip, not two
   auto page_of = [&](int key) -> int {
-    return PAGED ? bt[min(key, kv_len - 1) / p.block_size] : 0;
+    return PAGED ? bt[page_slot(min(key, kv_len - 1), p.block_size, p.block_shift)] : 0;
   };
   auto key_offset = [&](int key, int page, bool is_v) -> int64_t {
     key = min(key, kv_len - 1);
     if (PAGED) {
-      const int row = key % p.block_size;
+      const int row = page_row(key, p.block_size, p.block_shift);
       return is_v ? (int64_t)page * p.v_block_stride + (int64_t)row * p.v_row_stride
                   : (int64_t)page * p.k_block_stride + (int64_t)row * p.k_row_stride;
     }
@@ -110,13 +112,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   int page_next[NL];      // pages of the tile that will be loaded next
   auto lookup_pages = [&](int t) {
 #pragma unroll
-    for (int j = 0; j < NL; ++j) page_next[j] = page_of(t * 32 + my_row[j]);
+    for (int j = 0; j < NL; ++j) page_next[j] = page_of(t * KT + my_row[j]);
   };
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       if (TILE_CHUNKS % 256 == 0 || threadIdx.x + 256 * j < TILE_CHUNKS) {
-        const int key = t * 32 + my_row[j];
+        const int key = t * KT + my_row[j];
         kreg[j] = *reinterpret_cast<const u16x8*>(kbase + key_offset(key, page_next[j], false) + 8 * my_chunk[j]);
         vreg[j] = *reinterpret_cast<const u16x8*>(vbase + key_offset(key, page_next[j], true) + 8 * my_chunk[j]);
       }
@@ -159,14 +161,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       lookup_pages(t + 2);                       // (clamped to the last key) for the next iteration
     }
 
-    if (t * 32 <= last_key_wave) {               // wave-uniform: tiles past this wave's diagonal
+    if (t * KT <= last_key_wave) {               // wave-uniform: tiles past this wave's diagonal
       const char* kt = kbuf + cur * TILE_BYTES;
       const char* vt = vbuf + cur * TILE_BYTES;
-      // ---- S^T = K . Q^T for the two 16-key sub-tiles (A fragments from the shared K image,
+      // ---- S^T = K . Q^T for the 2 KU 16-key sub-tiles (A fragments from the shared K image,
       //      each used for the QR row blocks of this wave)
-      f32x4 s[QR][2];
+      f32x4 s[QR][2 * KU];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < 2 * KU; ++u) {
 #pragma unroll
         for (int rb = 0; rb < QR; ++rb) s[rb][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -176,33 +178,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
           for (int rb = 0; rb < QR; ++rb) s[rb][u] = Mfma<T>::mma(kf, qf[rb][st], s[rb][u]);
         }
       }
-      // ---- mask + online softmax (per query column c; state replicated over g)
-      u16x8 pf[QR];
+      // ---- mask + online softmax (per query column c; state replicated over g).  The scale is
+      //      folded into the exponent's fma; tiles that no row of this wave masks skip the compares
+      //      (wave-uniform) — the inner loop is VALU-bound (PMC: ~15 vector instructions per MFMA).
+      const bool interior = t * KT + KT - 1 <= min(kv_len - 1, p.causal ? q_row0 + shift : kv_len - 1);
+      u16x8 pf[QR][KU];
 #pragma unroll
       for (int rb = 0; rb < QR; ++rb) {
-        float x[8];
         float mx = HX_NEG_BIG;
+        if (interior) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+          for (int u = 0; u < 2 * KU; ++u)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int key = t * 32 + u * 16 + 4 * g + i;
-            const float v = (key <= limit_c[rb]) ? s[rb][u][i] * p.scale_log2 : -INFINITY;
-            x[u * 4 + i] = v;
-            mx = fmaxf(mx, v);
-          }
+            for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[rb][u][i]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 2 * KU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int key = t * KT + u * 16 + 4 * g + i;
+              if (key > limit_c[rb]) s[rb][u][i] = -INFINITY;
+              mx = fmaxf(mx, s[rb][u][i]);
+            }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m[rb], mx);
+        const float m_new = fmaxf(m[rb], mx * p.scale_log2);
         const float alpha = fast_exp2(m[rb] - m_new);
         m[rb] = m_new;
         float ps = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float e = fast_exp2(x[j] - m_new);
-          ps += e;
-          pf[rb][j] = T::from_float(e);
-        }
+        for (int hf = 0; hf < KU; ++hf)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float e = fast_exp2(fmaf(s[rb][2 * hf + (j >> 2)][j & 3], p.scale_log2, -m_new));
+            ps += e;
+            pf[rb][hf][j] = T::from_float(e);
+          }
         l[rb] = l[rb] * alpha + ps;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {   // wave-uniform: some row's maximum moved
 #pragma unroll
@@ -210,16 +222,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         }
       }
       // ---- O^T += V^T . P^T (V^T fragments by transposed LDS reads of the shared V image)
-      const char* vrd = vt + (4 * g + q4) * RS + p4 * 8;
 #pragma unroll
-      for (int db = 0; db < NDB; ++db) {
-        const u16x4 lo = lds_tr_read(vrd + db * 32);
-        const u16x4 hi = lds_tr_read(vrd + 16 * RS + db * 32);
-        u16x8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+      for (int hf = 0; hf < KU; ++hf) {
+        const char* vrd = vt + (32 * hf + 4 * g + q4) * RS + p4 * 8;
 #pragma unroll
-        for (int rb = 0; rb < QR; ++rb) acc[rb][db] = Mfma<T>::mma(vf, pf[rb], acc[rb][db]);
+        for (int db = 0; db < NDB; ++db) {
+          const u16x4 lo = lds_tr_read(vrd + db * 32);
+          const u16x4 hi = lds_tr_read(vrd + 16 * RS + db * 32);
+          u16x8 vf;
+          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+          vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+#pragma unroll
+          for (int rb = 0; rb < QR; ++rb) acc[rb][db] = Mfma<T>::mma(vf, pf[rb][hf], acc[rb][db]);
+        }
       }
     }
     if (t + 1 < n_tiles) store_tile(cur ^ 1);
@@ -248,25 +263,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
-template <typename T, int D, bool PAGED, int QR>
+template <typename T, int D, bool PAGED, int QR, int KU>
 int launch_fwd_cfg(const AttnParams& p, int batch, int max_seqlen_q, hipStream_t stream) {
   constexpr int RS = 2 * D + 32;
-  const size_t lds = 4 * 32 * RS;   // K[2][32][RS] + V[2][32][RS]
+  const size_t lds = 4 * 32 * KU * RS;   // K[2][KT][RS] + V[2][KT][RS]
   dim3 grid((max_seqlen_q + 64 * QR - 1) / (64 * QR), p.n_heads, batch);
   if (grid.x == 0) return HX_OK;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, PAGED, QR>,
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, PAGED, QR, KU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  attn_fwd_kernel<T, D, PAGED, QR><<<grid, 256, lds, stream>>>(p);
+  attn_fwd_kernel<T, D, PAGED, QR, KU><<<grid, 256, lds, stream>>>(p);
   return check_launch();
 }
 
 int g_fwd_rows = 0;   // tuning: 0 = automatic, 1 / 2 = row blocks per wave
+int g_fwd_keys = 0;   // tuning: 0 = automatic, 1 / 2 = 32-key units per tile
 
-template <typename T, int D>
-int launch_fwd(const AttnParams& p, int batch, int max_seqlen_q, bool paged, hipStream_t stream) {
+template <typename T, int D, bool PAGED>
+int launch_fwd_paged(const AttnParams& p, int batch, int max_seqlen_q, hipStream_t stream) {
   // two row blocks per wave for long query runs (measured on MI355X, tools/bench_attn_prefill.py:
   // 2048 new tokens 177 -> 141 us; at 704 tokens and for the 577-token CLIP tower one row block
   // is faster — those launches are short of workgroups, not of LDS bandwidth).  D = 256 keeps
@@ -274,12 +290,24 @@ int launch_fwd(const AttnParams& p, int batch, int max_seqlen_q, bool paged, hip
   bool two = D <= 128 && max_seqlen_q >= 1024;
   if (g_fwd_rows == 1) two = false;
   if (g_fwd_rows == 2 && D <= 128) two = true;
+  // 64-key tiles for paged prompts that are not long enough for two row blocks (measured:
+  // 1 x 704 tokens 36 -> 31 us, 4 x 704 75 -> 74, 3 x 683 61 -> 60; with two row blocks, and for the
+  // dense 8-image CLIP batch, 32-key tiles stay ahead)
+  bool wide = PAGED && D <= 128 && max_seqlen_q > 64 && !two;
+  if (g_fwd_keys == 1) wide = false;
+  if (g_fwd_keys == 2 && D <= 128) wide = true;
   if constexpr (D <= 128) {
-    if (two) return paged ? launch_fwd_cfg<T, D, true, 2>(p, batch, max_seqlen_q, stream)
-                          : launch_fwd_cfg<T, D, false, 2>(p, batch, max_seqlen_q, stream);
+    if (two && wide) return launch_fwd_cfg<T, D, PAGED, 2, 2>(p, batch, max_seqlen_q, stream);
+    if (two) return launch_fwd_cfg<T, D, PAGED, 2, 1>(p, batch, max_seqlen_q, stream);
+    if (wide) return launch_fwd_cfg<T, D, PAGED, 1, 2>(p, batch, max_seqlen_q, stream);
   }
-  return paged ? launch_fwd_cfg<T, D, true, 1>(p, batch, max_seqlen_q, stream)
-               : launch_fwd_cfg<T, D, false, 1>(p, batch, max_seqlen_q, stream);
+  return launch_fwd_cfg<T, D, PAGED, 1, 1>(p, batch, max_seqlen_q, stream);
+}
+
+template <typename T, int D>
+int launch_fwd(const AttnParams& p, int batch, int max_seqlen_q, bool paged, hipStream_t stream) {
+  return paged ? launch_fwd_paged<T, D, true>(p, batch, max_seqlen_q, stream)
+               : launch_fwd_paged<T, D, false>(p, batch, max_seqlen_q, stream);
 }
 
 }  // namespace
@@ -288,6 +316,7 @@ namespace hx {
 
 int fwd_set_option(const char* name, int value) {
   if (!strcmp(name, "fwd_row_blocks")) { g_fwd_rows = value; return HX_OK; }
+  if (!strcmp(name, "fwd_key_units")) { g_fwd_keys = value; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 

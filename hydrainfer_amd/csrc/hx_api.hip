@@ -170,6 +170,7 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.n_heads = a->n_heads;
   p.group = a->n_heads / a->n_kv_heads;
   p.block_size = a->block_table ? a->block_size : 16;
+  p.block_shift = (p.block_size & (p.block_size - 1)) == 0 ? __builtin_ctz((unsigned)p.block_size) : -1;
   p.causal = a->causal;
   p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
   p.n_splits = 1;

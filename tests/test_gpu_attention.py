@@ -359,8 +359,9 @@ def test_zero_token_calls_are_noops():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("keys", [1, 2])
 @pytest.mark.parametrize("rows", [1, 2])
-def test_prefill_row_block_variants_vs_oracle(rows):
+def test_prefill_row_block_variants_vs_oracle(rows, keys):
     """Both tilings of the prefill kernel (one / two 16-row blocks per wave; the second is what runs
     automatically for query runs >= 1024 tokens) on ragged paged causal, chunked and dense inputs,
     and bit-identical to each other on a long run."""
@@ -370,6 +371,7 @@ def test_prefill_row_block_variants_vs_oracle(rows):
     lib = _lib.lib()
     try:
         _lib.check(lib.hx_debug_set_option(b"fwd_row_blocks", rows), "option")
+        _lib.check(lib.hx_debug_set_option(b"fwd_key_units", keys), "option")
         for dt in (torch.float16, torch.bfloat16):
             atol, rtol = ATTN_TOL[dt]
             q_lens, kv_lens = [1, 129, 64, 200, 31, 128], [77, 129, 300, 200, 31, 1000]
@@ -390,6 +392,7 @@ def test_prefill_row_block_variants_vs_oracle(rows):
                            what=f"rows={rows} dense {dt}")
     finally:
         lib.hx_debug_set_option(b"fwd_row_blocks", 0)
+        lib.hx_debug_set_option(b"fwd_key_units", 0)
 
 
 @pytest.mark.gpu
@@ -402,13 +405,19 @@ def test_prefill_long_run_takes_two_row_blocks_and_matches():
     q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(2, 4, 4, 128, kv_lens, q_lens, dt, seed=9)
     auto = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))      # automatic: two row blocks
     try:
+        lib.hx_debug_set_option(b"fwd_key_units", 1)            # same key tiling: same arithmetic per row
         lib.hx_debug_set_option(b"fwd_row_blocks", 1)
         one = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
         lib.hx_debug_set_option(b"fwd_row_blocks", 2)
         two = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
+        lib.hx_debug_set_option(b"fwd_key_units", 2)            # 64-key tiles rescale at other points
+        wide = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
     finally:
         lib.hx_debug_set_option(b"fwd_row_blocks", 0)
-    assert torch.equal(auto, two) and torch.equal(one, two)      # same per-row arithmetic, other tiling
+        lib.hx_debug_set_option(b"fwd_key_units", 0)
+    assert torch.equal(auto, two) and torch.equal(one, two)      # same per-row arithmetic, other row tiling
+    atol, rtol = ATTN_TOL[dt]
+    assert_close_t(wide, two.cpu(), atol, rtol, what="64-key vs 32-key tiles")
     sel = torch.cat([torch.arange(0, 1100, 37), torch.arange(1100, 2130, 41)])
     ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b)
     atol, rtol = ATTN_TOL[dt]

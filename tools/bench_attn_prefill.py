@@ -55,8 +55,11 @@ cases = {"prefill 4x704": paged(4, 704, 704), "prefill 1x704": paged(1, 704, 704
 for name, (fn, flops) in cases.items():
     row = []
     for rows in (1, 2):
-        _lib.check(_lib.lib().hx_debug_set_option(b"fwd_row_blocks", rows), "opt")
-        us = timeit(fn)
-        row.append(f"rows={rows}: {us:7.1f} us {flops / us / 1e6:6.1f} TF/s")
-    print(f"{name:24s}", " | ".join(row))
+        for keys in (1, 2):
+            _lib.check(_lib.lib().hx_debug_set_option(b"fwd_row_blocks", rows), "opt")
+            _lib.check(_lib.lib().hx_debug_set_option(b"fwd_key_units", keys), "opt")
+            us = timeit(fn)
+            row.append(f"r{rows}k{keys}: {us:6.1f}us {flops / us / 1e6:5.0f}TF")
+    print(f"{name:22s}", " | ".join(row))
 _lib.lib().hx_debug_set_option(b"fwd_row_blocks", 0)
+_lib.lib().hx_debug_set_option(b"fwd_key_units", 0)
