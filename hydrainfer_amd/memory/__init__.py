@@ -1,5 +1,5 @@
 from .block_allocator import BlockAllocator, BlockAllocatorMetrics
-from .shared_cache import SharedBlock, SharedCache, SharedCacheConfig, compute_block_hash, compute_hash
+from .shared_cache import SharedBlock, SharedCache, SharedCacheConfig, compute_block_hash, compute_hash, compute_image_hash
 
 
 def __getattr__(name):

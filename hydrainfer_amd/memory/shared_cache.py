@@ -81,3 +81,15 @@ def compute_hash(token_ids: List[int], block_size: int, prefix: int) -> List[int
         h = compute_block_hash(token_ids[i * block_size: (i + 1) * block_size], prefix=h)
         hashes.append(h)
     return hashes
+
+
+def compute_image_hash(image) -> int:
+    """xxh64 over the RGB bytes of the image (shared_cache.py:91-97 of the reference); accepts a
+    PIL image or an H x W x 3 uint8 array."""
+    if hasattr(image, "mode"):                      # PIL.Image
+        if image.mode != "RGB":
+            image = image.convert("RGB")
+        image = np.array(image)
+    h = xxhash.xxh64()
+    h.update(np.ascontiguousarray(image).tobytes())
+    return h.intdigest()

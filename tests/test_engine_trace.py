@@ -8,12 +8,12 @@ from types import SimpleNamespace as NS
 import numpy as np
 import pytest
 import torch
-import xxhash
 
 from hydrainfer_amd.engine import (BatchScheduler, BatchSchedulerConfig, BatchSchedulerContext, Fill,
                                    InstructionCreator, SamplingParameters, TokenRequest)
 from hydrainfer_amd.engine.executor import BatchFillExecutor, BatchImageEmbedExecutor, InstructionExecutor
 from hydrainfer_amd.engine.node import EPDNode, LocalCluster, NodeType
+from hydrainfer_amd.memory import compute_image_hash
 from tests.engine_util import CpuPoolManager
 from tests.golden import cases as C
 
@@ -106,7 +106,7 @@ def test_engine_trace_matches_reference(cfg):
             pixels, image_hash = None, 0
             if r.image_seed >= 0:
                 pixels = torch.full((1, 3, 2, 2), float(i))
-                image_hash = xxhash.xxh64(C.engine_trace_image(r.image_seed).tobytes()).intdigest()  # shared_cache.py:91-97
+                image_hash = compute_image_hash(C.engine_trace_image(r.image_seed))   # pinned by G11's prefix hashes
             rcb = creator.process(TokenRequest(i, r.token_ids, pixels, (8, 8), image_hash,
                                                SamplingParameters(max_tokens=r.max_tokens)))
             first = rcb.instructions.head.next
