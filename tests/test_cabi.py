@@ -63,3 +63,28 @@ def test_cpu_tensors_are_refused_not_emulated():
     x = torch.randn(2, 8)
     with pytest.raises(_lib.HydraHipError):
         rms_norm(torch.empty_like(x), x, torch.ones(8), 1e-5)
+
+
+def test_op_modules_match_the_reference_stubs():
+    """Module paths, function names and positional parameter lists of hydrainfer._C.* as the
+    reference's own .pyi stubs declare them (tests/golden/op_signatures.json, extracted by
+    tests/golden/generate_stub_signatures.py).  flash_infer is the one package deliberately absent
+    (north_star: the flashinfer path is removed)."""
+    import importlib
+    import inspect
+    import json
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "op_signatures.json")))
+    missing = []
+    for module, fns in want.items():
+        if module.endswith("flash_infer"):
+            continue
+        mod = importlib.import_module(f"hydrainfer_amd.{module}")
+        for name, params in fns.items():
+            fn = getattr(mod, name, None)
+            if fn is None:
+                missing.append(f"{module}.{name}")
+                continue
+            got = [p.name for p in inspect.signature(fn).parameters.values()
+                   if p.default is inspect.Parameter.empty and p.kind == p.POSITIONAL_OR_KEYWORD]
+            assert len(got) == len(params), f"{module}.{name}: {got} vs reference {params}"
+    assert not missing, missing
