@@ -189,7 +189,9 @@ class RankEngine:
             rcb = rcb_from_wire(payload)
             self.node.migrate(self.peers[src_rank], rcb)
         elif kind == "free":
-            self.node.free_migrate_request(self.held.pop(payload))
+            rcb = self.held.pop(payload)
+            self.node.free_migrate_request(rcb)
+            rcb.release_instructions()          # this process's copy is dead (the receiver rebuilt its own)
         else:
             raise RuntimeError(kind)
 

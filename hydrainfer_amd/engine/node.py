@@ -146,6 +146,7 @@ class EPDNode:
                     self.executor.resolve_pending()
                     rcb.metric.finished_time = now
                     self._free_cache(rcb)
+                    rcb.release_instructions()
                     self.finished.append(rcb)
                 else:
                     self.batch_scheduler.schedule_running(rcb)

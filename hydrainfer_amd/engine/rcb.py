@@ -91,6 +91,21 @@ class RequestControlBlock:
             return True
         return bool(self.output_token_ids) and self.output_token_ids[-1] in self.sampling_params.eos_token_ids
 
+    def release_instructions(self) -> None:
+        """A finished request's chain is a doubly linked list — reference cycles that only the
+        cyclic collector can free, and serving loops run with it off (serve.quiet_gc).  Cut the
+        links so plain reference counting reclaims the instructions."""
+        if self.instructions is None:
+            return
+        node = self.instructions.head
+        while node is not None:
+            nxt = node.next
+            node.next = node.prev = None
+            if hasattr(node, "sample_dst"):
+                node.sample_dst = None
+            node = nxt
+        self.instructions.curr = None
+
     def register_output_token_processor(self, p: OutputTokenProcessor) -> None:
         self.output_token_processors.append(p)
 
