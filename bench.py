@@ -535,8 +535,15 @@ def main():
     vision = pixels = engine = None
     if not (args.skip_prefill or (args.no_ttft and args.no_serving and (world == 1 or args.no_disaggregated))):
         vision, pixels = make_vision(shape, dtype, dev)
+    engine_error = None
     if world > 1 and not args.no_disaggregated and vision is not None and not args.no_migration:
-        engine = build_rank_engine(ctx, model, vision, shape, dtype, dev, args.batch, prompt_len - 576, n_generate)
+        try:      # an optional leg must never cost the benchmark line
+            engine = build_rank_engine(ctx, model, vision, shape, dtype, dev, args.batch, prompt_len - 576, n_generate)
+        except Exception as e:
+            engine, engine_error = None, repr(e)[:300]
+        # every rank must agree on whether the leg runs (its collectives involve all of them)
+        if ctx.sum_over_ranks(0.0 if engine is not None else 1.0, dev) > 0:
+            engine = None
     if world > 1 and not args.no_migration:
         import threading
         box = {}
@@ -688,7 +695,7 @@ def main():
 
     if rank == 0:
         out["migration"] = migration
-        out["disaggregated"] = disagg
+        out["disaggregated"] = disagg if engine_error is None else {"error": engine_error}
         print(json.dumps(out), flush=True)
     if stuck:
         sys.stdout.flush()
