@@ -339,6 +339,7 @@ class EngineTraceRequest:
 ENGINE_TRACES = [
     EngineTraceConfig("A", "prefill", True, 48, 2, 5, 36, 8),
     EngineTraceConfig("B", "decode", False, 80, 1, 6, 31, 6),
+    EngineTraceConfig("C", "decode", True, 56, 1, 4, 40, 6),     # decode priority WITH chunked prefill
 ]
 
 
@@ -349,6 +350,12 @@ def engine_trace_requests(cfg: EngineTraceConfig) -> List[EngineTraceRequest]:
     def text(n):
         return torch.randint(1000, 31999, (n,), generator=g).tolist()
 
+    if cfg.tag == "C":   # image requests only (the reference's TextFill.chunk_prefill raises), staggered
+        lens = [25, 9, 31, 14, 22, 6, 28, 17, 11, 20]
+        arrive = [0, 0, 2, 2, 3, 8, 8, 9, 15, 15]
+        for i, (n, a) in enumerate(zip(lens, arrive)):
+            reqs.append(EngineTraceRequest(a, [1] + [cfg.image_token_id] + text(n), 900 + i, 2 + (i * 5) % 9))
+        return reqs
     if cfg.tag == "A":   # image requests only; 4, 9 and 12 repeat request 0 -> prefix-cache hits
         lens = [21, 7, 30, 12, 21, 5, 26, 18, 9, 21, 14, 28, 21, 11]
         arrive = [0, 0, 0, 1, 9, 9, 10, 14, 14, 22, 22, 23, 40, 40]

@@ -216,7 +216,7 @@ def test_decode_lookahead_is_invisible(cfg):
     plain, _ = _run_plain(cfg, None, None)
     dec = FakeGraphDecoder()
     ahead, n_times = _run_plain(cfg, None, dec)
-    assert ahead == plain and dec.n_launch_ahead > 10
+    assert ahead == plain and dec.n_launch_ahead >= 5
     assert n_times == [len(t) for t in plain]
     # pick an end-of-sequence id that really occurs mid-request
     eos = next(t[2] for t in plain if len(t) >= 6)
