@@ -206,7 +206,7 @@ def measure_serving(model, vision, pixels, shape, dtype, dev, batch, n_text, max
     from hydrainfer_amd.engine.node import LocalCluster
     from hydrainfer_amd.engine.request_processor import InstructionCreator
     from hydrainfer_amd.engine.scheduler import BatchSchedulerConfig
-    from hydrainfer_amd.engine.serve import build_node, replay, synthetic_requests
+    from hydrainfer_amd.engine.serve import build_node, replay, synthetic_requests, warm_library_gemms
     from hydrainfer_amd.model.llava import LlavaLanguageModel
     itid = image_token_id(shape.vocab_size)
     lm = LlavaLanguageModel(model, image_token_id=itid)
@@ -216,6 +216,7 @@ def measure_serving(model, vision, pixels, shape, dtype, dev, batch, n_text, max
     node = build_node("EPD0", "EPD", lm, vision, shape, dtype, dev, per_req * (batch + 2), batch + 2, 576, sched,
                       max_blocks_per_seq=per_req)
     node.executor.fill_executor.graph_decoder.warmup(list(range(4, batch + 1, 4)), kv_max=1024)
+    warm_library_gemms(lm, sched.token_budgets, batch, vision, pixels, sched.image_budgets)
     cluster = LocalCluster([node])
     creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16)
     text_hi = min(31999, itid - 1)

@@ -53,6 +53,30 @@ def build_node(name: str, node_type: str, language_model, vision_model, lm_shape
     return EPDNode(name, nt, scheduler, InstructionExecutor(fill, emb), kv, img, eager_migrate=eager_migrate)
 
 
+def warm_library_gemms(language_model, token_budget: int, max_decode_rows: int = 64, vision_model=None,
+                       pixel_values: Optional[torch.Tensor] = None, image_budget: int = 8) -> None:
+    """The prefill-side linears are library GEMMs, and the library picks (and lazily loads) a
+    different kernel for different row counts: the first step with a new batch shape can stall for
+    100-400 ms while a code object is loaded — seen as TTFT outliers in short serving runs.  Run
+    every projection shape once over the row counts a chunked-prefill step can have."""
+    model = language_model.language_model
+    st, dev, dt = model.state, model.device, model.dtype
+    rows = sorted(set(list(range(64, token_budget + 1, 64)) + [token_budget + r for r in (1, 8, max_decode_rows)]))
+    for name in ("l0.wqkv", "l0.wo", "l0.wgu", "l0.wdown"):
+        w = st[name]
+        x = torch.zeros((rows[-1], w.shape[1]), dtype=dt, device=dev)
+        for m in rows:
+            torch.matmul(x[:m], w.t())
+    x = torch.zeros((max_decode_rows, st["lm_head"].shape[1]), dtype=dt, device=dev)
+    for m in (1, 2, 4, 8, 16, 32, max_decode_rows):
+        torch.matmul(x[:m], st["lm_head"].t())
+    if vision_model is not None and pixel_values is not None:      # the tower for 1 .. image_budget images
+        px = pixel_values.to(device=dev, dtype=dt)
+        for n in range(1, image_budget + 1):
+            vision_model.forward(px.expand(n, -1, -1, -1))
+    torch.cuda.synchronize(dev)
+
+
 def synthetic_requests(n: int, n_text: int, max_tokens: int, image_token_id: int, pixels: Optional[torch.Tensor],
                        vocab_text: Tuple[int, int] = (1000, 31999), seed: int = 0) -> List[TokenRequest]:
     """The benchmark request of SURVEY.md §8(d): one image + n_text random text ids, distinct per request."""

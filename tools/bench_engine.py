@@ -34,7 +34,8 @@ def main():
     from hydrainfer_amd.engine.request_processor import InstructionCreator
     from hydrainfer_amd.engine.scheduler import BatchSchedulerConfig
     from hydrainfer_amd.engine.node import LocalCluster
-    from hydrainfer_amd.engine.serve import build_node, poisson_arrivals, replay, synthetic_requests
+    from hydrainfer_amd.engine.serve import (build_node, poisson_arrivals, replay, synthetic_requests,
+                                             warm_library_gemms)
     from hydrainfer_amd.model.clip import CLIP_VIT_L_14_336, ClipShape, LlavaVisionModel
     from hydrainfer_amd.model.llama import LLAVA_1_5_13B, LLAVA_1_5_7B, LlamaForCausalLM, LlamaShape
     from hydrainfer_amd.model.llava import LlavaLanguageModel
@@ -71,6 +72,7 @@ def main():
     cluster = LocalCluster(nodes)
     creator = InstructionCreator(image_token_id=32000, n_image_tokens_per_image=576, block_size=16)
 
+    warm_library_gemms(lm, args.token_budget, args.max_running, vision, pixels, args.image_budget)
     # warm-up: two short requests (kernel loading, allocator, workspace growth)
     warm = synthetic_requests(2, args.n_text, 4, 32000, pixels, seed=99)
     replay(cluster, creator, warm, [0.0, 0.0], dev)
