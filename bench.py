@@ -270,6 +270,16 @@ def measure_disaggregated(ctx, engine, shape, dev, pixels, batch, n_text, max_to
     fe = engine.node.executor.fill_executor
     if fe is not None and fe.graph_decoder is not None:
         fe.graph_decoder.warmup(list(range(4, batch + 1, 4)), kv_max=1024)
+    from hydrainfer_amd.engine.serve import warm_library_gemms
+    nt = engine.node.node_type
+    if fe is not None and nt.enable_prefill:
+        warm_library_gemms(fe.language_model, engine.node.batch_scheduler.token_budgets, batch)
+    ie = engine.node.executor.image_embed_executor
+    if ie is not None:      # the vision tower for 1 .. image budget images
+        px = pixels.to(device=dev, dtype=ie.dtype)
+        for n in range(1, engine.node.batch_scheduler.image_budgets + 1):
+            ie.vision_model.forward(px.expand(n, -1, -1, -1))
+        torch.cuda.synchronize(dev)
     creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16)
     hi = min(31999, itid - 1)
     vocab_text = (min(1000, hi - 1), hi)
