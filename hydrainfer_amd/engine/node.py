@@ -8,7 +8,7 @@ Data path of a pull = TokenCacheBlockManager.migrate_blocks -> hx_migrate_blocks
 kernel over the peer pool); the control plane moves block tables only."""
 import copy
 import time
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 from hydrainfer_amd.engine.executor import InstructionExecutor
 from hydrainfer_amd.engine.isa import (EmptyInstruction, EPMigrate, Fill, ImageEmbed, MigrateRequest,

@@ -11,7 +11,6 @@ import time
 from dataclasses import dataclass
 from typing import Callable, Optional
 
-import numpy as np
 import torch
 
 from hydrainfer_amd.engine.isa import ImageEmbed, Instruction, InstructionListBuilder, TextFill

@@ -2,7 +2,7 @@
 (InstructionCreator) without the tokenizer / image processor (the caller passes token ids and
 pre-processed pixel values; there are no checkpoints or tokenizers offline)."""
 from dataclasses import dataclass
-from typing import List, Optional, Tuple
+from typing import List, Tuple
 
 from hydrainfer_amd.engine.isa import (EPMigrate, ImageEmbed, ImageEmbedFill, InstructionListBuilder,
                                        PDMigrate, PullCache, TextFill)

@@ -2,7 +2,6 @@
 Used by bench.py's `serving` leg and tools/bench_engine.py; mirrors what
 hydrainfer/cluster/epdnode.py:_update_engine assembles and what benchmark/benchmark.py drives."""
 import contextlib
-import dataclasses
 import gc
 import time
 from typing import List, Optional, Tuple

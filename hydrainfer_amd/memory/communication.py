@@ -9,7 +9,7 @@ MI355X redesign of the data path:
   * rccl : pack kernel -> ONE send/recv of the packed buffer -> unpack kernel, instead of one
            P2POp per (block, layer, k/v) view (communication.py:57-74)."""
 from dataclasses import dataclass
-from typing import Dict, List, Literal, Optional
+from typing import Dict, Literal, Optional
 
 import torch
 import torch.distributed as dist

@@ -9,7 +9,6 @@ from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
 import torch
-from torch import Tensor
 
 from hydrainfer_amd._C.data_transfer.block_migration import get_ipc_mem_handle
 from hydrainfer_amd.memory.block_allocator import BlockAllocator, BlockAllocatorMetrics

@@ -5,8 +5,7 @@ from typing import List
 
 import torch
 
-from hydrainfer_amd.engine import (BatchScheduler, BatchSchedulerConfig, BatchSchedulerContext,
-                                   InstructionCreator, SamplingParameters, TokenRequest)
+from hydrainfer_amd.engine import BatchScheduler, BatchSchedulerConfig, BatchSchedulerContext, InstructionCreator
 from hydrainfer_amd.engine.executor import BatchFillExecutor, BatchImageEmbedExecutor, InstructionExecutor
 from hydrainfer_amd.engine.node import EPDNode, LocalCluster, NodeType
 from hydrainfer_amd.memory.token_cache_manger import BlockTableManager
