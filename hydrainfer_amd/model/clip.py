@@ -47,6 +47,12 @@ class LlavaVisionModel:
         L = shape.num_hidden_layers
         self.n_run = (shape.vision_feature_layer + L) % L + 1   # clip.py:106-108
 
+    def required_tensor_names(self):
+        """The reference-named tensors forward() reads (layers past vision_feature_layer are never run)."""
+        names = [k for k in random_state_dict(self.shape, std=0.0)
+                 if ".encoder.layers." not in k or int(k.split(".encoder.layers.")[1].split(".")[0]) < self.n_run]
+        return names
+
     @classmethod
     def random_init(cls, shape: ClipShape, dtype, device, seed: int = 0, std: float = 0.02):
         return cls(shape, dtype, device,
