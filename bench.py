@@ -190,11 +190,11 @@ def make_vision(shape, dtype, dev):
     else:
         cshape = dataclasses.replace(CLIP_VIT_L_14_336, projector_hidden_size=shape.hidden_size)
     vision = LlavaVisionModel.random_init(cshape, dtype, dev, seed=1)
+    from PIL import Image
+    from hydrainfer_amd.model.processor import ClipImageProcessor
     rng = np.random.RandomState(0)
-    img = rng.randint(0, 256, (336, 336, 3)).astype(np.float32) / 255.0
-    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
-    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
-    pixels = torch.from_numpy((img - mean) / std).permute(2, 0, 1)[None]
+    image = Image.fromarray(rng.randint(0, 256, (336, 336, 3), dtype=np.uint8))
+    pixels = ClipImageProcessor().process(image)
     return vision, pixels
 
 
