@@ -8,6 +8,8 @@ import bench
 from hydrainfer_amd.model.llama import LlamaForCausalLM
 from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
 
+if os.environ.get("HX_BLAS"):          # "cublas" (= rocBLAS) | "cublaslt" (= hipBLASLt)
+    torch.backends.cuda.preferred_blas_library(os.environ["HX_BLAS"])
 dev = torch.device("cuda:0")
 dtype = torch.bfloat16
 shape, _ = bench.model_shape(sys.argv[1] if len(sys.argv) > 1 else "7b")
@@ -27,4 +29,5 @@ for _ in range(12):
     pg.replay(); p_first[0].item()
     ts.append((time.perf_counter() - t0) * 1e3)
 ts.sort()
-print("graph-replayed 704-token prefill p50 ms:", round(ts[len(ts) // 2], 3), "tunable:", os.environ.get("PYTORCH_TUNABLEOP_ENABLED"))
+print("graph-replayed 704-token prefill p50 ms:", round(ts[len(ts) // 2], 3), "tunable:", os.environ.get("PYTORCH_TUNABLEOP_ENABLED"),
+      "blas:", torch.backends.cuda.preferred_blas_library())
