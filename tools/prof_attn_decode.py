@@ -26,10 +26,15 @@ v_new = torch.randn((B, H, D), generator=g, device=dev, dtype=torch.float32).to(
 pos = torch.full((B,), ctx - 1, dtype=torch.int32, device=dev)
 cs = build_cos_sin(LLAVA_1_5_7B, dt, dev)
 slots = (perm[cu_b[:-1].long() + (ctx - 1) // bs] * bs + (ctx - 1) % bs).to(torch.int32)
+# the variant the decode graph runs: q / k / v arrive as the split-K slabs of the qkv projection
+from hydrainfer_amd._C.kernel import gemm as hip_gemm
+x = torch.randn((B, H * D), generator=g, device=dev, dtype=torch.float32).to(dt)
+wqkv = (torch.randn((3 * H * D, H * D), generator=g, device=dev, dtype=torch.float32) * 0.02).to(dt)
+slabs = torch.empty(hip_gemm.workspace_floats(B, 3 * H * D, H * D), dtype=torch.float32, device=dev)
+n_slabs = hip_gemm.linear_decode_partial(x, wqkv, slabs)
 for i in range(12):
-    # the variant the decode graph runs: fused RoPE + cache append + attention
     decode_attention_fused(out, q, k_new, v_new, pool[i % L, 0], pool[i % L, 1], pos, cs, slots, cu_q, cu_k,
-                           perm, cu_b, ctx, 1 / math.sqrt(D), 1)
+                           perm, cu_b, ctx, 1 / math.sqrt(D), 1, slabs, n_slabs)
 torch.cuda.synchronize()
 nbytes = 2 * (2 * H * D * ctx * B + 2 * B * H * D) + 4 * B * nb_seq
-print("algorithmic_bytes_per_launch", nbytes)
+print("algorithmic_bytes_per_launch", nbytes, "qkv_slab_bytes", n_slabs * B * 3 * H * D * 4)
