@@ -135,33 +135,42 @@ def time_attention_kernel(runner, start_len, steps):
 
     if runner.cfg.use_graph:
         # Issued from Python one by one, a launch that is shorter than the host's ~40 us per call
-        # would be timed with the host's gaps in it.  So the whole context sequence is captured
-        # twice — (metadata advance + attention) x steps, and the advances alone — and the
-        # attention time per launch is the difference of the two replays / steps: what the kernel
-        # costs inside a graph, dispatch gap included, exactly as in the decode step.
-        def capture(with_attention):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for _ in range(steps):
-                    runner._advance()
-                    if with_attention:
-                        launch()
-            return graph
-        rewind(); runner._advance(); launch(); torch.cuda.synchronize()      # warm outside capture
-        both, adv = capture(True), capture(False)
+        # would be timed with the host's gaps in it.  So the launches of the whole context sequence
+        # are captured back to back into one graph — each with its own precomputed metadata
+        # (positions, slots, cumulative lengths of that step), no other kernel in between — and the
+        # replay is timed with HIP events: kernel + dispatch gap, as inside the decode step.
+        bs = runner.cfg.block_size
+        i32 = dict(dtype=torch.int32, device=runner.dev)
+        metas = []
+        for s_ in range(steps):
+            ctx_len = start_len + 1 + s_
+            pos = ctx_len - 1
+            metas.append((torch.full((B,), pos, **i32),
+                          torch.tensor([runner.tables[b][pos // bs] * bs + pos % bs for b in range(B)], **i32),
+                          torch.arange(0, (B + 1) * ctx_len, ctx_len, **i32)))
 
-        def replay_ms(graph):
-            best = float("inf")
-            for _ in range(3):
-                rewind()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                graph.replay()
-                e1.record()
-                e1.synchronize()
-                best = min(best, e0.elapsed_time(e1))
-            return best
-        ms = (replay_ms(both) - replay_ms(adv)) / steps
+        def launch_step(m):
+            if fused:
+                decode_attention_fused(out, q, k_new, v_new, kc, vc, m[0], runner.model.cos_sin, m[1],
+                                       ap.q_cu_seq_lens, m[2], ap.block_tables, ap.cu_blocks_lens,
+                                       runner.max_len, scale, 0, slabs, n_slabs)
+            else:
+                mha_varlen_fwd(out, q, kc, vc, ap.q_cu_seq_lens, m[2], ap.block_tables, ap.cu_blocks_lens, None, 1,
+                               runner.max_len, scale, 0.0, -1, 0, 0)
+        launch_step(metas[0]); torch.cuda.synchronize()      # warm outside capture
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for m in metas:
+                launch_step(m)
+        best = float("inf")
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        ms = best / steps
     else:
         for s in range(steps + 2):
             runner._advance()
