@@ -225,6 +225,7 @@ def measure_serving(model, vision, pixels, shape, dtype, dev, batch, n_text, max
     node = build_node("EPD0", "EPD", lm, vision, shape, dtype, dev, per_req * (batch + 2), batch + 2, 576, sched,
                       max_blocks_per_seq=per_req)
     node.executor.fill_executor.graph_decoder.warmup(list(range(4, batch + 1, 4)), kv_max=1024)
+    node.executor.image_embed_executor.warmup(pixels, sched.image_budgets)
     warm_library_gemms(lm, sched.token_budgets, batch, vision, pixels, sched.image_budgets)
     cluster = LocalCluster([node])
     creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16)
@@ -284,11 +285,8 @@ def measure_disaggregated(ctx, engine, shape, dev, pixels, batch, n_text, max_to
     if fe is not None and nt.enable_prefill:
         warm_library_gemms(fe.language_model, engine.node.batch_scheduler.token_budgets, batch)
     ie = engine.node.executor.image_embed_executor
-    if ie is not None:      # the vision tower for 1 .. image budget images
-        px = pixels.to(device=dev, dtype=ie.dtype)
-        for n in range(1, engine.node.batch_scheduler.image_budgets + 1):
-            ie.vision_model.forward(px.expand(n, -1, -1, -1))
-        torch.cuda.synchronize(dev)
+    if ie is not None:      # the vision tower's graphs for 1 .. image budget images
+        ie.warmup(pixels, engine.node.batch_scheduler.image_budgets)
     creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16)
     hi = min(31999, itid - 1)
     vocab_text = (min(1000, hi - 1), hi)

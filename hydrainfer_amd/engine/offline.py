@@ -56,6 +56,9 @@ class OfflineInferenceEngine:
         self.processor = ClipImageProcessor(size=vision_model.shape.image_size)
         if warm_up:
             warm_library_gemms(language_model, token_budgets, max_running_requests)
+            size = vision_model.shape.image_size
+            self.node.executor.image_embed_executor.warmup(torch.zeros(1, 3, size, size), image_budgets)
+            self.node.executor.fill_executor.graph_decoder.warmup(list(range(4, max_running_requests + 1, 4)))
 
     @classmethod
     def from_checkpoint(cls, model_path: str, dtype: torch.dtype = torch.float16, device: str = "cuda:0", **kw):

@@ -47,7 +47,7 @@ def build_node(name: str, node_type: str, language_model, vision_model, lm_shape
                                      max_blocks_per_seq=max_blocks_per_seq)
         fill = BatchFillExecutor(language_model, kv, img, dtype, device, graph_decoder=decoder)
     emb = BatchImageEmbedExecutor(vision_model, img, lm_shape.num_attention_heads, lm_shape.head_dim, dtype,
-                                  device) if nt.has_vision_model else None
+                                  device, use_graphs=graph_decode) if nt.has_vision_model else None
     scheduler = BatchScheduler(sched, BatchSchedulerContext(kv, img))
     return EPDNode(name, nt, scheduler, InstructionExecutor(fill, emb), kv, img, eager_migrate=eager_migrate)
 

@@ -109,7 +109,7 @@ def make_node(name, node_type, lm, vision, kv, img, lm_shape, dtype, device, sch
                                  max_blocks_per_seq=8)
     fill = BatchFillExecutor(lm, kv, img, dtype, device, graph_decoder=decoder) if nt.has_language_model else None
     emb = BatchImageEmbedExecutor(vision, img, lm_shape.num_attention_heads, lm_shape.head_dim, dtype,
-                                  device) if nt.has_vision_model else None
+                                  device, use_graphs=graph_decode) if nt.has_vision_model else None
     if fill is not None and batch_log is not None:
         real = fill.execute
 

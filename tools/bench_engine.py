@@ -69,6 +69,9 @@ def main():
         fe = node.executor.fill_executor
         if fe is not None and fe.graph_decoder is not None:
             fe.graph_decoder.warmup(list(range(4, args.max_running + 1, 4)), kv_max=1024)
+        ie = node.executor.image_embed_executor
+        if ie is not None and not args.no_graph:
+            ie.warmup(pixels, args.image_budget)
     cluster = LocalCluster(nodes)
     creator = InstructionCreator(image_token_id=32000, n_image_tokens_per_image=576, block_size=16)
 
