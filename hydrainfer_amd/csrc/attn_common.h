@@ -60,6 +60,7 @@ struct AttnParams {
   int32_t block_shift;      // log2(block_size) when it is a power of two, else -1 (runtime integer
                             // division costs ~30 VALU instructions; the kernels do two per key row)
   int32_t causal;
+  int32_t xcd_remap;        // prefill kernel: renumber workgroups so that one head's query tiles share an XCD
   float scale_log2;         // softmax_scale * log2(e)
   int32_t n_splits;
   float* ws_o;              // [batch, n_heads, n_splits, D] unnormalised partial outputs

@@ -5,9 +5,9 @@
 // mask.h:130-211 (bottom-right aligned causal).
 //
 // Design (gfx950, MFMA 16x16x32, "swapped" products so no P transpose is needed):
-//   * workgroup = 4 waves x QR x 16 query rows (QR = 2 for query runs of >= 1024 tokens: every
-//     K / V fragment read from LDS then feeds two MFMAs, halving the LDS traffic per flop);
-//     grid = (ceil(max_q/(64 QR)), head, sequence), longest causal tiles launched first.  The 32-key K and V tiles are staged ONCE per workgroup (coalesced
+//   * workgroup = 4 waves x QR x 16 query rows (QR = 2, an option: every K / V fragment read from
+//     LDS then feeds two MFMAs); grid = (ceil(max_q/(64 QR)), head, sequence), renumbered so that
+//     the query tiles of one head run on one XCD (shared L2), longest causal tiles first.  The 32-key K and V tiles are staged ONCE per workgroup (coalesced
 //     16-byte loads of whole rows, register prefetch of tile t+1 under tile t's MFMAs,
 //     double-buffered LDS images, one barrier per tile) and shared by the four waves.
 //   * the running output is rescaled only when some row's maximum moved (wave-uniform test):
@@ -42,8 +42,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   constexpr int TILE_BYTES = KT * RS;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2][KT][RS] | V[2][KT][RS]
 
-  // causal tiles get longer with the row index: launch the long ones first
-  const int mblk = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // Workgroup -> (query tile, head, sequence).  Hardware deals consecutive workgroups round-robin
+  // to the 8 XCDs, each with its own L2; the query tiles of one (sequence, head) all stream the
+  // same K / V, so they are renumbered to land on ONE XCD (ids congruent mod 8 form a contiguous
+  // range of tiles): K / V is then fetched into one L2 instead of eight.  Within a head the causal
+  // tiles get longer with the row index: the long ones go first.
+  int mblk, h, b;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy * gridDim.z;
+    int wg = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if (p.xcd_remap && total % 8 == 0) wg = (wg % 8) * (total / 8) + wg / 8;
+    mblk = gx - 1 - wg % gx;
+    h = (wg / gx) % gy;
+    b = wg / (gx * gy);
+  }
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
@@ -283,17 +296,17 @@ int g_fwd_keys = 0;   // tuning: 0 = automatic, 1 / 2 = 32-key units per tile
 
 template <typename T, int D, bool PAGED>
 int launch_fwd_paged(const AttnParams& p, int batch, int max_seqlen_q, hipStream_t stream) {
-  // two row blocks per wave for long query runs (measured on MI355X, tools/bench_attn_prefill.py:
-  // 2048 new tokens 177 -> 141 us; at 704 tokens and for the 577-token CLIP tower one row block
-  // is faster — those launches are short of workgroups, not of LDS bandwidth).  D = 256 keeps
-  // one: its accumulators alone are 128 registers per row block.
-  bool two = D <= 128 && max_seqlen_q >= 1024;
-  if (g_fwd_rows == 1) two = false;
+  // Tiling choice, measured on MI355X with the XCD-aware numbering on (tools/bench_attn_prefill.py):
+  //  * two row blocks per wave (QR = 2) no longer pay once a head's tiles share an L2
+  //    (2048 new tokens: 116 us with one row block, 130 with two) — kept as an option only;
+  //  * 64-key tiles (KU = 2) win where the launch is a few long dependency chains — up to ~768
+  //    workgroups (1 x 704 tokens: 30 vs 35 us) — and for the dense CLIP batches (8 x 577: 34 vs 36);
+  //    with more workgroups in flight 32-key tiles and their higher occupancy are ahead
+  //    (3 x 683: 53 vs 56, 1 x 2048: 116 vs 119).
+  bool two = false;
   if (g_fwd_rows == 2 && D <= 128) two = true;
-  // 64-key tiles for paged prompts that are not long enough for two row blocks (measured:
-  // 1 x 704 tokens 36 -> 31 us, 4 x 704 75 -> 74, 3 x 683 61 -> 60; with two row blocks, and for the
-  // dense 8-image CLIP batch, 32-key tiles stay ahead)
-  bool wide = PAGED && D <= 128 && max_seqlen_q > 64 && !two;
+  const int64_t n_wg = (int64_t)((max_seqlen_q + 63) / 64) * p.n_heads * batch;
+  bool wide = D <= 128 && max_seqlen_q > 64 && (!PAGED || n_wg <= 768);
   if (g_fwd_keys == 1) wide = false;
   if (g_fwd_keys == 2 && D <= 128) wide = true;
   if constexpr (D <= 128) {

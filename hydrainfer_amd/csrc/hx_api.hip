@@ -33,11 +33,13 @@ extern "C" int hx_abi_version(void) { return HX_ABI_VERSION; }
 
 extern "C" int hx_last_hip_error(void) { return last_hip_error(); }
 
+static int g_fwd_xcd = 1;      // tuning: XCD-aware workgroup numbering in the prefill kernel
 static int g_decode_gqa = 1;   // tuning: 0 routes grouped-query decode through the per-query-head kernel
 
 extern "C" int hx_debug_set_option(const char* name, int value) {
   if (!name) return HX_ERR_NULL;
   if (!strcmp(name, "decode_gqa")) { g_decode_gqa = value ? 1 : 0; return HX_OK; }
+  if (!strcmp(name, "fwd_xcd_remap")) { g_fwd_xcd = value ? 1 : 0; return HX_OK; }
   int rc = decode_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = gemm_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = fwd_set_option(name, value);
@@ -172,6 +174,7 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.block_size = a->block_table ? a->block_size : 16;
   p.block_shift = (p.block_size & (p.block_size - 1)) == 0 ? __builtin_ctz((unsigned)p.block_size) : -1;
   p.causal = a->causal;
+  p.xcd_remap = g_fwd_xcd;
   p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
   p.n_splits = 1;
   p.ws_o = nullptr;

@@ -49,8 +49,9 @@ int hx_last_hip_error(void);
 /* Tuning knobs for A/B measurements in one process (not part of the reference surface):
  * "decode_waves" = 4|8 waves per decode-attention workgroup, "decode_nt" = 0|1 non-temporal
  * K/V loads, "decode_small_lo" / "decode_small_hi" = range of (sequence, head) pair counts served
- * by the 8-wave no-split form, "fwd_row_blocks" = 0(auto)|1|2 query row blocks per wave in the
- * prefill kernel,
+ * by the 8-wave no-split form, "fwd_row_blocks" = 0(auto)|1|2 query row blocks per wave,
+ * "fwd_key_units" = 0(auto)|1|2 32-key units per tile and "fwd_xcd_remap" = 0|1 XCD-aware
+ * workgroup numbering in the prefill kernel,
  * "gemm_rows_per_wave" / "gemm_waves" / "gemm_slab_nt" for the decode GEMM — results are
  * identical for every setting of these.  "decode_gqa" = 0|1 selects the per-query-head or the
  * grouped-query decode kernel for n_heads > n_kv_heads (both within the stated tolerance; the

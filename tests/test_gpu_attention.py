@@ -396,14 +396,14 @@ def test_prefill_row_block_variants_vs_oracle(rows, keys):
 
 
 @pytest.mark.gpu
-def test_prefill_long_run_takes_two_row_blocks_and_matches():
+def test_prefill_long_run_tilings_agree():
     from hydrainfer_amd import _lib
     from oracle import ops
     lib = _lib.lib()
     dt = torch.bfloat16
     q_lens, kv_lens = [1100, 1030], [1100, 1500]
     q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(2, 4, 4, 128, kv_lens, q_lens, dt, seed=9)
-    auto = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))      # automatic: two row blocks
+    auto = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))      # automatic choice (64-key tiles here)
     try:
         lib.hx_debug_set_option(b"fwd_key_units", 1)            # same key tiling: same arithmetic per row
         lib.hx_debug_set_option(b"fwd_row_blocks", 1)
@@ -411,11 +411,16 @@ def test_prefill_long_run_takes_two_row_blocks_and_matches():
         lib.hx_debug_set_option(b"fwd_row_blocks", 2)
         two = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
         lib.hx_debug_set_option(b"fwd_key_units", 2)            # 64-key tiles rescale at other points
+        lib.hx_debug_set_option(b"fwd_row_blocks", 1)
         wide = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
+        lib.hx_debug_set_option(b"fwd_xcd_remap", 0)            # workgroup numbering never changes a result
+        plain = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens))
     finally:
         lib.hx_debug_set_option(b"fwd_row_blocks", 0)
         lib.hx_debug_set_option(b"fwd_key_units", 0)
-    assert torch.equal(auto, two) and torch.equal(one, two)      # same per-row arithmetic, other row tiling
+        lib.hx_debug_set_option(b"fwd_xcd_remap", 1)
+    assert torch.equal(one, two)                                 # same per-row arithmetic, other row tiling
+    assert torch.equal(auto, wide) and torch.equal(plain, wide)
     atol, rtol = ATTN_TOL[dt]
     assert_close_t(wide, two.cpu(), atol, rtol, what="64-key vs 32-key tiles")
     sel = torch.cat([torch.arange(0, 1100, 37), torch.arange(1100, 2130, 41)])

@@ -54,6 +54,12 @@ cases = {"prefill 4x704": paged(4, 704, 704), "prefill 1x704": paged(1, 704, 704
          "clip 1x577 d64": dense(1), "clip 8x577 d64": dense(8)}
 for name, (fn, flops) in cases.items():
     row = []
+    for xcd in (0, 1):
+        _lib.check(_lib.lib().hx_debug_set_option(b"fwd_xcd_remap", xcd), "opt")
+        _lib.lib().hx_debug_set_option(b"fwd_row_blocks", 0); _lib.lib().hx_debug_set_option(b"fwd_key_units", 0)
+        us = timeit(fn)
+        row.append(f"auto xcd={xcd}: {us:6.1f}us {flops / us / 1e6:5.0f}TF")
+    _lib.lib().hx_debug_set_option(b"fwd_xcd_remap", 1)
     for rows in (1, 2):
         for keys in (1, 2):
             _lib.check(_lib.lib().hx_debug_set_option(b"fwd_row_blocks", rows), "opt")
