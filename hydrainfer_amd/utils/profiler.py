@@ -15,7 +15,9 @@ _SYNC = os.environ.get("HX_PROFILE_SYNC") == "1"
 _totals = defaultdict(lambda: [0, 0.0])
 _roctx = None
 if ENABLED:
-    for _name in ("libroctx64.so", "/opt/rocm/lib/libroctx64.so"):
+    # rocprofv3 intercepts the rocprofiler-sdk flavour of roctx; the legacy library is the fallback
+    for _name in ("librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                  "libroctx64.so", "/opt/rocm/lib/libroctx64.so"):
         try:
             _roctx = ctypes.CDLL(_name)
             _roctx.roctxRangePushA.argtypes = [ctypes.c_char_p]
