@@ -56,6 +56,8 @@ struct AttnParams {
   int64_t k_block_stride, k_row_stride, k_head_stride;
   int64_t v_block_stride, v_row_stride, v_head_stride;
   int32_t n_heads, group;   // group = n_heads / n_kv_heads
+  int32_t batch;            // number of sequences
+  int64_t total_q;          // query rows over all sequences
   int32_t block_size;       // paged: tokens per page (multiple of 16)
   int32_t block_shift;      // log2(block_size) when it is a power of two, else -1 (runtime integer
                             // division costs ~30 VALU instructions; the kernels do two per key row)

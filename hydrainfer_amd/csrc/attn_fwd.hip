@@ -42,20 +42,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   constexpr int TILE_BYTES = KT * RS;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2][KT][RS] | V[2][KT][RS]
 
-  // Workgroup -> (query tile, head, sequence).  Hardware deals consecutive workgroups round-robin
-  // to the 8 XCDs, each with its own L2; the query tiles of one (sequence, head) all stream the
-  // same K / V, so they are renumbered to land on ONE XCD (ids congruent mod 8 form a contiguous
-  // range of tiles): K / V is then fetched into one L2 instead of eight.  Within a head the causal
-  // tiles get longer with the row index: the long ones go first.
+  // Workgroup -> (sequence, query tile, head).  The grid is COMPACT: x runs over tile slots, at most
+  // total_q / tile_rows + batch of them, and each workgroup finds the sequence that owns its slot
+  // by walking the cumulative lengths (a launch sized (max_q tiles) x batch would, for one 2017-token
+  // chunk next to 31 decode rows, dispatch 30 752 workgroups that exit at once — measured 847 us for
+  // work that takes 190 us).  Hardware deals consecutive workgroups round-robin to the 8 XCDs, each
+  // with its own L2; the query tiles of one (sequence, head) stream the same K / V, so ids are
+  // renumbered to put them on ONE XCD (ids congruent mod 8 form a contiguous range of slots).
+  // Within a sequence the causal tiles get longer with the row index: the long ones go first.
+  constexpr int WROWS = 16 * QR;             // query rows per wave
+  constexpr int TQ = 4 * WROWS;              // query rows per workgroup
   int mblk, h, b;
   {
     const int gx = gridDim.x, gy = gridDim.y;
-    const int total = gx * gy * gridDim.z;
-    int wg = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int total = gx * gy;
+    int wg = blockIdx.x + gx * blockIdx.y;
     if (p.xcd_remap && total % 8 == 0) wg = (wg % 8) * (total / 8) + wg / 8;
-    mblk = gx - 1 - wg % gx;
-    h = (wg / gx) % gy;
-    b = wg / (gx * gy);
+    int slot = wg % gx;
+    h = wg / gx;
+    b = 0;
+    int tiles = 0;
+    for (; b < p.batch; ++b) {
+      tiles = (p.cu_q[b + 1] - p.cu_q[b] + TQ - 1) / TQ;
+      if (slot < tiles) break;
+      slot -= tiles;
+    }
+    if (b == p.batch) return;                // spare slot (the grid is an upper bound)
+    mblk = tiles - 1 - slot;
   }
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -66,8 +79,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int q_len = p.cu_q[b + 1] - q_start;
   const int k_start = p.cu_k[b];
   const int kv_len = p.cu_k[b + 1] - k_start;
-  constexpr int WROWS = 16 * QR;             // query rows per wave
-  const int q_row0_wg = mblk * (4 * WROWS);
+  const int q_row0_wg = mblk * TQ;
   if (q_row0_wg >= q_len) return;            // workgroup-uniform
   const int q_row0 = q_row0_wg + w * WROWS;  // may exceed q_len for the last workgroup's waves:
                                              // those waves still load / synchronise, never store
@@ -280,8 +292,9 @@ template <typename T, int D, bool PAGED, int QR, int KU>
 int launch_fwd_cfg(const AttnParams& p, int batch, int max_seqlen_q, hipStream_t stream) {
   constexpr int RS = 2 * D + 32;
   const size_t lds = 4 * 32 * KU * RS;   // K[2][KT][RS] + V[2][KT][RS]
-  dim3 grid((max_seqlen_q + 64 * QR - 1) / (64 * QR), p.n_heads, batch);
-  if (grid.x == 0) return HX_OK;
+  // tile slots: sum_b ceil(q_b / TQ) <= total_q / TQ + batch
+  dim3 grid((unsigned)(p.total_q / (64 * QR) + batch), p.n_heads, 1);
+  if (p.total_q == 0) return HX_OK;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, PAGED, QR, KU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -305,7 +318,7 @@ int launch_fwd_paged(const AttnParams& p, int batch, int max_seqlen_q, hipStream
   //    (3 x 683: 53 vs 56, 1 x 2048: 116 vs 119).
   bool two = false;
   if (g_fwd_rows == 2 && D <= 128) two = true;
-  const int64_t n_wg = (int64_t)((max_seqlen_q + 63) / 64) * p.n_heads * batch;
+  const int64_t n_wg = (p.total_q / 64 + batch) * (int64_t)p.n_heads;
   bool wide = D <= 128 && max_seqlen_q > 64 && (!PAGED || n_wg <= 768);
   if (g_fwd_keys == 1) wide = false;
   if (g_fwd_keys == 2 && D <= 128) wide = true;

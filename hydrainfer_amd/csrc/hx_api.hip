@@ -170,6 +170,8 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.v_row_stride = a->v_row_stride;
   p.v_head_stride = a->v_head_stride;
   p.n_heads = a->n_heads;
+  p.batch = a->batch;
+  p.total_q = a->total_q;
   p.group = a->n_heads / a->n_kv_heads;
   p.block_size = a->block_table ? a->block_size : 16;
   p.block_shift = (p.block_size & (p.block_size - 1)) == 0 ? __builtin_ctz((unsigned)p.block_size) : -1;

@@ -69,3 +69,21 @@ for name, (fn, flops) in cases.items():
     print(f"{name:22s}", " | ".join(row))
 _lib.lib().hx_debug_set_option(b"fwd_row_blocks", 0)
 _lib.lib().hx_debug_set_option(b"fwd_key_units", 0)
+
+# mixed step of a chunked-prefill engine: one long chunk + many decode rows in ONE launch
+def mixed(n_dec, chunk, ctx=832, H=32, D=128, bs=16):
+    q_lens = [chunk] + [1] * n_dec
+    kv_lens = [chunk] + [ctx] * n_dec
+    nbs = [(k + bs - 1) // bs for k in kv_lens]
+    kc, vc = rnd(sum(nbs), bs, H, D), rnd(sum(nbs), bs, H, D)
+    q = rnd(sum(q_lens), H, D)
+    out = torch.empty_like(q)
+    perm = torch.randperm(sum(nbs), generator=g, device=dev).to(torch.int32)
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=dev)
+    cu = lambda xs: i32([0] + list(torch.tensor(xs).cumsum(0)))
+    cu_q, cu_k, cu_b = cu(q_lens), cu(kv_lens), cu(nbs)
+    return lambda: mha_varlen_fwd(out, q, kc, vc, cu_q, cu_k, perm, cu_b, None, chunk, max(kv_lens), 1 / math.sqrt(D), 0, -1, 0, 0)
+
+print("--- mixed launches (one prefill chunk + decode rows)")
+for n_dec, chunk in ((0, 2017), (31, 2017), (31, 704), (0, 704), (31, 64)):
+    print(f"decode rows {n_dec:2d} + chunk {chunk:4d}: {timeit(mixed(n_dec, chunk)):7.1f} us")
