@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
   for (int rb = 0; rb < QR; ++rb)
     limit_c[rb] = p.causal ? min(kv_len - 1, q_row0 + 16 * rb + c + shift) : kv_len - 1;
-  const int last_key_wave = p.causal ? min(kv_len - 1, q_row0 + WROWS - 1 + shift) : kv_len - 1;
+  // a wave whose rows all lie past the sequence (q_len = 1: three of the four) only helps staging
+  const int last_key_wave = q_row0 >= q_len ? -1
+                          : p.causal ? min(kv_len - 1, q_row0 + WROWS - 1 + shift) : kv_len - 1;
   const int last_key_wg =
       p.causal ? min(kv_len - 1, min(q_row0_wg + 4 * WROWS - 1, q_len - 1) + shift) : kv_len - 1;
   const int n_tiles = (last_key_wg >= 0) ? last_key_wg / KT + 1 : 0;   // workgroup-uniform
