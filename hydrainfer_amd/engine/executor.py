@@ -148,11 +148,12 @@ class BatchFillExecutor:
         builder.add_batch(batch)
         inputs = builder.build_language_model_parameters()
         params = LanguageModelParameters(inputs.attention_params, inputs.all_sequences_decode,
-                                         inputs.selected_token_ids_tensor)
+                                         inputs.selected_token_ids_tensor, inputs.image_row_index)
         if not inputs.selected_token_ids:
             # nothing samples: the forward still has to run for its cache writes
             self.language_model.language_model.forward_hidden(
-                self.language_model.embed(inputs.input_ids, inputs.image_features), inputs.position_ids, params)
+                self.language_model.embed(inputs.input_ids, inputs.image_features, inputs.image_row_index),
+                inputs.position_ids, params)
             batch.step()
             return
         sampled = self.language_model.forward(inputs.input_ids, inputs.image_features, inputs.position_ids,

@@ -29,6 +29,7 @@ class FillInputs:
     all_sequences_decode: bool
     selected_token_ids: List[int]
     selected_token_ids_tensor: Optional[Tensor]   # int64 on the device
+    image_row_index: Optional[Tensor] = None      # int64 on the device: rows that are image tokens
 
 
 class LanguageModelParametersBuilder:
@@ -77,18 +78,20 @@ class LanguageModelParametersBuilder:
         n, n_sel, n_img = len(self.token_ids), len(self.selected_token_ids), len(self.image_slot_ids)
         n_image_rows = sum(t == self.image_token_id for t in self.token_ids)
         assert n_image_rows == n_img, "image token rows and cached image embeddings differ"
+        image_rows = [i for i, t in enumerate(self.token_ids) if t == self.image_token_id] if n_img else []
         flat = self._to_device(self.token_ids + self.position_ids + self.selected_token_ids +
-                               self.image_slot_ids)
+                               self.image_slot_ids + image_rows)
         input_ids, position_ids = flat[:n], flat[n:2 * n]
         selected = flat[2 * n:2 * n + n_sel].to(torch.int64) if n_sel else None
         image_features = None
         if n_img:
             cache = self.image_block_manager.get_layer_cache(layer_id=0).get_caches()[0]
             rows = cache.view(-1, self.n_qo_heads * self.head_dim)
-            image_features = rows.index_select(0, flat[2 * n + n_sel:]).to(self.dtype)
+            image_features = rows.index_select(0, flat[2 * n + n_sel:2 * n + n_sel + n_img]).to(self.dtype)
         for layer_id in range(self.n_layers):
             self.attention_params_builder.add_kv_cache(
                 KVCache.from_token_cache(self.kv_cache_block_manager.get_layer_cache(layer_id)))
         attn = self.attention_params_builder.build_attention_parameters()
+        row_index = flat[2 * n + n_sel + n_img:].to(torch.int64) if n_img else None
         return FillInputs(input_ids, position_ids, image_features, attn, attn[0].all_sequences_decode,
-                          self.selected_token_ids, selected)
+                          self.selected_token_ids, selected, row_index)

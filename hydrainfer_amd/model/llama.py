@@ -50,6 +50,8 @@ class LanguageModelParameters:
     attention_params: List[AttentionParameters]
     all_sequences_decode: bool
     selected_token_ids: Optional[Tensor] = None  # int64 index tensor on the device
+    image_row_index: Optional[Tensor] = None     # int64 rows of the batch that are image tokens (host knows them:
+                                                 # spares the nonzero() sync of a boolean-mask assignment)
 
 
 def build_cos_sin(shape: LlamaShape, dtype: torch.dtype, device) -> Tensor:

@@ -7,7 +7,7 @@ import csv, glob, json, os, statistics, sys
 csv.field_size_limit(1 << 30)
 
 
-def stats(d, out, title, top=16):
+def stats(d, out, title, top=int(os.environ.get("HX_TOP", "16"))):
     f = sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True))[0]
     rows = list(csv.DictReader(open(f)))
     with open(out, "w") as o:
