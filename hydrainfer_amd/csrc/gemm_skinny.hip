@@ -231,6 +231,13 @@ int launch_gemm_mb(const GemmParams& p, hipStream_t stream) {
   // workgroups with 3 resp. 2 row groups per wave; qkv / o keep 4 waves x 1
   if (units > 4096) { nw = 8; rpw = 3; }
   else if (p.n_splits >= 8) { nw = 8; rpw = 2; }
+  // 33..64 batch rows: the x slice alone is 133 KB of LDS, so one workgroup per CU whatever its
+  // size — four waves cannot keep the CU streaming.  8 waves everywhere; cold-weight timing at
+  // M = 48 / 64 (tools/bench_gemm_m.py): qkv 51 -> 31 us with two row groups per wave, o 21.5 -> 18.5
+  if (MB == 4) {
+    nw = 8;
+    if (units <= 4096 && p.n_splits < 8) rpw = units >= 2048 ? 2 : 1;
+  }
   // per-shape override for tuning runs: HX_GEMM_CFG="N:K:R:NW;N:K:R:NW;..."
   static const char* nt_env = getenv("HX_GEMM_SLAB_NT");
   if (nt_env) g_slab_nt = atoi(nt_env);
