@@ -87,3 +87,9 @@ def mixed(n_dec, chunk, ctx=832, H=32, D=128, bs=16):
 print("--- mixed launches (one prefill chunk + decode rows)")
 for n_dec, chunk in ((0, 2017), (31, 2017), (31, 704), (0, 704), (31, 64)):
     print(f"decode rows {n_dec:2d} + chunk {chunk:4d}: {timeit(mixed(n_dec, chunk)):7.1f} us")
+
+print("--- long contexts (chunk q of kv)")
+for q_, kv_, B_ in ((2048, 4096, 1), (512, 8192, 1), (2048, 2048, 4), (128, 4096, 8)):
+    fn, fl = paged(B_, q_, kv_)
+    us = timeit(fn, reps=10)
+    print(f"B={B_} q={q_} kv={kv_}: {us:8.1f} us {fl / us / 1e6:6.0f} TF/s")

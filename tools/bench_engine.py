@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--no-chunk", action="store_true")
     ap.add_argument("--priority", default="prefill")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-image", action="store_true", help="text-only requests")
     ap.add_argument("--repeat", type=int, default=1, help="replay the trace this many times in one process")
     args = ap.parse_args()
 
@@ -79,7 +80,7 @@ def main():
     # warm-up: two short requests (kernel loading, allocator, workspace growth)
     warm = synthetic_requests(2, args.n_text, 4, 32000, pixels, seed=99)
     replay(cluster, creator, warm, [0.0, 0.0], dev)
-    reqs = synthetic_requests(args.requests, args.n_text, args.max_tokens, 32000, pixels, seed=1)
+    reqs = synthetic_requests(args.requests, args.n_text, args.max_tokens, 32000, None if args.no_image else pixels, seed=1)
     arrivals = poisson_arrivals(args.requests, args.rate, 0) if args.rate > 0 else [0.0] * args.requests
     for rep in range(args.repeat - 1):
         r0 = replay(cluster, creator, synthetic_requests(args.requests, args.n_text, args.max_tokens, 32000, pixels,
