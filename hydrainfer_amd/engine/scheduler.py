@@ -56,6 +56,7 @@ class BatchScheduler:
         self.max_overload_requests = config.max_running_requests
         self.running_cnt = 0
         self.migrating_cnt = 0
+        self.stalled_steps = 0
 
     # -- requests handed to a downstream node but not pulled yet still hold their blocks here
     def migrating_acquire(self) -> None:
@@ -108,12 +109,25 @@ class BatchScheduler:
                and isinstance(self.waiting[0].current_instruction(), PullCache)):
             self.schedule_running(self.waiting.popleft())
 
-    def _grow_caches(self) -> None:
+    def _grow_caches(self) -> set:
+        """Grows every running request's block table for its current instruction.  Returns the ids
+        of requests whose growth does not fit the pool right now: they sit this step out and retry
+        (the reference allocates blindly and dies on 'not enough blocks', token_cache_manger.py:101)."""
         kv, img = self.context.kv_cache_block_manager, self.context.image_cache_block_manager
+        deferred = set()
+
+        def fits(manager, vc, n_tokens) -> bool:
+            have = len(vc.block_table) if vc is not None else 0
+            need = (n_tokens + manager.block_size - 1) // manager.block_size - have
+            return need <= len(manager.shared_cache.to_be_evicted)
+
         for rcb in self.running:
             inst = rcb.current_instruction()
             if isinstance(inst, Fill):
                 if rcb.virtual_kv_cache is None:
+                    if not fits(kv, None, max(inst.cache_ids) + 1):
+                        deferred.add(id(rcb))
+                        continue
                     rcb.virtual_kv_cache = kv.allocate_virtual_cache(inst.hashes)
                     n_hit = rcb.virtual_kv_cache.n_cache_tokens
                     assert n_hit <= len(inst.token_ids)
@@ -129,13 +143,24 @@ class BatchScheduler:
                         rcb.step()
                 inst = rcb.current_instruction()
                 if isinstance(inst, Fill):
-                    kv.realloc(rcb.virtual_kv_cache,
-                               max(rcb.virtual_kv_cache.n_cache_tokens, max(inst.cache_ids) + 1))
+                    want = max(rcb.virtual_kv_cache.n_cache_tokens, max(inst.cache_ids) + 1)
+                    if not fits(kv, rcb.virtual_kv_cache, want):
+                        deferred.add(id(rcb))
+                        continue
+                    kv.realloc(rcb.virtual_kv_cache, want)
             elif isinstance(inst, ImageEmbed):
+                want = max(inst.cache_ids) + 1
                 if rcb.virtual_image_cache is None:
+                    if not fits(img, None, want):
+                        deferred.add(id(rcb))
+                        continue
                     rcb.virtual_image_cache = img.allocate_virtual_cache()
-                img.realloc(rcb.virtual_image_cache,
-                            max(rcb.virtual_image_cache.n_cache_tokens, max(inst.cache_ids) + 1))
+                want = max(rcb.virtual_image_cache.n_cache_tokens, want)
+                if not fits(img, rcb.virtual_image_cache, want):
+                    deferred.add(id(rcb))
+                    continue
+                img.realloc(rcb.virtual_image_cache, want)
+        return deferred
 
     def step(self) -> BatchRequest:
         self.step_cnt += 1
@@ -143,14 +168,16 @@ class BatchScheduler:
         self.running_cnt = len(self.running)
         if not self.running:
             return BatchRequest()
-        self._grow_caches()
+        deferred = self._grow_caches()
 
         embeds, prefills, decodes = [], [], []
         this_step: List[RequestControlBlock] = []
         next_step: List[RequestControlBlock] = []
         for rcb in self.running:
             inst = rcb.current_instruction()
-            if isinstance(inst, Fill):
+            if id(rcb) in deferred:
+                next_step.append(rcb)      # no room in the pool this step
+            elif isinstance(inst, Fill):
                 (decodes if len(inst.token_ids) == 1 else prefills).append(rcb)
             elif isinstance(inst, ImageEmbed):
                 embeds.append(rcb)
@@ -179,6 +206,12 @@ class BatchScheduler:
             else:
                 next_step.append(rcb)
 
+        if deferred and not this_step:
+            self.stalled_steps += 1
+            if self.stalled_steps > 1000:
+                raise RuntimeError("cache pool exhausted: every running request is waiting for blocks")
+        else:
+            self.stalled_steps = 0
         self.running = next_step
         return BatchRequest(this_step)
 

@@ -172,3 +172,31 @@ def test_engine_fuzz_closed_form(seed):
                 assert len(m.shared_cache.to_be_evicted) == m.n_blocks, f"{node.name}: blocks still pinned"
         assert node.batch_scheduler.migrating_cnt == 0
     assert sum(len(n.finished) for n in nodes) == n_req
+
+
+def test_request_that_does_not_fit_waits_for_blocks():
+    """A pool with room for one request at a time: the second request is deferred (not crashed on,
+    as the reference would) until the first has finished and freed its blocks."""
+    kv = CpuPoolManager(1, 2, 6, BS, 1, 8)                    # 6 blocks = 96 tokens
+    img = CpuPoolManager(1, 1, 2, N_IMG, 1, 8)
+    cfg = BatchSchedulerConfig(max_running_requests=2, token_budgets=200, image_budgets=2)
+    node = make_node("EPD", "EPD", LM(), Vision(), kv, img, LM.language_model.shape, torch.float32,
+                     torch.device("cpu"), cfg)
+    cluster = LocalCluster([node])
+    creator = InstructionCreator(IMAGE_TOKEN, N_IMG, BS)
+    g = torch.Generator().manual_seed(1)
+    reqs = [TokenRequest(i, torch.randint(1000, 31999, (60,), generator=g).tolist(), None, (0, 0), 0,
+                         SamplingParameters(max_tokens=20)) for i in range(3)]      # 80 tokens = 5 blocks each
+    rcbs = [creator.process(r) for r in reqs]
+    for rcb in rcbs:
+        cluster.add_request(rcb)
+    steps = 0
+    while not cluster.idle():
+        cluster.step()
+        steps += 1
+        assert steps < 500
+    for r, rcb in zip(reqs, rcbs):
+        assert rcb.output_token_ids == closed_form(r, None)
+    assert len(kv.shared_cache.to_be_evicted) == kv.n_blocks
+    # they ran one after the other: each needs 20 decode steps
+    assert steps >= 3 * 20
