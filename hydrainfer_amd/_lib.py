@@ -50,6 +50,22 @@ class hx_fused_decode_args(ctypes.Structure):
     ]
 
 
+class hx_chain_args(ctypes.Structure):
+    _fields_ = [
+        ("M", c_int32), ("hidden", c_int32), ("inter", c_int32), ("q_size", c_int32),
+        ("qkv_n", c_int32), ("dtype", c_int32), ("eps", c_float), ("reserved", c_int32),
+        ("attn_out", c_void_p), ("attn_out_stride", c_int64), ("h_in", c_void_p),
+        ("w_o", c_void_p), ("w_gate_up", c_void_p), ("w_down", c_void_p), ("w_qkv_next", c_void_p),
+        ("ld_o", c_int64), ("ld_gate_up", c_int64), ("ld_down", c_int64), ("ld_qkv", c_int64),
+        ("norm_post_weight", c_void_p), ("norm_next_weight", c_void_p),
+        ("h_mid", c_void_p), ("h_out", c_void_p), ("x_post", c_void_p), ("act", c_void_p),
+        ("x_next", c_void_p), ("qkv_partial", c_void_p), ("qkv_partial_bytes", c_int64),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64), ("sync", c_void_p),
+    ]
+
+
+HX_CHAIN_SYNC_WORDS, HX_CHAIN_SYNC_ERR = 512, 480
+
 _SIGNATURES = {
     "hx_abi_version": (c_int, []),
     "hx_strerror": (c_char_p, [c_int]),
@@ -66,6 +82,8 @@ _SIGNATURES = {
     "hx_linear_decode_workspace_bytes": (c_int64, [c_int64] * 3),
     "hx_linear_decode": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_void_p, c_int64, c_int, c_void_p]),
     "hx_linear_decode_partial": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_int, c_void_p]),
+    "hx_decode_chain_workspace_bytes": (c_int64, [c_int64] * 4),
+    "hx_decode_chain": (c_int, [POINTER(hx_chain_args), c_void_p]),
     "hx_add_rms_norm_slabs": (c_int, [c_void_p] * 3 + [c_int32, c_void_p, c_float, c_int64, c_int64, c_int, c_void_p]),
     "hx_silu_and_mul_slabs": (c_int, [c_void_p] * 2 + [c_int32, c_int64, c_int64, c_int, c_void_p]),
     "hx_mha_varlen_fwd_workspace_bytes": (c_int64, [POINTER(hx_attn_args)]),

@@ -81,6 +81,11 @@ class LlamaForCausalLM:
         # reads each KV head once (3x faster at group 4 and more than pays for the two launches)
         self.fuse_decode_attention = (shape.head_dim in (64, 128, 256)
                                       and shape.num_key_value_heads == shape.num_attention_heads)
+        # decode batches of <= 32 rows: everything between two attention launches (o GEMM, both
+        # norms, gate|up GEMM, silu*mul, down GEMM, the next layer's qkv GEMM) is ONE launch
+        # (csrc/decode_chain.hip) — 2 launches per layer instead of 8, bit-identical results
+        self.use_chain = False   # enabled once the chain launch beats the separate launches
+        self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
 
     def linear(self, x: Tensor, w: Tensor) -> Tensor:
         if self.use_hip_gemm and x.shape[0] <= 64 and hip_gemm.supported(x, w):
@@ -193,6 +198,46 @@ class LlamaForCausalLM:
             add_rms_norm_slabs(x, h, ws, s_dn, nxt, eps)
         return x
 
+    def _decode_hidden_chain(self, h: Tensor, position_ids: Tensor,
+                             model_params: LanguageModelParameters) -> Tensor:
+        """All-decode step, <= 32 rows: per layer ONE attention launch (slab reduce + RoPE + cache
+        append + paged attention) and ONE chain launch (o GEMM .. next layer's qkv GEMM)."""
+        sh, st = self.shape, self.state
+        n = h.shape[0]
+        H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
+        q_size, kv_size, inter, hid = self.q_size, self.kv_size, sh.intermediate_size, sh.hidden_size
+        eps, L = sh.rms_norm_eps, sh.num_hidden_layers
+        qkv_n = q_size + 2 * kv_size
+        dev, dt = h.device, h.dtype
+        ws_qkv = torch.empty(hip_gemm.workspace_floats(n, qkv_n, hid), dtype=torch.float32, device=dev)
+        ws = torch.empty(hip_gemm.chain_workspace_floats(n, hid, inter, q_size), dtype=torch.float32, device=dev)
+        sync = torch.zeros((L, hip_gemm.SYNC_WORDS), dtype=torch.int32, device=dev)
+        self.chain_sync = sync
+        hbuf = [h, torch.empty_like(h), torch.empty_like(h)]   # residual stream: in / mid / out rotate
+        x_post, x_next = torch.empty_like(h), torch.empty_like(h)
+        act = torch.empty((n, inter), dtype=dt, device=dev)
+        rms_norm(x_next, h, st["l0.norm1"], eps)
+        s_qkv = hip_gemm.linear_decode_partial(x_next, st["l0.wqkv"], ws_qkv)
+        i_in = 0
+        for l in range(L):
+            ap = model_params.attention_params[l]
+            kc, vc = ap.kv_cache.get_kv_cache()
+            o = torch.empty((n, H, D), dtype=dt, device=dev)
+            decode_attention_fused(o, o, o[:, :HK], o[:, :HK], kc, vc, position_ids, self.cos_sin,
+                                   ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
+                                   ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws_qkv, s_qkv)
+            last = l + 1 == L
+            s_next = hip_gemm.decode_chain(
+                o.view(n, q_size), hbuf[i_in], st[f"l{l}.wo"], st[f"l{l}.wgu"], st[f"l{l}.wdown"],
+                None if last else st[f"l{l + 1}.wqkv"], st[f"l{l}.norm2"],
+                st["norm"] if last else st[f"l{l + 1}.norm1"], eps,
+                hbuf[(i_in + 1) % 3], hbuf[(i_in + 2) % 3], x_post, act, x_next,
+                None if last else ws_qkv, ws, sync[l])
+            if not last:
+                s_qkv = s_next
+            i_in = (i_in + 2) % 3
+        return x_next
+
     def forward_hidden(self, input_ids_or_embeds: Tensor, position_ids: Tensor,
                        model_params: LanguageModelParameters) -> Tensor:
         sh, st = self.shape, self.state
@@ -206,6 +251,9 @@ class LlamaForCausalLM:
         if (self.use_hip_gemm and model_params.all_sequences_decode and self.fuse_decode_attention
                 and n <= 64 and h.dtype in (torch.float16, torch.bfloat16)
                 and sh.hidden_size % 256 == 0 and sh.intermediate_size % 256 == 0):
+            if self.use_chain and n <= 32 and hip_gemm.chain_supported(n, sh.hidden_size, sh.intermediate_size,
+                                                                      self.q_size, h.dtype):
+                return self._decode_hidden_chain(h, position_ids, model_params)
             return self._decode_hidden_hip_gemm(h, position_ids, model_params)
         H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
         q_size, kv_size, inter = self.q_size, self.kv_size, sh.intermediate_size

@@ -242,6 +242,61 @@ int hx_decode_attention_fused(const hx_attn_args* args, const hx_fused_decode_ar
                               hx_stream stream);
 
 /* ------------------------------------------------------------------------
+ * Extension: the dense part of ONE decoder layer of a decode step as one launch
+ * (hydrainfer/model/model_forward.py:84-105 for this layer + the qkv projection :72-77 of the
+ * next one), M <= 32 rows:
+ *   a = attn_out @ w_o^T;            h_mid = h_in + a;      x_post = rms_norm(h_mid) * norm_post
+ *   gu = x_post @ w_gate_up^T;       act = silu(gu[:, :inter]) * gu[:, inter:]
+ *   d = act @ w_down^T;              h_out = h_mid + d;     x_next = rms_norm(h_out) * norm_next
+ *   qkv_partial[s] = split-K slabs of x_next @ w_qkv_next^T   (skipped when qkv_n == 0)
+ * Same rounding points as hx_linear_decode_partial + hx_add_rms_norm_slabs +
+ * hx_silu_and_mul_slabs run one after the other: bit-identical results.  The phases are work
+ * items of one grid handed out by atomic ticket; `sync` is HX_CHAIN_SYNC_WORDS zeroed uint32
+ * words per launch (the caller zeroes them on the same stream before the launch); word
+ * HX_CHAIN_SYNC_ERR is non-zero afterwards if a dependency wait timed out (results invalid).
+ * h_in, h_mid, h_out, x_post, x_next, act and attn_out must be distinct buffers.
+ * Returns the number of qkv slabs (>= 0) or a negative hx_status.
+ * ---------------------------------------------------------------------- */
+#define HX_CHAIN_SYNC_WORDS 512
+#define HX_CHAIN_SYNC_ERR 480
+typedef struct hx_chain_args {
+  int32_t M;
+  int32_t hidden;
+  int32_t inter;
+  int32_t q_size;            /* n_heads * head_dim = K of the o projection */
+  int32_t qkv_n;             /* rows of w_qkv_next, 0 = no next layer */
+  int32_t dtype;             /* HX_F16 | HX_BF16 */
+  float eps;
+  int32_t reserved;
+  const void* attn_out;      /* [M, q_size], row stride attn_out_stride elements */
+  int64_t attn_out_stride;
+  const void* h_in;          /* [M, hidden] residual stream entering the layer's o projection */
+  const void* w_o;           /* [hidden, q_size] */
+  const void* w_gate_up;     /* [2*inter, hidden] */
+  const void* w_down;        /* [hidden, inter] */
+  const void* w_qkv_next;    /* [qkv_n, hidden] or NULL */
+  int64_t ld_o;
+  int64_t ld_gate_up;
+  int64_t ld_down;
+  int64_t ld_qkv;
+  const void* norm_post_weight;  /* [hidden] post-attention RMSNorm */
+  const void* norm_next_weight;  /* [hidden] next layer's input RMSNorm (or the final norm) */
+  void* h_mid;               /* [M, hidden] out */
+  void* h_out;               /* [M, hidden] out: residual stream leaving the layer */
+  void* x_post;              /* [M, hidden] out */
+  void* act;                 /* [M, inter] out */
+  void* x_next;              /* [M, hidden] out */
+  float* qkv_partial;        /* [splits][M][qkv_n] fp32 out, as hx_linear_decode_partial */
+  int64_t qkv_partial_bytes;
+  void* workspace;           /* >= hx_decode_chain_workspace_bytes(...) */
+  int64_t workspace_bytes;
+  uint32_t* sync;            /* HX_CHAIN_SYNC_WORDS zeroed words */
+} hx_chain_args;
+
+int64_t hx_decode_chain_workspace_bytes(int64_t M, int64_t hidden, int64_t inter, int64_t q_size);
+int hx_decode_chain(const hx_chain_args* args, hx_stream stream);
+
+/* ------------------------------------------------------------------------
  * Cache-block migration between GPUs / processes.
  * replaces: csrc/data_transfer/block_migration.cpp:55-59 (get_ipc_mem_handle),
  *           :69-80 (register_ipc_mem_handle), :194-245 (migrate_blocks)
