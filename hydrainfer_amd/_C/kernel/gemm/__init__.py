@@ -124,3 +124,34 @@ def decode_chain(attn_out: Tensor, h_in: Tensor, w_o: Tensor, w_gate_up: Tensor,
     if rc < 0:
         _lib.check(rc, "decode_chain")
     return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# packed weights (csrc/gemm_skinny.hip: gemm_packed_kernel)
+# ------------------------------------------------------------------------------------------------
+def pack_weight(weight: Tensor) -> Tensor:
+    """weight [N, K] -> flat [N*K] in MFMA-fragment order (hx_pack_decode_weight)."""
+    _lib.require_gpu(weight)
+    N, K = weight.shape
+    if weight.dtype not in (torch.float16, torch.bfloat16) or N % 16 or K % 256 or weight.stride(1) != 1:
+        raise _lib.HydraHipError("pack_weight: fp16/bf16 [N % 16 == 0, K % 256 == 0], contiguous rows")
+    packed = torch.empty(N * K, dtype=weight.dtype, device=weight.device)
+    _lib.check(_lib.lib().hx_pack_decode_weight(packed.data_ptr(), weight.data_ptr(), N, K, weight.stride(0),
+                                                _lib.dtype_code(weight), _lib.current_stream()), "pack_weight")
+    return packed
+
+
+def linear_decode_partial_packed(x: Tensor, packed: Tensor, N: int, partial: Tensor) -> int:
+    """As linear_decode_partial with `packed` = pack_weight(weight [N, K])."""
+    _lib.require_gpu(x, packed, partial)
+    M, K = x.shape
+    if packed.numel() != N * K or packed.dtype != x.dtype or not packed.is_contiguous() or x.stride(1) != 1:
+        raise _lib.HydraHipError("linear_decode_partial_packed: packed must be pack_weight(weight [N, K]) of x's dtype")
+    if partial.dtype != torch.float32 or not partial.is_contiguous():
+        raise _lib.HydraHipError("linear_decode_partial_packed: partial must be contiguous float32")
+    rc = _lib.lib().hx_linear_decode_partial_packed(partial.data_ptr(), x.data_ptr(), packed.data_ptr(), M, N, K,
+                                                    x.stride(0), partial.numel() * 4, _lib.dtype_code(x),
+                                                    _lib.current_stream())
+    if rc < 0:
+        _lib.check(rc, "linear_decode_partial_packed")
+    return rc

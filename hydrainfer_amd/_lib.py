@@ -64,7 +64,7 @@ class hx_chain_args(ctypes.Structure):
     ]
 
 
-HX_CHAIN_SYNC_WORDS, HX_CHAIN_SYNC_ERR = 512, 480
+HX_CHAIN_SYNC_WORDS, HX_CHAIN_SYNC_ERR = 18432, 480
 
 _SIGNATURES = {
     "hx_abi_version": (c_int, []),
@@ -82,8 +82,11 @@ _SIGNATURES = {
     "hx_linear_decode_workspace_bytes": (c_int64, [c_int64] * 3),
     "hx_linear_decode": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_void_p, c_int64, c_int, c_void_p]),
     "hx_linear_decode_partial": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_int, c_void_p]),
+    "hx_debug_stream_read": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hx_decode_chain_workspace_bytes": (c_int64, [c_int64] * 4),
     "hx_decode_chain": (c_int, [POINTER(hx_chain_args), c_void_p]),
+    "hx_pack_decode_weight": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "hx_linear_decode_partial_packed": (c_int, [c_void_p] * 3 + [c_int64] * 5 + [c_int, c_void_p]),
     "hx_add_rms_norm_slabs": (c_int, [c_void_p] * 3 + [c_int32, c_void_p, c_float, c_int64, c_int64, c_int, c_void_p]),
     "hx_silu_and_mul_slabs": (c_int, [c_void_p] * 2 + [c_int32, c_int64, c_int64, c_int, c_void_p]),
     "hx_mha_varlen_fwd_workspace_bytes": (c_int64, [POINTER(hx_attn_args)]),

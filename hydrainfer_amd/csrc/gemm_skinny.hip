@@ -35,6 +35,7 @@ struct GemmParams {
   int32_t M, N, K;
   int32_t ks_per_split;  // k-steps (of 32) per split, multiple of 8
   int32_t n_splits;
+  int32_t packed;        // w is in fragment order (hx_pack_decode_weight)
 };
 
 constexpr int kChunk = 16;       // k-steps per register buffer (16 KiB of W per wave)
@@ -162,6 +163,128 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
   }
 }
 
+// The same product with the weights PACKED in MFMA-fragment order (hx_pack_decode_weight): the
+// 1 KiB block (row group rg, k-step s) holds, at lane (r = l & 15, g = l >> 4), the 16 bytes
+// W[16 rg + r][32 s + 8 g .. + 8] — exactly one A operand.  A wave reads its (row group, split) as
+// ONE contiguous 32 KiB run, 1 KiB per instruction, straight into the MFMA operand registers: no
+// transpose through LDS, and the access shape that streams fastest on this GPU
+// (tools/bench_stream.py: contiguous 1 KiB per wave instruction 6.6-6.8 TB/s non-temporal at any
+// occupancy, 8 rows x 128 B 4.6-6.2 TB/s depending on the waves per CU).  Same k order, same
+// accumulation chains: bit-identical to gemm_skinny_kernel.
+template <typename T, int MB, int R, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p, const int g_nt_store) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kThreads = NW * 64;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int split = blockIdx.y;
+  const int total_ks = p.K >> 5;
+  const int ks0 = split * p.ks_per_split;
+  const int nks = min(p.ks_per_split, total_ks - ks0);
+  const int KR = nks << 5;
+  const int n_rg_all = p.N >> 4;
+  const int rg0 = blockIdx.x * (NW * R) + w;
+
+  constexpr int kCpr = kMaxKs * 4;
+  constexpr int XPT = MB * 16 * kCpr / kThreads;
+  u16x8 xr[XPT];
+  {
+    const u16* xb = reinterpret_cast<const u16*>(p.x) + (int64_t)ks0 * 32;
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+      const int i = threadIdx.x + j * kThreads;
+      const int row = i / kCpr, ch = i % kCpr;
+      const bool ok = row < p.M && ch * 8 < KR;
+      xr[j] = *reinterpret_cast<const u16x8*>(xb + (int64_t)(ok ? row : 0) * p.ldx + (ok ? ch * 8 : 0));
+    }
+  }
+  // the fragments of (split, rg) are one run of nks KiB at KiB offset ks0 * n_rg + rg * nks: the
+  // row groups of a split are adjacent, so the waves of a launch sweep consecutive memory (a
+  // layout with each row group's whole K contiguous puts concurrent waves 128 KiB apart — all on
+  // the same channels: measured 2x slower).  k-steps past the split's range re-read its last one
+  // (x is zero there)
+  const u16* wb = reinterpret_cast<const u16*>(p.w) + 8 * lane;
+  auto load = [&](u16x8 (&buf)[kChunk], int it) {
+    const int rgi = it >> 1, ch = it & 1;
+    const int rg = min(rg0 + rgi * NW, n_rg_all - 1);
+    const u16* wp = wb + ((int64_t)ks0 * n_rg_all + (int64_t)rg * nks) * 512;
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+      const int s = min(ch * kChunk + j, nks - 1);
+      buf[j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(wp + (int64_t)s * 512));
+    }
+  };
+  u16x8 buf[2][kChunk];
+  load(buf[0], 0);
+  load(buf[1], 1);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < XPT; ++j) {
+    const int i = threadIdx.x + j * kThreads;
+    const int row = i / kCpr, ch = i % kCpr;
+    const bool ok = row < p.M && ch * 8 < KR;
+    *reinterpret_cast<u16x8*>(smem + row * kRS + ch * 16) = ok ? xr[j] : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  __syncthreads();
+
+  const char* xl = smem + c * kRS + g * 16;
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 2 * R; ++it) {
+    const int rgi = it >> 1, ch = it & 1;
+    const char* xp = xl + ch * (kChunk * 64);
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const u16x8 xf = *reinterpret_cast<const u16x8*>(xp + mb * 16 * kRS + j * 64);
+        acc[mb] = Mfma<T>::mma(buf[it & 1][j], xf, acc[mb]);
+      }
+    }
+    // pin the refill behind this chunk's MFMAs: left to itself the scheduler hoists the next
+    // loads above them (new registers for every in-flight fragment) and spills
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 2 < 2 * R) load(buf[it & 1], it + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ch == 1) {
+      const int rg = rg0 + rgi * NW;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int m = mb * 16 + c;
+        if (m < p.M && rg < n_rg_all) {
+          f32x4* dst = reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g);
+          if (g_nt_store) __builtin_nontemporal_store(acc[mb], dst);
+          else *dst = acc[mb];
+        }
+        acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+}
+
+// fragment (rg, s) of split = s / kMaxKs lives at KiB index ks0 * n_rg + rg * nks + (s - ks0)
+// (ks0 = split * kMaxKs, nks = k-steps of that split); inside it lane l holds
+// W[16 rg + (l & 15)][32 s + 8 (l >> 4) .. + 8]
+__global__ __launch_bounds__(256) void pack_weight_kernel(u16* __restrict__ packed, const u16* __restrict__ w,
+                                                          int64_t n_pieces, int total_ks, int n_rg, int64_t ldw) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // 16-byte piece index of the OUTPUT
+  if (i >= n_pieces) return;
+  const int lane = (int)(i & 63);
+  const int64_t blk = i >> 6;                                   // KiB index
+  const int64_t per_split = (int64_t)kMaxKs * n_rg;
+  const int split = (int)(blk / per_split);
+  const int ks0 = split * kMaxKs;
+  const int nks = min(kMaxKs, total_ks - ks0);
+  const int64_t rem = blk - (int64_t)ks0 * n_rg;
+  const int64_t rg = rem / nks;
+  const int s = ks0 + (int)(rem % nks);
+  const u16* src = w + (16 * rg + (lane & 15)) * ldw + 32 * s + 8 * (lane >> 4);
+  *reinterpret_cast<u16x8*>(packed + i * 8) = *reinterpret_cast<const u16x8*>(src);
+}
+
 // out[m][n] = (T) sum_s partial[s][m][n]   (fixed summation order)
 template <typename T>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial,
@@ -204,9 +327,19 @@ int gemm_skinny_splits(int64_t K) {
 
 template <typename T, int MB, int R, int NW>
 int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)MB * 16 * kRS + (size_t)NW * 2048;   // x slice + per-wave transpose images
   const int n_rg = p.N >> 4;
   dim3 grid((unsigned)((n_rg + NW * R - 1) / (NW * R)), (unsigned)p.n_splits);
+  if (p.packed) {
+    const size_t plds = (size_t)MB * 16 * kRS;   // x slice only
+    if (plds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_packed_kernel<T, MB, R, NW>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+      if (e != hipSuccess) return hip_rc(e);
+    }
+    gemm_packed_kernel<T, MB, R, NW><<<grid, NW * 64, plds, stream>>>(p, g_slab_nt);
+    return check_launch();
+  }
+  const size_t lds = (size_t)MB * 16 * kRS + (size_t)NW * 2048;   // x slice + per-wave transpose images
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<T, MB, R, NW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -275,7 +408,7 @@ int launch_gemm_mb(const GemmParams& p, hipStream_t stream) {
 
 // partial must hold splits*M*N floats
 int launch_gemm_skinny(const void* x, const void* w, float* partial, int64_t M, int64_t N,
-                       int64_t K, int64_t ldx, int64_t ldw, int dtype, hipStream_t stream) {
+                       int64_t K, int64_t ldx, int64_t ldw, int dtype, hipStream_t stream, int packed = 0) {
   if (!gemm_skinny_supported(M, N, K, ldx, ldw)) return HX_ERR_SHAPE;
   if (!aligned16(x) || !aligned16(w) || !aligned16(partial)) return HX_ERR_STRIDE;
   GemmParams p;
@@ -283,6 +416,7 @@ int launch_gemm_skinny(const void* x, const void* w, float* partial, int64_t M, 
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.ks_per_split = kMaxKs;
   p.n_splits = gemm_skinny_splits(K);
+  p.packed = packed;
   const int MB = (int)((M + 15) / 16);
   if (dtype == HX_F16) {
     if (MB == 1) return launch_gemm_mb<F16, 1>(p, stream);
@@ -344,6 +478,31 @@ extern "C" int hx_linear_decode_partial(float* partial, const void* x, const voi
   if (!gemm_skinny_supported(M, N, K, ldx, ldw)) return HX_ERR_SHAPE;
   if (partial_bytes < hx_linear_decode_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
   int rc = launch_gemm_skinny(x, weight, partial, M, N, K, ldx, ldw, dtype, (hipStream_t)stream);
+  if (rc) return rc;
+  return gemm_skinny_splits(K);
+}
+
+// ---- packed weights ----------------------------------------------------------------------------
+extern "C" int hx_pack_decode_weight(void* packed, const void* weight, int64_t N, int64_t K, int64_t ldw,
+                                     int dtype, hx_stream stream) {
+  if (!packed || !weight) return HX_ERR_NULL;
+  if (N <= 0 || K <= 0 || N % 16 || K % 32 || ldw % 8) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (!aligned16(packed) || !aligned16(weight)) return HX_ERR_STRIDE;
+  const int64_t n_pieces = N * K / 8;
+  pack_weight_kernel<<<(unsigned)((n_pieces + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      (u16*)packed, (const u16*)weight, n_pieces, (int)(K >> 5), (int)(N >> 4), ldw);
+  return check_launch();
+}
+
+extern "C" int hx_linear_decode_partial_packed(float* partial, const void* x, const void* packed_weight,
+                                               int64_t M, int64_t N, int64_t K, int64_t ldx,
+                                               int64_t partial_bytes, int dtype, hx_stream stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return HX_ERR_SHAPE;
+  if (!partial || !x || !packed_weight) return HX_ERR_NULL;
+  if (!gemm_skinny_supported(M, N, K, ldx, K)) return HX_ERR_SHAPE;
+  if (partial_bytes < hx_linear_decode_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
+  int rc = launch_gemm_skinny(x, packed_weight, partial, M, N, K, ldx, K, dtype, (hipStream_t)stream, 1);
   if (rc) return rc;
   return gemm_skinny_splits(K);
 }

@@ -153,6 +153,18 @@ int hx_linear_decode(void* out, const void* x, const void* weight, int64_t M, in
 int hx_linear_decode_partial(float* partial, const void* x, const void* weight, int64_t M,
                              int64_t N, int64_t K, int64_t ldx, int64_t ldw,
                              int64_t partial_bytes, int dtype, hx_stream stream);
+/* The same GEMM on weights PACKED for streaming: hx_pack_decode_weight copies weight [N, K] (row
+ * stride ldw elements) into packed [N*K], where the 1 KiB block (n/16, k/32) holds at lane
+ * l = (r = l & 15, g = l >> 4) the 8 elements weight[16*(n/16) + r][32*(k/32) + 8g .. + 8] — the
+ * MFMA A operand of that (row group, k-step) — and the blocks are ordered [K split of 1024][row
+ * group][k-step in split].  The kernel then reads each (row group, K split) as one contiguous run,
+ * adjacent to its neighbours' (the fastest read shape on MI355X, tools/bench_stream.py), and needs
+ * no transpose.  Results are bit-identical to hx_linear_decode_partial.  N % 16 == 0, K % 256 == 0. */
+int hx_pack_decode_weight(void* packed, const void* weight, int64_t N, int64_t K, int64_t ldw,
+                          int dtype, hx_stream stream);
+int hx_linear_decode_partial_packed(float* partial, const void* x, const void* packed_weight,
+                                    int64_t M, int64_t N, int64_t K, int64_t ldx,
+                                    int64_t partial_bytes, int dtype, hx_stream stream);
 /* Slab consumers: sum the n_splits slabs in order, round once to T (the projection's output
  * rounding), then behave exactly like hx_add_rms_norm / hx_silu_and_mul on that tensor.
  * partial: [n_splits][rows][hidden] resp. [n_splits][rows][2*inter] (gate | up columns). */
@@ -257,7 +269,7 @@ int hx_decode_attention_fused(const hx_attn_args* args, const hx_fused_decode_ar
  * h_in, h_mid, h_out, x_post, x_next, act and attn_out must be distinct buffers.
  * Returns the number of qkv slabs (>= 0) or a negative hx_status.
  * ---------------------------------------------------------------------- */
-#define HX_CHAIN_SYNC_WORDS 512
+#define HX_CHAIN_SYNC_WORDS 18432
 #define HX_CHAIN_SYNC_ERR 480
 typedef struct hx_chain_args {
   int32_t M;
@@ -295,6 +307,14 @@ typedef struct hx_chain_args {
 
 int64_t hx_decode_chain_workspace_bytes(int64_t M, int64_t hidden, int64_t inter, int64_t q_size);
 int hx_decode_chain(const hx_chain_args* args, hx_stream stream);
+
+/* Debug / tooling (not on the product path): read-streaming microbenchmark used by
+ * tools/bench_stream.py to choose load shapes.  variant 0: contiguous 1 KiB per wave instruction;
+ * 1..4: 8x128 B, 4x256 B, 2x512 B, 1x1024 B (rows x bytes per instruction) of a row-major matrix
+ * with row pitch `pitch` bytes.  unroll = loads in flight per wave (4, 8, 16, 32); policy 1 =
+ * non-temporal loads.  Reads `bytes` bytes once. */
+int hx_debug_stream_read(const void* p, int64_t bytes, int variant, int64_t pitch, int unroll,
+                         int policy, int wgs, float* sink, hx_stream stream);
 
 /* ------------------------------------------------------------------------
  * Cache-block migration between GPUs / processes.

@@ -103,7 +103,7 @@ def test_chain_equals_separate_launches(shape, M, dt):
     _check(got, want, f"{shape} M={M} {dt}")
 
 
-@pytest.mark.parametrize("r", ["1,1,1,1", "2,3,2,2", "3,2,3,1"])
+@pytest.mark.parametrize("r", ["1,1,1,1", "2,4,2,2", "4,2,4,1"])
 def test_chain_item_sizes_do_not_change_results(r):
     """row groups per wave (the work-item size of each GEMM phase) is a tuning knob only."""
     from hydrainfer_amd import _lib

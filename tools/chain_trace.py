@@ -41,11 +41,12 @@ t0 = tr[:, 0].min()
 tick = (tr[:, 0] - t0) / 100.0
 ready = np.where(tr[:, 1] > 0, (tr[:, 1] - t0) / 100.0, tick)
 end = (tr[:, 2] - t0) / 100.0
-ph = tr[:, 3] & 0xFF
-names = ["o", "norm1", "gu", "silu", "down", "norm2", "qkv"]
+ph = tr[:, 3] & 0xF
+ph = np.where((ph == 1) & (((tr[:, 3] >> 4) & 15) == 1), 6, ph)   # second norm
+names = ["o", "norm1", "gu", "silu", "down", "qkv", "norm2"]
 print(f"{model} M={M}: {n} items, launch span {end.max():.1f} us, R={os.environ.get('HX_CHAIN_R', 'default')}")
 print("phase  items  first_ticket  last_ticket  first_ready  last_ready  first_end  last_end  med_run(ready->end)  med_wait(ticket->ready)")
-for p in range(7):
+for p in (0, 1, 2, 3, 4, 6, 5):
     m = ph == p
     if not m.any():
         continue
@@ -56,3 +57,13 @@ for p in range(7):
 order = np.sort(tick)
 print("tickets handed out by time (us):", " ".join(f"{int((order <= t).sum())}@{t}" for t in (1, 2, 4, 8, 16, 32, 64, 96, 128)))
 print("xcc histogram:", np.bincount(((tr[:, 3] >> 8) & 15).astype(int), minlength=8))
+if os.environ.get("HX_TRACE_DUMP"):
+    k = int(os.environ["HX_TRACE_DUMP"])
+    print("ticket kind start ready end  (every %d-th item)" % k)
+    for t in range(0, n, k):
+        print(f"{t:5d} {names[int(ph[t])]:6s} {tick[t]:8.2f} {ready[t]:8.2f} {end[t]:8.2f}   wait {ready[t]-tick[t]:6.2f} run {end[t]-ready[t]:6.2f}")
+    # streaming concurrency: number of GEMM items between ready and end, per 4 us bin
+    bins = np.arange(0, end.max() + 4, 4)
+    gem = np.isin(ph, (0, 2, 4, 5))
+    act = [(int(((ready[gem] <= b + 2) & (end[gem] > b + 2)).sum())) for b in bins]
+    print("running GEMM items per 4-us bin:", " ".join(f"{int(b)}:{a}" for b, a in zip(bins, act)))
