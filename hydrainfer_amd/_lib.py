@@ -56,7 +56,6 @@ class hx_chain_args(ctypes.Structure):
         ("qkv_n", c_int32), ("dtype", c_int32), ("eps", c_float), ("reserved", c_int32),
         ("attn_out", c_void_p), ("attn_out_stride", c_int64), ("h_in", c_void_p),
         ("w_o", c_void_p), ("w_gate_up", c_void_p), ("w_down", c_void_p), ("w_qkv_next", c_void_p),
-        ("ld_o", c_int64), ("ld_gate_up", c_int64), ("ld_down", c_int64), ("ld_qkv", c_int64),
         ("norm_post_weight", c_void_p), ("norm_next_weight", c_void_p),
         ("h_mid", c_void_p), ("h_out", c_void_p), ("x_post", c_void_p), ("act", c_void_p),
         ("x_next", c_void_p), ("qkv_partial", c_void_p), ("qkv_partial_bytes", c_int64),

@@ -49,7 +49,7 @@ constexpr int kChunk = 16;              // k-steps (of 32) per register buffer: 
 constexpr int kMaxKs = 32;              // k-steps per split (1024 k)
 constexpr int kRS = kMaxKs * 64 + 32;   // LDS row stride of the x slice, bytes
 constexpr int kXBytes = 32 * kRS;       // x slice, two 16-row blocks
-constexpr int kLdsBytes = kXBytes + kNW * 2048 + 64;   // + transpose images + ticket / reduction words
+constexpr int kLdsBytes = kXBytes + 64;   // + ticket / reduction words
 
 // item kinds; a SEGMENT is a run of consecutive tickets of one kind (and one slice)
 enum { K_GEMM_O = 0, K_NORM, K_GEMM_GU, K_SILU, K_GEMM_DOWN, K_GEMM_QKV };
@@ -204,7 +204,7 @@ __device__ __forceinline__ void gemm_item(const CParams& p, const Desc& gp, int 
   constexpr int MB = 2;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 15, g = lane >> 4, c = lane & 15;
+  const int g = lane >> 4, c = lane & 15;
   const int total_ks = gp.K >> 5;
   const int ks0 = split * kMaxKs;
   const int nks = min(kMaxKs, total_ks - ks0);   // multiple of 8
@@ -218,20 +218,21 @@ __device__ __forceinline__ void gemm_item(const CParams& p, const Desc& gp, int 
   uint32_t first = 0;
   if (handoff && w == 0) first = load_word(my_flags(p.sync), wait_word);
 
-  // 1. W prefetch (independent of every activation).  Load layout: instruction j of a chunk covers
-  // rows 8*(j&1) + (lane>>3) and the 128-byte column block j>>1; lane&7 selects the 16-byte piece.
-  const int lrow = lane >> 3, lpiece = lane & 7;
-  const u16* wb = gp.w + (int64_t)ks0 * 32 + 8 * lpiece;
+  // 1. W prefetch (independent of every activation).  Packed weights (hx_pack_decode_weight): the
+  // fragments of (split, rg) are one run of nks KiB at KiB offset ks0 * n_rg + rg * nks; lane l's
+  // 16 bytes of a fragment are the MFMA A operand itself
+  // buffer loads: the 1 KiB fragment address is wave-uniform (scalar offset), the lane adds 16 l —
+  // no per-lane 64-bit pointers to keep alive across the MFMA loop
+  const rsrc_t wrs = make_rsrc(gp.w);
+  const uint32_t lane_off = lane * 16;
   auto load = [&](u16x8 (&buf)[kChunk], int it) {
     const int rgi = it >> 1, ch = it & 1;
-    const int n0 = min(rg0 + rgi * kNW, rg_limit - 1) << 4;
-    const int last_cb = ((nks - ch * kChunk) >> 1) - 1;
-    const u16* wp = wb + (int64_t)(n0 + lrow) * gp.ldw + ch * (kChunk * 32);
+    const int rg = min(rg0 + rgi * kNW, rg_limit - 1);
+    const uint32_t base = (uint32_t)(ks0 * n_rg_all + rg * nks) * 1024u;
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
-      const int cb = max(min(j >> 1, last_cb), -ch * (kChunk / 2));
-      buf[j] = __builtin_nontemporal_load(
-          reinterpret_cast<const u16x8*>(wp + (int64_t)(8 * (j & 1)) * gp.ldw + 64 * cb));
+      const int s = min(ch * kChunk + j, nks - 1);
+      buf[j] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_off, base + s * 1024u, 2));
     }
   };
   u16x8 buf[2][kChunk];
@@ -272,10 +273,7 @@ __device__ __forceinline__ void gemm_item(const CParams& p, const Desc& gp, int 
   }
   __syncthreads();
 
-  // 4. stream W through the wave-private transpose image into MFMA A fragments
-  char* tl = smem + kXBytes + w * 2048;
-  const int wr_off0 = lrow * 128 + 16 * (lpiece ^ ((lrow >> 1) & 7));
-  const int wr_off1 = (lrow + 8) * 128 + 16 * (lpiece ^ (((lrow + 8) >> 1) & 7));
+  // 4. the fragments are the A operands; B = x^T fragments from LDS
   const char* xl = smem + c * kRS + g * 16;
   f32x4 acc[MB];
 #pragma unroll
@@ -287,22 +285,16 @@ __device__ __forceinline__ void gemm_item(const CParams& p, const Desc& gp, int 
     const int rgi = it >> 1, ch = it & 1;
     const char* xp = xl + ch * (kChunk * 64);
 #pragma unroll
-    for (int cb = 0; cb < kChunk / 2; ++cb) {
-      *reinterpret_cast<u16x8*>(tl + wr_off0) = buf[it & 1][2 * cb];
-      *reinterpret_cast<u16x8*>(tl + wr_off1) = buf[it & 1][2 * cb + 1];
-      __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < kChunk; ++j) {
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const u16x8 af = *reinterpret_cast<const u16x8*>(tl + r * 128 + 16 * ((4 * st + g) ^ ((r >> 1) & 7)));
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const u16x8 xf = *reinterpret_cast<const u16x8*>(xp + mb * 16 * kRS + (2 * cb + st) * 64);
-          acc[mb] = Mfma<T>::mma(af, xf, acc[mb]);
-        }
+      for (int mb = 0; mb < MB; ++mb) {
+        const u16x8 xf = *reinterpret_cast<const u16x8*>(xp + mb * 16 * kRS + j * 64);
+        acc[mb] = Mfma<T>::mma(buf[it & 1][j], xf, acc[mb]);
       }
-      __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_sched_barrier(0);   // keep the refill behind this chunk's MFMAs (register pressure)
     if (it + 2 < 2 * R) load(buf[it & 1], it + 2);
+    __builtin_amdgcn_sched_barrier(0);
     if (ch == 1) {
       const int rg = rg0 + rgi * kNW;
       if (rg < rg_limit) {
@@ -366,7 +358,7 @@ __device__ __forceinline__ void tile_sum8(rsrc_t rs, int n_splits, int n_rg, int
 template <typename T, int MAXV>
 __device__ __forceinline__ void norm_item(const CParams& p, const Desc& np, int row, int wait_word,
                                           char* smem, int tid, unsigned long long* tr) {
-  float* red = reinterpret_cast<float*>(smem + kXBytes + kNW * 2048 + 16);   // 8 floats
+  float* red = reinterpret_cast<float*>(smem + kXBytes + 16);   // 8 floats
   uint32_t first = 0;
   if (tid < 64) first = load_word(my_flags(p.sync), wait_word);
   wait_flag(p.sync, wait_word, first, tid, tr);
@@ -458,7 +450,7 @@ __device__ __forceinline__ void silu_item(const CParams& p, const Desc& sp, int 
 template <typename T>
 __global__ __launch_bounds__(kThreads, 2) void decode_chain_kernel(const CParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* s_next = reinterpret_cast<int*>(smem + kXBytes + kNW * 2048);
+  int* s_next = reinterpret_cast<int*>(smem + kXBytes);
   if (threadIdx.x == 0)
     *s_next = (int)__hip_atomic_fetch_add(p.sync + L_TICKET * SY_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
@@ -577,8 +569,7 @@ extern "C" int hx_decode_chain(const hx_chain_args* a, hx_stream stream) {
     return HX_ERR_WORKSPACE;
   if (a->qkv_n && a->qkv_partial_bytes < (int64_t)chain_splits(a->hidden) * a->M * a->qkv_n * (int64_t)sizeof(float))
     return HX_ERR_WORKSPACE;
-  if (a->attn_out_stride % 8 || a->ld_o % 8 || a->ld_gate_up % 8 || a->ld_down % 8 || (a->qkv_n && a->ld_qkv % 8))
-    return HX_ERR_STRIDE;
+  if (a->attn_out_stride % 8) return HX_ERR_STRIDE;
   const void* ptrs[] = {a->attn_out, a->h_in, a->w_o, a->w_gate_up, a->w_down, a->w_qkv_next, a->norm_post_weight,
                         a->norm_next_weight, a->h_mid, a->h_out, a->x_post, a->act, a->x_next, a->qkv_partial,
                         a->workspace};
@@ -606,19 +597,18 @@ extern "C" int hx_decode_chain(const hx_chain_args* a, hx_stream stream) {
   float* slabs_o = ws;
   float* slabs_gu = slabs_o + (int64_t)chain_splits(a->q_size) * p.Mpad * a->hidden;
   float* slabs_dn = slabs_gu + (int64_t)chain_splits(a->hidden) * p.Mpad * 2 * a->inter;
-  auto gemm = [&](int di, int ri, const void* w, int64_t ldw, const void* x, int64_t ldx, float* partial, int N, int K,
-                  int tiled) {
+  auto gemm = [&](int di, int ri, const void* w, const void* x, int64_t ldx, float* partial, int N, int K, int tiled) {
     Desc& g = p.desc[di];
-    g.w = (const u16*)w; g.x = (const u16*)x; g.partial = partial; g.ldw = ldw; g.ldx = ldx;
+    g.w = (const u16*)w; g.x = (const u16*)x; g.partial = partial; g.ldw = K; g.ldx = ldx;
     g.N = N; g.K = K; g.n_splits = chain_splits(K); g.R = g_chain_r[ri];
     g.gx = ((N >> 4) + kNW * g.R - 1) / (kNW * g.R);
     g.tiled = tiled;
     return N ? g.gx * g.n_splits : 0;
   };
-  const int items_o = gemm(D_O, 0, a->w_o, a->ld_o, a->attn_out, a->attn_out_stride, slabs_o, a->hidden, a->q_size, 1);
-  gemm(D_GU, 1, a->w_gate_up, a->ld_gate_up, a->x_post, a->hidden, slabs_gu, 2 * a->inter, a->hidden, 1);
-  const int items_dn = gemm(D_DOWN, 2, a->w_down, a->ld_down, a->act, a->inter, slabs_dn, a->hidden, a->inter, 1);
-  const int items_qkv = gemm(D_QKV, 3, a->w_qkv_next, a->ld_qkv, a->x_next, a->hidden, a->qkv_partial, a->qkv_n, a->hidden, 0);
+  const int items_o = gemm(D_O, 0, a->w_o, a->attn_out, a->attn_out_stride, slabs_o, a->hidden, a->q_size, 1);
+  gemm(D_GU, 1, a->w_gate_up, a->x_post, a->hidden, slabs_gu, 2 * a->inter, a->hidden, 1);
+  const int items_dn = gemm(D_DOWN, 2, a->w_down, a->act, a->inter, slabs_dn, a->hidden, a->inter, 1);
+  const int items_qkv = gemm(D_QKV, 3, a->w_qkv_next, a->x_next, a->hidden, a->qkv_partial, a->qkv_n, a->hidden, 0);
   auto norm = [&](int di, float* slabs, int n_splits, const void* res_in, void* res_out, void* x_out, const void* weight,
                   int handoff) {
     Desc& n = p.desc[di];

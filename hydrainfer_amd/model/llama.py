@@ -85,7 +85,33 @@ class LlamaForCausalLM:
         # norms, gate|up GEMM, silu*mul, down GEMM, the next layer's qkv GEMM) is ONE launch
         # (csrc/decode_chain.hip) — 2 launches per layer instead of 8, bit-identical results
         self.use_chain = False   # enabled once the chain launch beats the separate launches
+        # decode GEMMs stream PACKED copies of the weights (MFMA-fragment order, contiguous 1 KiB
+        # reads: csrc/gemm_skinny.hip gemm_packed_kernel); the row-major tensors stay for the
+        # prefill GEMMs (library).  288 GB of HBM: the second copy of a 7B / 13B model is 13 / 26 GB.
+        self.use_packed = True
+        self.packed: Dict[str, Tensor] = {}
         self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
+
+    def pack_decode_weights(self) -> None:
+        """Builds the packed copies of every decoder-layer weight (once; not during graph capture)."""
+        if not (self.use_packed and self.use_hip_gemm and self.dtype in (torch.float16, torch.bfloat16)):
+            return
+        for l in range(self.shape.num_hidden_layers):
+            for n in ("wqkv", "wo", "wgu", "wdown"):
+                key = f"l{l}.{n}"
+                w = self.state[key]
+                if key not in self.packed and w.shape[0] % 16 == 0 and w.shape[1] % 256 == 0 and w.stride(1) == 1:
+                    self.packed[key] = hip_gemm.pack_weight(w)
+
+    def _partial(self, x: Tensor, key: str, ws: Tensor) -> int:
+        """split-K slabs of x @ state[key]^T into ws; packed weights when available."""
+        pk = self.packed.get(key)
+        if pk is None and self.use_packed and not torch.cuda.is_current_stream_capturing():
+            self.pack_decode_weights()
+            pk = self.packed.get(key)
+        if pk is not None:
+            return hip_gemm.linear_decode_partial_packed(x, pk, self.state[key].shape[0], ws)
+        return hip_gemm.linear_decode_partial(x, self.state[key], ws)
 
     def linear(self, x: Tensor, w: Tensor) -> Tensor:
         if self.use_hip_gemm and x.shape[0] <= 64 and hip_gemm.supported(x, w):
@@ -183,17 +209,17 @@ class LlamaForCausalLM:
         for l in range(L):
             ap = model_params.attention_params[l]
             kc, vc = ap.kv_cache.get_kv_cache()
-            s_qkv = hip_gemm.linear_decode_partial(x, st[f"l{l}.wqkv"], ws)
+            s_qkv = self._partial(x, f"l{l}.wqkv", ws)
             o = torch.empty((n, H, D), dtype=h.dtype, device=h.device)
             # q / k_new / v_new arguments are shape carriers here: the kernel reads the slabs
             decode_attention_fused(o, o, o[:, :HK], o[:, :HK], kc, vc, position_ids, self.cos_sin,
                                    ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
                                    ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws, s_qkv)
-            s_o = hip_gemm.linear_decode_partial(o.view(n, q_size), st[f"l{l}.wo"], ws)
+            s_o = self._partial(o.view(n, q_size), f"l{l}.wo", ws)
             add_rms_norm_slabs(x, h, ws, s_o, st[f"l{l}.norm2"], eps)
-            s_gu = hip_gemm.linear_decode_partial(x, st[f"l{l}.wgu"], ws)
+            s_gu = self._partial(x, f"l{l}.wgu", ws)
             act = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype)
-            s_dn = hip_gemm.linear_decode_partial(act, st[f"l{l}.wdown"], ws)
+            s_dn = self._partial(act, f"l{l}.wdown", ws)
             nxt = st[f"l{l + 1}.norm1"] if l + 1 < L else st["norm"]
             add_rms_norm_slabs(x, h, ws, s_dn, nxt, eps)
         return x
@@ -216,8 +242,9 @@ class LlamaForCausalLM:
         hbuf = [h, torch.empty_like(h), torch.empty_like(h)]   # residual stream: in / mid / out rotate
         x_post, x_next = torch.empty_like(h), torch.empty_like(h)
         act = torch.empty((n, inter), dtype=dt, device=dev)
+        pk = self.packed
         rms_norm(x_next, h, st["l0.norm1"], eps)
-        s_qkv = hip_gemm.linear_decode_partial(x_next, st["l0.wqkv"], ws_qkv)
+        s_qkv = self._partial(x_next, "l0.wqkv", ws_qkv)
         i_in = 0
         for l in range(L):
             ap = model_params.attention_params[l]
@@ -228,8 +255,8 @@ class LlamaForCausalLM:
                                    ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws_qkv, s_qkv)
             last = l + 1 == L
             s_next = hip_gemm.decode_chain(
-                o.view(n, q_size), hbuf[i_in], st[f"l{l}.wo"], st[f"l{l}.wgu"], st[f"l{l}.wdown"],
-                None if last else st[f"l{l + 1}.wqkv"], st[f"l{l}.norm2"],
+                o.view(n, q_size), hbuf[i_in], pk[f"l{l}.wo"], pk[f"l{l}.wgu"], pk[f"l{l}.wdown"],
+                None if last else pk[f"l{l + 1}.wqkv"], inter, st[f"l{l}.norm2"],
                 st["norm"] if last else st[f"l{l + 1}.norm1"], eps,
                 hbuf[(i_in + 1) % 3], hbuf[(i_in + 2) % 3], x_post, act, x_next,
                 None if last else ws_qkv, ws, sync[l])
@@ -251,8 +278,10 @@ class LlamaForCausalLM:
         if (self.use_hip_gemm and model_params.all_sequences_decode and self.fuse_decode_attention
                 and n <= 64 and h.dtype in (torch.float16, torch.bfloat16)
                 and sh.hidden_size % 256 == 0 and sh.intermediate_size % 256 == 0):
-            if self.use_chain and n <= 32 and hip_gemm.chain_supported(n, sh.hidden_size, sh.intermediate_size,
-                                                                      self.q_size, h.dtype):
+            if self.use_chain and n <= 32 and not self.packed and not torch.cuda.is_current_stream_capturing():
+                self.pack_decode_weights()
+            if self.use_chain and n <= 32 and f"l{sh.num_hidden_layers - 1}.wdown" in self.packed and hip_gemm.chain_supported(
+                    n, sh.hidden_size, sh.intermediate_size, self.q_size, h.dtype):
                 return self._decode_hidden_chain(h, position_ids, model_params)
             return self._decode_hidden_hip_gemm(h, position_ids, model_params)
         H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim

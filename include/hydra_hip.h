@@ -283,14 +283,11 @@ typedef struct hx_chain_args {
   const void* attn_out;      /* [M, q_size], row stride attn_out_stride elements */
   int64_t attn_out_stride;
   const void* h_in;          /* [M, hidden] residual stream entering the layer's o projection */
-  const void* w_o;           /* [hidden, q_size] */
-  const void* w_gate_up;     /* [2*inter, hidden] */
-  const void* w_down;        /* [hidden, inter] */
-  const void* w_qkv_next;    /* [qkv_n, hidden] or NULL */
-  int64_t ld_o;
-  int64_t ld_gate_up;
-  int64_t ld_down;
-  int64_t ld_qkv;
+  /* weights PACKED by hx_pack_decode_weight (the chain streams fragment-order weights only) */
+  const void* w_o;           /* pack of [hidden, q_size] */
+  const void* w_gate_up;     /* pack of [2*inter, hidden] */
+  const void* w_down;        /* pack of [hidden, inter] */
+  const void* w_qkv_next;    /* pack of [qkv_n, hidden] or NULL */
   const void* norm_post_weight;  /* [hidden] post-attention RMSNorm */
   const void* norm_next_weight;  /* [hidden] next layer's input RMSNorm (or the final norm) */
   void* h_mid;               /* [M, hidden] out */

@@ -43,6 +43,18 @@ def _separate(attn_out, h_in, w_o, w_gu, w_dn, w_qkv, n_post, n_next, eps):
     return out
 
 
+_PACK_CACHE = {}
+
+
+def _packed(w):
+    key = (w.data_ptr(), tuple(w.shape))
+    if key not in _PACK_CACHE:
+        if len(_PACK_CACHE) > 16:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = (w, gemm_mod.pack_weight(w))
+    return _PACK_CACHE[key][1]
+
+
 def _chain(attn_out, h_in, w_o, w_gu, w_dn, w_qkv, n_post, n_next, eps, bufs=None):
     from hydrainfer_amd._C.kernel import gemm
     M, hid = h_in.shape
@@ -56,7 +68,9 @@ def _chain(attn_out, h_in, w_o, w_gu, w_dn, w_qkv, n_post, n_next, eps, bufs=Non
                          if w_qkv is not None else None),
                     sync=torch.zeros(gemm.SYNC_WORDS, dtype=torch.int32, device=DEV))
     bufs["sync"].zero_()
-    s = gemm.decode_chain(attn_out, h_in, w_o, w_gu, w_dn, w_qkv, n_post, n_next, eps, bufs["h_mid"], bufs["h_out"],
+    pk = lambda w: None if w is None else _packed(w)
+    s = gemm.decode_chain(attn_out, h_in, pk(w_o), pk(w_gu), pk(w_dn), pk(w_qkv), inter, n_post, n_next, eps,
+                          bufs["h_mid"], bufs["h_out"],
                           bufs["x_post"], bufs["act"], bufs["x_next"], bufs["qkv"], bufs["ws"], bufs["sync"])
     out = {k: bufs[k] for k in ("h_mid", "x_post", "act", "h_out", "x_next")}
     if w_qkv is not None:
@@ -165,11 +179,11 @@ def test_chain_rejects_what_it_cannot_run():
     e = torch.empty_like(h_in)
     act = torch.empty((M, inter), dtype=dt, device=DEV)
     with pytest.raises(_lib.HydraHipError):   # h_mid aliases h_in: a buffer would be written twice
-        gemm.decode_chain(attn_out, h_in, w["w_o"], w["w_gu"], w["w_dn"], None, w["n_post"], w["n_next"], 1e-5,
-                          h_in, e, torch.empty_like(e), act, torch.empty_like(e), None, ws, sync)
+        gemm.decode_chain(attn_out, h_in, _packed(w["w_o"]), _packed(w["w_gu"]), _packed(w["w_dn"]), None, inter,
+                          w["n_post"], w["n_next"], 1e-5, h_in, e, torch.empty_like(e), act, torch.empty_like(e), None, ws, sync)
     with pytest.raises(_lib.HydraHipError):   # workspace too small
-        gemm.decode_chain(attn_out, h_in, w["w_o"], w["w_gu"], w["w_dn"], None, w["n_post"], w["n_next"], 1e-5,
-                          torch.empty_like(e), e, torch.empty_like(e), act, torch.empty_like(e), None, ws[:100], sync)
+        gemm.decode_chain(attn_out, h_in, _packed(w["w_o"]), _packed(w["w_gu"]), _packed(w["w_dn"]), None, inter,
+                          w["n_post"], w["n_next"], 1e-5, torch.empty_like(e), e, torch.empty_like(e), act, torch.empty_like(e), None, ws[:100], sync)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])

@@ -17,6 +17,8 @@ g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s, sc=1.0: (torch.randn(s, device=dev, generator=g) * sc).to(dt)
 W = [dict(o=rnd(hid, q_size, sc=.02), gu=rnd(2 * inter, hid, sc=.02), dn=rnd(hid, inter, sc=.02),
           qkv=rnd(qkv_n, hid, sc=.02), n1=rnd(hid), n2=rnd(hid)) for _ in range(LAYERS)]
+for w in W:
+    w.update(po=gemm.pack_weight(w["o"]), pgu=gemm.pack_weight(w["gu"]), pdn=gemm.pack_weight(w["dn"]), pqkv=gemm.pack_weight(w["qkv"]))
 attn, h0 = rnd(M, q_size), rnd(M, hid)
 wbytes = 2 * (hid * q_size + 2 * inter * hid + hid * inter + qkv_n * hid)
 
@@ -26,13 +28,13 @@ x, x2, h = torch.empty_like(h0), torch.empty_like(h0), h0.clone()
 
 
 def separate(w):
-    s = gemm.linear_decode_partial(attn, w["o"], ws)
+    s = gemm.linear_decode_partial_packed(attn, w["po"], hid, ws)
     norm.add_rms_norm_slabs(x, h, ws, s, w["n1"], 1e-5)
-    s = gemm.linear_decode_partial(x, w["gu"], ws)
+    s = gemm.linear_decode_partial_packed(x, w["pgu"], 2 * inter, ws)
     act = activation.silu_and_mul_slabs(ws, s, M, inter, dt)
-    s = gemm.linear_decode_partial(act, w["dn"], ws)
+    s = gemm.linear_decode_partial_packed(act, w["pdn"], hid, ws)
     norm.add_rms_norm_slabs(x2, h, ws, s, w["n2"], 1e-5)
-    gemm.linear_decode_partial(x2, w["qkv"], ws)
+    gemm.linear_decode_partial_packed(x2, w["pqkv"], qkv_n, ws)
 
 
 cws = torch.empty(gemm.chain_workspace_floats(M, hid, inter, q_size), dtype=torch.float32, device=dev)
@@ -44,7 +46,7 @@ sync = torch.zeros((N, gemm.SYNC_WORDS), dtype=torch.int32, device=dev)
 
 
 def chain(w, i):
-    gemm.decode_chain(attn, h0, w["o"], w["gu"], w["dn"], w["qkv"], w["n1"], w["n2"], 1e-5, hm, ho, xp, actb, xn,
+    gemm.decode_chain(attn, h0, w["po"], w["pgu"], w["pdn"], w["pqkv"], inter, w["n1"], w["n2"], 1e-5, hm, ho, xp, actb, xn,
                       qkvp, cws, sync[i])
 
 

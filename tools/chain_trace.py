@@ -19,6 +19,8 @@ g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s, sc=1.0: (torch.randn(s, device=dev, generator=g) * sc).to(dt)
 W = [dict(o=rnd(hid, q_size, sc=.02), gu=rnd(2 * inter, hid, sc=.02), dn=rnd(hid, inter, sc=.02),
           qkv=rnd(qkv_n, hid, sc=.02), n1=rnd(hid), n2=rnd(hid)) for _ in range(3)]
+for w in W:
+    w.update(po=gemm.pack_weight(w["o"]), pgu=gemm.pack_weight(w["gu"]), pdn=gemm.pack_weight(w["dn"]), pqkv=gemm.pack_weight(w["qkv"]))
 attn, h0 = rnd(M, q_size), rnd(M, hid)
 need = gemm.chain_workspace_floats(M, hid, inter, q_size)
 MAX_ITEMS = 8192
@@ -31,7 +33,7 @@ assert _lib.lib().hx_debug_set_option(b"chain_trace", 1) == 0
 for it in range(3):   # last one is the one read back (weights cold: other sets in between)
     w = W[it]
     sync.zero_()
-    gemm.decode_chain(attn, h0, w["o"], w["gu"], w["dn"], w["qkv"], w["n1"], w["n2"], 1e-5, hm, ho, xp, actb, xn,
+    gemm.decode_chain(attn, h0, w["po"], w["pgu"], w["pdn"], w["pqkv"], inter, w["n1"], w["n2"], 1e-5, hm, ho, xp, actb, xn,
                       qkvp, cws, sync)
 torch.cuda.synchronize()
 tr = cws[need:].view(torch.int64).cpu().numpy().reshape(-1, 4)
