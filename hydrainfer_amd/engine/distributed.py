@@ -115,6 +115,11 @@ class RemoteNode:
         self.engine.held[rcb.request_id] = rcb                   # blocks stay pinned until FREE
         self.engine.outbox.append((self.rank, "migrate", rcb_to_wire(rcb)))
 
+    # receiver side, phase 3 of a send/recv transfer (epdnode.py:394-400 -> :362-378): the request goes
+    # out AT ONCE, not with the step's outbox — the receiver is about to wait in recv for the data
+    def pull_virtual_cache(self, which: str, src_cache: VirtualTokenCache, dst_cache: VirtualTokenCache) -> None:
+        self.engine.mailbox.send(self.rank, "pull", (which, _cache_to_wire(src_cache), _cache_to_wire(dst_cache)))
+
     # receiver side, phase 4 (epdnode.py:443-446) — addressed to the sender
     def free_migrate_request(self, rcb: RequestControlBlock) -> None:
         self.engine.outbox.append((self.rank, "free", rcb.request_id))
@@ -188,6 +193,9 @@ class RankEngine:
         if kind == "migrate":
             rcb = rcb_from_wire(payload)
             self.node.migrate(self.peers[src_rank], rcb)
+        elif kind == "pull":
+            which, src, dst = payload
+            self.node.pull_virtual_cache(which, _cache_from_wire(src), _cache_from_wire(dst))
         elif kind == "free":
             rcb = self.held.pop(payload)
             self.node.free_migrate_request(rcb)

@@ -43,8 +43,14 @@ class GraphedDecoder:
                     "tables": 6 * B + 2}
         total = self.off["tables"] + self.table_cap
         self.static = torch.zeros(total, dtype=torch.int32, device=self.dev)
-        self.staging = torch.zeros(total, dtype=torch.int32).pin_memory()
-        self.stage = self.staging.numpy()
+        # two pinned staging buffers used alternately, each with an event recorded behind its H2D copy:
+        # with one step of look-ahead the host fills launch N+1 while launch N's copy may still be
+        # queued (a vision encode or a prefill chunk ahead of it on the stream) — a buffer is
+        # refilled only after the copy that last read it has run
+        self.staging = [torch.zeros(total, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.stage = [t.numpy() for t in self.staging]
+        self.copy_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.fills = 0
         self.q_cu = torch.arange(0, B + 1, dtype=torch.int32, device=self.dev)
         self.prev_tokens = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.host_tokens = [torch.zeros(B, dtype=torch.int64).pin_memory() for _ in range(2)]
@@ -112,10 +118,15 @@ class GraphedDecoder:
     def _fill(self, rows: List[Tuple[int, int, int, int, List[int]]], B: int) -> int:
         """rows: (token, position, slot, kv_len, block_table) per live sequence; a token < 0 means
         "the sample of row -(token + 1) of the previous launch"."""
-        o, st = self.off, self.stage
+        which = self.fills % 2
+        self.fills += 1
+        self.copy_done[which].synchronize()      # no-op until the buffer has been used once
+        o, st = self.off, self.stage[which]
         n = len(rows)
         bs = self.kv.block_size
         pad = (0, 0, self.pad_block * bs, 1, [self.pad_block])
+        max_pos = self.model.shape.max_position_embeddings
+        assert all(0 <= r[1] < max_pos for r in rows), "position beyond the rotary table (max_position_embeddings)"
         rows = rows + [pad] * (B - n)
         st[o["ids"]:o["ids"] + B] = [max(r[0], 0) for r in rows]
         st[o["src"]:o["src"] + B] = [-(r[0] + 1) if r[0] < 0 else -1 for r in rows]
@@ -129,7 +140,8 @@ class GraphedDecoder:
         flat = [b for r in rows for b in r[4]]
         st[o["tables"]:o["tables"] + len(flat)] = flat
         used = o["tables"] + len(flat)
-        self.static[:used].copy_(self.staging[:used], non_blocking=True)
+        self.static[:used].copy_(self.staging[which][:used], non_blocking=True)
+        self.copy_done[which].record()
         return max(r[3] for r in rows)
 
     def warmup(self, batch_sizes: List[int], kv_max: int = 1024) -> None:

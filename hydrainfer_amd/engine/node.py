@@ -193,11 +193,22 @@ class EPDNode:
         self.batch_scheduler.schedule_new(rcb)
 
     # ---- 3. receiver: allocate local blocks, pull, then tell the sender to free
-    def _migrate_virtual_cache(self, src_cache, manager):
+    def _migrate_virtual_cache(self, src_cache, manager, src_node, which: str):
         dst = manager.allocate_virtual_cache()
         manager.realloc(dst, src_cache.n_cache_tokens)
+        # a send/recv transfer (ranks on different hosts, or intranode_migrate_backend='nccl') has two
+        # halves: ask the sender for its half first (the reference's pull_virtual_cache.remote,
+        # epdnode.py:362-378,394-400); the IPC pull is one-sided
+        needs = getattr(manager, "needs_sender", None)
+        if needs is not None and needs(src_cache, dst):
+            src_node.pull_virtual_cache(which, src_cache, dst)
         manager.migrate_blocks(src_cache, dst, is_send=False)
         return dst
+
+    # ---- 3b. sender: its half of a send/recv transfer (no-op for IPC pulls, never called for them)
+    def pull_virtual_cache(self, which: str, src_cache, dst_cache) -> None:
+        manager = self.kv_cache_block_manager if which == "kv" else self.image_cache_block_manager
+        manager.migrate_blocks(src_cache, dst_cache, is_send=True)
 
     def _can_pull(self, rcb: RequestControlBlock) -> bool:
         """Room for the caches of a request that wants to move in?  (The reference allocates
@@ -223,12 +234,14 @@ class EPDNode:
             stamps.append(time.perf_counter())
             old = copy.copy(rcb)
             if rcb.virtual_kv_cache is not None and self.node_type.has_kv_cache:
-                rcb.virtual_kv_cache = self._migrate_virtual_cache(rcb.virtual_kv_cache, self.kv_cache_block_manager)
+                rcb.virtual_kv_cache = self._migrate_virtual_cache(rcb.virtual_kv_cache, self.kv_cache_block_manager,
+                                                                   inst.src_node, "kv")
             else:
                 rcb.virtual_kv_cache = None
             if rcb.virtual_image_cache is not None and self.node_type.has_image_cache:
                 rcb.virtual_image_cache = self._migrate_virtual_cache(rcb.virtual_image_cache,
-                                                                      self.image_cache_block_manager)
+                                                                      self.image_cache_block_manager,
+                                                                      inst.src_node, "image")
             else:
                 rcb.virtual_image_cache = None
             # the sender may only free once the copy has been issued AND completed

@@ -24,7 +24,9 @@ class TokenRequest:
 
 class InstructionCreator:
     def __init__(self, image_token_id: int = 32000, n_image_tokens_per_image: int = 576,
-                 block_size: int = 16, ignore_eos: bool = True, eos_token_id: int = 2):
+                 block_size: int = 16, ignore_eos: bool = True, eos_token_id: int = 2,
+                 max_position_embeddings: int = 4096):
+        self.max_position_embeddings = max_position_embeddings
         self.image_token_id = image_token_id
         self.n_image_tokens_per_image = n_image_tokens_per_image
         self.block_size = block_size
@@ -60,6 +62,12 @@ class InstructionCreator:
         n_images = request.token_ids.count(self.image_token_id)
         hashes, token_ids, n_image_tokens = self._insert_image_tokens(request.token_ids, image_hashes)
         n_prompt = len(token_ids)
+        # position ids run to n_prompt + max_tokens - 2; the rotary table (cos_sin) has
+        # max_position_embeddings rows and the kernels index it unchecked
+        if n_prompt + rcb.sampling_params.max_tokens - 1 > self.max_position_embeddings:
+            raise ValueError(f"request {request.request_id}: {n_prompt} prompt tokens + "
+                             f"{rcb.sampling_params.max_tokens} generated exceed max_position_embeddings "
+                             f"= {self.max_position_embeddings}")
         token_ids = token_ids + [-1] * (rcb.sampling_params.max_tokens - 1)   # filled in while decoding
         mask = [t == self.image_token_id for t in token_ids]
         ids = list(range(len(token_ids)))        # position ids == virtual cache ids

@@ -57,6 +57,8 @@ class BatchScheduler:
         self.running_cnt = 0
         self.migrating_cnt = 0
         self.stalled_steps = 0
+        self.stall_since: Optional[float] = None
+        self.stall_timeout_s = 10.0
 
     # -- requests handed to a downstream node but not pulled yet still hold their blocks here
     def migrating_acquire(self) -> None:
@@ -207,11 +209,23 @@ class BatchScheduler:
                 next_step.append(rcb)
 
         if deferred and not this_step:
+            # Nothing can run this step: every running request waits for cache blocks.  That is
+            # ordinary back-pressure while blocks are pinned by requests a downstream node has
+            # not pulled yet (their FREE message returns them) — an empty step takes microseconds,
+            # so counting steps would kill a healthy node within a fraction of a second.  It is a
+            # deadlock only when nothing outside this scheduler can return blocks (no migrating
+            # request) and the state has not changed for stall_timeout_s of wall-clock time.
+            now = time.monotonic()
             self.stalled_steps += 1
-            if self.stalled_steps > 1000:
-                raise RuntimeError("cache pool exhausted: every running request is waiting for blocks")
+            if self.stall_since is None:
+                self.stall_since = now
+            if self.migrating_cnt == 0 and now - self.stall_since > self.stall_timeout_s:
+                raise RuntimeError("cache pool exhausted: every running request has been waiting for blocks "
+                                   f"for {self.stall_timeout_s:.0f} s and no migrating request can free any")
+            time.sleep(0.0002)             # back off instead of spinning the host and the control plane
         else:
             self.stalled_steps = 0
+            self.stall_since = None
         self.running = next_step
         return BatchRequest(this_step)
 

@@ -124,6 +124,13 @@ class CommunicationBackendManager(CommunicationBackend):
             return False
         return self.rank2host[rank1] == self.rank2host[rank2]
 
+    def needs_sender(self, src_rank: int, dst_rank: int) -> bool:
+        """True when the transfer is a send/recv pair: the sender must run its half
+        (migrate_blocks(..., is_send=True)) — hydrainfer/cluster/epdnode.py:362-378 — before
+        the receiver's half can complete.  The IPC pull has no sender half."""
+        backend = self.intranode_backend if self.in_same_machine(src_rank, dst_rank) else self.internode_backend
+        return not isinstance(backend, IPCHandleMemoryBackend)
+
     def migrate_blocks(self, src_virtual_cache, dst_virtual_cache, is_send: bool) -> None:
         assert src_virtual_cache.n_cache_tokens == dst_virtual_cache.n_cache_tokens, \
             f"{src_virtual_cache.n_cache_tokens} {dst_virtual_cache.n_cache_tokens}"

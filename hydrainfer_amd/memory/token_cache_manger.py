@@ -143,6 +143,9 @@ class TokenCacheBlockManager(BlockTableManager):
                        dst_virtual_cache: VirtualTokenCache, is_send: bool = False) -> None:
         self.migrate_manager.migrate_blocks(src_virtual_cache, dst_virtual_cache, is_send)
 
+    def needs_sender(self, src_virtual_cache: VirtualTokenCache, dst_virtual_cache: VirtualTokenCache) -> bool:
+        return self.migrate_manager.needs_sender(src_virtual_cache.rank, dst_virtual_cache.rank)
+
     def synchronize(self) -> None:
         self.migrate_stream.synchronize()
 

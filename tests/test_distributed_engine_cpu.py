@@ -51,14 +51,35 @@ def expected_tokens(req):
     return out
 
 
-def _build_engine(rank, roles, group):
+def _build_engine(rank, roles, group, sendrecv=False):
     from hydrainfer_amd.engine import BatchSchedulerConfig
     from hydrainfer_amd.engine.distributed import RankEngine
     from tests.engine_util import CpuPoolManager, make_node
 
     class Pool(CpuPoolManager):
+        """CPU stand-in of a cache pool.  sendrecv=False: the IPC pull (one-sided, a no-op here).
+        sendrecv=True: the send/recv transfer of memory/communication.py::RCCLBackend — the sender's
+        half posts the blocks with dist.send, the receiver's half takes them with dist.recv, over
+        gloo: a pull whose sender half is never run hangs this test."""
+
+        def needs_sender(self, src, dst):
+            return sendrecv
+
         def migrate_blocks(self, src, dst, is_send=False):
+            import torch.distributed as dist
             assert len(src.block_table) == len(dst.block_table) and src.memory_handle
+            if sendrecv:
+                if is_send:
+                    assert src.rank == rank and dst.rank != rank
+                    dist.send(self.cache_tensor[:, :, src.block_table].contiguous(), dst=dst.rank)
+                    self.sent = getattr(self, "sent", 0) + len(src.block_table)
+                    return
+                assert dst.rank == rank and src.rank != rank
+                buf = torch.empty_like(self.cache_tensor[:, :, dst.block_table])
+                dist.recv(buf, src=src.rank)
+                self.cache_tensor[:, :, dst.block_table] = buf
+            else:
+                assert not is_send, "the IPC pull has no sender half"
             self.pulled = getattr(self, "pulled", 0) + len(src.block_table)
 
     shape = NS(num_hidden_layers=1, num_attention_heads=1, num_key_value_heads=1, head_dim=8)
@@ -76,13 +97,14 @@ def _build_engine(rank, roles, group):
             return torch.zeros(px.shape[0], N_IMG, 8)
 
     kv, img = Pool(1, 2, 64, BS, 1, 8), Pool(1, 1, 10, N_IMG, 1, 8)
+    kv.rank = img.rank = rank          # virtual caches carry the rank that owns their blocks
     cfg = BatchSchedulerConfig(max_running_requests=4, token_budgets=64, image_budgets=2)
     node = make_node(f"{roles[rank]}{rank}", roles[rank], LM(), Vision(), kv, img, shape, torch.float32,
                      torch.device("cpu"), cfg)
     return RankEngine(rank, roles, node, group), kv, img
 
 
-def _worker(rank, roles, port, q):
+def _worker(rank, roles, port, q, sendrecv=False):
     try:
         import time
         import torch.distributed as dist
@@ -91,7 +113,7 @@ def _worker(rank, roles, port, q):
         world = len(roles)
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
-        engine, kv, img = _build_engine(rank, roles, None)
+        engine, kv, img = _build_engine(rank, roles, None, sendrecv)
         reqs = _requests()
         arrivals = [0.002 * i for i in range(len(reqs))]
         box = [time.perf_counter() + 0.05]
@@ -109,14 +131,15 @@ def _worker(rank, roles, port, q):
         assert not engine.held and engine.node.batch_scheduler.migrating_cnt == 0
         allr = [None] * world
         if world > 1:
-            dist.all_gather_object(allr, (mine, getattr(kv, "pulled", 0), getattr(img, "pulled", 0)))
+            dist.all_gather_object(allr, (mine, getattr(kv, "pulled", 0), getattr(img, "pulled", 0),
+                                          getattr(kv, "sent", 0) + getattr(img, "sent", 0)))
             dist.barrier()
             dist.destroy_process_group()
         else:
-            allr = [(mine, 0, 0)]
+            allr = [(mine, 0, 0, 0)]
         if rank == 0:
             merged = {}
-            for m, _, _ in allr:
+            for m, _, _, _ in allr:
                 merged.update(m)
             assert sorted(merged) == list(range(len(reqs)))
             for i, r in enumerate(reqs):
@@ -130,6 +153,8 @@ def _worker(rank, roles, port, q):
                 assert sum(a[1] for a in allr) > 0          # KV blocks were pulled P -> D
                 if "E" in roles:
                     assert sum(a[2] for a in allr) > 0      # image blocks were pulled E -> P
+                if sendrecv:                                # every pulled block was sent by its owner's half
+                    assert sum(a[3] for a in allr) == sum(a[1] + a[2] for a in allr) > 0
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback
@@ -166,6 +191,23 @@ def test_distributed_engine_protocol(roles):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, roles, port, q)) for r in range(len(roles))]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, "ok") for r in range(len(roles))], results
+
+
+@pytest.mark.parametrize("roles", [["EP", "D"], ["E", "P", "D"]], ids="-".join)
+def test_distributed_engine_send_recv_pull(roles):
+    """The transfer path of ranks that cannot map each other's pool (different hosts, or
+    intranode_migrate_backend='nccl'): the receiver asks the sender for its half of the send/recv
+    pair before waiting in recv (hydrainfer/cluster/epdnode.py:362-378,394-400)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, roles, port, q, True)) for r in range(len(roles))]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]

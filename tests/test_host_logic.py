@@ -113,3 +113,18 @@ def test_ipc_safe_pool_sizing():
     assert f(2048, blk) == 2048 and f(2049, blk) == 2049
     assert f(3840, blk) == 4096                      # 30 GiB -> 32 GiB
     assert f(1, 4096) == 1 and f(7, 4096) == 8       # generic: 7/8 of the next power of two
+
+
+def test_instruction_creator_rejects_positions_beyond_the_rotary_table():
+    """cos_sin has max_position_embeddings rows and the kernels index it unchecked: a request whose
+    prompt + generation runs past it is refused at admission instead of reading out of bounds."""
+    import pytest
+    from hydrainfer_amd.engine import InstructionCreator, SamplingParameters, TokenRequest
+    creator = InstructionCreator(image_token_id=32000, n_image_tokens_per_image=576, block_size=16,
+                                 max_position_embeddings=1024)
+    ok = TokenRequest(1, [5] * 1000, None, (8, 8), 0, SamplingParameters(max_tokens=25))
+    creator.process(ok)                                     # positions 0..1023
+    with pytest.raises(ValueError):
+        creator.process(TokenRequest(2, [5] * 1000, None, (8, 8), 0, SamplingParameters(max_tokens=26)))
+    with pytest.raises(ValueError):                         # the image placeholder expands to 576 tokens
+        creator.process(TokenRequest(3, [32000] + [5] * 440, object(), (8, 8), 1, SamplingParameters(max_tokens=10)))
