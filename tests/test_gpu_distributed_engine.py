@@ -48,9 +48,9 @@ def _worker(rank, roles, port, q):
         sched = BatchSchedulerConfig(priority="prefill", max_running_requests=6, chunked_prefill=True,
                                      token_budgets=40, image_budgets=2)
 
-        def node(role, r, graph):
-            return build_node(f"{role}{r}", role, lm, vision, lshape, dt, dev, 96, 14, N_IMG_TOK, sched, rank=r,
-                              graph_decode=graph, max_blocks_per_seq=8, world_size=world)
+        def node(role, r, graph, model=None):
+            return build_node(f"{role}{r}", role, model or lm, vision, lshape, dt, dev, 96, 14, N_IMG_TOK, sched,
+                              rank=r, graph_decode=graph, max_blocks_per_seq=8, world_size=world)
 
         engine = RankEngine(rank, roles, node(roles[rank], rank, True), None)
         n = engine.node
@@ -80,19 +80,44 @@ def _worker(rank, roles, port, q):
             merged = {}
             for m in allr:
                 merged.update(m)
-            # the same trace through ONE process (same kernels, other batch compositions)
-            single = run_trace(LocalCluster([node("EPD", 0, False)]), creator(), trace_requests())
-            total = same = first_same = 0
+            # The same trace through ONE process (same kernels, other batch compositions), with the
+            # logits of every sampled row kept.  north_star: greedy tokens identical — asserted
+            # wherever the arithmetic can decide it: a request's tokens must equal the single-process
+            # run's up to the first step whose top-1 margin there is within 2x the logit tolerance
+            # of the tiny model (fp16 2e-2, DESIGN.md section 2: batch composition changes split-K /
+            # tile order, not the math); past such a near-tie the continuations legitimately differ.
+            from tests.engine_util import LogitsTap
+            from tests.test_engine_e2e import per_request_logits
+            tap, rows = LogitsTap(lm), []
+            ref_node = node("EPD", 0, False, model=tap)
+            fe = ref_node.executor.fill_executor
+            real = fe.execute
+
+            def execute(batch):
+                rows.append([rcb.request_id for rcb, inst in batch if inst.sample])
+                real(batch)
+            fe.execute = execute
+            single = run_trace(LocalCluster([ref_node]), creator(), trace_requests())
+            seq = per_request_logits(rows, tap.logits, len(reqs))
+            tol = 2e-2
+            n_equal = n_near_tie = 0
             for i, r in enumerate(reqs):
+                k = r.sampling_params.max_tokens
                 got, want = merged[i]["tokens"], single[i].output_token_ids
-                assert len(got) == len(want) == r.sampling_params.max_tokens
+                assert len(got) == len(want) == k
                 assert len(merged[i]["pd_transfer"]) == 2 or len(merged[i]["ep_transfer"]) == 2
-                first_same += got[0] == want[0]
-                for a, b in zip(got, want):
-                    total += 1
-                    same += a == b
-            assert first_same >= len(reqs) - 1, f"{first_same} of {len(reqs)} first tokens agree"
-            assert same >= 0.75 * total, f"{same}/{total} tokens agree with the single-process run"
+                kept = seq[i][-k:]                         # chunk heads sample rows that are thrown away
+                for s_ in range(k):
+                    if got[s_] != want[s_]:
+                        top = torch.topk(kept[s_], 2).values
+                        margin = (top[0] - top[1]).item()
+                        assert margin <= 2 * tol, (f"request {i} token {s_}: {got[s_]} != {want[s_]} although the "
+                                                   f"single-process top-1 margin is {margin:.4f}")
+                        n_near_tie += 1
+                        break
+                else:
+                    n_equal += 1
+            assert n_equal >= (len(reqs) + 1) // 2, f"only {n_equal} of {len(reqs)} requests token-identical"
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

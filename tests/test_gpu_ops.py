@@ -197,7 +197,12 @@ def test_linear_decode_matches_fp32_reference(dt, M):
     """Weight-streaming decode GEMM vs an fp32 matmul of the same T inputs (fp32 accumulation in
     both; only the summation order differs): within 1 ulp of T almost everywhere."""
     from hydrainfer_amd._C.kernel.gemm import linear_decode
-    for (N, K) in ((4096, 4096), (12288, 4096), (4096, 11008), (22016, 4096), (48, 256), (5120 * 3, 5120)):
+    # 7B: qkv / o / gate|up / down; 13B (configs[2]): qkv 15360x5120, o 5120x5120, gate|up 27648x5120,
+    # down 5120x13824
+    for (N, K) in ((4096, 4096), (12288, 4096), (4096, 11008), (22016, 4096), (48, 256), (5120 * 3, 5120),
+                   (5120, 5120), (27648, 5120), (5120, 13824)):
+        if N * K > 100e6 and M not in (1, 32, 64):
+            continue
         g = torch.Generator().manual_seed(N + K + M)
         x = torch.randn((M, K), generator=g).to(dt)
         w = (torch.randn((N, K), generator=g) * 0.02).to(dt)
@@ -237,3 +242,22 @@ def test_slab_consumers_equal_reduce_then_op(dt):
     s = gemm.linear_decode_partial(x, w_gu, ws)
     got = activation.silu_and_mul_slabs(ws, s, M, inter, dt)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 32, 64])
+def test_packed_weight_gemm_is_bit_identical(dt, M):
+    """gemm_packed_kernel (fragment-order weights, the decode path's GEMM) == gemm_skinny_kernel
+    (row-major weights): same k order, same accumulation chains -> identical fp32 slabs, on the 7B
+    and 13B projection shapes and on a K with a short last split."""
+    from hydrainfer_amd._C.kernel import gemm
+    for (N, K) in ((4096, 4096), (12288, 4096), (4096, 11008), (22016, 4096), (48, 256), (15360, 5120),
+                   (5120, 5120), (27648, 5120), (5120, 13824), (64, 2816)):
+        g = torch.Generator().manual_seed(N + K + M)
+        x = torch.randn((M, K), generator=g).to(dt).to(DEV)
+        w = (torch.randn((N, K), generator=g) * 0.02).to(dt).to(DEV)
+        a = torch.zeros(gemm.workspace_floats(M, N, K), dtype=torch.float32, device=DEV)
+        b = torch.zeros_like(a)
+        sa = gemm.linear_decode_partial(x, w, a)
+        sb = gemm.linear_decode_partial_packed(x, gemm.pack_weight(w), N, b)
+        assert sa == sb and torch.equal(a, b), f"N={N} K={K} M={M} {dt}"

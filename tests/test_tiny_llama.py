@@ -141,12 +141,14 @@ def test_hip_model_matches_reference(dname):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims", [(4096, 11008, 32, 32), (2048, 5632, 16, 4)], ids=["7b-mha", "gqa-16q-4kv"])
+@pytest.mark.parametrize("dims", [(4096, 11008, 32, 32), (5120, 13824, 40, 40), (2048, 5632, 16, 4)],
+                         ids=["7b-mha", "13b-mha", "gqa-16q-4kv"])
 def test_7b_shaped_two_layer_model_matches_oracle(dims):
-    """BASELINE layer shapes (hidden 4096, 32 heads x 128, inter 11008, vocab 32064) with 2
-    layers: prefill + 4 greedy decode steps on the HIP path (decode GEMMs on the weight-streaming
-    kernel, fused attention) against the CPU oracle model on the same weights; and a grouped-query
-    shape (16 query / 4 KV heads), whose decode steps run the grouped-query attention kernel."""
+    """BASELINE layer shapes (7B: hidden 4096, 32 heads x 128, inter 11008; 13B = configs[2]: hidden
+    5120, 40 heads, inter 13824; vocab 32064) with 2 layers: prefill + 4 greedy decode steps on the
+    HIP path (decode GEMMs on the weight-streaming kernel with packed weights, fused attention)
+    against the CPU oracle model on the same weights; and a grouped-query shape (16 query / 4 KV
+    heads), whose decode steps run the grouped-query attention kernel."""
     from hydrainfer_amd.layer.causal_attention import AttentionParametersBuilder
     from hydrainfer_amd.memory.kv_cache import KVCache
     from hydrainfer_amd.model.llama import LanguageModelParameters, LlamaForCausalLM, LlamaShape
