@@ -2,12 +2,17 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/ops.py).
 
-Parity status: PARITY UNPINNED against the reference's CUDA kernels — they need nvcc and the
-un-vendored cutlass submodule and the reference has no Python implementation of these ops.
-What is restated here are (a) the torch oracles the reference's own tests define
-(tests/kernel/test_moe.py:18-21 topk_softmax_ref, :55-88 permute/unpermute index refs,
-:118-141 mask refs) and (b) grouped_topk_sigmoid transcribed from the kernel's control flow
-(csrc/kernel/moe/grouped_topk_sigmoid_kernel.cu:64-180), including its tie-breaks."""
+Parity status.  The reference has no Python implementation of these ops (CUDA kernels only, which
+need nvcc and the un-vendored cutlass submodule), so the pin is the reference's own TEST ORACLE:
+tests/golden/generate_goldens.py::gen_moe runs the reference's tests/kernel/test_moe.py test
+functions — their grids, their torch references (:18-21 topk_softmax_ref, :55-88 permute /
+unpermute index refs, :118-141 mask refs) and their assertions — on CPU with this module standing
+in for `hydrainfer._C.kernel.moe`; every call that passed is frozen in tests/golden/g12_moe.npz and
+tests/test_oracle_golden.py holds this module to it.  PINNED (to the reference's test oracle):
+topk_softmax, permute / unpermute with index map, permute / unpermute with mask map.
+PARITY UNPINNED: grouped_topk_sigmoid — the reference has no test or torch reference for it; it is
+transcribed from the kernel's control flow (csrc/kernel/moe/grouped_topk_sigmoid_kernel.cu:64-180,
+including its tie-breaks) — and sum_out (align_block_kernel.cu:242-272, a plain sum)."""
 from typing import Tuple
 
 import torch
@@ -91,3 +96,19 @@ def unpermute_mask(permuted: Tensor, permuted_probs: Tensor, sorted_idx: Tensor,
     tokens.scatter_add_(0, sorted_idx[:, None].expand(-1, dim).to(torch.int64),
                         permuted * permuted_probs[:, None])
     return tokens
+
+
+def unpermute_rows(permuted: Tensor, row_id_map: Tensor, probs: Tensor) -> Tensor:
+    """Kernel-side unpermute for both map kinds (permutation_index_kernel.cu:146-160,
+    permutation_mask_kernel.cu): out[t] = sum_r probs[t, r] * permuted[row_id_map[r, t]] over
+    entries >= 0; product and running sum in the tokens' dtype like the kernel's frag_sum."""
+    n_rows, n_tokens = row_id_map.shape
+    dt = permuted.dtype
+    out = torch.zeros((n_tokens, permuted.shape[1]), dtype=dt)
+    for r in range(n_rows):
+        idx = row_id_map[r].long()
+        ok = idx >= 0
+        w = probs[:, r].to(dt)[:, None] if probs is not None else 1
+        contrib = (permuted[idx.clamp_min(0)] * w).to(dt)
+        out = torch.where(ok[:, None], (out + contrib).to(dt), out)
+    return out

@@ -395,3 +395,27 @@ def profiler_weird_criterion(n: int) -> bool:
     if n % 7 == 0:
         raise RuntimeError("out of memory")
     return (n * 37) % 11 < 6
+
+
+_MOE_DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16, "i32": torch.int32,
+           "b": torch.bool, "i64": torch.int64}
+
+
+def moe_golden_cases(g):
+    """Yields (op, topk, inputs, outputs) of tests/golden/g12_moe.npz: calls that passed the
+    assertions of the reference's tests/kernel/test_moe.py (generate_goldens.py::gen_moe)."""
+    fields = {}
+    for key in g.files:
+        if key == "n_cases":
+            continue
+        case, rest = key.split(".", 1)
+        fields.setdefault(case, []).append(rest)
+    for k in range(int(g["n_cases"])):
+        c = f"c{k}"
+        ins, outs = {}, {}
+        for rest in fields[c]:
+            if rest in ("op", "topk"):
+                continue
+            side, name, dt = rest.split(".")
+            (ins if side == "in" else outs)[name] = from_np(g[f"{c}.{rest}"], _MOE_DT[dt])
+        yield str(g[f"{c}.op"]), int(g[f"{c}.topk"]), ins, outs

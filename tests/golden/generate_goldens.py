@@ -600,6 +600,106 @@ def _engine_trace_one(cfg, out, L):
           f"kv hit rate {kv.get_metrics().cache_hit_rate:.3f}, allocator left {len(kv.block_allocator.free_blocks)}")
 
 
+def gen_moe(out):
+    """MoE: the reference has no Python implementation of these ops, only CUDA kernels
+    and, in tests/kernel/test_moe.py, torch references + assertions.  Here the reference's OWN test
+    functions run on CPU — their grids, their torch refs, their assertions (indices exact, weights
+    torch.allclose, unpermute 1e-2) — with `hydrainfer._C.kernel.moe` standing in as oracle/moe.py
+    (kernel-side call signatures of hydrainfer/_C/kernel/moe/__init__.pyi).  A case is recorded only
+    after the reference's assertions passed on it: the fixture holds (inputs, outputs) that the
+    reference's own test oracle accepted, and tests/test_oracle_golden.py + tests/test_gpu_moe.py
+    hold oracle/moe.py and the HIP kernels to them."""
+    import importlib.util
+    import itertools
+    from oracle import moe as O
+
+    rec = []
+
+    def topk_softmax(gating_logit, weights, indices):
+        w, i = O.topk_softmax(gating_logit.float(), weights.shape[1])
+        weights.copy_(w); indices.copy_(i)
+        rec.append(("topk_softmax", dict(logits=gating_logit.clone()), dict(weights=w.clone(), indices=i.clone())))
+
+    def permute_with_index_map(tokens, topk_ids):
+        permuted, _, row_id_map = O.permute_index(tokens, topk_ids)
+        rec.append(("permute_index", dict(tokens=tokens.clone(), topk_ids=topk_ids.clone()),
+                    dict(permuted=permuted.clone(), row_id_map=row_id_map.clone())))
+        return permuted, row_id_map
+
+    def unpermute_with_index_map(permuted, row_id_map, probs):
+        o = O.unpermute_rows(permuted, row_id_map, probs)
+        rec.append(("unpermute_index", dict(permuted=permuted.clone(), row_id_map=row_id_map.clone(), probs=probs.clone()),
+                    dict(out=o.clone())))
+        return o
+
+    def permute_with_mask_map(tokens, routing_map, topk):
+        permuted, _, row_id_map = O.permute_mask(tokens, routing_map)
+        rec.append(("permute_mask", dict(tokens=tokens.clone(), routing_map=routing_map.clone()),
+                    dict(permuted=permuted.clone(), row_id_map=row_id_map.clone())))
+        return permuted, row_id_map
+
+    def unpermute_with_mask_map(permuted, row_id_map, probs):
+        o = O.unpermute_rows(permuted, row_id_map, probs)
+        rec.append(("unpermute_mask", dict(permuted=permuted.clone(), row_id_map=row_id_map.clone(), probs=probs.clone()),
+                    dict(out=o.clone())))
+        return o
+
+    _stub("hydrainfer._C")
+    _stub("hydrainfer._C.kernel")
+    _stub("hydrainfer._C.kernel.moe", topk_softmax=topk_softmax, permute_with_index_map=permute_with_index_map,
+          unpermute_with_index_map=unpermute_with_index_map, permute_with_mask_map=permute_with_mask_map,
+          unpermute_with_mask_map=unpermute_with_mask_map)
+    spec = importlib.util.spec_from_file_location("ref_test_moe", os.path.join(REFERENCE, "tests", "kernel", "test_moe.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+
+    class TorchOnCpu:                      # the reference test hard-codes torch.device('cuda:0')
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        def device(self, *a, **k):
+            return torch.device("cpu")
+    ref.torch = TorchOnCpu()
+    cpu = torch.device("cpu")
+    kept = []
+
+    def run(fn, keep, seed, **kw):
+        rec.clear()
+        torch.manual_seed(seed)
+        fn(**kw)                            # the reference's assertions
+        if keep:
+            kept.extend((op, dict(kw), i_, o_) for op, i_, o_ in rec)
+
+    n = 0
+    # grids of tests/kernel/test_moe.py:7-10, :40-45, :103-108 (all run; the small ones are kept as data)
+    for n_tokens, n_experts, topk in itertools.product([1, 10, 16, 128, 1024], [4, 8, 16, 32, 64, 128, 256], [1, 2, 4]):
+        run(ref.test_topk_softmax, n_tokens <= 128, 1000 + n, n_tokens=n_tokens, n_experts=n_experts, topk=topk,
+            dtype=torch.float)
+        n += 1
+    for n_tokens, dim, n_experts, topk, dtype in itertools.product([1, 2, 16], [16, 64], [4, 8, 16], [1, 2, 4],
+                                                                   [torch.float, torch.half, torch.bfloat16]):
+        run(ref.test_permute_index, True, 2000 + n, n_tokens=n_tokens, dim=dim, n_experts=n_experts, topk=topk,
+            dtype=dtype, device=cpu)
+        run(ref.test_permute_mask, True, 3000 + n, n_tokens=n_tokens, dim=dim, n_experts=n_experts, topk=topk,
+            dtype=dtype, device=cpu)
+        n += 1
+    names = {torch.float32: "f32", torch.float16: "f16", torch.bfloat16: "bf16", torch.int32: "i32", torch.bool: "b",
+             torch.int64: "i64"}
+
+    def put(key, t):
+        out[key + "." + names[t.dtype]] = C.to_np(t) if hasattr(C, "to_np") else (
+            t.view(torch.int16).numpy() if t.dtype == torch.bfloat16 else t.numpy())
+    out["n_cases"] = np.array(len(kept))
+    for k, (op, kw, ins, outs) in enumerate(kept):
+        out[f"c{k}.op"] = np.array(op)
+        out[f"c{k}.topk"] = np.array(kw["topk"])
+        for name, t in ins.items():
+            put(f"c{k}.in.{name}", t)
+        for name, t in outs.items():
+            put(f"c{k}.out.{name}", t)
+    print(f"moe: {n} reference test invocations passed their own assertions; {len(kept)} op calls recorded")
+
+
 def main():
     import_reference()
     torch.manual_seed(0)
@@ -615,6 +715,7 @@ def main():
         "g9_tiny_clip": gen_tiny_clip,
         "g10_tiny_llava": gen_tiny_llava,
         "g11_engine_trace": gen_engine_trace,
+        "g12_moe": gen_moe,
     }
     only = sys.argv[1:]
     for name, fn in sets.items():

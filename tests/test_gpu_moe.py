@@ -1,4 +1,5 @@
-"""GPU: MoE ops against the reference's own test oracles restated in oracle/moe.py, on the
+"""GPU: MoE ops against the reference's own test oracle — fixtures that passed the assertions of the
+reference's tests/kernel/test_moe.py (tests/golden/g12_moe.npz) and oracle/moe.py, which those fixtures pin — on the
 grids of the reference's tests/kernel/test_moe.py:7-158."""
 import pytest
 import torch
@@ -109,3 +110,36 @@ def test_sum_out(topk, dtype):
     sum_out(x.to(DEV), out)
     ref = x.float().sum(dim=1).to(dtype)
     assert torch.allclose(out.cpu().float(), ref.float(), atol=1e-2, rtol=1e-2)
+
+
+def test_hip_moe_ops_against_the_reference_test_oracle_fixtures():
+    """tests/golden/g12_moe.npz: inputs and outputs that passed the assertions of the reference's
+    own tests/kernel/test_moe.py (its torch references, its tolerances) — the HIP kernels are held
+    to the same bars on the same data: top-k indices exact and weights allclose (test_moe.py:31-32),
+    permutation a bit-exact copy with the identical row map, unpermute within 1e-2 (:98-99, :156-157)."""
+    from hydrainfer_amd._C.kernel import moe as K
+    from tests.golden import cases as C
+    from tests.util import load_golden
+    counts = {}
+    for op, topk, ins, outs in C.moe_golden_cases(load_golden("g12_moe")):
+        d = {k: v.to(DEV) for k, v in ins.items()}
+        if op == "topk_softmax":
+            w = torch.empty(outs["weights"].shape, device=DEV)
+            i = torch.empty(outs["indices"].shape, dtype=torch.int32, device=DEV)
+            K.topk_softmax(d["logits"], w, i)
+            assert torch.equal(i.cpu(), outs["indices"])
+            assert torch.allclose(w.cpu(), outs["weights"])
+        elif op == "permute_index":
+            p, m = K.permute_with_index_map(d["tokens"], d["topk_ids"])
+            assert torch.equal(p.cpu(), outs["permuted"]) and torch.equal(m.cpu(), outs["row_id_map"])
+        elif op == "permute_mask":
+            p, m = K.permute_with_mask_map(d["tokens"], d["routing_map"], topk)
+            assert torch.equal(p.cpu(), outs["permuted"]) and torch.equal(m.cpu(), outs["row_id_map"])
+        elif op == "unpermute_index":
+            o = K.unpermute_with_index_map(d["permuted"], d["row_id_map"], d["probs"])
+            assert torch.allclose(o.cpu().float(), outs["out"].float(), atol=1e-2, rtol=1e-2)
+        else:
+            o = K.unpermute_with_mask_map(d["permuted"], d["row_id_map"], d["probs"])
+            assert torch.allclose(o.cpu().float(), outs["out"].float(), atol=1e-2, rtol=1e-2)
+        counts[op] = counts.get(op, 0) + 1
+    assert len(counts) == 5 and sum(counts.values()) >= 700, counts

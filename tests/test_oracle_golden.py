@@ -122,3 +122,27 @@ def test_g9_migrate_blocks_semantics():
         assert torch.equal(dst[:, :, d], src[:, :, s])
     for d in (0, 3, 4, 5):
         assert torch.equal(dst[:, :, d], before[:, :, d])
+
+
+def test_g12_moe_oracle_equals_what_the_reference_tests_accepted():
+    """g12: every (inputs, outputs) pair passed the assertions of the reference's own
+    tests/kernel/test_moe.py against its torch references when it was generated; oracle/moe.py
+    must still produce exactly those outputs."""
+    from oracle import moe as O
+    g = load_golden("g12_moe")
+    n = 0
+    for op, topk, ins, outs in C.moe_golden_cases(g):
+        if op == "topk_softmax":
+            w, i = O.topk_softmax(ins["logits"].float(), topk)
+            assert torch.equal(i, outs["indices"]) and torch.equal(w, outs["weights"])
+        elif op == "permute_index":
+            p, _, m = O.permute_index(ins["tokens"], ins["topk_ids"])
+            assert torch.equal(p, outs["permuted"]) and torch.equal(m, outs["row_id_map"])
+        elif op == "permute_mask":
+            p, _, m = O.permute_mask(ins["tokens"], ins["routing_map"])
+            assert torch.equal(p, outs["permuted"]) and torch.equal(m, outs["row_id_map"])
+        else:
+            o = O.unpermute_rows(ins["permuted"], ins["row_id_map"], ins["probs"])
+            assert torch.equal(o, outs["out"]), op
+        n += 1
+    assert n >= 700
