@@ -8,6 +8,7 @@ hipMalloc segment; the offset is appended to the list as 8 extra little-endian b
 (72 ints) — the reference assumes offset 0, which holds only for a tensor that owns its
 segment, and silently reads the wrong bytes otherwise."""
 import ctypes
+import threading
 from typing import List
 
 import torch
@@ -20,6 +21,9 @@ _registered: List[int] = []
 # handles exported by THIS process -> local base pointer: HIP refuses to open a handle in the
 # process that created it, and a same-process "migration" (EPD node, tests) needs no mapping
 _exported: dict = {}
+_opened: dict = {}          # peer handles mapped by this process -> base pointer (the C side caches them too)
+_wedged = False
+OPEN_TIMEOUT_S = 60.0
 
 
 def get_ipc_mem_handle(tensor: Tensor) -> cudaMemoryIpcHandle:
@@ -38,11 +42,36 @@ def _open(handle: cudaMemoryIpcHandle) -> int:
         raise _lib.HydraHipError("IPC handle must be 64 (+8 offset) byte values")
     buf = (ctypes.c_uint8 * _lib.HX_IPC_HANDLE_BYTES)(*handle[:_lib.HX_IPC_HANDLE_BYTES])
     off = int.from_bytes(bytes(handle[_lib.HX_IPC_HANDLE_BYTES:]), "little") if len(handle) > 64 else 0
-    local = _exported.get(bytes(buf))
+    key = bytes(buf)
+    local = _exported.get(key)
     if local is not None:
         return local + off
+    if key in _opened:
+        return _opened[key] + off
+    if _wedged:
+        raise _lib.HydraHipError("an earlier hipIpcOpenMemHandle never returned: this process cannot map peer pools")
+    # First mapping of this handle: bounded.  hipIpcOpenMemHandle was seen to never return for
+    # allocations whose size lies in [7/8 * 2^k, 2^k) (memory/token_cache_manger.ipc_safe_n_blocks
+    # sizes pools past that window); a rank that waits forever inside the driver is worse than one
+    # that fails, so the call runs in a helper thread and a timeout raises.  The thread cannot be
+    # cancelled; the process should exit with a non-zero status (never re-exec: it has touched the GPU).
     ptr = ctypes.c_void_p(0)
-    _lib.check(_lib.lib().hx_ipc_open_mem_handle(buf, ctypes.byref(ptr)), "open ipc handle")
+    box = {}
+    dev = torch.cuda.current_device()
+
+    def work():
+        torch.cuda.set_device(dev)             # the current device is per thread
+        box["rc"] = _lib.lib().hx_ipc_open_mem_handle(buf, ctypes.byref(ptr))
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout=OPEN_TIMEOUT_S)
+    if th.is_alive():
+        globals()["_wedged"] = True
+        raise _lib.HydraHipError(
+            f"hipIpcOpenMemHandle did not return within {OPEN_TIMEOUT_S:.0f} s (peer pool size in the window "
+            "[7/8 * 2^k, 2^k)? see ipc_safe_n_blocks); exit this process with a non-zero status")
+    _lib.check(box["rc"], "open ipc handle")
+    _opened[key] = int(ptr.value)
     return int(ptr.value) + off
 
 
