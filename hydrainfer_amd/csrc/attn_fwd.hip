@@ -290,6 +290,313 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 32x32x16 form for D = 64 / 128 and more than 64 query rows (prefill, the CLIP tower): a wave owns
+// 32 query rows, a workgroup 128; 64-key tiles.  Per FLOP it spends half the softmax VALU work of
+// the 16x16x32 form above (each exp / max / convert now feeds a 32-wide MFMA column instead of a
+// 16-wide one) — round 1's profile had that form at 9 % MFMA busy with ~15 vector instructions
+// per MFMA (profiles/r1_attn_prefill_pmc.json).
+//   * S^T[key][query] = K . Q^T with v_mfma_f32_32x32x16: A = K rows from the LDS image (lane
+//     (c = l & 31, h = l >> 5): key c, dims 16 ks + 8 h .. + 8), B = Q^T in registers.  The
+//     accumulator leaves lane (c, h) with query c and the 16 keys (r & 3) + 8 (r >> 2) + 4 h: a
+//     row statistic is a local reduction plus ONE exchange with lane l ^ 32.
+//   * O^T[dim][query] += V^T . P^T: the accumulator registers 8 ks2 .. 8 ks2 + 7, rounded to T, ARE
+//     the B operand of k-step ks2 (k-slot 8 h + j <-> key 16 ks2 + 8 (j >> 2) + 4 h + (j & 3)); V^T
+//     is the A operand, two ds_read_b64_tr_b16 per MFMA (4-row blocks at keys .. + 4 h and
+//     .. + 8 + 4 h, 16 dims per 16-lane group).
+//   * LDS images: K rows 2 D + 16 bytes apart (the 32-key ds_read_b128 is bank-conflict free),
+//     V rows 2 D + 64 bytes apart (the transposed reads of a 32-lane half are conflict free).
+// Same tile pipeline (register prefetch of tile t + 1, double-buffered images, one barrier per
+// tile), same masking, same rounding points (P to T before P.V) as the 16x16x32 kernel.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <typename T> struct Mfma32;
+template <> struct Mfma32<F16> {
+  static __device__ __forceinline__ f32x16 mma(u16x8 a, u16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma32<BF16> {
+  static __device__ __forceinline__ f32x16 mma(u16x8 a, u16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+// two workgroups per CU (LDS: 2 x 74 KiB): registers + accumulator registers must stay within 256,
+// or one wave per SIMD runs with nothing to hide its latencies behind (measured: 0.8 waves per SIMD
+// on average and 80 us for 4 x 704 tokens with the default bound)
+template <typename T, int D, bool PAGED>
+__global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) {
+  constexpr int KS = D / 16;         // QK k-steps
+  constexpr int NDB = D / 32;        // 32-dim output blocks
+  constexpr int KT = 64;             // keys per tile (two 32-key sub-tiles)
+  constexpr int RSK = 2 * D + 16;
+  constexpr int RSV = 2 * D + 64;
+  constexpr int LPR = D / 8;
+  constexpr int NL = KT * LPR / 256;
+  constexpr int KTILE = KT * RSK, VTILE = KT * RSV;
+  constexpr int TQ = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2][KT][RSK] | V[2][KT][RSV]
+
+  // Workgroup -> (sequence, query tile, head).  Compact grid (x = tile slots, y = heads) as in the
+  // kernel above, with two differences that matter for the causal tail: slots are ordered by tile
+  // LENGTH across all sequences (the r-th longest tile of every sequence before any (r+1)-th), and
+  // inside an XCD's contiguous id range the head is the fastest index — so an XCD starts with the
+  // longest tiles of ALL its heads and sequences, not with every tile of its first head
+  // (4 x 704 tokens: 49 -> see tools/bench_attn_prefill32.py).
+  int mblk = -1, h, b = 0;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int total = gx * gy;
+    int wg = blockIdx.x + gx * blockIdx.y;
+    int slot;
+    if (p.xcd_remap && total % 8 == 0 && gy % 8 == 0) {
+      const int hp = gy / 8;                               // XCD x runs ids x, x + 8, ...: hp heads each
+      const int x = wg % 8, i = wg / 8;
+      h = x * hp + i % hp;
+      slot = i / hp;
+    } else {
+      slot = wg % gx;
+      h = wg / gx;
+    }
+    // the slot-th (tile rank, sequence) pair: sequences in groups of 4; inside a group rank 0 (each
+    // sequence's longest tile) of its sequences, then rank 1, ...  (Rank-major over ALL sequences
+    // spreads the tiles of one (sequence, head) so far apart in time that they stop sharing K / V
+    // in L2: 32 x 704 tokens ran 1.5x slower that way.)
+    for (int g0 = 0; g0 < p.batch && mblk < 0; g0 += 4) {
+      const int g1 = min(g0 + 4, p.batch);
+      int max_tiles = 0, group_tiles = 0;
+      for (int i = g0; i < g1; ++i) {
+        const int tiles = (p.cu_q[i + 1] - p.cu_q[i] + TQ - 1) / TQ;
+        max_tiles = max(max_tiles, tiles);
+        group_tiles += tiles;
+      }
+      if (slot >= group_tiles) { slot -= group_tiles; continue; }
+      for (int rank = 0; rank < max_tiles && mblk < 0; ++rank) {
+        for (int i = g0; i < g1; ++i) {
+          const int tiles = (p.cu_q[i + 1] - p.cu_q[i] + TQ - 1) / TQ;
+          if (tiles > rank) {
+            if (slot == 0) { b = i; mblk = tiles - 1 - rank; break; }
+            --slot;
+          }
+        }
+      }
+    }
+    if (mblk < 0) return;                // spare slot (the grid is an upper bound)
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, hi = lane >> 5;
+  const int hk = h / p.group;
+  const int q_start = p.cu_q[b];
+  const int q_len = p.cu_q[b + 1] - q_start;
+  const int k_start = p.cu_k[b];
+  const int kv_len = p.cu_k[b + 1] - k_start;
+  const int q_row0_wg = mblk * TQ;
+  if (q_row0_wg >= q_len) return;
+  const int q_row0 = q_row0_wg + w * 32;
+
+  char* kbuf = smem;
+  char* vbuf = smem + 2 * KTILE;
+  const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
+  const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
+  const int32_t* bt = PAGED ? p.block_table + p.cu_block_lens[b] : nullptr;
+
+  u16x8 qf[KS];
+  {
+    const int qr = min(q_row0 + c, q_len - 1);
+    const u16* qp = reinterpret_cast<const u16*>(p.q) + (int64_t)(q_start + qr) * p.q_row_stride + (int64_t)h * D + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qp + 16 * ks);
+  }
+  const int shift = kv_len - q_len;
+  const int limit_c = p.causal ? min(kv_len - 1, q_row0 + c + shift) : kv_len - 1;
+  const int last_key_wave = q_row0 >= q_len ? -1 : p.causal ? min(kv_len - 1, q_row0 + 31 + shift) : kv_len - 1;
+  const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + TQ - 1, q_len - 1) + shift) : kv_len - 1;
+  const int n_tiles = (last_key_wg >= 0) ? last_key_wg / KT + 1 : 0;
+
+  // ---- cooperative tile staging.  Thread (gq = tid >> 6, r = (tid >> 2) & 15, q4 = tid & 3) owns key
+  // 16 gq + r of the tile and its 16-byte chunks q4 + 4 j: ONE page id and ONE row address per
+  // tile and cache (a 16-key group never straddles a page: block_size % 16 == 0), the chunks are
+  // immediate offsets from it.  (With a chunk index spread over rows the address arithmetic —
+  // a page lookup and two 64-bit multiplies per chunk — was most of the tile's instructions.)
+  const int st_row = 16 * (threadIdx.x >> 6) + ((threadIdx.x >> 2) & 15);
+  const int st_q4 = threadIdx.x & 3;
+  int page_next = 0;      // page of my key in the tile that will be loaded next
+  auto lookup_page = [&](int t) {
+    if (PAGED) page_next = bt[page_slot(min(t * KT + st_row, kv_len - 1), p.block_size, p.block_shift)];
+  };
+  u16x8 kreg[NL], vreg[NL];
+  auto load_tile = [&](int t) {
+    const int key = min(t * KT + st_row, kv_len - 1);
+    int64_t ko, vo;
+    if (PAGED) {
+      const int row = page_row(key, p.block_size, p.block_shift);
+      ko = (int64_t)page_next * p.k_block_stride + (int64_t)row * p.k_row_stride;
+      vo = (int64_t)page_next * p.v_block_stride + (int64_t)row * p.v_row_stride;
+    } else {
+      ko = (int64_t)(k_start + key) * p.k_row_stride;
+      vo = (int64_t)(k_start + key) * p.v_row_stride;
+    }
+    const u16* kp = kbase + ko + 8 * st_q4;
+    const u16* vp = vbase + vo + 8 * st_q4;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      kreg[j] = *reinterpret_cast<const u16x8*>(kp + 32 * j);
+      vreg[j] = *reinterpret_cast<const u16x8*>(vp + 32 * j);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* kd = kbuf + buf * KTILE + st_row * RSK + 16 * st_q4;
+    char* vd = vbuf + buf * VTILE + st_row * RSV + 16 * st_q4;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      *reinterpret_cast<u16x8*>(kd + 64 * j) = kreg[j];
+      *reinterpret_cast<u16x8*>(vd + 64 * j) = vreg[j];
+    }
+  };
+
+  f32x16 acc[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float m = HX_NEG_BIG, l = 0.f;
+
+  if (n_tiles > 0) {
+    lookup_page(0);
+    load_tile(0);
+    lookup_page(1);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  // transposed-read lane address inside a 4-row x 32-dim block: lane 4q + pp of each 16-lane group
+  // supplies row q, dims 16 half + 4 pp .. + 3 (half = which 16 of the 32 dims this group takes)
+  const int tr_q = (lane & 15) >> 2, tr_pp = lane & 3, tr_half = (lane >> 4) & 1;
+  const int tr_off = (4 * hi + tr_q) * RSV + (16 * tr_half + 4 * tr_pp) * 2;
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < n_tiles) {
+      load_tile(t + 1);                          // in flight under this tile's MFMAs
+      lookup_page(t + 2);                        // (clamped to the last key) for the next iteration
+    }
+    if (t * KT <= last_key_wave) {
+      const char* kt = kbuf + cur * KTILE;
+      const char* vt = vbuf + cur * VTILE;
+      f32x16 s[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+      {
+        // all K fragments of sub-tile 0 are requested before its first MFMA, those of sub-tile 1
+        // under sub-tile 0's MFMAs: no MFMA waits for a read issued just before it
+        const char* krd = kt + c * RSK + 16 * hi;
+        u16x8 kfa[KS], kfb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kfa[ks] = *reinterpret_cast<const u16x8*>(krd + 32 * ks);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          kfb[ks] = *reinterpret_cast<const u16x8*>(krd + 32 * RSK + 32 * ks);
+          s[0] = Mfma32<T>::mma(kfa[ks], qf[ks], s[0]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[1] = Mfma32<T>::mma(kfb[ks], qf[ks], s[1]);
+      }
+      const bool interior = t * KT + KT - 1 <= min(kv_len - 1, p.causal ? q_row0 + shift : kv_len - 1);
+      float mx = HX_NEG_BIG;
+      if (interior) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KT + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key > limit_c) s[u][r] = -INFINITY;
+            mx = fmaxf(mx, s[u][r]);
+          }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx * p.scale_log2);
+      const float alpha = fast_exp2(m - m_new);
+      m = m_new;
+      float ps = 0.f;
+      u16x8 pf[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = fast_exp2(fmaf(s[u][r], p.scale_log2, -m_new));
+          ps += e;
+          pf[u][r >> 3][r & 7] = T::from_float(e);
+        }
+      l = l * alpha + ps;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const char* vrd = vt + (32 * u + 16 * k2) * RSV + tr_off;
+#pragma unroll
+          for (int db = 0; db < NDB; ++db) {
+            const u16x4 lo = lds_tr_read(vrd + db * 64);
+            const u16x4 hh = lds_tr_read(vrd + 8 * RSV + db * 64);
+            u16x8 vf;
+            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+            vf[4] = hh[0]; vf[5] = hh[1]; vf[6] = hh[2]; vf[7] = hh[3];
+            acc[db] = Mfma32<T>::mma(vf, pf[u][k2], acc[db]);
+          }
+        }
+    }
+    if (t + 1 < n_tiles) store_tile(cur ^ 1);
+    __syncthreads();    // tile t+1 visible; everyone is done with tile t's image
+  }
+
+  // epilogue: O[query c][dim 32 db + 8 (r >> 2) + 4 hi + (r & 3)] = acc[db][r] / L
+  float lr = l + __shfl_xor(l, 32, 64);
+  const float inv = (lr > 0.f) ? 1.0f / lr : 0.f;
+  const int row = q_row0 + c;
+  if (row < q_len) {
+    u16* op = reinterpret_cast<u16*>(p.out) + (int64_t)(q_start + row) * p.o_row_stride + (int64_t)h * D + 4 * hi;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        u16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = T::from_float(acc[db][4 * rq + i] * inv);
+        *reinterpret_cast<u16x4*>(op + 32 * db + 8 * rq) = o;
+      }
+  }
+}
+
+template <typename T, int D, bool PAGED>
+int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
+  const size_t lds = 2 * 64 * ((2 * D + 16) + (2 * D + 64));
+  dim3 grid((unsigned)(p.total_q / 128 + batch), p.n_heads, 1);
+  if (p.total_q == 0) return HX_OK;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32_kernel<T, D, PAGED>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_rc(e);
+  }
+  attn_fwd32_kernel<T, D, PAGED><<<grid, 256, lds, stream>>>(p);
+  return check_launch();
+}
+
+int g_fwd_mfma32 = 1;   // tuning: 0 = always the 16x16x32 kernel
+
 template <typename T, int D, bool PAGED, int QR, int KU>
 int launch_fwd_cfg(const AttnParams& p, int batch, int max_seqlen_q, hipStream_t stream) {
   constexpr int RS = 2 * D + 32;
@@ -318,6 +625,10 @@ int launch_fwd_paged(const AttnParams& p, int batch, int max_seqlen_q, hipStream
   //    workgroups (1 x 704 tokens: 30 vs 35 us) — and for the dense CLIP batches (8 x 577: 34 vs 36);
   //    with more workgroups in flight 32-key tiles and their higher occupancy are ahead
   //    (3 x 683: 53 vs 56, 1 x 2048: 116 vs 119).
+  if constexpr (D == 64 || D == 128) {
+    // more than 64 query rows in some sequence: prefill / vision tower -> 32 rows per wave
+    if (g_fwd_mfma32 && max_seqlen_q > 64) return launch_fwd32<T, D, PAGED>(p, batch, stream);
+  }
   bool two = false;
   if (g_fwd_rows == 2 && D <= 128) two = true;
   const int64_t n_wg = (p.total_q / 64 + batch) * (int64_t)p.n_heads;
@@ -345,6 +656,7 @@ namespace hx {
 int fwd_set_option(const char* name, int value) {
   if (!strcmp(name, "fwd_row_blocks")) { g_fwd_rows = value; return HX_OK; }
   if (!strcmp(name, "fwd_key_units")) { g_fwd_keys = value; return HX_OK; }
+  if (!strcmp(name, "fwd_mfma32")) { g_fwd_mfma32 = value ? 1 : 0; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 

@@ -377,10 +377,24 @@ __global__ __launch_bounds__(256) void silu_elem_kernel(
 template <typename T>
 __device__ __forceinline__ void slab_sum8(const float* __restrict__ p, int n_splits,
                                           int64_t slab_stride, float (&acc)[8]) {
-  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-  for (int s = 1; s < n_splits; ++s) {
-    a += *reinterpret_cast<const f32x4*>(p + s * slab_stride);
-    b += *reinterpret_cast<const f32x4*>(p + s * slab_stride + 4);
+  // the slab pieces are L2 / HBM round trips: all loads of a batch of 6 splits are issued before
+  // the first add (a loop of load-add pairs made the 11-split down projection pay 11 dependent
+  // round trips); the adds stay in split order, so the sum is bit-identical
+  constexpr int kB = 6;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < n_splits; s0 += kB) {
+    f32x4 pa[kB], pb[kB];
+#pragma unroll
+    for (int k = 0; k < kB; ++k) {
+      const int s = min(s0 + k, n_splits - 1);
+      pa[k] = *reinterpret_cast<const f32x4*>(p + s * slab_stride);
+      pb[k] = *reinterpret_cast<const f32x4*>(p + s * slab_stride + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < kB; ++k) {
+      if (s0 + k == 0) { a = pa[0]; b = pb[0]; }
+      else if (s0 + k < n_splits) { a += pa[k]; b += pb[k]; }
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
