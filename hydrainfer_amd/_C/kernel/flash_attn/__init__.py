@@ -41,12 +41,15 @@ def mha_varlen_fwd(out: Tensor, q: Tensor, k: Tensor, v: Tensor, cu_seqlens_q: T
         raise _lib.HydraHipError("q/out heads must be contiguous")
     if alibi_slopes is not None:
         raise _lib.HydraHipError("alibi_slopes is not supported by the MI355X implementation")
-    if softcap != 0:
-        raise _lib.HydraHipError("softcap != 0 is not supported by the MI355X implementation")
-    # flash_api.cpp:80-87: causal iff window (-1, 0); full iff (-1, -1)
-    if window_size_left >= 0 or window_size_right > 0:
-        raise _lib.HydraHipError("local (sliding window) attention is not supported by the MI355X implementation")
+    if softcap < 0:
+        raise _lib.HydraHipError("softcap must be >= 0")
+    # flash_api.cpp:99-107: causal iff window (-1, 0); full iff (-1, -1); anything else is local
+    # (sliding window) attention, served by the general kernel
     causal = window_size_left < 0 and window_size_right == 0
+    local = not causal and (window_size_left >= 0 or window_size_right >= 0)
+    # a window that covers every key is no window (flash-attn's own normalisation)
+    if local and window_size_left >= max_seqlen_k and window_size_right >= max_seqlen_k:
+        local = False
 
     paged = block_table_ is not None
     a = _lib.hx_attn_args()
@@ -96,6 +99,9 @@ def mha_varlen_fwd(out: Tensor, q: Tensor, k: Tensor, v: Tensor, cu_seqlens_q: T
     a.dtype = _lib.dtype_code(q)
     a.num_splits = int(num_splits)
     a.workspace, a.workspace_bytes = None, 0
+    a.softcap = float(softcap)
+    a.window_left = int(window_size_left) if local else -1
+    a.window_right = int(window_size_right) if local else -1
 
     l = _lib.lib()
     need = l.hx_mha_varlen_fwd_workspace_bytes(ctypes.byref(a))
@@ -148,6 +154,7 @@ def decode_attention_fused(out: Tensor, q: Tensor, k_new: Tensor, v_new: Tensor,
     a.v_block_stride, a.v_row_stride, a.v_head_stride = v.stride(0), v.stride(1), v.stride(2)
     a.softmax_scale, a.causal, a.dtype, a.num_splits = float(softmax_scale), 1, _lib.dtype_code(q), int(num_splits)
     a.workspace, a.workspace_bytes = None, 0
+    a.softcap, a.window_left, a.window_right = 0.0, -1, -1
     fz = _lib.hx_fused_decode_args()
     fz.k_new, fz.v_new = k_new.data_ptr(), v_new.data_ptr()
     fz.k_new_row_stride, fz.v_new_row_stride = k_new.stride(0), v_new.stride(0)

@@ -38,6 +38,7 @@ class hx_attn_args(ctypes.Structure):
         ("v_block_stride", c_int64), ("v_row_stride", c_int64), ("v_head_stride", c_int64),
         ("softmax_scale", c_float), ("causal", c_int32), ("dtype", c_int32),
         ("num_splits", c_int32), ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("softcap", c_float), ("window_left", c_int32), ("window_right", c_int32), ("reserved", c_int32),
     ]
 
 

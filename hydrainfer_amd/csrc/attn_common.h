@@ -62,6 +62,8 @@ struct AttnParams {
   int32_t block_shift;      // log2(block_size) when it is a power of two, else -1 (runtime integer
                             // division costs ~30 VALU instructions; the kernels do two per key row)
   int32_t causal;
+  int32_t window_left, window_right;   // local attention (general kernel only): -1 = unbounded
+  float softcap_scale;                 // softmax_scale / softcap when softcap > 0 (then scale_log2 = softcap * log2 e), else 0
   int32_t xcd_remap;        // prefill kernel: renumber workgroups so that one head's query tiles share an XCD
   float scale_log2;         // softmax_scale * log2(e)
   int32_t n_splits;

@@ -102,15 +102,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   }
 
   const int shift = kv_len - q_len;
-  int limit_c[QR];
+  // visible keys of query row i: [i + shift - window_left, i + shift + window_right] (mask.h:173-193);
+  // causal = (unbounded, 0); no mask = both unbounded
+  const bool local = p.window_left >= 0;             // the dispatcher sets both sides for a local call
+  const int wr = p.causal ? 0 : local ? p.window_right : 0x3fffffff;
+  const int wl = local ? p.window_left : 0x3fffffff;
+  int limit_c[QR], first_c[QR];
 #pragma unroll
-  for (int rb = 0; rb < QR; ++rb)
-    limit_c[rb] = p.causal ? min(kv_len - 1, q_row0 + 16 * rb + c + shift) : kv_len - 1;
+  for (int rb = 0; rb < QR; ++rb) {
+    const int row = q_row0 + 16 * rb + c + shift;
+    limit_c[rb] = (int)min((int64_t)kv_len - 1, (int64_t)row + wr);
+    first_c[rb] = (int)max((int64_t)0, (int64_t)row - wl);
+  }
   // a wave whose rows all lie past the sequence (q_len = 1: three of the four) only helps staging
-  const int last_key_wave = q_row0 >= q_len ? -1
-                          : p.causal ? min(kv_len - 1, q_row0 + WROWS - 1 + shift) : kv_len - 1;
+  const int last_key_wave = q_row0 >= q_len ? -1 : (int)min((int64_t)kv_len - 1, (int64_t)q_row0 + WROWS - 1 + shift + wr);
   const int last_key_wg =
-      p.causal ? min(kv_len - 1, min(q_row0_wg + 4 * WROWS - 1, q_len - 1) + shift) : kv_len - 1;
+      (int)min((int64_t)kv_len - 1, (int64_t)min(q_row0_wg + 4 * WROWS - 1, q_len - 1) + shift + wr);
+  const int first_key_wg = (int)max((int64_t)0, (int64_t)q_row0_wg + shift - wl);
+  const int first_key_wave = (int)max((int64_t)0, (int64_t)q_row0 + shift - wl);
+  const int t_first = local ? first_key_wg / KT : 0;                   // tiles left of the window are skipped
   const int n_tiles = (last_key_wg >= 0) ? last_key_wg / KT + 1 : 0;   // workgroup-uniform
 
   // ---- cooperative tile staging: thread owns chunks idx = tid + 256*j of the [32][D] tile
@@ -172,23 +182,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     l[rb] = 0.f;
   }
 
-  if (n_tiles > 0) {
-    lookup_pages(0);
-    load_tile(0);
-    lookup_pages(1);
-    store_tile(0);
+  if (n_tiles > t_first) {
+    lookup_pages(t_first);
+    load_tile(t_first);
+    lookup_pages(t_first + 1);
+    store_tile(t_first & 1);
   }
   __syncthreads();
 
   const int q4 = c >> 2, p4 = c & 3;
-  for (int t = 0; t < n_tiles; ++t) {
+  for (int t = t_first; t < n_tiles; ++t) {
     const int cur = t & 1;
     if (t + 1 < n_tiles) {
       load_tile(t + 1);                          // in flight under this tile's MFMAs
       lookup_pages(t + 2);                       // (clamped to the last key) for the next iteration
     }
 
-    if (t * KT <= last_key_wave) {               // wave-uniform: tiles past this wave's diagonal
+    if (t * KT <= last_key_wave && t * KT + KT - 1 >= first_key_wave) {   // wave-uniform: tiles outside this wave's band
       const char* kt = kbuf + cur * TILE_BYTES;
       const char* vt = vbuf + cur * TILE_BYTES;
       // ---- S^T = K . Q^T for the 2 KU 16-key sub-tiles (A fragments from the shared K image,
@@ -205,10 +215,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
           for (int rb = 0; rb < QR; ++rb) s[rb][u] = Mfma<T>::mma(kf, qf[rb][st], s[rb][u]);
         }
       }
+      if (p.softcap_scale > 0.f) {                 // scores = softcap * tanh(q.k * scale / softcap), utils.h:383-388
+#pragma unroll
+        for (int rb = 0; rb < QR; ++rb)
+#pragma unroll
+          for (int u = 0; u < 2 * KU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[rb][u][i] = tanhf(s[rb][u][i] * p.softcap_scale);
+      }
       // ---- mask + online softmax (per query column c; state replicated over g).  The scale is
       //      folded into the exponent's fma; tiles that no row of this wave masks skip the compares
       //      (wave-uniform) — the inner loop is VALU-bound (PMC: ~15 vector instructions per MFMA).
-      const bool interior = t * KT + KT - 1 <= min(kv_len - 1, p.causal ? q_row0 + shift : kv_len - 1);
+      const bool interior = !local && t * KT + KT - 1 <= min(kv_len - 1, p.causal ? q_row0 + shift : kv_len - 1);
       u16x8 pf[QR][KU];
 #pragma unroll
       for (int rb = 0; rb < QR; ++rb) {
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int key = t * KT + u * 16 + 4 * g + i;
-              if (key > limit_c[rb]) s[rb][u][i] = -INFINITY;
+              if (key > limit_c[rb] || key < first_c[rb]) s[rb][u][i] = -INFINITY;
               mx = fmaxf(mx, s[rb][u][i]);
             }
         }
@@ -627,7 +645,8 @@ int launch_fwd_paged(const AttnParams& p, int batch, int max_seqlen_q, hipStream
   //    (3 x 683: 53 vs 56, 1 x 2048: 116 vs 119).
   if constexpr (D == 64 || D == 128) {
     // more than 64 query rows in some sequence: prefill / vision tower -> 32 rows per wave
-    if (g_fwd_mfma32 && max_seqlen_q > 64) return launch_fwd32<T, D, PAGED>(p, batch, stream);
+    if (g_fwd_mfma32 && max_seqlen_q > 64 && p.window_left < 0 && p.softcap_scale == 0.f)
+      return launch_fwd32<T, D, PAGED>(p, batch, stream);
   }
   bool two = false;
   if (g_fwd_rows == 2 && D <= 128) two = true;

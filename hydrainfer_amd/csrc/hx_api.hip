@@ -114,7 +114,7 @@ int validate(const hx_attn_args* a) {
 }  // namespace
 
 extern "C" int64_t hx_mha_varlen_fwd_workspace_bytes(const hx_attn_args* a) {
-  if (validate(a) != HX_OK || !use_decode(a)) return 0;
+  if (validate(a) != HX_OK || !use_decode(a) || a->softcap > 0.f || a->window_left >= 0 || a->window_right >= 0) return 0;
   // the same query serves hx_mha_varlen_fwd and hx_decode_attention_fused, which may pick
   // different kernels (and split counts) for a grouped-query shape: size for the larger
   const int s1 = pick_splits(a, false), s2 = pick_splits(a, true);
@@ -180,6 +180,22 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.causal = a->causal;
   p.xcd_remap = g_fwd_xcd;
   p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+  // flash_api.cpp:93-111
+  p.window_left = a->window_left;
+  p.window_right = a->window_right;
+  p.softcap_scale = 0.f;
+  if (a->softcap > 0.f) {
+    p.softcap_scale = a->softmax_scale / a->softcap;
+    p.scale_log2 = a->softcap * 1.4426950408889634f;
+  }
+  const bool local = a->window_left >= 0 || a->window_right >= 0;
+  if (local && a->causal) return HX_ERR_UNSUPPORTED;
+  if ((local || a->softcap > 0.f) && fused) return HX_ERR_UNSUPPORTED;
+  if (local) {   // one-sided windows: the open side reaches the end of the sequence
+    if (p.window_left < 0) p.window_left = a->max_seqlen_k;
+    if (p.window_right < 0) p.window_right = a->max_seqlen_k;
+  }
+  const bool plain = !local && a->softcap <= 0.f;
   p.n_splits = 1;
   p.ws_o = nullptr;
   p.ws_ml = nullptr;
@@ -209,7 +225,7 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   }
 
   hipStream_t s = (hipStream_t)stream;
-  if (use_decode(a)) {
+  if (plain && use_decode(a)) {
     // with q_len == 1 the causal mask admits every cached key (bottom-right aligned),
     // so causal and non-causal decode coincide.
     const bool gqa = use_gqa(a, fused != nullptr);

@@ -221,6 +221,15 @@ typedef struct hx_attn_args {
   int32_t num_splits;    /* 0 = choose automatically, 1 = never split */
   void* workspace;
   int64_t workspace_bytes;
+  /* flash_api.cpp:93-111.  softcap > 0: scores = softcap * tanh(q.k * softmax_scale / softcap)
+   * before masking.  window_left / window_right >= 0: local attention — query row i (of q_len rows,
+   * kv_len keys) sees keys [i + kv_len - q_len - window_left, i + kv_len - q_len + window_right]
+   * (mask.h:173-193); -1 = unbounded on that side; `causal` must be 0 when a window is given
+   * (causal IS window (-1, 0)). */
+  float softcap;
+  int32_t window_left;
+  int32_t window_right;
+  int32_t reserved;
 } hx_attn_args;
 
 int64_t hx_mha_varlen_fwd_workspace_bytes(const hx_attn_args* args);

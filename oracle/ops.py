@@ -137,7 +137,8 @@ def silu_and_mul(gate: Tensor, up: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------
 def paged_attention(query: Tensor, key_cache: Tensor, value_cache: Tensor, q_cu_seq_lens: Tensor,
                     kv_cu_seq_lens: Tensor, block_tables: Tensor, cu_blocks_lens: Tensor,
-                    causal: bool = True, sm_scale: Optional[float] = None) -> Tensor:
+                    causal: bool = True, sm_scale: Optional[float] = None, softcap: float = 0.0,
+                    window: Optional[tuple] = None) -> Tensor:
     """TorchCausalGroupedQueryPageAttentionHandler.forward,
     hydrainfer/layer/causal_attention.py:307-374: per sequence gather pages, fp32 math,
     GQA by repeat_interleave, bottom-right aligned causal mask `(x - y) > (k_len - q_len)`,
@@ -154,12 +155,13 @@ def paged_attention(query: Tensor, key_cache: Tensor, value_cache: Tensor, q_cu_
         k = key_cache[bt].reshape(-1, n_kv_heads, head_dim)[:kv_len].to(torch.float)
         v = value_cache[bt].reshape(-1, n_kv_heads, head_dim)[:kv_len].to(torch.float)
         q = query[int(q_cu_seq_lens[i]): int(q_cu_seq_lens[i + 1])].to(torch.float)
-        outs.append(_attend(q, k, v, sm_scale, causal))
+        outs.append(_attend(q, k, v, sm_scale, causal, softcap=softcap, window=window))
     return torch.cat(outs, dim=0).to(query.dtype)
 
 
 def varlen_attention(query: Tensor, key: Tensor, value: Tensor, cu_seqlens_q: Tensor,
-                     cu_seqlens_k: Tensor, causal: bool, sm_scale: Optional[float] = None) -> Tensor:
+                     cu_seqlens_k: Tensor, causal: bool, sm_scale: Optional[float] = None,
+                     softcap: float = 0.0, window: Optional[tuple] = None) -> Tensor:
     """Dense varlen attention: TorchMultiHeadAttentionHandler.forward,
     hydrainfer/layer/multihead_attention.py:46-70 (non-causal, fp32 softmax(QK^T/sqrt(d))V)
     generalised to ragged cu_seqlens as mha_varlen_fwd's dense path takes them
@@ -173,12 +175,17 @@ def varlen_attention(query: Tensor, key: Tensor, value: Tensor, cu_seqlens_q: Te
         k = key[int(cu_seqlens_k[i]): int(cu_seqlens_k[i + 1])].to(torch.float)
         v = value[int(cu_seqlens_k[i]): int(cu_seqlens_k[i + 1])].to(torch.float)
         # multihead_attention.py:59-60 scales the query before the product
-        outs.append(_attend(q, k, v, sm_scale, causal, scale_query_first=True))
+        outs.append(_attend(q, k, v, sm_scale, causal, scale_query_first=True, softcap=softcap, window=window))
     return torch.cat(outs, dim=0).to(query.dtype)
 
 
 def _attend(q: Tensor, k: Tensor, v: Tensor, sm_scale: float, causal: bool,
-            scale_query_first: bool = False) -> Tensor:
+            scale_query_first: bool = False, softcap: float = 0.0, window: Optional[tuple] = None) -> Tensor:
+    """softcap / window are NOT in the reference's torch handlers (parity unpinned for them): they
+    restate the CUDA kernel's semantics — scores = softcap * tanh(q.k * scale / softcap) before
+    masking (flash_api.cpp:93-97, utils.h:383-388); local window (left, right), -1 = unbounded on
+    that side: query row y of lq sees keys x with y + lk - lq - left <= x <= y + lk - lq + right
+    (mask.h:173-193, flash_api.cpp:103-107).  Rows that see no key give zeros."""
     # q [Lq, H, D]; k, v [Lk, HK, D] fp32
     group = q.shape[1] // k.shape[1]
     k = k.repeat_interleave(group, dim=1)
@@ -187,12 +194,20 @@ def _attend(q: Tensor, k: Tensor, v: Tensor, sm_scale: float, causal: bool,
         scores = torch.einsum("qhd,khd->hqk", q * sm_scale, k)
     else:
         scores = torch.einsum("qhd,khd->hqk", q, k) * sm_scale
+    if softcap > 0:
+        scores = softcap * torch.tanh(scores / softcap)
+    lq, lk = q.shape[0], k.shape[0]
+    x = torch.arange(lk)[None, None, :]
+    y = torch.arange(lq)[None, :, None]
     if causal:
-        lq, lk = q.shape[0], k.shape[0]
-        x = torch.arange(lk)[None, None, :]
-        y = torch.arange(lq)[None, :, None]
         scores = scores.masked_fill((x - y) > (lk - lq), float("-inf"))
+    if window is not None and (window[0] >= 0 or window[1] >= 0):
+        left = window[0] if window[0] >= 0 else lk
+        right = window[1] if window[1] >= 0 else lk
+        d = x - y - (lk - lq)
+        scores = scores.masked_fill((d > right) | (d < -left), float("-inf"))
     p = torch.softmax(scores, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)          # a row whose window holds no key
     return torch.einsum("hqk,khd->qhd", p, v)
 
 

@@ -461,3 +461,49 @@ def test_gqa_decode_kernel_vs_oracle_and_per_head_kernel(dt, heads, D):
     finally:
         _lib.lib().hx_debug_set_option(b"decode_gqa", 1)
     assert_close_t(outs[1], old.cpu(), atol, rtol, what="gqa kernel vs per-head kernel")
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("window", [(16, 0), (0, 16), (7, 3), (64, -1), (-1, 5), (200, 200), (0, 0)])
+@pytest.mark.parametrize("softcap", [0.0, 30.0])
+def test_local_window_and_softcap(dt, window, softcap):
+    """The arguments the reference's CUDA kernel accepts beyond the LLaVA path (flash_api.cpp:93-111):
+    sliding-window (local) attention and score soft-capping, paged and dense, prefill / chunk /
+    decode row counts, against the oracle's restatement of mask.h:173-193 and utils.h:383-388 (the
+    reference's torch handler has neither: parity unpinned for these two features).  fast_tanh in
+    the reference vs tanhf here: covered by the attention tolerance."""
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    from oracle import ops
+    H, HK, D = 8, 2, 128
+    atol, rtol = ATTN_TOL[dt]
+    for (q_lens, kv_lens) in (([1, 1, 1], [100, 17, 260]), ([15, 111], [15, 234]), ([130], [130])):
+        q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(len(q_lens), H, HK, D, kv_lens, q_lens, dt, seed=sum(kv_lens))
+        out = torch.empty_like(q, device=DEV)
+        mha_varlen_fwd(out, q.to(DEV), kc.to(DEV), vc.to(DEV), cu_q.to(DEV), cu_k.to(DEV), bt.to(DEV), cu_b.to(DEV),
+                       None, max(q_lens), max(kv_lens), 1 / math.sqrt(D), softcap, window[0], window[1], 0)
+        ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b, causal=False, softcap=softcap, window=window)
+        assert_close_t(out.cpu(), ref, atol, rtol, what=f"paged window={window} softcap={softcap} q={q_lens}")
+    # dense (the vision-tower entry) with a window
+    g = torch.Generator().manual_seed(3)
+    n = [70, 33]
+    qd = torch.randn((sum(n), H, D), generator=g).to(dt)
+    kd = torch.randn((sum(n), HK, D), generator=g).to(dt)
+    vd = torch.randn((sum(n), HK, D), generator=g).to(dt)
+    cu = torch.tensor([0, 70, 103], dtype=torch.int32)
+    out = torch.empty_like(qd, device=DEV)
+    mha_varlen_fwd(out, qd.to(DEV), kd.to(DEV), vd.to(DEV), cu.to(DEV), cu.to(DEV), None, None, None, 70, 70,
+                   1 / math.sqrt(D), softcap, window[0], window[1], 0)
+    ref = ops.varlen_attention(qd, kd, vd, cu, cu, causal=False, softcap=softcap, window=window)
+    assert_close_t(out.cpu(), ref, atol, rtol, what=f"dense window={window} softcap={softcap}")
+
+
+def test_softcap_with_causal_mask():
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    from oracle import ops
+    dt, H, D = torch.float16, 4, 64
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(2, H, H, D, [90, 33], [90, 20], dt, seed=8)
+    out = torch.empty_like(q, device=DEV)
+    mha_varlen_fwd(out, q.to(DEV), kc.to(DEV), vc.to(DEV), cu_q.to(DEV), cu_k.to(DEV), bt.to(DEV), cu_b.to(DEV),
+                   None, 90, 90, 1 / math.sqrt(D), 20.0, -1, 0, 0)
+    ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b, causal=True, softcap=20.0)
+    assert_close_t(out.cpu(), ref, 1e-3, 1e-3, what="causal + softcap")
