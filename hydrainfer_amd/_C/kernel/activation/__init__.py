@@ -32,16 +32,24 @@ def silu_and_mul(gate: Tensor, up: Tensor) -> Tensor:
     return out
 
 
-def silu_and_mul_slabs(partial: Tensor, n_splits: int, rows: int, inter: int, dtype: torch.dtype) -> Tensor:
+def silu_and_mul_slabs(partial: Tensor, n_splits: int, rows: int, inter: int, dtype: torch.dtype,
+                       fragment_major: bool = False) -> Tensor:
     """Extension: gate|up = (T) sum of the fp32 slabs [n_splits, rows, 2*inter]; returns
-    (T)silu(gate) * up.  Bit-identical to reduce + silu_and_mul."""
+    (T)silu(gate) * up.  Bit-identical to reduce + silu_and_mul.  fragment_major: the result is a flat
+    tensor of ceil16(rows) * inter elements in the order the activations-in-registers GEMM reads."""
     _lib.require_gpu(partial)
     if partial.dtype != torch.float32 or partial.numel() < n_splits * rows * 2 * inter:
         raise _lib.HydraHipError("silu_and_mul_slabs: partial must be float32 [n_splits, rows, 2*inter]")
-    out = torch.empty((rows, inter), dtype=dtype, device=partial.device)
+    if fragment_major:
+        if inter % 32:
+            raise _lib.HydraHipError("silu_and_mul_slabs: fragment-major output needs inter % 32 == 0")
+        out = torch.empty((rows + 15) // 16 * 16 * inter, dtype=dtype, device=partial.device)
+    else:
+        out = torch.empty((rows, inter), dtype=dtype, device=partial.device)
     code = {torch.float16: _lib.HX_F16, torch.bfloat16: _lib.HX_BF16}.get(dtype)
     if code is None:
         raise _lib.HydraHipError("silu_and_mul_slabs: fp16 / bf16 only")
-    _lib.check(_lib.lib().hx_silu_and_mul_slabs(out.data_ptr(), partial.data_ptr(), int(n_splits), rows, inter,
-                                                code, _lib.current_stream()), "silu_and_mul_slabs")
+    _lib.check(_lib.lib().hx_silu_and_mul_slabs_ex(out.data_ptr(), partial.data_ptr(), int(n_splits), rows, inter,
+                                                   code, 1 if fragment_major else 0, _lib.current_stream()),
+               "silu_and_mul_slabs")
     return out

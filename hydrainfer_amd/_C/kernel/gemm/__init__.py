@@ -155,3 +155,93 @@ def linear_decode_partial_packed(x: Tensor, packed: Tensor, N: int, partial: Ten
     if rc < 0:
         _lib.check(rc, "linear_decode_partial_packed")
     return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# activations-in-registers kernel (csrc/gemm_xreg.hip): M <= 32, one slab for K <= 4096
+# ------------------------------------------------------------------------------------------------
+def xreg_supported(M: int, N: int, K: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.float16, torch.bfloat16) and _lib.lib().hx_linear_decode_xreg_supported(M, N, K) == 1
+
+
+def gate_up_silu_supported(M: int, inter: int, K: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.float16, torch.bfloat16) and _lib.lib().hx_gate_up_silu_xreg_supported(M, inter, K) == 1
+
+
+def xreg_workspace_floats(M: int, N: int, K: int) -> int:
+    return _lib.lib().hx_linear_decode_xreg_workspace_bytes(M, N, K) // 4
+
+
+def fragment_major_elems(rows: int, K: int) -> int:
+    """Elements of the fragment-major form of a [rows, K] activation (rows padded to 16)."""
+    return (rows + 15) // 16 * 16 * K
+
+
+def to_fragment_major(x: Tensor) -> Tensor:
+    """[M, K] -> flat fragment-major tensor (torch ops; tests and tools — the product path gets this
+    layout straight from the producing kernels)."""
+    M, K = x.shape
+    MB = (M + 15) // 16
+    xp = torch.zeros((MB * 16, K), dtype=x.dtype, device=x.device)
+    xp[:M] = x
+    return xp.view(MB, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().view(-1)
+
+
+def from_fragment_major(flat: Tensor, M: int, K: int) -> Tensor:
+    MB = (M + 15) // 16
+    return flat[: MB * 16 * K].view(K // 32, MB, 4, 16, 8).permute(1, 3, 0, 2, 4).reshape(MB * 16, K)[:M]
+
+
+def pack_weight_xreg(weight: Tensor, interleave_halves: bool = False) -> Tensor:
+    """weight [N, K] -> flat [N*K] in the block order of the activations-in-registers kernel;
+    interleave_halves: gate|up weight for gate_up_silu_xreg."""
+    _lib.require_gpu(weight)
+    N, K = weight.shape
+    if weight.dtype not in (torch.float16, torch.bfloat16) or N % 16 or K % 32 or weight.stride(1) != 1:
+        raise _lib.HydraHipError("pack_weight_xreg: fp16/bf16 [N % 16 == 0, K % 32 == 0], contiguous rows")
+    packed = torch.empty(N * K, dtype=weight.dtype, device=weight.device)
+    _lib.check(_lib.lib().hx_pack_decode_weight_xreg(packed.data_ptr(), weight.data_ptr(), N, K, weight.stride(0),
+                                                     1 if interleave_halves else 0, _lib.dtype_code(weight),
+                                                     _lib.current_stream()), "pack_weight_xreg")
+    return packed
+
+
+def _x_args(x: Tensor, frag_shape):
+    if frag_shape is None:
+        if x.dim() != 2 or x.stride(1) != 1:
+            raise _lib.HydraHipError("xreg: x must be [M, K] with contiguous rows (or fragment-major with frag_shape)")
+        return x.shape[0], x.shape[1], x.stride(0), 0
+    M, K = frag_shape
+    if not x.is_contiguous() or x.numel() < fragment_major_elems(M, K):
+        raise _lib.HydraHipError("xreg: fragment-major x needs ceil16(M) * K contiguous elements")
+    return M, K, K, 1
+
+
+def linear_decode_partial_xreg(x: Tensor, packed: Tensor, N: int, partial: Tensor, frag_shape=None) -> int:
+    """fp32 slabs [n_splits, M, N] of x[M <= 32, K] @ W^T with `packed` = pack_weight_xreg(W [N, K]).
+    x is [M, K], or the flat fragment-major form with frag_shape = (M, K).  Returns n_splits."""
+    _lib.require_gpu(x, packed, partial)
+    M, K, ldx, fm = _x_args(x, frag_shape)
+    if packed.numel() != N * K or packed.dtype != x.dtype or not packed.is_contiguous():
+        raise _lib.HydraHipError("linear_decode_partial_xreg: packed must be pack_weight_xreg(weight [N, K]) of x's dtype")
+    if partial.dtype != torch.float32 or not partial.is_contiguous():
+        raise _lib.HydraHipError("linear_decode_partial_xreg: partial must be contiguous float32")
+    rc = _lib.lib().hx_linear_decode_partial_xreg(partial.data_ptr(), x.data_ptr(), packed.data_ptr(), M, N, K,
+                                                  ldx, fm, partial.numel() * 4, _lib.dtype_code(x),
+                                                  _lib.current_stream())
+    if rc < 0:
+        _lib.check(rc, "linear_decode_partial_xreg")
+    return rc
+
+
+def gate_up_silu_xreg(x: Tensor, packed_gate_up: Tensor, inter: int, act: Tensor, frag_shape=None) -> None:
+    """act (flat, fragment-major [M, inter]) = silu(x Wg^T) * (x Wu^T), one launch;
+    packed_gate_up = pack_weight_xreg(W [2*inter, K], interleave_halves=True)."""
+    _lib.require_gpu(x, packed_gate_up, act)
+    M, K, ldx, fm = _x_args(x, frag_shape)
+    if packed_gate_up.numel() != 2 * inter * K or packed_gate_up.dtype != x.dtype or act.dtype != x.dtype:
+        raise _lib.HydraHipError("gate_up_silu_xreg: packed weight [2*inter, K] and act of x's dtype")
+    if not act.is_contiguous() or act.numel() < fragment_major_elems(M, inter):
+        raise _lib.HydraHipError("gate_up_silu_xreg: act needs ceil16(M) * inter contiguous elements")
+    _lib.check(_lib.lib().hx_gate_up_silu_xreg(act.data_ptr(), x.data_ptr(), packed_gate_up.data_ptr(), M, inter, K,
+                                               ldx, fm, _lib.dtype_code(x), _lib.current_stream()), "gate_up_silu_xreg")

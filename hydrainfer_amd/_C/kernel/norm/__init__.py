@@ -37,9 +37,11 @@ def add_rms_norm(out: Tensor, residual: Tensor, x: Tensor, weight: Tensor, epsil
 
 
 def add_rms_norm_slabs(out: Tensor, residual: Tensor, partial: Tensor, n_splits: int, weight: Tensor,
-                       epsilon: float) -> None:
+                       epsilon: float, fragment_major: bool = False) -> None:
     """Extension: x = (T) sum of the n_splits fp32 slabs in `partial` ([n_splits, rows, hidden]);
-    residual += x (in place); out = rms_norm(residual).  Bit-identical to reduce + add_rms_norm."""
+    residual += x (in place); out = rms_norm(residual).  Bit-identical to reduce + add_rms_norm.
+    fragment_major: `out` (at least gemm.fragment_major_elems(rows, hidden) elements) receives the same
+    values in the MFMA-B-fragment order the activations-in-registers GEMM reads (hydra_hip.h)."""
     _lib.require_gpu(out, residual, partial, weight)
     rows, hidden = residual.shape
     if partial.dtype != torch.float32 or partial.numel() < n_splits * rows * hidden:
@@ -47,7 +49,10 @@ def add_rms_norm_slabs(out: Tensor, residual: Tensor, partial: Tensor, n_splits:
     for t in (out, residual, weight):
         if not t.is_contiguous() or t.dtype != residual.dtype:
             raise _lib.HydraHipError("add_rms_norm_slabs: tensors must be contiguous and of one dtype")
-    _lib.check(_lib.lib().hx_add_rms_norm_slabs(out.data_ptr(), residual.data_ptr(), partial.data_ptr(),
-                                                int(n_splits), weight.data_ptr(), float(epsilon), rows,
-                                                hidden, _lib.dtype_code(residual), _lib.current_stream()),
+    if fragment_major and (hidden % 32 or out.numel() < (rows + 15) // 16 * 16 * hidden):
+        raise _lib.HydraHipError("add_rms_norm_slabs: fragment-major output needs hidden % 32 == 0 and ceil16(rows) * hidden elements")
+    _lib.check(_lib.lib().hx_add_rms_norm_slabs_ex(out.data_ptr(), residual.data_ptr(), partial.data_ptr(),
+                                                   int(n_splits), weight.data_ptr(), float(epsilon), rows,
+                                                   hidden, _lib.dtype_code(residual), 1 if fragment_major else 0,
+                                                   _lib.current_stream()),
                "add_rms_norm_slabs")

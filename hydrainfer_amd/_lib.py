@@ -87,6 +87,16 @@ _SIGNATURES = {
     "hx_decode_chain": (c_int, [POINTER(hx_chain_args), c_void_p]),
     "hx_pack_decode_weight": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hx_linear_decode_partial_packed": (c_int, [c_void_p] * 3 + [c_int64] * 5 + [c_int, c_void_p]),
+    "hx_linear_decode_xreg_supported": (c_int, [c_int64] * 3),
+    "hx_linear_decode_xreg_splits": (c_int, [c_int64]),
+    "hx_linear_decode_xreg_workspace_bytes": (c_int64, [c_int64] * 3),
+    "hx_fragment_major_elems": (c_int64, [c_int64] * 2),
+    "hx_pack_decode_weight_xreg": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "hx_linear_decode_partial_xreg": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_int64, c_int, c_void_p]),
+    "hx_gate_up_silu_xreg_supported": (c_int, [c_int64] * 3),
+    "hx_gate_up_silu_xreg": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_int, c_void_p]),
+    "hx_add_rms_norm_slabs_ex": (c_int, [c_void_p] * 3 + [c_int32, c_void_p, c_float, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "hx_silu_and_mul_slabs_ex": (c_int, [c_void_p] * 2 + [c_int32, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hx_add_rms_norm_slabs": (c_int, [c_void_p] * 3 + [c_int32, c_void_p, c_float, c_int64, c_int64, c_int, c_void_p]),
     "hx_silu_and_mul_slabs": (c_int, [c_void_p] * 2 + [c_int32, c_int64, c_int64, c_int, c_void_p]),
     "hx_mha_varlen_fwd_workspace_bytes": (c_int64, [POINTER(hx_attn_args)]),

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
 // (tools/bench_stream.py: contiguous 1 KiB per wave instruction 6.6-6.8 TB/s non-temporal at any
 // occupancy, 8 rows x 128 B 4.6-6.2 TB/s depending on the waves per CU).  Same k order, same
 // accumulation chains: bit-identical to gemm_skinny_kernel.
-template <typename T, int MB, int R, int NW>
+template <typename T, int MB, int R, int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p, const int g_nt_store) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kThreads = NW * 64;
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
       const int i = threadIdx.x + j * kThreads;
       const int row = i / kCpr, ch = i % kCpr;
       const bool ok = row < p.M && ch * 8 < KR;
-      xr[j] = *reinterpret_cast<const u16x8*>(xb + (int64_t)(ok ? row : 0) * p.ldx + (ok ? ch * 8 : 0));
+      if (DBG & 4) xr[j] = u16x8{1, 2, 3, 4, 5, 6, 7, 8};   // ablation: no x loads
+      else xr[j] = *reinterpret_cast<const u16x8*>(xb + (int64_t)(ok ? row : 0) * p.ldx + (ok ? ch * 8 : 0));
     }
   }
   // the fragments of (split, rg) are one run of nks KiB at KiB offset ks0 * n_rg + rg * nks: the
@@ -240,6 +241,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
     for (int j = 0; j < kChunk; ++j) {
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
+        if (DBG & 8) {   // ablation: no LDS reads, no MFMA
+          acc[mb][0] += __builtin_bit_cast(float, (uint32_t)buf[it & 1][j][0] << 16);
+          continue;
+        }
         const u16x8 xf = *reinterpret_cast<const u16x8*>(xp + mb * 16 * kRS + j * 64);
         acc[mb] = Mfma<T>::mma(buf[it & 1][j], xf, acc[mb]);
       }
@@ -254,9 +259,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int m = mb * 16 + c;
-        if (m < p.M && rg < n_rg_all) {
+        if (m < p.M && rg < n_rg_all && !((DBG & 2) && acc[mb][0] != 123.25f)) {   // bit 1: ablation, no stores
           f32x4* dst = reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g);
-          if (g_nt_store) __builtin_nontemporal_store(acc[mb], dst);
+          if (g_nt_store & 1) __builtin_nontemporal_store(acc[mb], dst);
           else *dst = acc[mb];
         }
         acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -336,7 +341,12 @@ int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
       if (e != hipSuccess) return hip_rc(e);
     }
-    gemm_packed_kernel<T, MB, R, NW><<<grid, NW * 64, plds, stream>>>(p, g_slab_nt);
+    if (MB == 2 && (g_slab_nt >> 1)) {   // ablation variants (tools/gemm_ablate.py), batch 17..32 only
+      if ((g_slab_nt >> 1) == 1) gemm_packed_kernel<T, MB, R, NW, 2><<<grid, NW * 64, plds, stream>>>(p, g_slab_nt & 1);
+      else gemm_packed_kernel<T, MB, R, NW, 14><<<grid, NW * 64, plds, stream>>>(p, g_slab_nt & 1);
+      return check_launch();
+    }
+    gemm_packed_kernel<T, MB, R, NW><<<grid, NW * 64, plds, stream>>>(p, g_slab_nt & 1);
     return check_launch();
   }
   const size_t lds = (size_t)MB * 16 * kRS + (size_t)NW * 2048;   // x slice + per-wave transpose images

@@ -1,0 +1,395 @@
+// gemm_xreg.hip — decode-batch (M <= 32) weight-streaming GEMM with the ACTIVATIONS IN REGISTERS:
+//     partial[s][m][n] = sum_{k in split s} x[m][k] * W[n][k]         (fp32 slabs, usually ONE)
+// the nn.Linear products of a decoder layer (hydrainfer/model/llama.py:24-27,48-50) at decode batch
+// sizes.  gemm_skinny.hip keeps a 1024-wide slice of x in LDS, so K = 4096 needs 4 K-splits whose
+// fp32 partial slabs (25 MB per 7B layer) cost 8.7 us of a 159 us layer in stores alone
+// (tools/gemm_ablate.py) and force a reduce kernel behind every product.  Here:
+//   * a workgroup is 4 waves and spans the WHOLE K of its split: wave w owns KW consecutive
+//     k-steps (of 32) and keeps the x fragments of exactly those k-steps in registers (B operands:
+//     KW * MB * 4 registers, 256 for K = 4096 at batch 32; one wave per SIMD, 512 registers each);
+//   * the workgroup walks row groups rg = b, b + nb, b + 2 nb, ...; per row group a wave streams its
+//     KW KiB of packed weight fragments (1 KiB contiguous per wave instruction, non-temporal)
+//     through ceil(KW / 8) register buffers that are refilled for the NEXT row group as soon as they
+//     are consumed: up to 32 KiB in flight per wave, 128 KiB per CU, no LDS and no barrier in the
+//     loop;
+//   * the four waves' partial tiles go to LDS; ONE barrier at the end of the workgroup's life, then
+//     the tiles are summed in wave order (deterministic) and stored;
+//   * waves start their k-steps at a workgroup-dependent rotation so that the fragments the chip
+//     reads at one instant are spread over all memory channels (in lock-step they would sit
+//     128 KiB apart).
+// K = 4096 needs no K-split at all (one slab); K = 11008 three (was 11).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include "attn_common.h"
+
+namespace {
+
+using namespace hx;
+
+struct XregParams {
+  const void* x;
+  const void* w;        // packed: fragment (split s, row group rg, k-step j of the split) at KiB index
+                        //         s*P*n_rg + rg*nks(s) + j,   P = 4*KW,  nks(s) = min(P, total_ks - s*P)
+  float* partial;       // [S][M][N]
+  int64_t ldx;
+  int32_t M, N, K;
+  int32_t stagger;
+  int32_t x_packed;     // x is fragment-major: piece ((ks*MB + mb)*64 + lane) = x[16mb + (lane&15)][32ks + 8(lane>>4) ..+8]
+  void* act;            // EPI = 1: silu(gate)*up, fragment-major [inter/32][MB][64 lanes][8]
+};
+
+__device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __attribute__((aligned(128))) u16 g_zero_line[64] = {0};
+
+constexpr int kMaxG = 16;     // row groups per workgroup (LDS: kMaxG * 4 waves * MB KiB)
+
+// EPI = 0: fp32 slabs.  EPI = 1 (one split only): the weight is a gate|up projection packed with its
+// 16-row groups interleaved (group 2j = gate rows 16j.., group 2j+1 = up rows 16j..); a workgroup
+// takes whole pairs and writes act = silu(gate) * up with the rounding of hx_silu_and_mul_slabs on the
+// one-slab result (sum -> T, silu -> T, product -> T), fragment-major for the down projection.
+template <typename T, int MB, int KW, int EPI = 0, int DBG = 0>
+__global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NBUF = (KW + 7) / 8;
+  constexpr int P = 4 * KW;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int split = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
+  const int total_ks = p.K >> 5;
+  const int n_rg = p.N >> 4;
+  const int ks0 = split * P;
+  const int nks = min(P, total_ks - ks0);
+  const int kw = max(0, min(KW, nks - w * KW));            // this wave's real k-steps
+  // this workgroup's row groups (>= 1): rg_of(0), rg_of(1), ...
+  const int G = EPI ? 2 * (((n_rg >> 1) - b + nb - 1) / nb) : (n_rg - b + nb - 1) / nb;
+  auto rg_of = [&](int i) { return EPI ? 2 * (b + (i >> 1) * nb) + (i & 1) : b + i * nb; };
+  const int j0 = p.stagger ? (int)(((unsigned)b * 7u + (unsigned)w * 3u) % (unsigned)KW) : 0;
+
+  // k-step of slot t: rot(t) = (j0 + t) mod KW; slots whose k-step is past the wave's range are
+  // padding: x fragment zero, weight address clamped to a valid fragment
+  auto rot = [&](int t) { const int r = j0 + t; return r >= KW ? r - KW : r; };
+  const u16* wbase = reinterpret_cast<const u16*>(p.w) + 8 * lane + ((int64_t)ks0 * n_rg) * 512;
+  const int wave_k0 = min(w * KW, max(nks - 1, 0));
+  auto frag_ptr = [&](int rg, int t) {
+    const int r = rot(t);
+    const int j = wave_k0 + (r < kw ? r : 0);
+    return wbase + ((int64_t)rg * nks + j) * 512;
+  };
+
+  u16x8 buf[NBUF][8];
+  auto load_buf = [&](int rg, int q) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (8 * q + j < KW) buf[q][j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(frag_ptr(rg, 8 * q + j)));
+  };
+  // x fragments of this wave's k-steps, in slot order.  Prologue order: for each block of 8 slots,
+  // its x fragments, then its weight buffer — the first MFMAs need only the first block, so the
+  // x broadcast (256 KiB per CU out of the XCD's L2, ~2 us chip-wide) overlaps the arrival of the
+  // first weights instead of preceding it.  No use of a loaded value before the first MFMA
+  // (padding slots read a zero line instead of being masked: a select on the loaded value made
+  // hipcc wait for every earlier load after each of these).
+  u16x8 xb[KW][MB];
+  {
+    const u16* xp = reinterpret_cast<const u16*>(p.x) + 8 * g;
+    const u16* zp = reinterpret_cast<const u16*>(g_zero_line) + 8 * g;
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 8 * q + j;
+        if (t < KW) {
+          const int r = rot(t);
+          const bool ok = r < kw;
+          const int ks = min(ks0 + w * KW + r, total_ks - 1);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const int m = min(mb * 16 + c, p.M - 1);
+            const u16* src = ok ? (p.x_packed ? reinterpret_cast<const u16*>(p.x) + ((int64_t)(ks * MB + mb) * 64 + lane) * 8
+                                              : xp + (int64_t)m * p.ldx + (int64_t)ks * 32)
+                                : zp;
+            if (DBG & 1) xb[t][mb] = u16x8{1, 2, 3, 4, 5, 6, (u16)t, (u16)lane};   // ablation: no x loads
+            else xb[t][mb] = *reinterpret_cast<const u16x8*>(src);
+          }
+        }
+      }
+      load_buf(rg_of(0), q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x4 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4* slot = reinterpret_cast<f32x4*>(smem) + (w * MB) * 64 + lane;   // + i*4*MB*64 + mb*64
+
+  auto row_group = [&](int i, auto refill_tag) {
+    constexpr bool REFILL = decltype(refill_tag)::value;
+    const int rg_next = rg_of(i + 1);
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (8 * q + j < KW) {
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb] = Mfma<T>::mma(buf[q][j], xb[8 * q + j][mb], acc[mb]);
+        }
+      }
+      // refill behind this buffer's MFMAs (hoisted loads would need fresh registers: spills)
+      __builtin_amdgcn_sched_barrier(0);
+      if (REFILL) load_buf(rg_next, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      slot[(i * 4 * MB + mb) * 64] = acc[mb];
+      acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  for (int i = 0; i < G - 1; ++i) row_group(i, std::true_type{});
+  row_group(G - 1, std::false_type{});
+  if ((DBG & 2) && acc[0][0] != 123.25f) return;   // ablation: no reduction, no stores
+  __syncthreads();
+
+  // tile (i, mb) is summed by wave (i*MB + mb) % 4 over the four waves in order
+  const f32x4* tiles = reinterpret_cast<const f32x4*>(smem) + lane;
+  auto tile_sum = [&](int i, int mb) {
+    f32x4 s = tiles[((i * 4 + 0) * MB + mb) * 64];
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) s += tiles[((i * 4 + ww) * MB + mb) * 64];
+    return s;
+  };
+  if (EPI == 0) {
+    for (int pr = w; pr < G * MB; pr += 4) {
+      const int i = pr / MB, mb = pr - i * MB;
+      const f32x4 s = tile_sum(i, mb);
+      const int m = mb * 16 + c;
+      if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg_of(i) << 4) + 4 * g) = s;
+    }
+  } else {
+    for (int pr = w; pr < (G >> 1) * MB; pr += 4) {
+      const int ip = pr / MB, mb = pr - ip * MB;
+      const f32x4 gt = tile_sum(2 * ip, mb), up = tile_sum(2 * ip + 1, mb);
+      u16x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        r[e] = T::from_float(round_to<T>(silu_f32(round_to<T>(gt[e]))) * round_to<T>(up[e]));
+      // act[m = 16mb + c][k = 16j + 4g + e], j = pair index: piece ((k/32)*MB + mb)*64 + ((k%32)/8)*16 + c, element k%8
+      const int k = 16 * (b + ip * nb) + 4 * g;
+      u16* dst = reinterpret_cast<u16*>(p.act) + ((((int64_t)(k >> 5) * MB + mb) * 64 + ((k & 31) >> 3) * 16 + c) << 3) + (k & 7);
+      *reinterpret_cast<u16x4*>(dst) = r;
+    }
+  }
+}
+
+// output piece i (16 bytes) of the packed tensor <- its source in the row-major weight
+__global__ __launch_bounds__(256) void pack_xreg_kernel(u16* __restrict__ packed, const u16* __restrict__ w,
+                                                        int64_t n_pieces, int total_ks, int n_rg, int64_t ldw, int P,
+                                                        int interleave) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pieces) return;
+  const int lane = (int)(i & 63);
+  const int64_t blk = i >> 6;                                   // KiB index
+  const int64_t per_split = (int64_t)P * n_rg;
+  const int split = (int)(blk / per_split);
+  const int ks0 = split * P;
+  const int nks = min(P, total_ks - ks0);
+  const int64_t rem = blk - (int64_t)ks0 * n_rg;
+  const int64_t rg = rem / nks;
+  const int s = ks0 + (int)(rem % nks);
+  // interleave: packed group 2j = source group j (gate), 2j+1 = source group n_rg/2 + j (up)
+  const int64_t srg = interleave ? (rg >> 1) + ((rg & 1) ? (n_rg >> 1) : 0) : rg;
+  const u16* src = w + (16 * srg + (lane & 15)) * ldw + 32 * s + 8 * (lane >> 4);
+  *reinterpret_cast<u16x8*>(packed + i * 8) = *reinterpret_cast<const u16x8*>(src);
+}
+
+int g_stagger = 1;
+int g_dbg = 0;
+int g_force_wgs = 0;     // tuning: cap on workgroups per launch (0 = the CU count)
+
+constexpr int kKwSet[] = {4, 8, 16, 20, 22, 27, 29, 32};
+
+int round_kw(int kw) {
+  for (int v : kKwSet) if (v >= kw) return v;
+  return 0;
+}
+
+// K -> (splits, k-steps per wave).  Fewest splits whose per-wave share fits the register budget
+// (KW <= 32); HX_XREG_S="K:S;K:S" overrides the split count per K (tuning).
+void xreg_plan(int64_t K, int* S, int* KW) {
+  const int total_ks = (int)(K >> 5);
+  int s = (total_ks + 127) / 128;
+  static const char* env = getenv("HX_XREG_S");
+  if (env) {
+    const char* q = env;
+    while (*q) {
+      long k = 0, sv = 0;
+      if (sscanf(q, "%ld:%ld", &k, &sv) == 2 && k == K && sv >= s && sv <= 16) s = (int)sv;
+      const char* semi = strchr(q, ';');
+      if (!semi) break;
+      q = semi + 1;
+    }
+  }
+  const int per = (total_ks + s - 1) / s;
+  *KW = round_kw((per + 3) / 4);
+  // the split size is 4*KW k-steps; the number of splits that actually hold data
+  *S = (total_ks + 4 * *KW - 1) / (4 * *KW);
+}
+
+int n_cus() {
+  static int n = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return n;
+}
+
+template <typename T, int MB, int KW, int EPI>
+int launch_kw(const XregParams& p, int S, hipStream_t stream) {
+  const int n_units = EPI ? (p.N >> 5) : (p.N >> 4);     // row groups, or gate/up pairs of them
+  const int per_unit = EPI ? 2 : 1;
+  const int cap = g_force_wgs > 0 ? g_force_wgs : n_cus();
+  int nb = cap / S;
+  if (nb < 1) nb = 1;
+  if (nb > n_units) nb = n_units;
+  int G = (n_units + nb - 1) / nb;
+  if (G * per_unit > kMaxG) G = kMaxG / per_unit;
+  nb = (n_units + G - 1) / G;                 // same depth, no idle tail workgroups
+  const size_t lds = (size_t)G * per_unit * 4 * MB * 1024;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_kernel<T, MB, KW, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_rc(e);
+  }
+  const dim3 grid((unsigned)nb, (unsigned)S);
+  if (EPI == 0 && g_dbg && MB == 2 && (KW == 32 || KW == 29)) {   // ablation variants (tools/bench_gemm_xreg.py OPTS=xreg_dbg=..)
+    if (g_dbg == 1) gemm_xreg_kernel<T, MB, KW, 0, 1><<<grid, 256, lds, stream>>>(p);
+    else if (g_dbg == 2) gemm_xreg_kernel<T, MB, KW, 0, 2><<<grid, 256, lds, stream>>>(p);
+    else gemm_xreg_kernel<T, MB, KW, 0, 3><<<grid, 256, lds, stream>>>(p);
+    return check_launch();
+  }
+  gemm_xreg_kernel<T, MB, KW, EPI><<<grid, 256, lds, stream>>>(p);
+  return check_launch();
+}
+
+template <typename T, int MB, int EPI>
+int launch_mb(const XregParams& p, int S, int KW, hipStream_t stream) {
+  switch (KW) {
+    case 4: return launch_kw<T, MB, 4, EPI>(p, S, stream);
+    case 8: return launch_kw<T, MB, 8, EPI>(p, S, stream);
+    case 16: return launch_kw<T, MB, 16, EPI>(p, S, stream);
+    case 20: if constexpr (EPI == 0) return launch_kw<T, MB, 20, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    case 22: if constexpr (EPI == 0) return launch_kw<T, MB, 22, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    case 27: if constexpr (EPI == 0) return launch_kw<T, MB, 27, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    case 29: if constexpr (EPI == 0) return launch_kw<T, MB, 29, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    case 32: return launch_kw<T, MB, 32, EPI>(p, S, stream);
+    default: return HX_ERR_SHAPE;
+  }
+}
+
+template <int EPI>
+int launch_any(const XregParams& p, int S, int KW, int dtype, hipStream_t stream) {
+  const int MB = (p.M + 15) / 16;
+  if (dtype == HX_F16) return MB == 1 ? launch_mb<F16, 1, EPI>(p, S, KW, stream) : launch_mb<F16, 2, EPI>(p, S, KW, stream);
+  return MB == 1 ? launch_mb<BF16, 1, EPI>(p, S, KW, stream) : launch_mb<BF16, 2, EPI>(p, S, KW, stream);
+}
+
+bool xreg_ok(int64_t M, int64_t N, int64_t K) {
+  if (M < 1 || M > 32 || N <= 0 || K <= 0 || N % 16 || K % 32) return false;
+  int S, KW;
+  xreg_plan(K, &S, &KW);
+  return KW > 0;
+}
+
+}  // namespace
+
+namespace hx {
+int xreg_set_option(const char* name, int value) {
+  if (!strcmp(name, "xreg_stagger")) { g_stagger = value; return HX_OK; }
+  if (!strcmp(name, "xreg_wgs")) { g_force_wgs = value; return HX_OK; }
+  if (!strcmp(name, "xreg_dbg")) { g_dbg = value; return HX_OK; }
+  return HX_ERR_UNSUPPORTED;
+}
+}  // namespace hx
+
+extern "C" int hx_linear_decode_xreg_supported(int64_t M, int64_t N, int64_t K) { return xreg_ok(M, N, K) ? 1 : 0; }
+
+extern "C" int hx_linear_decode_xreg_splits(int64_t K) {
+  if (K <= 0 || K % 32) return HX_ERR_SHAPE;
+  int S, KW;
+  xreg_plan(K, &S, &KW);
+  return KW > 0 ? S : HX_ERR_SHAPE;
+}
+
+extern "C" int64_t hx_linear_decode_xreg_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (!xreg_ok(M, N, K)) return 0;
+  int S, KW;
+  xreg_plan(K, &S, &KW);
+  return (int64_t)S * M * N * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t hx_fragment_major_elems(int64_t rows, int64_t K) {
+  if (rows <= 0 || K <= 0 || K % 32) return 0;
+  return (rows + 15) / 16 * 16 * K;
+}
+
+extern "C" int hx_pack_decode_weight_xreg(void* packed, const void* weight, int64_t N, int64_t K, int64_t ldw,
+                                          int interleave_halves, int dtype, hx_stream stream) {
+  if (!packed || !weight) return HX_ERR_NULL;
+  if (N <= 0 || K <= 0 || N % 16 || K % 32 || ldw % 8) return HX_ERR_SHAPE;
+  if (interleave_halves && N % 32) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (!aligned16(packed) || !aligned16(weight)) return HX_ERR_STRIDE;
+  int S, KW;
+  xreg_plan(K, &S, &KW);
+  if (KW <= 0) return HX_ERR_SHAPE;
+  const int64_t n_pieces = N * K / 8;
+  pack_xreg_kernel<<<(unsigned)((n_pieces + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      (u16*)packed, (const u16*)weight, n_pieces, (int)(K >> 5), (int)(N >> 4), ldw, 4 * KW, interleave_halves ? 1 : 0);
+  return check_launch();
+}
+
+extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, const void* packed_weight,
+                                             int64_t M, int64_t N, int64_t K, int64_t ldx, int x_fragment_major,
+                                             int64_t partial_bytes, int dtype, hx_stream stream) {
+  if (!partial || !x || !packed_weight) return HX_ERR_NULL;
+  if (!xreg_ok(M, N, K) || (!x_fragment_major && ldx % 8)) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (!aligned16(x) || !aligned16(packed_weight) || !aligned16(partial)) return HX_ERR_STRIDE;
+  if (partial_bytes < hx_linear_decode_xreg_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
+  int S, KW;
+  xreg_plan(K, &S, &KW);
+  XregParams p;
+  p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;
+  const int rc = launch_any<0>(p, S, KW, dtype, (hipStream_t)stream);
+  return rc ? rc : S;
+}
+
+extern "C" int hx_gate_up_silu_xreg_supported(int64_t M, int64_t inter, int64_t K) {
+  if (!xreg_ok(M, 2 * inter, K) || inter % 32) return 0;
+  int S, KW;
+  xreg_plan(K, &S, &KW);
+  return S == 1 && (KW == 4 || KW == 8 || KW == 16 || KW == 32) ? 1 : 0;   // the fused epilogue is built for these
+}
+
+extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed_gate_up, int64_t M,
+                                    int64_t inter, int64_t K, int64_t ldx, int x_fragment_major, int dtype,
+                                    hx_stream stream) {
+  if (!act || !x || !packed_gate_up) return HX_ERR_NULL;
+  if (!hx_gate_up_silu_xreg_supported(M, inter, K) || (!x_fragment_major && ldx % 8)) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (!aligned16(x) || !aligned16(packed_gate_up) || !aligned16(act)) return HX_ERR_STRIDE;
+  int S, KW;
+  xreg_plan(K, &S, &KW);
+  XregParams p;
+  p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;
+  return launch_any<1>(p, 1, KW, dtype, (hipStream_t)stream);
+}

@@ -16,6 +16,7 @@ int decode_set_option(const char* name, int value);
 int gemm_set_option(const char* name, int value);
 int fwd_set_option(const char* name, int value);
 int chain_set_option(const char* name, int value);
+int xreg_set_option(const char* name, int value);
 bool fwd_supported(int head_dim);
 int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested);
 bool decode_gqa_supported(int head_dim, int group);
@@ -45,6 +46,7 @@ extern "C" int hx_debug_set_option(const char* name, int value) {
   if (rc == HX_ERR_UNSUPPORTED) rc = gemm_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = fwd_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = chain_set_option(name, value);
+  if (rc == HX_ERR_UNSUPPORTED) rc = xreg_set_option(name, value);
   return rc;
 }
 

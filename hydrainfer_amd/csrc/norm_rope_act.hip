@@ -406,12 +406,17 @@ __device__ __forceinline__ void slab_sum8(const float* __restrict__ p, int n_spl
 template <typename T, int MAXV, int NT>
 __global__ __launch_bounds__(NT) void add_rms_norm_slab_kernel(
     u16* __restrict__ out, u16* __restrict__ residual, const float* __restrict__ partial,
-    int n_splits, int64_t slab_stride, const u16* __restrict__ weight, float eps, int32_t hidden) {
+    int n_splits, int64_t slab_stride, const u16* __restrict__ weight, float eps, int32_t hidden,
+    int frag_mb) {
   __shared__ float red[NT / 64];
   const int64_t row = blockIdx.x;
   const int nvec = hidden / 8;
   u16x8* res_v = reinterpret_cast<u16x8*>(residual + row * hidden);
-  u16x8* out_v = reinterpret_cast<u16x8*>(out + row * hidden);
+  // frag_mb > 0: `out` is written in MFMA-B-fragment order for the activations-in-registers GEMM
+  // (hydra_hip.h "fragment-major activations"): vector i of row r goes to piece
+  // ((i / 4) * frag_mb + r / 16) * 64 + (i % 4) * 16 + r % 16
+  u16x8* out_v = frag_mb ? reinterpret_cast<u16x8*>(out) + (row >> 4) * 64 + (row & 15)
+                         : reinterpret_cast<u16x8*>(out + row * hidden);
   const u16x8* w_v = reinterpret_cast<const u16x8*>(weight);
   float x[MAXV][8];
   float ss = 0.f;
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(NT) void add_rms_norm_slab_kernel(
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         o[e] = T::from_float(round_to<T>(x[j][e] * inv) * T::to_float(w[e]));
-      out_v[i] = o;
+      out_v[frag_mb ? (i >> 2) * frag_mb * 64 + (i & 3) * 16 : i] = o;
     }
   }
 }
@@ -460,7 +465,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void silu_mul_slab_kernel(u16* __restrict__ out,
                                                             const float* __restrict__ partial,
                                                             int n_splits, int64_t slab_stride,
-                                                            int32_t inter) {
+                                                            int32_t inter, int frag_mb) {
   const int64_t row = blockIdx.y;
   const int nvec = inter / 8;
   const float* base = partial + row * 2 * inter;
@@ -471,7 +476,8 @@ __global__ __launch_bounds__(256) void silu_mul_slab_kernel(u16* __restrict__ ou
     u16x8 r;
 #pragma unroll
     for (int e = 0; e < 8; ++e) r[e] = T::from_float(round_to<T>(silu_f32(gte[e])) * up[e]);
-    *reinterpret_cast<u16x8*>(out + row * inter + i * 8) = r;
+    if (frag_mb) reinterpret_cast<u16x8*>(out)[((i >> 2) * frag_mb + (row >> 4)) * 64 + (i & 3) * 16 + (row & 15)] = r;
+    else *reinterpret_cast<u16x8*>(out + row * inter + i * 8) = r;
   }
 }
 
@@ -643,7 +649,16 @@ extern "C" int hx_rope_set_kv_cache(void* query, void* key, const void* value,
 extern "C" int hx_add_rms_norm_slabs(void* out, void* residual, const float* partial,
                                      int32_t n_splits, const void* weight, float epsilon,
                                      int64_t rows, int64_t hidden, int dtype, hx_stream stream) {
+  return hx_add_rms_norm_slabs_ex(out, residual, partial, n_splits, weight, epsilon, rows, hidden, dtype, 0, stream);
+}
+
+extern "C" int hx_add_rms_norm_slabs_ex(void* out, void* residual, const float* partial,
+                                        int32_t n_splits, const void* weight, float epsilon,
+                                        int64_t rows, int64_t hidden, int dtype, int out_fragment_major,
+                                        hx_stream stream) {
   if (rows < 0 || hidden <= 0 || n_splits < 1) return HX_ERR_SHAPE;
+  if (out_fragment_major && hidden % 32) return HX_ERR_SHAPE;
+  const int frag_mb = out_fragment_major ? (int)((rows + 15) / 16) : 0;
   if (rows == 0) return HX_OK;
   if (!out || !residual || !partial || !weight) return HX_ERR_NULL;
   if (hidden % 8 || hidden / 8 > 2048) return HX_ERR_SHAPE;
@@ -657,7 +672,7 @@ extern "C" int hx_add_rms_norm_slabs(void* out, void* residual, const float* par
 #define HX_L(TT, MV)                                                                             \
   add_rms_norm_slab_kernel<TT, MV, 512><<<grid, 512, 0, s>>>((u16*)out, (u16*)residual, partial, \
                                                             n_splits, stride, (const u16*)weight, \
-                                                            epsilon, (int)hidden)
+                                                            epsilon, (int)hidden, frag_mb)
   const int mv = (int)((hidden / 8 + 511) / 512);
   if (dtype == HX_F16) {
     if (mv <= 1) HX_L(F16, 1); else if (mv <= 2) HX_L(F16, 2); else HX_L(F16, 4);
@@ -672,7 +687,15 @@ extern "C" int hx_add_rms_norm_slabs(void* out, void* residual, const float* par
 
 extern "C" int hx_silu_and_mul_slabs(void* out, const float* partial, int32_t n_splits,
                                      int64_t rows, int64_t inter, int dtype, hx_stream stream) {
+  return hx_silu_and_mul_slabs_ex(out, partial, n_splits, rows, inter, dtype, 0, stream);
+}
+
+extern "C" int hx_silu_and_mul_slabs_ex(void* out, const float* partial, int32_t n_splits,
+                                        int64_t rows, int64_t inter, int dtype, int out_fragment_major,
+                                        hx_stream stream) {
   if (rows < 0 || inter <= 0 || n_splits < 1) return HX_ERR_SHAPE;
+  if (out_fragment_major && inter % 32) return HX_ERR_SHAPE;
+  const int frag_mb = out_fragment_major ? (int)((rows + 15) / 16) : 0;
   if (rows == 0) return HX_OK;
   if (!out || !partial) return HX_ERR_NULL;
   if (inter % 8 || rows > 65535) return HX_ERR_SHAPE;
@@ -683,9 +706,9 @@ extern "C" int hx_silu_and_mul_slabs(void* out, const float* partial, int32_t n_
   dim3 grid(gx, (unsigned)rows);
   const int64_t stride = rows * 2 * inter;
   if (dtype == HX_F16)
-    silu_mul_slab_kernel<F16><<<grid, 256, 0, s>>>((u16*)out, partial, n_splits, stride, (int)inter);
+    silu_mul_slab_kernel<F16><<<grid, 256, 0, s>>>((u16*)out, partial, n_splits, stride, (int)inter, frag_mb);
   else if (dtype == HX_BF16)
-    silu_mul_slab_kernel<BF16><<<grid, 256, 0, s>>>((u16*)out, partial, n_splits, stride, (int)inter);
+    silu_mul_slab_kernel<BF16><<<grid, 256, 0, s>>>((u16*)out, partial, n_splits, stride, (int)inter, frag_mb);
   else
     return HX_ERR_DTYPE;
   return check_launch();

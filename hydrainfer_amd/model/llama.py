@@ -90,6 +90,12 @@ class LlamaForCausalLM:
         # prefill GEMMs (library).  288 GB of HBM: the second copy of a 7B / 13B model is 13 / 26 GB.
         self.use_packed = True
         self.packed: Dict[str, Tensor] = {}
+        # decode batches of <= 32 rows: the MLP runs on the activations-in-registers GEMM
+        # (csrc/gemm_xreg.hip) — gate|up + silu*mul in ONE launch that needs no K split, down with 3
+        # slabs instead of 11; the activations travel between these launches in MFMA-fragment order.
+        # 7 launches per layer, -7.5 us per 7B layer (tools/bench_layer_xreg.py).
+        self.use_xreg = True
+        self.packed_x: Dict[str, Tensor] = {}
         self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
 
     def pack_decode_weights(self) -> None:
@@ -102,6 +108,19 @@ class LlamaForCausalLM:
                 w = self.state[key]
                 if key not in self.packed and w.shape[0] % 16 == 0 and w.shape[1] % 256 == 0 and w.stride(1) == 1:
                     self.packed[key] = hip_gemm.pack_weight(w)
+        if self.use_xreg and self._xreg_mlp_ok(32):
+            hid, inter = self.shape.hidden_size, self.shape.intermediate_size
+            fused = hip_gemm.gate_up_silu_supported(32, inter, hid, self.dtype)
+            for l in range(self.shape.num_hidden_layers):
+                if f"l{l}.wgu" not in self.packed_x:
+                    self.packed_x[f"l{l}.wgu"] = hip_gemm.pack_weight_xreg(self.state[f"l{l}.wgu"], interleave_halves=fused)
+                    self.packed_x[f"l{l}.wdown"] = hip_gemm.pack_weight_xreg(self.state[f"l{l}.wdown"])
+
+    def _xreg_mlp_ok(self, n: int) -> bool:
+        hid, inter = self.shape.hidden_size, self.shape.intermediate_size
+        return (n <= 32 and self.dtype in (torch.float16, torch.bfloat16) and inter % 32 == 0 and hid % 32 == 0
+                and hip_gemm.xreg_supported(n, 2 * inter, hid, self.dtype) and hip_gemm.xreg_supported(n, hid, inter, self.dtype)
+                and all(self.state[f"l0.{k}"].stride(1) == 1 for k in ("wgu", "wdown")))
 
     def _partial(self, x: Tensor, key: str, ws: Tensor) -> int:
         """split-K slabs of x @ state[key]^T into ws; packed weights when available."""
@@ -195,7 +214,8 @@ class LlamaForCausalLM:
         """All-decode step with the weight-streaming HIP GEMMs and fused slab consumers: 8
         launches per layer — qkv GEMM, [slab reduce + RoPE + cache append + attention], o GEMM,
         [slab reduce + residual add + RMSNorm], gate|up GEMM, [slab reduce + silu*mul], down GEMM,
-        [slab reduce + residual add + RMSNorm].  Same rounding points as the unfused path."""
+        [slab reduce + residual add + RMSNorm]; 7 with use_xreg at <= 32 rows ([gate|up GEMM +
+        silu*mul] is one launch).  Same rounding points as the unfused path."""
         sh, st = self.shape, self.state
         n = h.shape[0]
         H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
@@ -205,6 +225,16 @@ class LlamaForCausalLM:
                    hip_gemm.workspace_floats(n, 2 * inter, hid), hip_gemm.workspace_floats(n, hid, inter))
         ws = torch.empty(ws_n, dtype=torch.float32, device=h.device)
         x = torch.empty_like(h)
+        xreg = self.use_xreg and self._xreg_mlp_ok(n)
+        if xreg and f"l{L - 1}.wdown" not in self.packed_x:
+            if torch.cuda.is_current_stream_capturing():
+                xreg = False
+            else:
+                self.pack_decode_weights()
+        if xreg:
+            fused = hip_gemm.gate_up_silu_supported(n, inter, hid, h.dtype)
+            xf = torch.empty(hip_gemm.fragment_major_elems(n, hid), dtype=h.dtype, device=h.device)
+            actf = torch.empty(hip_gemm.fragment_major_elems(n, inter), dtype=h.dtype, device=h.device) if fused else None
         rms_norm(x, h, st["l0.norm1"], eps)
         for l in range(L):
             ap = model_params.attention_params[l]
@@ -216,10 +246,22 @@ class LlamaForCausalLM:
                                    ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
                                    ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws, s_qkv)
             s_o = self._partial(o.view(n, q_size), f"l{l}.wo", ws)
-            add_rms_norm_slabs(x, h, ws, s_o, st[f"l{l}.norm2"], eps)
-            s_gu = self._partial(x, f"l{l}.wgu", ws)
-            act = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype)
-            s_dn = self._partial(act, f"l{l}.wdown", ws)
+            if xreg:
+                # fragment-major activations from here to the down projection
+                add_rms_norm_slabs(xf, h, ws, s_o, st[f"l{l}.norm2"], eps, fragment_major=True)
+                pgu, pdn = self.packed_x[f"l{l}.wgu"], self.packed_x[f"l{l}.wdown"]
+                if fused:
+                    hip_gemm.gate_up_silu_xreg(xf, pgu, inter, actf, frag_shape=(n, hid))
+                    a_f = actf
+                else:
+                    s_gu = hip_gemm.linear_decode_partial_xreg(xf, pgu, 2 * inter, ws, frag_shape=(n, hid))
+                    a_f = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype, fragment_major=True)
+                s_dn = hip_gemm.linear_decode_partial_xreg(a_f, pdn, hid, ws, frag_shape=(n, inter))
+            else:
+                add_rms_norm_slabs(x, h, ws, s_o, st[f"l{l}.norm2"], eps)
+                s_gu = self._partial(x, f"l{l}.wgu", ws)
+                act = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype)
+                s_dn = self._partial(act, f"l{l}.wdown", ws)
             nxt = st[f"l{l + 1}.norm1"] if l + 1 < L else st["norm"]
             add_rms_norm_slabs(x, h, ws, s_dn, nxt, eps)
         return x

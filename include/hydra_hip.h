@@ -165,6 +165,39 @@ int hx_pack_decode_weight(void* packed, const void* weight, int64_t N, int64_t K
 int hx_linear_decode_partial_packed(float* partial, const void* x, const void* packed_weight,
                                     int64_t M, int64_t N, int64_t K, int64_t ldx,
                                     int64_t partial_bytes, int dtype, hx_stream stream);
+/* The same product for M <= 32 with the activations held in REGISTERS (csrc/gemm_xreg.hip): a
+ * workgroup spans the whole K of its split, so K <= 4096 needs ONE slab (no K split) and K = 11008
+ * three instead of eleven — the fp32 slab traffic of a decode layer drops from 25 MB to 6.5 MB.
+ * The weight must be packed by hx_pack_decode_weight_xreg (same 1 KiB fragment format as
+ * hx_pack_decode_weight, blocks ordered [K split][row group][k-step in split] with the split size
+ * this kernel chooses for K; interleave_halves != 0 alternates the 16-row groups of the two halves
+ * of N — gate and up of a fused gate|up weight — for hx_gate_up_silu_xreg).
+ * x is row-major [M, K] (row stride ldx) or, with x_fragment_major != 0, FRAGMENT-MAJOR: the 16-byte
+ * piece ((k/32) * MB + m/16) * 64 + ((k%32)/8) * 16 + m%16, MB = ceil(M/16), holds x[m][8*(k/8) .. +8]
+ * — the MFMA B operands in the order the kernel loads them (buffer: hx_fragment_major_elems(M, K)
+ * elements; rows M .. 16*MB-1 are never read for a stored result).  hx_add_rms_norm_slabs_ex /
+ * hx_silu_and_mul_slabs_ex / hx_gate_up_silu_xreg produce that layout.
+ * hx_linear_decode_partial_xreg returns the number of slabs written (>= 1) or a negative HX_ERR_*.
+ * Accumulation order differs from hx_linear_decode_partial (per-wave k ranges, then the four waves
+ * in order): deterministic, not bit-identical to it.  N % 16 == 0, K % 32 == 0.
+ * hx_gate_up_silu_xreg: act = silu(x Wg^T) * (x Wu^T) in one launch for K with a single split
+ * (hx_gate_up_silu_xreg_supported), act fragment-major [inter]; rounding exactly as
+ * hx_linear_decode_partial_xreg -> hx_silu_and_mul_slabs (bit-identical, tested).
+ * Replaces: torch.nn.functional.linear at decode batch sizes and silu(gate) * up
+ * (hydrainfer/model/llama.py:24-27,48-50, model_forward.py:36). */
+int hx_linear_decode_xreg_supported(int64_t M, int64_t N, int64_t K);
+int hx_linear_decode_xreg_splits(int64_t K);
+int64_t hx_linear_decode_xreg_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int64_t hx_fragment_major_elems(int64_t rows, int64_t K);
+int hx_pack_decode_weight_xreg(void* packed, const void* weight, int64_t N, int64_t K, int64_t ldw,
+                               int interleave_halves, int dtype, hx_stream stream);
+int hx_linear_decode_partial_xreg(float* partial, const void* x, const void* packed_weight,
+                                  int64_t M, int64_t N, int64_t K, int64_t ldx, int x_fragment_major,
+                                  int64_t partial_bytes, int dtype, hx_stream stream);
+int hx_gate_up_silu_xreg_supported(int64_t M, int64_t inter, int64_t K);
+int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed_gate_up, int64_t M,
+                         int64_t inter, int64_t K, int64_t ldx, int x_fragment_major, int dtype,
+                         hx_stream stream);
 /* Slab consumers: sum the n_splits slabs in order, round once to T (the projection's output
  * rounding), then behave exactly like hx_add_rms_norm / hx_silu_and_mul on that tensor.
  * partial: [n_splits][rows][hidden] resp. [n_splits][rows][2*inter] (gate | up columns). */
@@ -173,6 +206,13 @@ int hx_add_rms_norm_slabs(void* out, void* residual, const float* partial, int32
                           int dtype, hx_stream stream);
 int hx_silu_and_mul_slabs(void* out, const float* partial, int32_t n_splits, int64_t rows,
                           int64_t inter, int dtype, hx_stream stream);
+/* The same two consumers with the output optionally FRAGMENT-MAJOR (see hx_linear_decode_partial_xreg;
+ * hidden resp. inter % 32 == 0): values bit-identical to the row-major form. */
+int hx_add_rms_norm_slabs_ex(void* out, void* residual, const float* partial, int32_t n_splits,
+                             const void* weight, float epsilon, int64_t rows, int64_t hidden,
+                             int dtype, int out_fragment_major, hx_stream stream);
+int hx_silu_and_mul_slabs_ex(void* out, const float* partial, int32_t n_splits, int64_t rows,
+                             int64_t inter, int dtype, int out_fragment_major, hx_stream stream);
 
 /* ------------------------------------------------------------------------
  * Variable-length attention forward, dense or paged.

@@ -261,3 +261,106 @@ def test_packed_weight_gemm_is_bit_identical(dt, M):
         sa = gemm.linear_decode_partial(x, w, a)
         sb = gemm.linear_decode_partial_packed(x, gemm.pack_weight(w), N, b)
         assert sa == sb and torch.equal(a, b), f"N={N} K={K} M={M} {dt}"
+
+
+# ---- activations-in-registers GEMM (csrc/gemm_xreg.hip) -----------------------------------------
+XREG_SHAPES = ((4096, 4096), (22016, 4096), (4096, 11008), (27648, 5120), (5120, 13824), (48, 64),
+               (64, 2816), (1024, 96), (32, 4128))   # 7B, 13B, tiny, ragged last split / padded waves
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 32])
+def test_xreg_gemm_matches_fp32_product_and_is_repeatable(dt, M):
+    """gemm_xreg_kernel against the fp32 product of the same T inputs (the GEMM accumulates in fp32:
+    only the summation order differs — rel. 1e-5 of the largest output), row-major x and
+    fragment-major x bit-identical to each other, two runs bit-identical (deterministic order)."""
+    from hydrainfer_amd._C.kernel import gemm
+    for (N, K) in XREG_SHAPES:
+        assert gemm.xreg_supported(M, N, K, dt)
+        g = torch.Generator().manual_seed(N + K + M)
+        x = torch.randn((M, K), generator=g).to(dt).to(DEV)
+        w = (torch.randn((N, K), generator=g) * 0.02).to(dt).to(DEV)
+        pk = gemm.pack_weight_xreg(w)
+        a = torch.zeros(gemm.xreg_workspace_floats(M, N, K), dtype=torch.float32, device=DEV)
+        b, c = torch.zeros_like(a), torch.zeros_like(a)
+        s = gemm.linear_decode_partial_xreg(x, pk, N, a)
+        assert s == a.numel() // (M * N) and 1 <= s <= (K + 4095) // 4096
+        assert gemm.linear_decode_partial_xreg(x, pk, N, b) == s
+        assert gemm.linear_decode_partial_xreg(gemm.to_fragment_major(x), pk, N, c, frag_shape=(M, K)) == s
+        assert torch.equal(a, b), f"not repeatable N={N} K={K}"
+        assert torch.equal(a, c), f"fragment-major x differs N={N} K={K}"
+        ref = x.float() @ w.float().t()
+        got = a.view(s, M, N).sum(0)
+        assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6, f"N={N} K={K} M={M} {dt}"
+    assert not gemm.xreg_supported(33, 4096, 4096, dt)
+    assert not gemm.xreg_supported(8, 4096, 4100, dt)
+    assert not gemm.xreg_supported(8, 4090, 4096, dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 5, 16, 31, 32])
+def test_fragment_major_producers_are_bit_identical(dt, M):
+    """hx_add_rms_norm_slabs_ex / hx_silu_and_mul_slabs_ex with fragment-major output == the row-major
+    forms (which are oracle-checked above), element for element."""
+    from hydrainfer_amd._C.kernel import gemm
+    from hydrainfer_amd._C.kernel.activation import silu_and_mul_slabs
+    from hydrainfer_amd._C.kernel.norm import add_rms_norm_slabs
+    for hid, inter, S in ((4096, 11008, 3), (5120, 13824, 4), (64, 96, 1), (1024, 2816, 2)):
+        g = torch.Generator().manual_seed(hid + M)
+        slabs = torch.randn((S, M, max(hid, 2 * inter)), generator=g).to(DEV)
+        h = torch.randn((M, hid), generator=g).to(dt).to(DEV)
+        h2, wn = h.clone(), torch.randn(hid, generator=g).to(dt).to(DEV)
+        ps = slabs[:, :, :hid].contiguous()
+        o1 = torch.empty_like(h)
+        o2 = torch.zeros(gemm.fragment_major_elems(M, hid), dtype=dt, device=DEV)
+        add_rms_norm_slabs(o1, h, ps, S, wn, 1e-5)
+        add_rms_norm_slabs(o2, h2, ps, S, wn, 1e-5, fragment_major=True)
+        assert torch.equal(h, h2) and torch.equal(gemm.from_fragment_major(o2, M, hid), o1)
+        pg = slabs[:, :, :2 * inter].contiguous()
+        a1 = silu_and_mul_slabs(pg, S, M, inter, dt)
+        a2 = silu_and_mul_slabs(pg, S, M, inter, dt, fragment_major=True)
+        assert torch.equal(gemm.from_fragment_major(a2, M, inter), a1)
+    x = torch.randn((M, 128)).to(dt).to(DEV)
+    assert torch.equal(gemm.from_fragment_major(gemm.to_fragment_major(x), M, 128), x)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 9, 16, 32])
+def test_fused_gate_up_silu_equals_gemm_then_silu(dt, M):
+    """hx_gate_up_silu_xreg (gate|up GEMM + silu*mul, one launch, no K split) == the xreg GEMM followed
+    by hx_silu_and_mul_slabs: bit-identical with the k rotation off (the rotation start depends on the
+    workgroup a row group lands on, which differs between the two launches), within a few ulp of T with
+    it on; and within the silu tolerance of the fp32 formula either way."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel import gemm
+    from hydrainfer_amd._C.kernel.activation import silu_and_mul_slabs
+    lib = _lib.lib()
+    try:
+        for stagger in (0, 1):
+            assert lib.hx_debug_set_option(b"xreg_stagger", stagger) == 0
+            for (inter, K) in ((11008, 4096), (2816, 1024), (96, 64), (13824, 4096)):
+                assert gemm.gate_up_silu_supported(M, inter, K, dt)
+                g = torch.Generator().manual_seed(inter + M)
+                x = torch.randn((M, K), generator=g).to(dt).to(DEV)
+                w = (torch.randn((2 * inter, K), generator=g) * 0.03).to(dt).to(DEV)
+                ws = torch.zeros(gemm.xreg_workspace_floats(M, 2 * inter, K), dtype=torch.float32, device=DEV)
+                s = gemm.linear_decode_partial_xreg(x, gemm.pack_weight_xreg(w), 2 * inter, ws)
+                assert s == 1
+                want = silu_and_mul_slabs(ws, s, M, inter, dt)
+                act = torch.zeros(gemm.fragment_major_elems(M, inter), dtype=dt, device=DEV)
+                gemm.gate_up_silu_xreg(gemm.to_fragment_major(x), gemm.pack_weight_xreg(w, interleave_halves=True),
+                                       inter, act, frag_shape=(M, K))
+                got = gemm.from_fragment_major(act, M, inter)
+                if stagger == 0:
+                    assert torch.equal(got, want), f"inter={inter} K={K} M={M} {dt}"
+                else:
+                    ulp = 2.0 ** (-10 if dt == torch.float16 else -7)
+                    # gate and up each move by <= 1 ulp of T (fp32 summation order), silu'(g) <= 1.1
+                    assert ((got.float() - want.float()).abs() <= 4 * ulp * want.float().abs() + 0.25 * ulp).all()
+                gu = x.float() @ w.float().t()
+                ref = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+                tol = 2e-3 if dt == torch.float16 else 1.6e-2
+                assert ((got.float() - ref).abs() <= tol * ref.abs() + tol * 0.05).all()
+        assert not gemm.gate_up_silu_supported(8, 13824, 5120, dt)   # K = 5120 needs two splits: unfused path
+    finally:
+        lib.hx_debug_set_option(b"xreg_stagger", 1)
