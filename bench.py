@@ -444,10 +444,30 @@ def time_decode_gemms(runner, reps=3):
                          for k, _ in shapes.values()), dtype=torch.float32, device=dev)
     L = sh.num_hidden_layers
     res = {}
+    hid, inter = sh.hidden_size, sh.intermediate_size
+    xreg = m.use_xreg and m._xreg_mlp_ok(B) and f"l{L - 1}.wdown" in m.packed_x
+    fused = xreg and hip_gemm.gate_up_silu_supported(B, inter, hid, dt)
+    if xreg:   # the activations as the decode step hands them over: fragment-major
+        xf_h, xf_i = hip_gemm.to_fragment_major(x_h), hip_gemm.to_fragment_major(x_i)
+        actf = torch.empty(hip_gemm.fragment_major_elems(B, inter), dtype=dt, device=dev)
+
+    def call(name, key, x, l):
+        """One projection exactly as LlamaForCausalLM._decode_hidden_hip_gemm launches it."""
+        full = f"l{l}.{key}"
+        if xreg and name == "gate_up":
+            if fused:
+                return hip_gemm.gate_up_silu_xreg(xf_h, m.packed_x[full], inter, actf, frag_shape=(B, hid))
+            return hip_gemm.linear_decode_partial_xreg(xf_h, m.packed_x[full], 2 * inter, ws, frag_shape=(B, hid))
+        if xreg and name == "down":
+            return hip_gemm.linear_decode_partial_xreg(xf_i, m.packed_x[full], hid, ws, frag_shape=(B, inter))
+        if xreg and name == "qkv" and full in m.packed_x:
+            return hip_gemm.linear_decode_partial_xreg(xf_h, m.packed_x[full], m.state[full].shape[0], ws, frag_shape=(B, hid))
+        return m._partial(x, full, ws)
+
     for name, (key, x) in shapes.items():
         def body():
             for l in range(L):
-                m._partial(x, f"l{l}.{key}", ws)
+                call(name, key, x, l)
         body(); torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
@@ -459,6 +479,8 @@ def time_decode_gemms(runner, reps=3):
             best = min(best, e0.elapsed_time(e1))
         w = m.state[f"l0.{key}"]
         res[name] = {"us": round(best / L * 1e3, 2), "weight_bytes": w.numel() * w.element_size()}
+    res["_kernels"] = ("gemm_xreg_kernel (activations in registers; gate|up with the silu*mul epilogue, down, qkv of "
+                       "layers >= 1) + gemm_packed_kernel (o, qkv of layer 0)") if xreg else "gemm_packed_kernel"
     return res
 
 
@@ -762,10 +784,11 @@ def main():
         gemm_t = time_decode_gemms(runner)
         roofline_gemm = None
         if gemm_t:
+            gemm_kernels = gemm_t.pop("_kernels")
             wb = sum(v["weight_bytes"] for v in gemm_t.values())
             us = sum(v["us"] for v in gemm_t.values())
-            roofline_gemm = {"bound": "hbm", "kernel": "gemm_packed_kernel (decode-batch linear layers, packed weights): "
-                                                       "qkv + o + gate|up + down of one layer",
+            roofline_gemm = {"bound": "hbm", "kernel": gemm_kernels + ": qkv + o + gate|up + down of one layer, as the "
+                                                       "decode step launches them",
                              "achieved": round(wb / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(wb / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
                              "weight_bytes_per_layer": wb, "us_per_layer": round(us, 2),

@@ -11,6 +11,7 @@ MI355X-first differences (all rounding-neutral with respect to the reference's u
   * residual-add + RMSNorm, RoPE (in place on the qkv buffer), set_kv_cache + attention and
     silu*mul each run as one HIP launch.
 GEMMs are plain library GEMMs (torch.matmul -> hipBLASLt); everything else is libhydra_hip."""
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -95,6 +96,9 @@ class LlamaForCausalLM:
         # slabs instead of 11; the activations travel between these launches in MFMA-fragment order.
         # 7 launches per layer, -7.5 us per 7B layer (tools/bench_layer_xreg.py).
         self.use_xreg = True
+        # qkv of layers >= 1 on the same kernel (its x comes fragment-major from the previous layer's
+        # add+norm; the attention prologue then reads 1 slab instead of 4): -45 us per 7B step
+        self.xreg_qkv = os.environ.get("HX_XREG_QKV", "1") == "1"
         self.packed_x: Dict[str, Tensor] = {}
         self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
 
@@ -115,6 +119,9 @@ class LlamaForCausalLM:
                 if f"l{l}.wgu" not in self.packed_x:
                     self.packed_x[f"l{l}.wgu"] = hip_gemm.pack_weight_xreg(self.state[f"l{l}.wgu"], interleave_halves=fused)
                     self.packed_x[f"l{l}.wdown"] = hip_gemm.pack_weight_xreg(self.state[f"l{l}.wdown"])
+                    wq = self.state[f"l{l}.wqkv"]
+                    if self.xreg_qkv and l > 0 and wq.stride(1) == 1 and hip_gemm.xreg_supported(32, wq.shape[0], hid, self.dtype):
+                        self.packed_x[f"l{l}.wqkv"] = hip_gemm.pack_weight_xreg(wq)
 
     def _xreg_mlp_ok(self, n: int) -> bool:
         hid, inter = self.shape.hidden_size, self.shape.intermediate_size
@@ -239,7 +246,11 @@ class LlamaForCausalLM:
         for l in range(L):
             ap = model_params.attention_params[l]
             kc, vc = ap.kv_cache.get_kv_cache()
-            s_qkv = self._partial(x, f"l{l}.wqkv", ws)
+            if xreg and f"l{l}.wqkv" in self.packed_x:
+                s_qkv = hip_gemm.linear_decode_partial_xreg(xf, self.packed_x[f"l{l}.wqkv"], q_size + 2 * kv_size, ws,
+                                                            frag_shape=(n, hid))
+            else:
+                s_qkv = self._partial(x, f"l{l}.wqkv", ws)
             o = torch.empty((n, H, D), dtype=h.dtype, device=h.device)
             # q / k_new / v_new arguments are shape carriers here: the kernel reads the slabs
             decode_attention_fused(o, o, o[:, :HK], o[:, :HK], kc, vc, position_ids, self.cos_sin,
@@ -263,7 +274,10 @@ class LlamaForCausalLM:
                 act = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype)
                 s_dn = self._partial(act, f"l{l}.wdown", ws)
             nxt = st[f"l{l + 1}.norm1"] if l + 1 < L else st["norm"]
-            add_rms_norm_slabs(x, h, ws, s_dn, nxt, eps)
+            if xreg and f"l{l + 1}.wqkv" in self.packed_x:
+                add_rms_norm_slabs(xf, h, ws, s_dn, nxt, eps, fragment_major=True)
+            else:
+                add_rms_norm_slabs(x, h, ws, s_dn, nxt, eps)
         return x
 
     def _decode_hidden_chain(self, h: Tensor, position_ids: Tensor,
