@@ -218,28 +218,6 @@ int round_kw(int kw) {
   return 0;
 }
 
-// K -> (splits, k-steps per wave).  Fewest splits whose per-wave share fits the register budget
-// (KW <= 32); HX_XREG_S="K:S;K:S" overrides the split count per K (tuning).
-void xreg_plan(int64_t K, int* S, int* KW) {
-  const int total_ks = (int)(K >> 5);
-  int s = (total_ks + 127) / 128;
-  static const char* env = getenv("HX_XREG_S");
-  if (env) {
-    const char* q = env;
-    while (*q) {
-      long k = 0, sv = 0;
-      if (sscanf(q, "%ld:%ld", &k, &sv) == 2 && k == K && sv >= s && sv <= 16) s = (int)sv;
-      const char* semi = strchr(q, ';');
-      if (!semi) break;
-      q = semi + 1;
-    }
-  }
-  const int per = (total_ks + s - 1) / s;
-  *KW = round_kw((per + 3) / 4);
-  // the split size is 4*KW k-steps; the number of splits that actually hold data
-  *S = (total_ks + 4 * *KW - 1) / (4 * *KW);
-}
-
 int n_cus() {
   static int n = [] {
     int dev = 0;
@@ -248,6 +226,46 @@ int n_cus() {
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }();
   return n;
+}
+
+// (N, K) -> (splits, k-steps per wave).  The fewest splits whose per-wave share fits the register
+// budget (KW <= 32), or one more when fewer than 80 % of the CUs would get a workgroup and the extra
+// split fills more (one workgroup per CU: K = 11008 with N = 4096 runs 192 workgroups at 3 splits,
+// 256 at 4) without padding more than 4 % of the k-steps.
+// HX_XREG_S="K:S;K:S" overrides the split count per K (tuning).  Pack and launch both come here.
+void xreg_plan(int64_t N, int64_t K, int* S, int* KW, bool fewest_splits = false) {
+  const int total_ks = (int)(K >> 5);
+  const int n_rg = (int)(N >> 4);
+  const int s0 = (total_ks + 127) / 128;
+  auto kw_of = [&](int s) { return round_kw(((total_ks + s - 1) / s + 3) / 4); };
+  auto wgs_of = [&](int s) {
+    int nb = n_cus() / s;
+    if (nb < 1) nb = 1;
+    if (nb > n_rg) nb = n_rg;
+    const int G = (n_rg + nb - 1) / nb;
+    return s * ((n_rg + G - 1) / G);
+  };
+  int s = s0;
+  if (!fewest_splits) {   // the fused gate|up epilogue needs ONE split: it never takes the extra one
+    const int kw1 = kw_of(s0 + 1);
+    const int used = (total_ks + 4 * kw1 - 1) / (4 * kw1);   // splits that hold data
+    if (kw1 > 0 && used == s0 + 1 && (int64_t)used * 4 * kw1 * 100 <= (int64_t)total_ks * 104 && wgs_of(s0) * 5 < n_cus() * 4 && wgs_of(s0 + 1) > wgs_of(s0))
+      s = s0 + 1;
+  }
+  static const char* env = getenv("HX_XREG_S");
+  if (env) {
+    const char* q = env;
+    while (*q) {
+      long k = 0, sv = 0;
+      if (sscanf(q, "%ld:%ld", &k, &sv) == 2 && k == K && sv >= s0 && sv <= 16) s = (int)sv;
+      const char* semi = strchr(q, ';');
+      if (!semi) break;
+      q = semi + 1;
+    }
+  }
+  *KW = kw_of(s);
+  // the split size is 4*KW k-steps; the number of splits that actually hold data
+  *S = *KW > 0 ? (total_ks + 4 * *KW - 1) / (4 * *KW) : 0;
 }
 
 template <typename T, int MB, int KW, int EPI>
@@ -303,7 +321,7 @@ int launch_any(const XregParams& p, int S, int KW, int dtype, hipStream_t stream
 bool xreg_ok(int64_t M, int64_t N, int64_t K) {
   if (M < 1 || M > 32 || N <= 0 || K <= 0 || N % 16 || K % 32) return false;
   int S, KW;
-  xreg_plan(K, &S, &KW);
+  xreg_plan(N, K, &S, &KW);
   return KW > 0;
 }
 
@@ -320,17 +338,17 @@ int xreg_set_option(const char* name, int value) {
 
 extern "C" int hx_linear_decode_xreg_supported(int64_t M, int64_t N, int64_t K) { return xreg_ok(M, N, K) ? 1 : 0; }
 
-extern "C" int hx_linear_decode_xreg_splits(int64_t K) {
-  if (K <= 0 || K % 32) return HX_ERR_SHAPE;
+extern "C" int hx_linear_decode_xreg_splits(int64_t N, int64_t K) {
+  if (N <= 0 || N % 16 || K <= 0 || K % 32) return HX_ERR_SHAPE;
   int S, KW;
-  xreg_plan(K, &S, &KW);
+  xreg_plan(N, K, &S, &KW);
   return KW > 0 ? S : HX_ERR_SHAPE;
 }
 
 extern "C" int64_t hx_linear_decode_xreg_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (!xreg_ok(M, N, K)) return 0;
   int S, KW;
-  xreg_plan(K, &S, &KW);
+  xreg_plan(N, K, &S, &KW);
   return (int64_t)S * M * N * (int64_t)sizeof(float);
 }
 
@@ -347,7 +365,7 @@ extern "C" int hx_pack_decode_weight_xreg(void* packed, const void* weight, int6
   if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
   if (!aligned16(packed) || !aligned16(weight)) return HX_ERR_STRIDE;
   int S, KW;
-  xreg_plan(K, &S, &KW);
+  xreg_plan(N, K, &S, &KW, interleave_halves != 0);
   if (KW <= 0) return HX_ERR_SHAPE;
   const int64_t n_pieces = N * K / 8;
   pack_xreg_kernel<<<(unsigned)((n_pieces + 255) / 256), 256, 0, (hipStream_t)stream>>>(
@@ -364,7 +382,7 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   if (!aligned16(x) || !aligned16(packed_weight) || !aligned16(partial)) return HX_ERR_STRIDE;
   if (partial_bytes < hx_linear_decode_xreg_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
   int S, KW;
-  xreg_plan(K, &S, &KW);
+  xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;
@@ -375,7 +393,7 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
 extern "C" int hx_gate_up_silu_xreg_supported(int64_t M, int64_t inter, int64_t K) {
   if (!xreg_ok(M, 2 * inter, K) || inter % 32) return 0;
   int S, KW;
-  xreg_plan(K, &S, &KW);
+  xreg_plan(2 * inter, K, &S, &KW, true);
   return S == 1 && (KW == 4 || KW == 8 || KW == 16 || KW == 32) ? 1 : 0;   // the fused epilogue is built for these
 }
 
@@ -387,7 +405,7 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
   if (!aligned16(x) || !aligned16(packed_gate_up) || !aligned16(act)) return HX_ERR_STRIDE;
   int S, KW;
-  xreg_plan(K, &S, &KW);
+  xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;

@@ -186,7 +186,7 @@ int hx_linear_decode_partial_packed(float* partial, const void* x, const void* p
  * Replaces: torch.nn.functional.linear at decode batch sizes and silu(gate) * up
  * (hydrainfer/model/llama.py:24-27,48-50, model_forward.py:36). */
 int hx_linear_decode_xreg_supported(int64_t M, int64_t N, int64_t K);
-int hx_linear_decode_xreg_splits(int64_t K);
+int hx_linear_decode_xreg_splits(int64_t N, int64_t K);
 int64_t hx_linear_decode_xreg_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int64_t hx_fragment_major_elems(int64_t rows, int64_t K);
 int hx_pack_decode_weight_xreg(void* packed, const void* weight, int64_t N, int64_t K, int64_t ldw,

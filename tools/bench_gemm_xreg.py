@@ -44,19 +44,18 @@ for name, (N, K) in {"qkv": (3 * hid, hid), "o": (hid, hid), "gate_up": (2 * int
     a = torch.empty(gemm.workspace_floats(M, N, K), dtype=torch.float32, device=dev)
     b = torch.empty(max(gemm.xreg_workspace_floats(M, N, K), 1), dtype=torch.float32, device=dev)
     x_rm = x
-    if "xreg_x_packed=1" in opts:   # experiment: x in B-fragment order [ks][mb][g][c][8]
-        MBk = (M + 15) // 16
-        xp_ = torch.zeros((MBk * 16, K), dtype=dt, device=dev); xp_[:M] = x
-        x = xp_.view(MBk, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().view(MBk * 16, K)[:M]
-    sb = gemm.linear_decode_partial_xreg(x, px[0], N, b)
+    fs = None
+    if os.environ.get("XFRAG", "1") == "1":   # x fragment-major, as the decode step hands it over
+        x, fs = gemm.to_fragment_major(x), (M, K)
+    sb = gemm.linear_decode_partial_xreg(x, px[0], N, b, frag_shape=fs)
     ref = x_rm.float() @ ws[0].float().t()
     got = b[: sb * M * N].view(sb, M, N).sum(0)
     err = (got - ref).abs().max().item() / ref.abs().max().item()
-    sb2 = gemm.linear_decode_partial_xreg(x, px[0], N, b)
+    sb2 = gemm.linear_decode_partial_xreg(x, px[0], N, b, frag_shape=fs)
     same = torch.equal(got, b[: sb2 * M * N].view(sb2, M, N).sum(0))
     del ws
     t0 = graph_time(lambda: [gemm.linear_decode_partial_packed(x_rm, pk[i % nc], N, a) for i in range(12)], 12)
-    t1 = graph_time(lambda: [gemm.linear_decode_partial_xreg(x, px[i % nc], N, b) for i in range(12)], 12)
+    t1 = graph_time(lambda: [gemm.linear_decode_partial_xreg(x, px[i % nc], N, b, frag_shape=fs) for i in range(12)], 12)
     nb = N * K * 2 // 8192 * 8192
     l = _lib.lib()
     t2 = graph_time(lambda: [_lib.check(l.hx_debug_stream_read(px[i % nc].data_ptr(), nb, 0, 0, 8, 1, 1024, sink.data_ptr(),
