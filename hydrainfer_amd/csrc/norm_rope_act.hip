@@ -420,13 +420,22 @@ __global__ __launch_bounds__(NT) void add_rms_norm_slab_kernel(
   const u16x8* w_v = reinterpret_cast<const u16x8*>(weight);
   float x[MAXV][8];
   float ss = 0.f;
+  // the residual and the norm weight are requested BEFORE the slab sums: the kernel is three
+  // dependent round trips otherwise (slabs -> residual -> weight), and it is latency-bound
+  u16x8 rr[MAXV], ww[MAXV];
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = min(threadIdx.x + j * NT, nvec - 1);
+    rr[j] = res_v[i];
+    ww[j] = w_v[i];
+  }
 #pragma unroll
   for (int j = 0; j < MAXV; ++j) {
     const int i = threadIdx.x + j * NT;
     if (i < nvec) {
       float a[8];
       slab_sum8<T>(partial + row * hidden + i * 8, n_splits, slab_stride, a);
-      const u16x8 r = res_v[i];
+      const u16x8 r = rr[j];
       u16x8 h;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -450,7 +459,7 @@ __global__ __launch_bounds__(NT) void add_rms_norm_slab_kernel(
   for (int j = 0; j < MAXV; ++j) {
     const int i = threadIdx.x + j * NT;
     if (i < nvec) {
-      const u16x8 w = w_v[i];
+      const u16x8 w = ww[j];
       u16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
