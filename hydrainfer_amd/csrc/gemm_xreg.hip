@@ -211,7 +211,7 @@ int g_stagger = 1;
 int g_dbg = 0;
 int g_force_wgs = 0;     // tuning: cap on workgroups per launch (0 = the CU count)
 
-constexpr int kKwSet[] = {4, 8, 16, 20, 22, 27, 29, 32};
+constexpr int kKwSet[] = {4, 8, 16, 20, 22, 27, 29, 32, 40};
 
 int round_kw(int kw) {
   for (int v : kKwSet) if (v >= kw) return v;
@@ -236,7 +236,7 @@ int n_cus() {
 void xreg_plan(int64_t N, int64_t K, int* S, int* KW, bool fewest_splits = false) {
   const int total_ks = (int)(K >> 5);
   const int n_rg = (int)(N >> 4);
-  const int s0 = (total_ks + 127) / 128;
+  const int s0 = (total_ks + 159) / 160;   // KW <= 40
   auto kw_of = [&](int s) { return round_kw(((total_ks + s - 1) / s + 3) / 4); };
   auto wgs_of = [&](int s) {
     int nb = n_cus() / s;
@@ -286,7 +286,7 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
     if (e != hipSuccess) return hip_rc(e);
   }
   const dim3 grid((unsigned)nb, (unsigned)S);
-  if (EPI == 0 && g_dbg && MB == 2 && (KW == 32 || KW == 29)) {   // ablation variants (tools/bench_gemm_xreg.py OPTS=xreg_dbg=..)
+  if constexpr (EPI == 0 && MB == 2 && (KW == 32 || KW == 29)) if (g_dbg) {   // ablation variants (tools/bench_gemm_xreg.py OPTS=xreg_dbg=..)
     if (g_dbg == 1) gemm_xreg_kernel<T, MB, KW, 0, 1><<<grid, 256, lds, stream>>>(p);
     else if (g_dbg == 2) gemm_xreg_kernel<T, MB, KW, 0, 2><<<grid, 256, lds, stream>>>(p);
     else gemm_xreg_kernel<T, MB, KW, 0, 3><<<grid, 256, lds, stream>>>(p);
@@ -307,6 +307,7 @@ int launch_mb(const XregParams& p, int S, int KW, hipStream_t stream) {
     case 27: if constexpr (EPI == 0) return launch_kw<T, MB, 27, 0>(p, S, stream); else return HX_ERR_SHAPE;
     case 29: if constexpr (EPI == 0) return launch_kw<T, MB, 29, 0>(p, S, stream); else return HX_ERR_SHAPE;
     case 32: return launch_kw<T, MB, 32, EPI>(p, S, stream);
+    case 40: return launch_kw<T, MB, 40, EPI>(p, S, stream);
     default: return HX_ERR_SHAPE;
   }
 }
@@ -394,7 +395,7 @@ extern "C" int hx_gate_up_silu_xreg_supported(int64_t M, int64_t inter, int64_t 
   if (!xreg_ok(M, 2 * inter, K) || inter % 32) return 0;
   int S, KW;
   xreg_plan(2 * inter, K, &S, &KW, true);
-  return S == 1 && (KW == 4 || KW == 8 || KW == 16 || KW == 32) ? 1 : 0;   // the fused epilogue is built for these
+  return S == 1 && (KW == 4 || KW == 8 || KW == 16 || KW == 32 || KW == 40) ? 1 : 0;   // the fused epilogue is built for these
 }
 
 extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed_gate_up, int64_t M,

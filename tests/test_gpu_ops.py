@@ -338,7 +338,7 @@ def test_fused_gate_up_silu_equals_gemm_then_silu(dt, M):
     try:
         for stagger in (0, 1):
             assert lib.hx_debug_set_option(b"xreg_stagger", stagger) == 0
-            for (inter, K) in ((11008, 4096), (4096, 2048), (96, 64), (13824, 4096)):   # shapes whose plain plan is one split too
+            for (inter, K) in ((11008, 4096), (4096, 2048), (96, 64), (13824, 5120)):   # shapes whose plain plan is one split too
                 assert gemm.gate_up_silu_supported(M, inter, K, dt)
                 g = torch.Generator().manual_seed(inter + M)
                 x = torch.randn((M, K), generator=g).to(dt).to(DEV)
@@ -361,6 +361,7 @@ def test_fused_gate_up_silu_equals_gemm_then_silu(dt, M):
                 ref = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
                 tol = 2e-3 if dt == torch.float16 else 1.6e-2
                 assert ((got.float() - ref).abs() <= tol * ref.abs() + tol * 0.05).all()
-        assert not gemm.gate_up_silu_supported(8, 13824, 5120, dt)   # K = 5120 needs two splits: unfused path
+        assert gemm.gate_up_silu_supported(8, 13824, 5120, dt)       # 13B: 40 k-steps per wave, still one split
+        assert not gemm.gate_up_silu_supported(8, 13824, 8192, dt)   # K = 8192 needs two splits: unfused path
     finally:
         lib.hx_debug_set_option(b"xreg_stagger", 1)
