@@ -30,8 +30,9 @@ slots = (perm[cu_b[:-1].long() + (ctx - 1) // bs] * bs + (ctx - 1) % bs).to(torc
 from hydrainfer_amd._C.kernel import gemm as hip_gemm
 x = torch.randn((B, H * D), generator=g, device=dev, dtype=torch.float32).to(dt)
 wqkv = (torch.randn((3 * H * D, H * D), generator=g, device=dev, dtype=torch.float32) * 0.02).to(dt)
-slabs = torch.empty(hip_gemm.workspace_floats(B, 3 * H * D, H * D), dtype=torch.float32, device=dev)
-n_slabs = hip_gemm.linear_decode_partial(x, wqkv, slabs)
+# (round 2: layers >= 1 get ONE slab from the activations-in-registers GEMM)
+slabs = torch.empty(hip_gemm.xreg_workspace_floats(B, 3 * H * D, H * D), dtype=torch.float32, device=dev)
+n_slabs = hip_gemm.linear_decode_partial_xreg(x, hip_gemm.pack_weight_xreg(wqkv), 3 * H * D, slabs)
 for i in range(12):
     decode_attention_fused(out, q, k_new, v_new, pool[i % L, 0], pool[i % L, 1], pos, cs, slots, cu_q, cu_k,
                            perm, cu_b, ctx, 1 / math.sqrt(D), 1, slabs, n_slabs)
