@@ -245,3 +245,58 @@ def gate_up_silu_xreg(x: Tensor, packed_gate_up: Tensor, inter: int, act: Tensor
         raise _lib.HydraHipError("gate_up_silu_xreg: act needs ceil16(M) * inter contiguous elements")
     _lib.check(_lib.lib().hx_gate_up_silu_xreg(act.data_ptr(), x.data_ptr(), packed_gate_up.data_ptr(), M, inter, K,
                                                ldx, fm, _lib.dtype_code(x), _lib.current_stream()), "gate_up_silu_xreg")
+
+
+# ---- add + RMSNorm fused in front of the product (hx_norm_*_xreg) ---------------------------------
+XREG_SYNC_WORDS = _lib.HX_XREG_SYNC_WORDS
+
+
+def norm_xreg_supported(M: int, N: int, K: int, dtype: torch.dtype, gate_up: bool = False) -> bool:
+    return (dtype in (torch.float16, torch.bfloat16)
+            and _lib.lib().hx_norm_xreg_supported(M, N, K, 1 if gate_up else 0) == 1)
+
+
+def _norm_checks(residual: Tensor, slabs_in: Tensor, n_splits_in: int, norm_weight: Tensor, x_frag: Tensor, sync: Tensor):
+    M, K = residual.shape
+    if not residual.is_contiguous() or norm_weight.dtype != residual.dtype or norm_weight.numel() != K:
+        raise _lib.HydraHipError("norm+xreg: residual [M, K] contiguous, norm_weight [K] of the same dtype")
+    if slabs_in.dtype != torch.float32 or not slabs_in.is_contiguous() or slabs_in.numel() < n_splits_in * M * K:
+        raise _lib.HydraHipError("norm+xreg: slabs_in must be contiguous float32 [n_splits_in, M, K]")
+    if x_frag.dtype != residual.dtype or not x_frag.is_contiguous() or x_frag.numel() < fragment_major_elems(M, K):
+        raise _lib.HydraHipError("norm+xreg: x_frag needs ceil16(M) * K contiguous elements of the activations' dtype")
+    if sync.dtype != torch.int32 or not sync.is_contiguous() or sync.numel() < XREG_SYNC_WORDS:
+        raise _lib.HydraHipError("norm+xreg: sync must be XREG_SYNC_WORDS contiguous int32 (zeroed)")
+    return M, K
+
+
+def norm_linear_decode_xreg(residual: Tensor, slabs_in: Tensor, n_splits_in: int, norm_weight: Tensor, epsilon: float,
+                            x_frag: Tensor, packed: Tensor, N: int, partial: Tensor, sync: Tensor) -> int:
+    """add_rms_norm_slabs(fragment-major) + linear_decode_partial_xreg as ONE launch: residual += (T) sum of
+    slabs_in; x_frag = rms_norm(residual) * norm_weight; partial = slabs of x @ W^T.  `sync`: zeroed
+    int32[XREG_SYNC_WORDS], one per launch in flight.  Returns the number of slabs written."""
+    _lib.require_gpu(residual, slabs_in, norm_weight, x_frag, packed, partial, sync)
+    M, K = _norm_checks(residual, slabs_in, n_splits_in, norm_weight, x_frag, sync)
+    if packed.numel() != N * K or packed.dtype != residual.dtype or partial.dtype != torch.float32 or not partial.is_contiguous():
+        raise _lib.HydraHipError("norm_linear_decode_xreg: packed = pack_weight_xreg(W [N, K]); partial contiguous float32")
+    rc = _lib.lib().hx_norm_linear_decode_xreg(partial.data_ptr(), residual.data_ptr(), slabs_in.data_ptr(), int(n_splits_in),
+                                               norm_weight.data_ptr(), float(epsilon), x_frag.data_ptr(), packed.data_ptr(),
+                                               M, N, K, sync.data_ptr(), partial.numel() * 4, _lib.dtype_code(residual),
+                                               _lib.current_stream())
+    if rc < 0:
+        _lib.check(rc, "norm_linear_decode_xreg")
+    return rc
+
+
+def norm_gate_up_silu_xreg(residual: Tensor, slabs_in: Tensor, n_splits_in: int, norm_weight: Tensor, epsilon: float,
+                           x_frag: Tensor, packed_gate_up: Tensor, inter: int, act: Tensor, sync: Tensor) -> None:
+    """add_rms_norm_slabs(fragment-major) + gate_up_silu_xreg as ONE launch (act fragment-major [M, inter])."""
+    _lib.require_gpu(residual, slabs_in, norm_weight, x_frag, packed_gate_up, act, sync)
+    M, K = _norm_checks(residual, slabs_in, n_splits_in, norm_weight, x_frag, sync)
+    if packed_gate_up.numel() != 2 * inter * K or packed_gate_up.dtype != residual.dtype or act.dtype != residual.dtype \
+            or not act.is_contiguous() or act.numel() < fragment_major_elems(M, inter):
+        raise _lib.HydraHipError("norm_gate_up_silu_xreg: packed [2*inter, K] (interleaved), act ceil16(M) * inter elements")
+    _lib.check(_lib.lib().hx_norm_gate_up_silu_xreg(act.data_ptr(), residual.data_ptr(), slabs_in.data_ptr(), int(n_splits_in),
+                                                    norm_weight.data_ptr(), float(epsilon), x_frag.data_ptr(),
+                                                    packed_gate_up.data_ptr(), M, inter, K, sync.data_ptr(),
+                                                    _lib.dtype_code(residual), _lib.current_stream()),
+               "norm_gate_up_silu_xreg")

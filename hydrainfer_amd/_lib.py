@@ -65,6 +65,7 @@ class hx_chain_args(ctypes.Structure):
 
 
 HX_CHAIN_SYNC_WORDS, HX_CHAIN_SYNC_ERR = 18432, 480
+HX_XREG_SYNC_WORDS = 512
 
 _SIGNATURES = {
     "hx_abi_version": (c_int, []),
@@ -93,6 +94,9 @@ _SIGNATURES = {
     "hx_fragment_major_elems": (c_int64, [c_int64] * 2),
     "hx_pack_decode_weight_xreg": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hx_linear_decode_partial_xreg": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_int64, c_int, c_void_p]),
+    "hx_norm_xreg_supported": (c_int, [c_int64] * 3 + [c_int]),
+    "hx_norm_linear_decode_xreg": (c_int, [c_void_p] * 3 + [c_int32, c_void_p, c_float, c_void_p, c_void_p] + [c_int64] * 3 + [c_void_p, c_int64, c_int, c_void_p]),
+    "hx_norm_gate_up_silu_xreg": (c_int, [c_void_p] * 3 + [c_int32, c_void_p, c_float, c_void_p, c_void_p] + [c_int64] * 3 + [c_void_p, c_int, c_void_p]),
     "hx_gate_up_silu_xreg_supported": (c_int, [c_int64] * 3),
     "hx_gate_up_silu_xreg": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_int, c_void_p]),
     "hx_add_rms_norm_slabs_ex": (c_int, [c_void_p] * 3 + [c_int32, c_void_p, c_float, c_int64, c_int64, c_int, c_int, c_void_p]),

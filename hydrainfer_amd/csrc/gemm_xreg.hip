@@ -37,6 +37,15 @@ struct XregParams {
   int32_t M, N, K;
   int32_t stagger;
   int32_t x_packed;     // x is fragment-major: piece ((ks*MB + mb)*64 + lane) = x[16mb + (lane&15)][32ks + 8(lane>>4) ..+8]
+  // NORM = 1: x is produced INSIDE the launch — workgroup r < M first computes row r of
+  //   residual += (T) sum of the nm_splits slabs;  x = rms_norm(residual) * nm_weight   (hx_add_rms_norm_slabs)
+  // and writes it fragment-major to `x` (write-through), the others prefetch weights meanwhile
+  const float* nm_partial;   // [nm_splits][M][K]
+  void* nm_residual;         // [M][K], in place
+  const void* nm_weight;     // [K]
+  uint32_t* sync;            // HX_XREG_SYNC_WORDS zeroed words: counter, error word, one flag line per XCD
+  int32_t nm_splits;
+  float nm_eps;
   void* act;            // EPI = 1: silu(gate)*up, fragment-major [inter/32][MB][64 lanes][8]
 };
 
@@ -44,13 +53,110 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-
 
 __device__ __attribute__((aligned(128))) u16 g_zero_line[64] = {0};
 
-constexpr int kMaxG = 16;     // row groups per workgroup (LDS: kMaxG * 4 waves * MB KiB)
+static_assert(HX_XREG_SYNC_WORDS >= 32 * 9, "sync area: word 0 arrivals, word 1 error, word 32*(1+xcc) the flag line of that XCD");
+constexpr int kMaxG = 16;
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int bu32x4 __attribute__((__vector_size__(16)));
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+// hx_add_rms_norm_slabs for ONE row by 256 threads, bit-identical to add_rms_norm_slab_kernel<T, MAXV, 512>:
+// thread u plays its virtual threads u and u + 256 (same per-thread sums, same wave sums, same order of
+// the eight wave sums).  x goes out fragment-major with sc1 (write-through) stores.
+template <typename T, int MAXV, int MB>
+__device__ __forceinline__ void norm_row_256(const float* __restrict__ partial, int n_splits, int64_t slab_stride,
+                                             u16* __restrict__ residual, const u16* __restrict__ weight, float eps,
+                                             int hidden, int row, void* x_frag, float* red) {
+  const int tid = threadIdx.x;
+  const int nvec = hidden / 8;
+  u16x8* res_v = reinterpret_cast<u16x8*>(residual + (int64_t)row * hidden);
+  const u16x8* w_v = reinterpret_cast<const u16x8*>(weight);
+  const rsrc_t xrs = make_rsrc(x_frag);
+  float x[2 * MAXV][8];
+  float ss[2] = {0.f, 0.f};
+  u16x8 rr[2 * MAXV], ww[2 * MAXV];
+#pragma unroll
+  for (int v = 0; v < 2; ++v)
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int i = min(tid + 256 * v + 512 * j, nvec - 1);
+      rr[v * MAXV + j] = res_v[i];
+      ww[v * MAXV + j] = w_v[i];
+    }
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int i = tid + 256 * v + 512 * j;
+      if (i < nvec) {
+        // slab pieces: all loads of a batch of 6 splits before the first add, adds in split order
+        // (norm_rope_act.hip slab_sum8)
+        const float* pp = partial + (int64_t)row * hidden + i * 8;
+        constexpr int kB = 6;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < n_splits; s0 += kB) {
+          f32x4 pa[kB], pb[kB];
+#pragma unroll
+          for (int k = 0; k < kB; ++k) {
+            const int sp = min(s0 + k, n_splits - 1);
+            pa[k] = *reinterpret_cast<const f32x4*>(pp + sp * slab_stride);
+            pb[k] = *reinterpret_cast<const f32x4*>(pp + sp * slab_stride + 4);
+          }
+#pragma unroll
+          for (int k = 0; k < kB; ++k) {
+            if (s0 + k == 0) { a = pa[0]; b = pb[0]; }
+            else if (s0 + k < n_splits) { a += pa[k]; b += pb[k]; }
+          }
+        }
+        const u16x8 r = rr[v * MAXV + j];
+        u16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sum = round_to<T>(round_to<T>(e < 4 ? a[e] : b[e - 4]) + T::to_float(r[e]));
+          x[v * MAXV + j][e] = sum;
+          h[e] = T::from_float(sum);
+          ss[v] += sum * sum;
+        }
+        res_v[i] = h;
+      }
+    }
+  }
+  const float t0 = wave_sum(ss[0]), t1 = wave_sum(ss[1]);
+  if ((tid & 63) == 0) {
+    red[tid >> 6] = t0;
+    red[4 + (tid >> 6)] = t1;
+  }
+  __syncthreads();
+  float total = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) total += red[k];
+  const float inv = rsqrtf(total / (float)hidden + eps);
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int i = tid + 256 * v + 512 * j;
+      if (i < nvec) {
+        const u16x8 w = ww[v * MAXV + j];
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = T::from_float(round_to<T>(x[v * MAXV + j][e] * inv) * T::to_float(w[e]));
+        // fragment-major piece ((i / 4) * MB + row / 16) * 64 + (i % 4) * 16 + row % 16
+        const uint32_t piece = (uint32_t)((i >> 2) * MB + (row >> 4)) * 64 + (i & 3) * 16 + (row & 15);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, o), xrs, piece * 16, 0, 16);
+      }
+    }
+  }
+}     // row groups per workgroup (LDS: kMaxG * 4 waves * MB KiB)
 
 // EPI = 0: fp32 slabs.  EPI = 1 (one split only): the weight is a gate|up projection packed with its
 // 16-row groups interleaved (group 2j = gate rows 16j.., group 2j+1 = up rows 16j..); a workgroup
 // takes whole pairs and writes act = silu(gate) * up with the rounding of hx_silu_and_mul_slabs on the
 // one-slab result (sum -> T, silu -> T, product -> T), fragment-major for the down projection.
-template <typename T, int MB, int KW, int EPI = 0, int DBG = 0>
+template <typename T, int MB, int KW, int EPI = 0, int DBG = 0, int NORM = 0>
 __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = (KW + 7) / 8;
@@ -93,34 +199,94 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   // (padding slots read a zero line instead of being masked: a select on the loaded value made
   // hipcc wait for every earlier load after each of these).
   u16x8 xb[KW][MB];
-  {
-    const u16* xp = reinterpret_cast<const u16*>(p.x) + 8 * g;
-    const u16* zp = reinterpret_cast<const u16*>(g_zero_line) + 8 * g;
+  const u16* xp = reinterpret_cast<const u16*>(p.x) + 8 * g;
+  const u16* zp = reinterpret_cast<const u16*>(g_zero_line) + 8 * g;
+  auto load_x_block = [&](int q) {
 #pragma unroll
-    for (int q = 0; q < NBUF; ++q) {
+    for (int j = 0; j < 8; ++j) {
+      const int t = 8 * q + j;
+      if (t < KW) {
+        const int r = rot(t);
+        const bool ok = r < kw;
+        const int ks = min(ks0 + w * KW + r, total_ks - 1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int t = 8 * q + j;
-        if (t < KW) {
-          const int r = rot(t);
-          const bool ok = r < kw;
-          const int ks = min(ks0 + w * KW + r, total_ks - 1);
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            const int m = min(mb * 16 + c, p.M - 1);
-            const u16* src = ok ? (p.x_packed ? reinterpret_cast<const u16*>(p.x) + ((int64_t)(ks * MB + mb) * 64 + lane) * 8
-                                              : xp + (int64_t)m * p.ldx + (int64_t)ks * 32)
-                                : zp;
-            if (DBG & 1) xb[t][mb] = u16x8{1, 2, 3, 4, 5, 6, (u16)t, (u16)lane};   // ablation: no x loads
-            else xb[t][mb] = *reinterpret_cast<const u16x8*>(src);
-          }
+        for (int mb = 0; mb < MB; ++mb) {
+          const int m = min(mb * 16 + c, p.M - 1);
+          const u16* src = ok ? (p.x_packed ? reinterpret_cast<const u16*>(p.x) + ((int64_t)(ks * MB + mb) * 64 + lane) * 8
+                                            : xp + (int64_t)m * p.ldx + (int64_t)ks * 32)
+                              : zp;
+          if (DBG & 1) xb[t][mb] = u16x8{1, 2, 3, 4, 5, 6, (u16)t, (u16)lane};   // ablation: no x loads
+          else xb[t][mb] = *reinterpret_cast<const u16x8*>(src);
         }
       }
+    }
+  };
+  if (NORM) {
+    // 1. producers: workgroup r < M computes row r of x (nothing of theirs is in flight yet, so the
+    //    row's loads are not queued behind weight loads), drains its stores and counts itself in; the
+    //    last one raises one flag line per XCD (a single polled line would stall its memory channel)
+    const int flat = blockIdx.y * gridDim.x + blockIdx.x;
+    const int n_wg = gridDim.x * gridDim.y;
+    if (flat < p.M) {
+      for (int row = flat; row < p.M; row += n_wg) {   // more rows than workgroups only on tiny N
+        norm_row_256<T, (KW + 31) / 32, MB>(p.nm_partial, p.nm_splits, (int64_t)p.M * p.K, reinterpret_cast<u16*>(p.nm_residual),
+                                            reinterpret_cast<const u16*>(p.nm_weight), p.nm_eps, p.K, row,
+                                            const_cast<void*>(p.x), reinterpret_cast<float*>(smem));
+        __syncthreads();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == (uint32_t)min(p.M, n_wg)) {
+#pragma unroll
+          for (int cpy = 0; cpy < 8; ++cpy)
+            __hip_atomic_store(p.sync + 32 * (1 + cpy), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    // 2. everyone: weight prefetch (independent of x), then wave 0 polls its XCD's flag line
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) load_buf(rg_of(0), q);
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x < 64) {
+      const uint32_t* fl = p.sync + 32 * (1 + (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7));
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+      while (!__builtin_amdgcn_readfirstlane(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {   // 1 s at 100 MHz: report, never hang the GPU
+          if (threadIdx.x == 0) __hip_atomic_fetch_or(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");
+    // 3. x: sc1 loads (served past this CU's L1; the bytes were written through by other CUs)
+    {
+      const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
+#pragma unroll
+      for (int t = 0; t < KW; ++t) {
+        const int r = rot(t);
+        const bool ok = r < kw;
+        const int ks = min(ks0 + w * KW + r, total_ks - 1);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          // padding slots (K rounded up to the wave's k-step count) read the zero line
+          xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
+              ok ? xrs : zrs, ok ? (uint32_t)((ks * MB + mb) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, 16));
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) {
+      load_x_block(q);
       load_buf(rg_of(0), q);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __builtin_amdgcn_sched_barrier(0);
 
   f32x4 acc[MB];
 #pragma unroll
@@ -268,7 +434,7 @@ void xreg_plan(int64_t N, int64_t K, int* S, int* KW, bool fewest_splits = false
   *S = *KW > 0 ? (total_ks + 4 * *KW - 1) / (4 * *KW) : 0;
 }
 
-template <typename T, int MB, int KW, int EPI>
+template <typename T, int MB, int KW, int EPI, int NORM = 0>
 int launch_kw(const XregParams& p, int S, hipStream_t stream) {
   const int n_units = EPI ? (p.N >> 5) : (p.N >> 4);     // row groups, or gate/up pairs of them
   const int per_unit = EPI ? 2 : 1;
@@ -281,42 +447,42 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
   nb = (n_units + G - 1) / G;                 // same depth, no idle tail workgroups
   const size_t lds = (size_t)G * per_unit * 4 * MB * 1024;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_kernel<T, MB, KW, EPI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
   const dim3 grid((unsigned)nb, (unsigned)S);
-  if constexpr (EPI == 0 && MB == 2 && (KW == 32 || KW == 29)) if (g_dbg) {   // ablation variants (tools/bench_gemm_xreg.py OPTS=xreg_dbg=..)
+  if constexpr (EPI == 0 && NORM == 0 && MB == 2 && (KW == 32 || KW == 29)) if (g_dbg) {   // ablation variants (tools/bench_gemm_xreg.py OPTS=xreg_dbg=..)
     if (g_dbg == 1) gemm_xreg_kernel<T, MB, KW, 0, 1><<<grid, 256, lds, stream>>>(p);
     else if (g_dbg == 2) gemm_xreg_kernel<T, MB, KW, 0, 2><<<grid, 256, lds, stream>>>(p);
     else gemm_xreg_kernel<T, MB, KW, 0, 3><<<grid, 256, lds, stream>>>(p);
     return check_launch();
   }
-  gemm_xreg_kernel<T, MB, KW, EPI><<<grid, 256, lds, stream>>>(p);
+  gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM><<<grid, 256, lds, stream>>>(p);
   return check_launch();
 }
 
-template <typename T, int MB, int EPI>
+template <typename T, int MB, int EPI, int NORM = 0>
 int launch_mb(const XregParams& p, int S, int KW, hipStream_t stream) {
   switch (KW) {
-    case 4: return launch_kw<T, MB, 4, EPI>(p, S, stream);
-    case 8: return launch_kw<T, MB, 8, EPI>(p, S, stream);
-    case 16: return launch_kw<T, MB, 16, EPI>(p, S, stream);
-    case 20: if constexpr (EPI == 0) return launch_kw<T, MB, 20, 0>(p, S, stream); else return HX_ERR_SHAPE;
-    case 22: if constexpr (EPI == 0) return launch_kw<T, MB, 22, 0>(p, S, stream); else return HX_ERR_SHAPE;
-    case 27: if constexpr (EPI == 0) return launch_kw<T, MB, 27, 0>(p, S, stream); else return HX_ERR_SHAPE;
-    case 29: if constexpr (EPI == 0) return launch_kw<T, MB, 29, 0>(p, S, stream); else return HX_ERR_SHAPE;
-    case 32: return launch_kw<T, MB, 32, EPI>(p, S, stream);
-    case 40: return launch_kw<T, MB, 40, EPI>(p, S, stream);
+    case 4: return launch_kw<T, MB, 4, EPI, NORM>(p, S, stream);
+    case 8: return launch_kw<T, MB, 8, EPI, NORM>(p, S, stream);
+    case 16: return launch_kw<T, MB, 16, EPI, NORM>(p, S, stream);
+    case 20: if constexpr (EPI == 0 && NORM == 0) return launch_kw<T, MB, 20, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    case 22: if constexpr (EPI == 0 && NORM == 0) return launch_kw<T, MB, 22, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    case 27: if constexpr (EPI == 0 && NORM == 0) return launch_kw<T, MB, 27, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    case 29: if constexpr (EPI == 0 && NORM == 0) return launch_kw<T, MB, 29, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    case 32: return launch_kw<T, MB, 32, EPI, NORM>(p, S, stream);
+    case 40: return launch_kw<T, MB, 40, EPI, NORM>(p, S, stream);
     default: return HX_ERR_SHAPE;
   }
 }
 
-template <int EPI>
+template <int EPI, int NORM = 0>
 int launch_any(const XregParams& p, int S, int KW, int dtype, hipStream_t stream) {
   const int MB = (p.M + 15) / 16;
-  if (dtype == HX_F16) return MB == 1 ? launch_mb<F16, 1, EPI>(p, S, KW, stream) : launch_mb<F16, 2, EPI>(p, S, KW, stream);
-  return MB == 1 ? launch_mb<BF16, 1, EPI>(p, S, KW, stream) : launch_mb<BF16, 2, EPI>(p, S, KW, stream);
+  if (dtype == HX_F16) return MB == 1 ? launch_mb<F16, 1, EPI, NORM>(p, S, KW, stream) : launch_mb<F16, 2, EPI, NORM>(p, S, KW, stream);
+  return MB == 1 ? launch_mb<BF16, 1, EPI, NORM>(p, S, KW, stream) : launch_mb<BF16, 2, EPI, NORM>(p, S, KW, stream);
 }
 
 bool xreg_ok(int64_t M, int64_t N, int64_t K) {
@@ -387,6 +553,7 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   XregParams p;
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;
+  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
   const int rc = launch_any<0>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
 }
@@ -410,5 +577,67 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   XregParams p;
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;
+  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
   return launch_any<1>(p, 1, KW, dtype, (hipStream_t)stream);
+}
+
+// ---- add + RMSNorm fused in front of the product (one launch instead of two) --------------------
+static bool norm_kw_ok(int S, int KW) { return S == 1 && (KW == 4 || KW == 8 || KW == 16 || KW == 32 || KW == 40); }
+
+extern "C" int hx_norm_xreg_supported(int64_t M, int64_t N, int64_t K, int gate_up) {
+  if (gate_up) return hx_gate_up_silu_xreg_supported(M, N / 2, K);   // same condition: one split, a built k-step count
+  if (!xreg_ok(M, N, K)) return 0;
+  int S, KW;
+  xreg_plan(N, K, &S, &KW);
+  return norm_kw_ok(S, KW) && K % 8 == 0 && K / 8 <= 2048 ? 1 : 0;
+}
+
+static int norm_args_ok(const void* residual, const float* slabs, int32_t n_splits, const void* weight, const void* x_frag,
+                        const void* sync) {
+  if (!residual || !slabs || !weight || !x_frag || !sync) return HX_ERR_NULL;
+  if (n_splits < 1) return HX_ERR_SHAPE;
+  if (!aligned16(residual) || !aligned16(slabs) || !aligned16(weight) || !aligned16(x_frag) || !aligned16(sync)) return HX_ERR_STRIDE;
+  return HX_OK;
+}
+
+extern "C" int hx_norm_linear_decode_xreg(float* partial, void* residual, const float* slabs_in, int32_t n_splits_in,
+                                          const void* norm_weight, float epsilon, void* x_frag,
+                                          const void* packed_weight, int64_t M, int64_t N, int64_t K, void* sync,
+                                          int64_t partial_bytes, int dtype, hx_stream stream) {
+  if (!partial || !packed_weight) return HX_ERR_NULL;
+  int rc = norm_args_ok(residual, slabs_in, n_splits_in, norm_weight, x_frag, sync);
+  if (rc) return rc;
+  if (!hx_norm_xreg_supported(M, N, K, 0)) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (!aligned16(packed_weight) || !aligned16(partial)) return HX_ERR_STRIDE;
+  if (partial_bytes < hx_linear_decode_xreg_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
+  int S, KW;
+  xreg_plan(N, K, &S, &KW);
+  XregParams p;
+  p.x = x_frag; p.w = packed_weight; p.partial = partial; p.ldx = K; p.act = nullptr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = g_stagger; p.x_packed = 1;
+  p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
+  p.nm_splits = n_splits_in; p.nm_eps = epsilon;
+  rc = launch_any<0, 1>(p, S, KW, dtype, (hipStream_t)stream);
+  return rc ? rc : S;
+}
+
+extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float* slabs_in, int32_t n_splits_in,
+                                         const void* norm_weight, float epsilon, void* x_frag,
+                                         const void* packed_gate_up, int64_t M, int64_t inter, int64_t K, void* sync,
+                                         int dtype, hx_stream stream) {
+  if (!act || !packed_gate_up) return HX_ERR_NULL;
+  int rc = norm_args_ok(residual, slabs_in, n_splits_in, norm_weight, x_frag, sync);
+  if (rc) return rc;
+  if (!hx_norm_xreg_supported(M, 2 * inter, K, 1)) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (!aligned16(packed_gate_up) || !aligned16(act)) return HX_ERR_STRIDE;
+  int S, KW;
+  xreg_plan(2 * inter, K, &S, &KW, true);
+  XregParams p;
+  p.x = x_frag; p.w = packed_gate_up; p.partial = nullptr; p.ldx = K; p.act = act;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = g_stagger; p.x_packed = 1;
+  p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
+  p.nm_splits = n_splits_in; p.nm_eps = epsilon;
+  return launch_any<1, 1>(p, 1, KW, dtype, (hipStream_t)stream);
 }

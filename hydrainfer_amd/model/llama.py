@@ -99,6 +99,10 @@ class LlamaForCausalLM:
         # qkv of layers >= 1 on the same kernel (its x comes fragment-major from the previous layer's
         # add+norm; the attention prologue then reads 1 slab instead of 4): -45 us per 7B step
         self.xreg_qkv = os.environ.get("HX_XREG_QKV", "1") == "1"
+        # the two add+norm launches of a layer run INSIDE the gate|up and qkv launches (the first 32
+        # workgroups produce x while all prefetch weights; in-kernel hand-over): 5 launches per layer
+        self.fuse_norm = os.environ.get("HX_FUSE_NORM", "1") == "1"
+        self.xreg_sync: Optional[Tensor] = None   # [L, 2, XREG_SYNC_WORDS] of the last step (word 1 = wait gave up)
         self.packed_x: Dict[str, Tensor] = {}
         self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
 
@@ -238,35 +242,56 @@ class LlamaForCausalLM:
                 xreg = False
             else:
                 self.pack_decode_weights()
+        qkv_n = q_size + 2 * kv_size
+        ws_q = ws          # where the current layer's qkv slabs live
+        nf_gu = nf_qkv = False
         if xreg:
             fused = hip_gemm.gate_up_silu_supported(n, inter, hid, h.dtype)
             xf = torch.empty(hip_gemm.fragment_major_elems(n, hid), dtype=h.dtype, device=h.device)
             actf = torch.empty(hip_gemm.fragment_major_elems(n, inter), dtype=h.dtype, device=h.device) if fused else None
+            # add+norm folded into the launch that consumes its output (hx_norm_*_xreg): 5 launches per layer
+            nf_gu = self.fuse_norm and fused and hip_gemm.norm_xreg_supported(n, 2 * inter, hid, h.dtype, gate_up=True)
+            nf_qkv = (self.fuse_norm and f"l{L - 1}.wqkv" in self.packed_x
+                      and hip_gemm.norm_xreg_supported(n, qkv_n, hid, h.dtype))
+            if nf_gu or nf_qkv:
+                # one zeroed hand-over area per fused launch of this step (a memset node when captured)
+                sync = torch.zeros((L, 2, hip_gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=h.device)
+                self.xreg_sync = sync
+            if nf_qkv:   # the fused launch reads the down slabs (ws) while it writes the qkv slab
+                ws_q = torch.empty(max(hip_gemm.xreg_workspace_floats(n, qkv_n, hid), hip_gemm.workspace_floats(n, qkv_n, hid)),
+                                   dtype=torch.float32, device=h.device)
         rms_norm(x, h, st["l0.norm1"], eps)
+        s_qkv = None
         for l in range(L):
             ap = model_params.attention_params[l]
             kc, vc = ap.kv_cache.get_kv_cache()
-            if xreg and f"l{l}.wqkv" in self.packed_x:
-                s_qkv = hip_gemm.linear_decode_partial_xreg(xf, self.packed_x[f"l{l}.wqkv"], q_size + 2 * kv_size, ws,
-                                                            frag_shape=(n, hid))
-            else:
-                s_qkv = self._partial(x, f"l{l}.wqkv", ws)
+            if s_qkv is None:
+                if xreg and f"l{l}.wqkv" in self.packed_x:
+                    s_qkv = hip_gemm.linear_decode_partial_xreg(xf, self.packed_x[f"l{l}.wqkv"], qkv_n, ws_q,
+                                                                frag_shape=(n, hid))
+                else:
+                    s_qkv = self._partial(x, f"l{l}.wqkv", ws_q)
             o = torch.empty((n, H, D), dtype=h.dtype, device=h.device)
             # q / k_new / v_new arguments are shape carriers here: the kernel reads the slabs
             decode_attention_fused(o, o, o[:, :HK], o[:, :HK], kc, vc, position_ids, self.cos_sin,
                                    ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
-                                   ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws, s_qkv)
+                                   ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws_q, s_qkv)
+            s_qkv = None
             s_o = self._partial(o.view(n, q_size), f"l{l}.wo", ws)
             if xreg:
                 # fragment-major activations from here to the down projection
-                add_rms_norm_slabs(xf, h, ws, s_o, st[f"l{l}.norm2"], eps, fragment_major=True)
                 pgu, pdn = self.packed_x[f"l{l}.wgu"], self.packed_x[f"l{l}.wdown"]
-                if fused:
-                    hip_gemm.gate_up_silu_xreg(xf, pgu, inter, actf, frag_shape=(n, hid))
+                if nf_gu:
+                    hip_gemm.norm_gate_up_silu_xreg(h, ws, s_o, st[f"l{l}.norm2"], eps, xf, pgu, inter, actf, sync[l, 0])
                     a_f = actf
                 else:
-                    s_gu = hip_gemm.linear_decode_partial_xreg(xf, pgu, 2 * inter, ws, frag_shape=(n, hid))
-                    a_f = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype, fragment_major=True)
+                    add_rms_norm_slabs(xf, h, ws, s_o, st[f"l{l}.norm2"], eps, fragment_major=True)
+                    if fused:
+                        hip_gemm.gate_up_silu_xreg(xf, pgu, inter, actf, frag_shape=(n, hid))
+                        a_f = actf
+                    else:
+                        s_gu = hip_gemm.linear_decode_partial_xreg(xf, pgu, 2 * inter, ws, frag_shape=(n, hid))
+                        a_f = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype, fragment_major=True)
                 s_dn = hip_gemm.linear_decode_partial_xreg(a_f, pdn, hid, ws, frag_shape=(n, inter))
             else:
                 add_rms_norm_slabs(x, h, ws, s_o, st[f"l{l}.norm2"], eps)
@@ -275,7 +300,11 @@ class LlamaForCausalLM:
                 s_dn = self._partial(act, f"l{l}.wdown", ws)
             nxt = st[f"l{l + 1}.norm1"] if l + 1 < L else st["norm"]
             if xreg and f"l{l + 1}.wqkv" in self.packed_x:
-                add_rms_norm_slabs(xf, h, ws, s_dn, nxt, eps, fragment_major=True)
+                if nf_qkv:   # h += down; x = norm1(h); next layer's qkv slab — one launch
+                    s_qkv = hip_gemm.norm_linear_decode_xreg(h, ws, s_dn, nxt, eps, xf, self.packed_x[f"l{l + 1}.wqkv"],
+                                                             qkv_n, ws_q, sync[l, 1])
+                else:
+                    add_rms_norm_slabs(xf, h, ws, s_dn, nxt, eps, fragment_major=True)
             else:
                 add_rms_norm_slabs(x, h, ws, s_dn, nxt, eps)
         return x

@@ -194,6 +194,26 @@ int hx_pack_decode_weight_xreg(void* packed, const void* weight, int64_t N, int6
 int hx_linear_decode_partial_xreg(float* partial, const void* x, const void* packed_weight,
                                   int64_t M, int64_t N, int64_t K, int64_t ldx, int x_fragment_major,
                                   int64_t partial_bytes, int dtype, hx_stream stream);
+/* hx_add_rms_norm_slabs FUSED IN FRONT of the product (one launch instead of two): workgroup r < M of
+ * the GEMM grid first computes row r of
+ *     residual += (T) sum of the n_splits_in slabs of slabs_in [n_splits_in][M][K];  x = rms_norm(residual) * norm_weight
+ * (bit-identical to hx_add_rms_norm_slabs_ex with fragment-major output), writes it to x_frag
+ * (hx_fragment_major_elems(M, K) elements, a scratch the caller may read afterwards) and counts itself
+ * in at `sync`; all workgroups prefetch their weights meanwhile, wait for the last row, then load x.
+ * sync: HX_XREG_SYNC_WORDS int32 words, ZERO before the launch, one area per launch in flight (word 1
+ * is set if a workgroup gave up waiting after 1 s — never expected).  Needs K in one split and
+ * M <= 32 (hx_norm_xreg_supported).  slabs_in must not alias the outputs.  Results equal
+ * hx_add_rms_norm_slabs_ex + hx_linear_decode_partial_xreg resp. hx_gate_up_silu_xreg bit for bit. */
+#define HX_XREG_SYNC_WORDS 512
+int hx_norm_xreg_supported(int64_t M, int64_t N, int64_t K, int gate_up);
+int hx_norm_linear_decode_xreg(float* partial, void* residual, const float* slabs_in, int32_t n_splits_in,
+                               const void* norm_weight, float epsilon, void* x_frag,
+                               const void* packed_weight, int64_t M, int64_t N, int64_t K, void* sync,
+                               int64_t partial_bytes, int dtype, hx_stream stream);
+int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float* slabs_in, int32_t n_splits_in,
+                              const void* norm_weight, float epsilon, void* x_frag,
+                              const void* packed_gate_up, int64_t M, int64_t inter, int64_t K, void* sync,
+                              int dtype, hx_stream stream);
 int hx_gate_up_silu_xreg_supported(int64_t M, int64_t inter, int64_t K);
 int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed_gate_up, int64_t M,
                          int64_t inter, int64_t K, int64_t ldx, int x_fragment_major, int dtype,

@@ -365,3 +365,46 @@ def test_fused_gate_up_silu_equals_gemm_then_silu(dt, M):
         assert not gemm.gate_up_silu_supported(8, 13824, 8192, dt)   # K = 8192 needs two splits: unfused path
     finally:
         lib.hx_debug_set_option(b"xreg_stagger", 1)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_norm_fused_in_front_of_xreg_product_is_bit_identical(dt):
+    """hx_norm_linear_decode_xreg / hx_norm_gate_up_silu_xreg (add + RMSNorm computed by the first M
+    workgroups of the GEMM grid, in-kernel hand-over) == hx_add_rms_norm_slabs_ex followed by the product:
+    residual, x and the outputs bit for bit; the hand-over areas report no give-up.  Includes shapes with
+    fewer workgroups than rows (every producer workgroup takes several rows) and many back-to-back launches
+    on the SAME buffers with changing inputs (a stale copy of x in any cache would show)."""
+    from hydrainfer_amd._C.kernel import gemm
+    from hydrainfer_amd._C.kernel.norm import add_rms_norm_slabs
+    for (M, hid, inter, S_in) in ((32, 4096, 11008, 4), (7, 4096, 11008, 3), (17, 5120, 13824, 4), (32, 256, 512, 1),
+                                  (3, 64, 128, 2), (32, 64, 32, 1)):
+        g = torch.Generator().manual_seed(hid + M)
+        nw = torch.randn(hid, generator=g).to(dt).to(DEV)
+        wq = (torch.randn((3 * hid, hid), generator=g) * 0.03).to(dt).to(DEV)
+        wgu = (torch.randn((2 * inter, hid), generator=g) * 0.03).to(dt).to(DEV)
+        assert gemm.norm_xreg_supported(M, 3 * hid, hid, dt) and gemm.norm_xreg_supported(M, 2 * inter, hid, dt, gate_up=True)
+        pq, pg = gemm.pack_weight_xreg(wq), gemm.pack_weight_xreg(wgu, interleave_halves=True)
+        xf, xf2 = (torch.zeros(gemm.fragment_major_elems(M, hid), dtype=dt, device=DEV) for _ in range(2))
+        a = torch.zeros(gemm.xreg_workspace_floats(M, 3 * hid, hid), dtype=torch.float32, device=DEV)
+        b = torch.zeros_like(a)
+        act1, act2 = (torch.zeros(gemm.fragment_major_elems(M, inter), dtype=dt, device=DEV) for _ in range(2))
+        n_it = 40 if hid == 4096 and M == 32 else 3
+        sync = torch.zeros((2 * n_it, gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=DEV)
+        for it in range(n_it):
+            slabs = torch.randn((S_in, M, hid), generator=g).to(DEV)
+            h = torch.randn((M, hid), generator=g).to(dt).to(DEV)
+            h1, h2, h3, h4 = h.clone(), h.clone(), h.clone(), h.clone()
+            add_rms_norm_slabs(xf, h1, slabs, S_in, nw, 1e-5, fragment_major=True)
+            s = gemm.linear_decode_partial_xreg(xf, pq, 3 * hid, a, frag_shape=(M, hid))
+            s2 = gemm.norm_linear_decode_xreg(h2, slabs, S_in, nw, 1e-5, xf2, pq, 3 * hid, b, sync[2 * it])
+            assert s == s2 and torch.equal(h1, h2) and torch.equal(a, b), f"qkv it={it} M={M} hid={hid}"
+            assert torch.equal(gemm.from_fragment_major(xf, M, hid), gemm.from_fragment_major(xf2, M, hid))
+            add_rms_norm_slabs(xf, h3, slabs, S_in, nw, 1e-5, fragment_major=True)
+            gemm.gate_up_silu_xreg(xf, pg, inter, act1, frag_shape=(M, hid))
+            gemm.norm_gate_up_silu_xreg(h4, slabs, S_in, nw, 1e-5, xf2, pg, inter, act2, sync[2 * it + 1])
+            assert torch.equal(h3, h4), f"gate|up residual it={it}"
+            assert torch.equal(gemm.from_fragment_major(act1, M, inter), gemm.from_fragment_major(act2, M, inter)), f"act it={it}"
+        assert int(sync[:, 1].abs().sum()) == 0          # no workgroup gave up waiting
+        assert int(sync[:, 0].min()) == min(M, 256) or int(sync[:, 0].min()) >= 1   # every launch counted its producers in
+    assert not gemm.norm_xreg_supported(32, 4096, 11008, dt)   # K = 11008 takes several splits
+    assert not gemm.norm_xreg_supported(33, 4096, 4096, dt)

@@ -203,3 +203,30 @@ def test_7b_shaped_two_layer_model_matches_oracle(dims):
         new = [[int(rt[0])], [int(rt[1])]]          # both sides follow the oracle's tokens
     # the KV pool written by the HIP path equals the oracle's up to T round-off of the projections
     assert (pool_d.cpu().float() - pool.float()).abs().max().item() <= 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_decode_with_norm_fused_launches_equals_separate_launches(dt):
+    """A 3-layer 7B-width model, 24 decode steps: the 5-launch layer (add+norm folded into the gate|up and
+    qkv launches, in-kernel hand-over over the same buffers every layer and step) == the 7-launch layer:
+    sampled tokens and the whole KV pool bit-identical, no hand-over gave up."""
+    from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
+    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
+    DEV = torch.device("cuda:0")
+    sh = LlamaShape(1024, 2816, 3, 8, 8, 128, 2048)
+    outs = []
+    for fuse in (False, True):
+        model = LlamaForCausalLM.random_init(sh, dt, DEV, seed=3)
+        model.fuse_norm = fuse
+        r = DecodeRunner(model, RunnerConfig(batch=5, prompt_len=40, n_generate=32, use_graph=fuse), seed=4)
+        g = torch.Generator().manual_seed(0)
+        r.prefill(torch.randint(5, 2000, (5, 40), generator=g).to(DEV))
+        for _ in range(24):
+            r.step()
+        torch.cuda.synchronize()
+        if fuse:
+            assert model.xreg_sync is not None and int(model.xreg_sync[:, :, 1].abs().sum()) == 0
+        outs.append((r.generated(), r.pool.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
