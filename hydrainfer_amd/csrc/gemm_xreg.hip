@@ -46,6 +46,7 @@ struct XregParams {
   uint32_t* sync;            // HX_XREG_SYNC_WORDS zeroed words: counter, error word, one flag line per XCD
   int32_t nm_splits;
   float nm_eps;
+  int32_t n_prod;            // > 0: the first n_prod workgroups ONLY produce rows (and exit); the GEMM grid follows
   void* act;            // EPI = 1: silu(gate)*up, fragment-major [inter/32][MB][64 lanes][8]
 };
 
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int split = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
+  const int n_prod = NORM ? p.n_prod : 0;
+  const int split = blockIdx.y, b = (int)blockIdx.x - n_prod, nb = (int)gridDim.x - n_prod;
   const int total_ks = p.K >> 5;
   const int n_rg = p.N >> 4;
   const int ks0 = split * P;
@@ -221,13 +223,36 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       }
     }
   };
+  if (NORM && n_prod > 0) {
+    // dedicated producers: the first n_prod workgroups of the grid (dispatched first) compute the rows of x
+    // on CUs the GEMM grid leaves free, publish and exit; no GEMM workgroup starts its stream late
+    if ((int)blockIdx.x < n_prod) {
+      for (int row = blockIdx.x; row < p.M; row += n_prod) {
+        norm_row_256<T, (KW + 31) / 32, MB>(p.nm_partial, p.nm_splits, (int64_t)p.M * p.K, reinterpret_cast<u16*>(p.nm_residual),
+                                            reinterpret_cast<const u16*>(p.nm_weight), p.nm_eps, p.K, row,
+                                            const_cast<void*>(p.x), reinterpret_cast<float*>(smem));
+        __syncthreads();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == (uint32_t)n_prod) {
+#pragma unroll
+          for (int cpy = 0; cpy < 8; ++cpy)
+            __hip_atomic_store(p.sync + 32 * (1 + cpy), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      return;
+    }
+  }
   if (NORM) {
     // 1. producers: workgroup r < M computes row r of x (nothing of theirs is in flight yet, so the
     //    row's loads are not queued behind weight loads), drains its stores and counts itself in; the
     //    last one raises one flag line per XCD (a single polled line would stall its memory channel)
     const int flat = blockIdx.y * gridDim.x + blockIdx.x;
     const int n_wg = gridDim.x * gridDim.y;
-    if (flat < p.M) {
+    if (n_prod == 0 && flat < p.M) {
       for (int row = flat; row < p.M; row += n_wg) {   // more rows than workgroups only on tiny N
         norm_row_256<T, (KW + 31) / 32, MB>(p.nm_partial, p.nm_splits, (int64_t)p.M * p.K, reinterpret_cast<u16*>(p.nm_residual),
                                             reinterpret_cast<const u16*>(p.nm_weight), p.nm_eps, p.K, row,
@@ -374,6 +399,9 @@ __global__ __launch_bounds__(256) void pack_xreg_kernel(u16* __restrict__ packed
 }
 
 int g_stagger = 1;
+int g_norm_dedicated = 0;   // tuning knob (xreg_norm_dedicated): NORM launches with up to this many producer-ONLY workgroups
+                            // in front of the GEMM grid instead of producers that also take GEMM work; measured equal
+                            // at 32 (83.1 vs 83.3 us per layer), worse below (16: 88.1: two rows per producer are not hidden)
 int g_dbg = 0;
 int g_force_wgs = 0;     // tuning: cap on workgroups per launch (0 = the CU count)
 
@@ -438,7 +466,9 @@ template <typename T, int MB, int KW, int EPI, int NORM = 0>
 int launch_kw(const XregParams& p, int S, hipStream_t stream) {
   const int n_units = EPI ? (p.N >> 5) : (p.N >> 4);     // row groups, or gate/up pairs of them
   const int per_unit = EPI ? 2 : 1;
-  const int cap = g_force_wgs > 0 ? g_force_wgs : n_cus();
+  // NORM: dedicated producer workgroups take M of the CUs (one workgroup per CU, all resident)
+  const int n_prod = (NORM && g_norm_dedicated > 0 && n_cus() >= 4 * p.M) ? (g_norm_dedicated < p.M ? g_norm_dedicated : p.M) : 0;
+  const int cap = (g_force_wgs > 0 ? g_force_wgs : n_cus()) - n_prod;
   int nb = cap / S;
   if (nb < 1) nb = 1;
   if (nb > n_units) nb = n_units;
@@ -451,7 +481,13 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  const dim3 grid((unsigned)nb, (unsigned)S);
+  const dim3 grid((unsigned)(nb + n_prod), (unsigned)S);
+  if constexpr (NORM != 0) {
+    XregParams q = p;
+    q.n_prod = n_prod;
+    gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM><<<grid, 256, lds, stream>>>(q);
+    return check_launch();
+  }
   if constexpr (EPI == 0 && NORM == 0 && MB == 2 && (KW == 32 || KW == 29)) if (g_dbg) {   // ablation variants (tools/bench_gemm_xreg.py OPTS=xreg_dbg=..)
     if (g_dbg == 1) gemm_xreg_kernel<T, MB, KW, 0, 1><<<grid, 256, lds, stream>>>(p);
     else if (g_dbg == 2) gemm_xreg_kernel<T, MB, KW, 0, 2><<<grid, 256, lds, stream>>>(p);
@@ -498,6 +534,7 @@ namespace hx {
 int xreg_set_option(const char* name, int value) {
   if (!strcmp(name, "xreg_stagger")) { g_stagger = value; return HX_OK; }
   if (!strcmp(name, "xreg_wgs")) { g_force_wgs = value; return HX_OK; }
+  if (!strcmp(name, "xreg_norm_dedicated")) { g_norm_dedicated = value; return HX_OK; }
   if (!strcmp(name, "xreg_dbg")) { g_dbg = value; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
@@ -553,7 +590,7 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   XregParams p;
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;
-  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
+  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f; p.n_prod = 0;
   const int rc = launch_any<0>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
 }
@@ -577,7 +614,7 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   XregParams p;
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;
-  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
+  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f; p.n_prod = 0;
   return launch_any<1>(p, 1, KW, dtype, (hipStream_t)stream);
 }
 
@@ -617,7 +654,7 @@ extern "C" int hx_norm_linear_decode_xreg(float* partial, void* residual, const 
   p.x = x_frag; p.w = packed_weight; p.partial = partial; p.ldx = K; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = g_stagger; p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
-  p.nm_splits = n_splits_in; p.nm_eps = epsilon;
+  p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.n_prod = 0;
   rc = launch_any<0, 1>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
 }
@@ -638,6 +675,6 @@ extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float*
   p.x = x_frag; p.w = packed_gate_up; p.partial = nullptr; p.ldx = K; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = g_stagger; p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
-  p.nm_splits = n_splits_in; p.nm_eps = epsilon;
+  p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.n_prod = 0;
   return launch_any<1, 1>(p, 1, KW, dtype, (hipStream_t)stream);
 }
