@@ -2,6 +2,8 @@
 (reference stub: hydrainfer/_C/kernel/norm/__init__.pyi:4-9;
 CUDA original: csrc/kernel/norm/rms_norm.cu:43-63).  bf16 is accepted (extension: the
 reference dispatch, csrc/kernel/dispatch.h:12-28, is fp32/fp16 only)."""
+from typing import Optional
+
 import torch
 from torch import Tensor
 
@@ -56,3 +58,41 @@ def add_rms_norm_slabs(out: Tensor, residual: Tensor, partial: Tensor, n_splits:
                                                    hidden, _lib.dtype_code(residual), 1 if fragment_major else 0,
                                                    _lib.current_stream()),
                "add_rms_norm_slabs")
+
+
+def embed_rms_norm(ids: Tensor, table: Tensor, weight: Tensor, epsilon: float):
+    """Extension: (h, x) with h = table[ids], x = rms_norm(h) * weight — one launch, bit-identical to
+    torch.nn.functional.embedding + rms_norm.  ids int32 / int64 [rows]; fp16 / bf16; hidden % 8 == 0, <= 8192."""
+    _lib.require_gpu(ids, table, weight)
+    if ids.dim() != 1 or ids.dtype not in (torch.int32, torch.int64) or not ids.is_contiguous():
+        raise _lib.HydraHipError("embed_rms_norm: ids must be contiguous int32 / int64 [rows]")
+    if table.dim() != 2 or not table.is_contiguous() or weight.dtype != table.dtype or weight.numel() != table.shape[1]:
+        raise _lib.HydraHipError("embed_rms_norm: table [vocab, hidden] contiguous, weight [hidden] of the same dtype")
+    rows, (vocab, hidden) = ids.numel(), table.shape
+    h = torch.empty((rows, hidden), dtype=table.dtype, device=table.device)
+    x = torch.empty_like(h)
+    _lib.check(_lib.lib().hx_embed_rms_norm(h.data_ptr(), x.data_ptr(), ids.data_ptr(), 1 if ids.dtype == torch.int64 else 0,
+                                            table.data_ptr(), weight.data_ptr(), float(epsilon), rows, hidden, vocab,
+                                            _lib.dtype_code(table), _lib.current_stream()), "embed_rms_norm")
+    return h, x
+
+
+def embed_rms_norm_supported(ids: Tensor, table: Tensor) -> bool:
+    return (ids.is_cuda and ids.dim() == 1 and ids.dtype in (torch.int32, torch.int64) and ids.is_contiguous()
+            and table.dtype in (torch.float16, torch.bfloat16) and table.is_contiguous()
+            and table.shape[1] % 8 == 0 and table.shape[1] <= 8192)
+
+
+def argmax_rows(logits: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """Extension: torch.argmax(logits, dim=-1) for fp16 / bf16 [rows, n] (greedy sampling), one small launch;
+    `out`: an int64 [rows] tensor to write into (a decode loop's next-input buffer)."""
+    _lib.require_gpu(logits)
+    if logits.dim() != 2 or logits.stride(1) != 1 or logits.dtype not in (torch.float16, torch.bfloat16):
+        raise _lib.HydraHipError("argmax_rows: logits must be fp16 / bf16 [rows, n] with contiguous rows")
+    if out is None:
+        out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    elif out.dtype != torch.int64 or out.shape != (logits.shape[0],) or not out.is_contiguous() or out.device != logits.device:
+        raise _lib.HydraHipError("argmax_rows: out must be a contiguous int64 [rows] tensor on the logits' device")
+    _lib.check(_lib.lib().hx_argmax_rows(out.data_ptr(), logits.data_ptr(), logits.shape[0], logits.shape[1],
+                                         logits.stride(0), _lib.dtype_code(logits), _lib.current_stream()), "argmax_rows")
+    return out

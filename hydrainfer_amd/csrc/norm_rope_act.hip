@@ -146,6 +146,114 @@ int launch_rms(void* out, void* residual, const void* input, const void* weight,
 }
 
 // ---------------------------------------------------------------------------
+// Step-edge fusions of the decode loop (extensions; each bit-identical to the two ops it replaces).
+// embed_rms_norm: h = table[ids] (torch.nn.functional.embedding, hydrainfer/model/llama.py:80-83) and
+// x = rms_norm(h) * w in one launch — same arithmetic and reduction as rms_norm_vec_kernel.
+// ---------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void embed_rms_norm_kernel(
+    typename T::storage* __restrict__ h_out, typename T::storage* __restrict__ x_out,
+    const void* __restrict__ ids, int ids_i64, const typename T::storage* __restrict__ table,
+    const typename T::storage* __restrict__ weight, float eps, int32_t hidden, int64_t vocab) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  int64_t id = ids_i64 ? reinterpret_cast<const int64_t*>(ids)[row] : (int64_t)reinterpret_cast<const int32_t*>(ids)[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);     // the torch op asserts; here out-of-range ids clamp
+  const int nvec = hidden / N;
+  const V* in_v = reinterpret_cast<const V*>(table + id * hidden);
+  V* h_v = reinterpret_cast<V*>(h_out + row * hidden);
+  V* out_v = reinterpret_cast<V*>(x_out + row * hidden);
+  const V* w_v = reinterpret_cast<const V*>(weight);
+  float x[MAXV][N];
+  V wv[MAXV];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < nvec) {
+      const V v = in_v[i];
+      wv[j] = w_v[i];
+      h_v[i] = v;
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        x[j][e] = T::to_float(v[e]);
+        ss += x[j][e] * x[j][e];
+      }
+    }
+  }
+  const float total = block_sum_256(ss, red);
+  const float inv = rsqrtf(total / (float)hidden + eps);
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < nvec) {
+      V o;
+#pragma unroll
+      for (int e = 0; e < N; ++e) o[e] = T::from_float(round_to<T>(x[j][e] * inv) * T::to_float(wv[j][e]));
+      out_v[i] = o;
+    }
+  }
+}
+
+// argmax over each row of logits [rows, n] (row stride ld): the greedy sampler
+// (hydrainfer/model/llama.py:99-104, torch.argmax).  torch's rule: the largest value, NaN counts as
+// larger than everything, ties go to the smallest index.
+__device__ __forceinline__ bool arg_better(float a, int ia, float b, int ib) {
+  const bool an = a != a, bn = b != b;
+  if (an != bn) return an;
+  if (!an && a != b) return a > b;
+  return ia < ib;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(int64_t* __restrict__ out,
+                                                           const typename T::storage* __restrict__ logits,
+                                                           int32_t n, int64_t ld) {
+  __shared__ float s_v[16];
+  __shared__ int s_i[16];
+  const int64_t row = blockIdx.x;
+  const typename T::storage* p = logits + row * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  const bool vec = (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+  if (vec) {
+    const int nvec = n / 8;
+    for (int i = threadIdx.x; i < nvec; i += 1024) {
+      const u16x8 v = *reinterpret_cast<const u16x8*>(p + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = T::to_float(v[e]);
+        if (arg_better(f, i * 8 + e, best, bi)) { best = f; bi = i * 8 + e; }
+      }
+    }
+    for (int i = nvec * 8 + threadIdx.x; i < n; i += 1024) {
+      const float f = T::to_float(p[i]);
+      if (arg_better(f, i, best, bi)) { best = f; bi = i; }
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const float f = T::to_float(p[i]);
+      if (arg_better(f, i, best, bi)) { best = f; bi = i; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (arg_better(ov, oi, best, bi)) { best = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k)
+      if (arg_better(s_v[k], s_i[k], best, bi)) { best = s_v[k]; bi = s_i[k]; }
+    out[row] = bi;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // RoPE.  Work item = (token, head (q heads then kv heads), pair index).
 // One thread rotates PV pairs: x' = x*c - y*s ; y' = x*s + y*c with every
 // operation rounded to T (rope.cu:22-27).  fp contraction is disabled so the
@@ -720,5 +828,41 @@ extern "C" int hx_silu_and_mul_slabs_ex(void* out, const float* partial, int32_t
     silu_mul_slab_kernel<BF16><<<grid, 256, 0, s>>>((u16*)out, partial, n_splits, stride, (int)inter, frag_mb);
   else
     return HX_ERR_DTYPE;
+  return check_launch();
+}
+
+extern "C" int hx_embed_rms_norm(void* h_out, void* x_out, const void* ids, int ids_are_int64, const void* table,
+                                 const void* weight, float epsilon, int64_t rows, int64_t hidden, int64_t vocab,
+                                 int dtype, hx_stream stream) {
+  if (rows < 0 || hidden <= 0 || vocab <= 0) return HX_ERR_SHAPE;
+  if (rows == 0) return HX_OK;
+  if (!h_out || !x_out || !ids || !table || !weight) return HX_ERR_NULL;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (hidden % 8 || hidden / 8 > 1024) return HX_ERR_SHAPE;
+  if (!aligned16(h_out) || !aligned16(x_out) || !aligned16(table) || !aligned16(weight)) return HX_ERR_STRIDE;
+  hipStream_t s = (hipStream_t)stream;
+  const int mv = (int)((hidden / 8 + 255) / 256);
+#define HX_L(TT, MV)                                                                                      \
+  embed_rms_norm_kernel<TT, MV><<<(unsigned)rows, 256, 0, s>>>((u16*)h_out, (u16*)x_out, ids, ids_are_int64, \
+                                                               (const u16*)table, (const u16*)weight, epsilon,  \
+                                                               (int)hidden, vocab)
+  if (dtype == HX_F16) {
+    if (mv <= 1) HX_L(F16, 1); else if (mv <= 2) HX_L(F16, 2); else HX_L(F16, 4);
+  } else {
+    if (mv <= 1) HX_L(BF16, 1); else if (mv <= 2) HX_L(BF16, 2); else HX_L(BF16, 4);
+  }
+#undef HX_L
+  return check_launch();
+}
+
+extern "C" int hx_argmax_rows(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t ld, int dtype,
+                              hx_stream stream) {
+  if (rows < 0 || n <= 0 || ld < n || n > 0x7ffffff0) return HX_ERR_SHAPE;
+  if (rows == 0) return HX_OK;
+  if (!out || !logits) return HX_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == HX_F16) argmax_rows_kernel<F16><<<(unsigned)rows, 1024, 0, s>>>(out, (const u16*)logits, (int)n, ld);
+  else if (dtype == HX_BF16) argmax_rows_kernel<BF16><<<(unsigned)rows, 1024, 0, s>>>(out, (const u16*)logits, (int)n, ld);
+  else return HX_ERR_DTYPE;
   return check_launch();
 }

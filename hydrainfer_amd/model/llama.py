@@ -19,7 +19,8 @@ import torch
 from torch import Tensor
 
 from hydrainfer_amd._C.kernel.activation import silu_and_mul, silu_and_mul_slabs
-from hydrainfer_amd._C.kernel.norm import add_rms_norm, add_rms_norm_slabs, rms_norm
+from hydrainfer_amd._C.kernel.norm import (add_rms_norm, add_rms_norm_slabs, argmax_rows, embed_rms_norm,
+                                             embed_rms_norm_supported, rms_norm)
 from hydrainfer_amd._C.kernel.position_embedding import rope_set_kv_cache
 from hydrainfer_amd.layer.causal_attention import AttentionParameters
 from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
@@ -102,6 +103,7 @@ class LlamaForCausalLM:
         # the two add+norm launches of a layer run INSIDE the gate|up and qkv launches (the first 32
         # workgroups produce x while all prefetch weights; in-kernel hand-over): 5 launches per layer
         self.fuse_norm = os.environ.get("HX_FUSE_NORM", "1") == "1"
+        self.sample_out: Optional[Tensor] = None   # int64 [rows]: forward() writes the sampled ids here (decode loops)
         self.xreg_sync: Optional[Tensor] = None   # [L, 2, XREG_SYNC_WORDS] of the last step (word 1 = wait gave up)
         self.packed_x: Dict[str, Tensor] = {}
         self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
@@ -221,7 +223,7 @@ class LlamaForCausalLM:
         return torch.nn.functional.embedding(input_ids, self.state["embed"])
 
     def _decode_hidden_hip_gemm(self, h: Tensor, position_ids: Tensor,
-                                model_params: LanguageModelParameters) -> Tensor:
+                                model_params: LanguageModelParameters, x0: Optional[Tensor] = None) -> Tensor:
         """All-decode step with the weight-streaming HIP GEMMs and fused slab consumers: 8
         launches per layer — qkv GEMM, [slab reduce + RoPE + cache append + attention], o GEMM,
         [slab reduce + residual add + RMSNorm], gate|up GEMM, [slab reduce + silu*mul], down GEMM,
@@ -260,7 +262,10 @@ class LlamaForCausalLM:
             if nf_qkv:   # the fused launch reads the down slabs (ws) while it writes the qkv slab
                 ws_q = torch.empty(max(hip_gemm.xreg_workspace_floats(n, qkv_n, hid), hip_gemm.workspace_floats(n, qkv_n, hid)),
                                    dtype=torch.float32, device=h.device)
-        rms_norm(x, h, st["l0.norm1"], eps)
+        if x0 is not None:
+            x = x0          # the first layer's norm came with the embedding gather
+        else:
+            rms_norm(x, h, st["l0.norm1"], eps)
         s_qkv = None
         for l in range(L):
             ap = model_params.attention_params[l]
@@ -353,8 +358,15 @@ class LlamaForCausalLM:
     def forward_hidden(self, input_ids_or_embeds: Tensor, position_ids: Tensor,
                        model_params: LanguageModelParameters) -> Tensor:
         sh, st = self.shape, self.state
+        x0 = None
         if input_ids_or_embeds.dtype in (torch.int32, torch.int64):
-            h = self.embed(input_ids_or_embeds)
+            ids = input_ids_or_embeds
+            if (model_params.all_sequences_decode and ids.dim() == 1 and ids.shape[0] <= 64
+                    and embed_rms_norm_supported(ids, st["embed"])):
+                # decode step: embedding gather + the first layer's norm, one launch
+                h, x0 = embed_rms_norm(ids, st["embed"], st["l0.norm1"], sh.rms_norm_eps)
+            else:
+                h = self.embed(ids)
         else:
             h = input_ids_or_embeds
         if not h.is_contiguous():
@@ -368,14 +380,17 @@ class LlamaForCausalLM:
             if self.use_chain and n <= 32 and f"l{sh.num_hidden_layers - 1}.wdown" in self.packed and hip_gemm.chain_supported(
                     n, sh.hidden_size, sh.intermediate_size, self.q_size, h.dtype):
                 return self._decode_hidden_chain(h, position_ids, model_params)
-            return self._decode_hidden_hip_gemm(h, position_ids, model_params)
+            return self._decode_hidden_hip_gemm(h, position_ids, model_params, x0)
         H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
         q_size, kv_size, inter = self.q_size, self.kv_size, sh.intermediate_size
         eps = sh.rms_norm_eps
         L = sh.num_hidden_layers
 
-        x = torch.empty_like(h)
-        rms_norm(x, h, st["l0.norm1"], eps)
+        if x0 is not None:
+            x = x0
+        else:
+            x = torch.empty_like(h)
+            rms_norm(x, h, st["l0.norm1"], eps)
         for l in range(L):
             ap = model_params.attention_params[l]
             qkv = self.linear(x, st[f"l{l}.wqkv"])
@@ -418,6 +433,11 @@ class LlamaForCausalLM:
 
     def forward(self, input_ids_or_embeds, position_ids, model_params) -> Tensor:
         """Returns sampled token ids (greedy), like the reference model."""
-        return torch.argmax(self.forward_logits(input_ids_or_embeds, position_ids, model_params), dim=-1)
+        logits = self.forward_logits(input_ids_or_embeds, position_ids, model_params)
+        if logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype in (torch.float16, torch.bfloat16):
+            # one 4 us launch (the library reduction: 15 us); straight into the caller's next-input buffer if it set one
+            out = self.sample_out if (self.sample_out is not None and self.sample_out.shape == (logits.shape[0],)) else None
+            return argmax_rows(logits, out)
+        return torch.argmax(logits, dim=-1)
 
     __call__ = forward

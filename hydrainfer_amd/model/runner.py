@@ -202,8 +202,13 @@ class DecodeRunner:
 
     def _step_body(self) -> None:
         self._advance()
-        nxt = self.model(self.input_ids, self.positions, self.decode_params)
-        self.input_ids.copy_(nxt)
+        self.model.sample_out = self.input_ids     # the sampled ids are the next step's input ids: no copy launch
+        try:
+            nxt = self.model(self.input_ids, self.positions, self.decode_params)
+        finally:
+            self.model.sample_out = None
+        if nxt.data_ptr() != self.input_ids.data_ptr():
+            self.input_ids.copy_(nxt)
 
     def capture(self) -> None:
         """Warm up on a side stream, then capture one decode step into a hipGraph.  Decode

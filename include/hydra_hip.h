@@ -165,6 +165,16 @@ int hx_pack_decode_weight(void* packed, const void* weight, int64_t N, int64_t K
 int hx_linear_decode_partial_packed(float* partial, const void* x, const void* packed_weight,
                                     int64_t M, int64_t N, int64_t K, int64_t ldx,
                                     int64_t partial_bytes, int dtype, hx_stream stream);
+/* Step-edge fusions of a decode loop (extensions, bit-identical to the ops they replace).
+ * hx_embed_rms_norm: h_out[r] = table[ids[r]] (torch.nn.functional.embedding; ids int32 or int64, out-of-range
+ * ids clamp) and x_out[r] = rms_norm(h_out[r]) * weight, one launch (hydrainfer/model/llama.py:80-83 + layer/norm.py).
+ * hx_argmax_rows: out[r] = argmax(logits[r, :n]) with torch.argmax's rule (NaN largest, ties to the smallest
+ * index): the greedy sampler of hydrainfer/model/llama.py:99-104. */
+int hx_embed_rms_norm(void* h_out, void* x_out, const void* ids, int ids_are_int64, const void* table,
+                      const void* weight, float epsilon, int64_t rows, int64_t hidden, int64_t vocab,
+                      int dtype, hx_stream stream);
+int hx_argmax_rows(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t ld, int dtype,
+                   hx_stream stream);
 /* The same product for M <= 32 with the activations held in REGISTERS (csrc/gemm_xreg.hip): a
  * workgroup spans the whole K of its split, so K <= 4096 needs ONE slab (no K split) and K = 11008
  * three instead of eleven — the fp32 slab traffic of a decode layer drops from 25 MB to 6.5 MB.

@@ -408,3 +408,32 @@ def test_norm_fused_in_front_of_xreg_product_is_bit_identical(dt):
         assert int(sync[:, 0].min()) == min(M, 256) or int(sync[:, 0].min()) >= 1   # every launch counted its producers in
     assert not gemm.norm_xreg_supported(32, 4096, 11008, dt)   # K = 11008 takes several splits
     assert not gemm.norm_xreg_supported(33, 4096, 4096, dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_embed_rms_norm_and_argmax_rows_equal_the_torch_ops(dt):
+    """The two step-edge fusions of the decode loop: hx_embed_rms_norm == embedding + rms_norm (which is
+    oracle-checked above) bit for bit; hx_argmax_rows == torch.argmax including ties (smallest index) and NaN."""
+    from hydrainfer_amd._C.kernel.norm import argmax_rows, embed_rms_norm, rms_norm
+    g = torch.Generator().manual_seed(5)
+    for rows, vocab, hidden, idt in ((32, 32064, 4096, torch.int64), (5, 100, 5120, torch.int32), (1, 7, 64, torch.int64),
+                                     (64, 1000, 8192, torch.int32)):
+        table = torch.randn((vocab, hidden), generator=g).to(dt).to(DEV)
+        w = torch.randn(hidden, generator=g).to(dt).to(DEV)
+        ids = torch.randint(0, vocab, (rows,), generator=g).to(idt).to(DEV)
+        h, x = embed_rms_norm(ids, table, w, 1e-5)
+        h_ref = torch.nn.functional.embedding(ids.long(), table)
+        x_ref = torch.empty_like(h_ref)
+        rms_norm(x_ref, h_ref, w, 1e-5)
+        assert torch.equal(h, h_ref) and torch.equal(x, x_ref)
+    for rows, n in ((32, 32064), (3, 1001), (1, 8), (17, 50000)):
+        logits = torch.randn((rows, n), generator=g).to(dt).to(DEV)
+        assert torch.equal(argmax_rows(logits), torch.argmax(logits, dim=-1))
+        logits[0, n // 2] = logits[0].max()          # a tie: bf16 / fp16 values repeat anyway, force one more
+        logits[-1, 3] = 1e4
+        logits[-1, n - 1] = 1e4
+        assert torch.equal(argmax_rows(logits), torch.argmax(logits, dim=-1))
+        logits[0, 5] = float("nan")
+        assert torch.equal(argmax_rows(logits), torch.argmax(logits, dim=-1))
+        view = logits[:, : n - 3]                     # row stride != n, unaligned tail
+        assert torch.equal(argmax_rows(view), torch.argmax(view, dim=-1))
