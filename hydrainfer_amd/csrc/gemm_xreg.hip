@@ -46,7 +46,6 @@ struct XregParams {
   uint32_t* sync;            // HX_XREG_SYNC_WORDS zeroed words: counter, error word, one flag line per XCD
   int32_t nm_splits;
   float nm_eps;
-  int32_t n_prod;            // > 0: the first n_prod workgroups ONLY produce rows (and exit); the GEMM grid follows
   void* act;            // EPI = 1: silu(gate)*up, fragment-major [inter/32][MB][64 lanes][8]
 };
 
@@ -54,7 +53,9 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-
 
 __device__ __attribute__((aligned(128))) u16 g_zero_line[64] = {0};
 
-static_assert(HX_XREG_SYNC_WORDS >= 32 * 9, "sync area: word 0 arrivals, word 1 error, word 32*(1+xcc) the flag line of that XCD");
+static_assert(HX_XREG_SYNC_WORDS >= 320 + 32, "sync area: word 0 arrivals, word 1 error, word 32*(1+xcc) the flag line of that XCD");
+constexpr int kStateWord = 320;        // sync area: one ownership word per row (<= 32)
+constexpr uint64_t kRescueTicks = 3000;   // 30 us of the 100 MHz clock (a normal wait is ~3 us)
 constexpr int kMaxG = 16;
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -66,18 +67,23 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
 // hx_add_rms_norm_slabs for ONE row by 256 threads, bit-identical to add_rms_norm_slab_kernel<T, MAXV, 512>:
 // thread u plays its virtual threads u and u + 256 (same per-thread sums, same wave sums, same order of
 // the eight wave sums).  x goes out fragment-major with sc1 (write-through) stores.
+// OWNERSHIP: a row is computed by whoever first exchanges its state word 0 -> 1 (thread 0; the answer
+// travels with the reduction barrier, so claiming costs no extra round trip); everybody else returns
+// false without having stored anything — the residual is updated exactly once.
 template <typename T, int MAXV, int MB>
-__device__ __forceinline__ void norm_row_256(const float* __restrict__ partial, int n_splits, int64_t slab_stride,
+__device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, int n_splits, int64_t slab_stride,
                                              u16* __restrict__ residual, const u16* __restrict__ weight, float eps,
-                                             int hidden, int row, void* x_frag, float* red) {
+                                             int hidden, int row, void* x_frag, uint32_t* state, float* red) {
   const int tid = threadIdx.x;
   const int nvec = hidden / 8;
+  uint32_t claimed = 1;
+  if (tid == 0) claimed = __hip_atomic_exchange(state + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   u16x8* res_v = reinterpret_cast<u16x8*>(residual + (int64_t)row * hidden);
   const u16x8* w_v = reinterpret_cast<const u16x8*>(weight);
   const rsrc_t xrs = make_rsrc(x_frag);
   float x[2 * MAXV][8];
   float ss[2] = {0.f, 0.f};
-  u16x8 rr[2 * MAXV], ww[2 * MAXV];
+  u16x8 rr[2 * MAXV], ww[2 * MAXV], hh[2 * MAXV];
 #pragma unroll
   for (int v = 0; v < 2; ++v)
 #pragma unroll
@@ -120,7 +126,7 @@ __device__ __forceinline__ void norm_row_256(const float* __restrict__ partial, 
           h[e] = T::from_float(sum);
           ss[v] += sum * sum;
         }
-        res_v[i] = h;
+        hh[v * MAXV + j] = h;
       }
     }
   }
@@ -129,29 +135,36 @@ __device__ __forceinline__ void norm_row_256(const float* __restrict__ partial, 
     red[tid >> 6] = t0;
     red[4 + (tid >> 6)] = t1;
   }
+  if (tid == 0) red[8] = claimed == 0u ? 1.f : 0.f;
   __syncthreads();
+  const bool own = red[8] != 0.f;
   float total = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) total += red[k];
   const float inv = rsqrtf(total / (float)hidden + eps);
+  if (own) {
 #pragma unroll
-  for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 2; ++v) {
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-      const int i = tid + 256 * v + 512 * j;
-      if (i < nvec) {
-        const u16x8 w = ww[v * MAXV + j];
-        u16x8 o;
+      for (int j = 0; j < MAXV; ++j) {
+        const int i = tid + 256 * v + 512 * j;
+        if (i < nvec) {
+          res_v[i] = hh[v * MAXV + j];
+          const u16x8 w = ww[v * MAXV + j];
+          u16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          o[e] = T::from_float(round_to<T>(x[v * MAXV + j][e] * inv) * T::to_float(w[e]));
-        // fragment-major piece ((i / 4) * MB + row / 16) * 64 + (i % 4) * 16 + row % 16
-        const uint32_t piece = (uint32_t)((i >> 2) * MB + (row >> 4)) * 64 + (i & 3) * 16 + (row & 15);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, o), xrs, piece * 16, 0, 16);
+          for (int e = 0; e < 8; ++e)
+            o[e] = T::from_float(round_to<T>(x[v * MAXV + j][e] * inv) * T::to_float(w[e]));
+          // fragment-major piece ((i / 4) * MB + row / 16) * 64 + (i % 4) * 16 + row % 16
+          const uint32_t piece = (uint32_t)((i >> 2) * MB + (row >> 4)) * 64 + (i & 3) * 16 + (row & 15);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, o), xrs, piece * 16, 0, 16);
+        }
       }
     }
   }
-}     // row groups per workgroup (LDS: kMaxG * 4 waves * MB KiB)
+  __syncthreads();   // red[] may be reused by the caller / the next row
+  return own;
+}
 
 // EPI = 0: fp32 slabs.  EPI = 1 (one split only): the weight is a gate|up projection packed with its
 // 16-row groups interleaved (group 2j = gate rows 16j.., group 2j+1 = up rows 16j..); a workgroup
@@ -165,8 +178,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int n_prod = NORM ? p.n_prod : 0;
-  const int split = blockIdx.y, b = (int)blockIdx.x - n_prod, nb = (int)gridDim.x - n_prod;
+  const int split = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
   const int total_ks = p.K >> 5;
   const int n_rg = p.N >> 4;
   const int ks0 = split * P;
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   // this workgroup's row groups (>= 1): rg_of(0), rg_of(1), ...
   const int G = EPI ? 2 * (((n_rg >> 1) - b + nb - 1) / nb) : (n_rg - b + nb - 1) / nb;
   auto rg_of = [&](int i) { return EPI ? 2 * (b + (i >> 1) * nb) + (i & 1) : b + i * nb; };
-  const int j0 = p.stagger ? (int)(((unsigned)b * 7u + (unsigned)w * 3u) % (unsigned)KW) : 0;
+  const int j0 = (p.stagger & 1) ? (int)(((unsigned)b * 7u + (unsigned)w * 3u) % (unsigned)KW) : 0;
 
   // k-step of slot t: rot(t) = (j0 + t) mod KW; slots whose k-step is past the wave's range are
   // padding: x fragment zero, weight address clamped to a valid fragment
@@ -223,71 +235,75 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       }
     }
   };
-  if (NORM && n_prod > 0) {
-    // dedicated producers: the first n_prod workgroups of the grid (dispatched first) compute the rows of x
-    // on CUs the GEMM grid leaves free, publish and exit; no GEMM workgroup starts its stream late
-    if ((int)blockIdx.x < n_prod) {
-      for (int row = blockIdx.x; row < p.M; row += n_prod) {
-        norm_row_256<T, (KW + 31) / 32, MB>(p.nm_partial, p.nm_splits, (int64_t)p.M * p.K, reinterpret_cast<u16*>(p.nm_residual),
-                                            reinterpret_cast<const u16*>(p.nm_weight), p.nm_eps, p.K, row,
-                                            const_cast<void*>(p.x), reinterpret_cast<float*>(smem));
+  if (NORM) {
+    // Sync area (zeroed by the caller): word 0 rows done, word 1 error, word 32*(1+xcc) the flag line of
+    // that XCD, words kStateWord.. one ownership word per row.
+    uint32_t* st = p.sync + kStateWord;
+    float* red = reinterpret_cast<float*>(smem);
+    int* cmd = reinterpret_cast<int*>(smem) + 16;
+    auto produce = [&](int row) {      // whole workgroup; true if this workgroup computed the row
+      const bool own = norm_row_256<T, (KW + 31) / 32, MB>(p.nm_partial, p.nm_splits, (int64_t)p.M * p.K,
+                                                           reinterpret_cast<u16*>(p.nm_residual),
+                                                           reinterpret_cast<const u16*>(p.nm_weight), p.nm_eps, p.K, row,
+                                                           const_cast<void*>(p.x), st, red);
+      if (own) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // x is written through: drained = visible
         __syncthreads();
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == (uint32_t)n_prod) {
+        if (threadIdx.x == 0) {
+          const uint32_t old = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (old + 1 == (uint32_t)p.M) {   // last row: one flag line per XCD (a single polled line stalls its channel)
 #pragma unroll
-          for (int cpy = 0; cpy < 8; ++cpy)
-            __hip_atomic_store(p.sync + 32 * (1 + cpy), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int cpy = 0; cpy < 8; ++cpy)
+              __hip_atomic_store(p.sync + 32 * (1 + cpy), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
-      return;
-    }
-  }
-  if (NORM) {
-    // 1. producers: workgroup r < M computes row r of x (nothing of theirs is in flight yet, so the
-    //    row's loads are not queued behind weight loads), drains its stores and counts itself in; the
-    //    last one raises one flag line per XCD (a single polled line would stall its memory channel)
+      return own;
+    };
+    // 1. producers: workgroup r < M computes row r of x FIRST (nothing of its own in flight yet: the row's
+    //    loads and the store drain are not queued behind weight loads — prefetching first cost the whole gain)
     const int flat = blockIdx.y * gridDim.x + blockIdx.x;
     const int n_wg = gridDim.x * gridDim.y;
-    if (n_prod == 0 && flat < p.M) {
-      for (int row = flat; row < p.M; row += n_wg) {   // more rows than workgroups only on tiny N
-        norm_row_256<T, (KW + 31) / 32, MB>(p.nm_partial, p.nm_splits, (int64_t)p.M * p.K, reinterpret_cast<u16*>(p.nm_residual),
-                                            reinterpret_cast<const u16*>(p.nm_weight), p.nm_eps, p.K, row,
-                                            const_cast<void*>(p.x), reinterpret_cast<float*>(smem));
-        __syncthreads();
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == (uint32_t)min(p.M, n_wg)) {
-#pragma unroll
-          for (int cpy = 0; cpy < 8; ++cpy)
-            __hip_atomic_store(p.sync + 32 * (1 + cpy), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-    // 2. everyone: weight prefetch (independent of x), then wave 0 polls its XCD's flag line
+    if (flat < p.M && !(p.stagger & 2))   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
+      for (int row = flat; row < p.M; row += n_wg) produce(row);   // several rows only when N is tiny
+    // 2. everyone: weight prefetch (independent of x)
 #pragma unroll
     for (int q = 0; q < NBUF; ++q) load_buf(rg_of(0), q);
     __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x < 64) {
-      const uint32_t* fl = p.sync + 32 * (1 + (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7));
-      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-      while (!__builtin_amdgcn_readfirstlane(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {   // 1 s at 100 MHz: report, never hang the GPU
-          if (threadIdx.x == 0) __hip_atomic_fetch_or(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
+    // 3. wait for the last row.  Wave 0 polls its XCD's flag line.  RESCUE: a producer workgroup that has
+    //    not been dispatched yet cannot be waited for if every CU it could get is held by waiters (two
+    //    processes sharing the GPU, each with such a launch: their workgroups interleave per XCD) — so a
+    //    workgroup that has waited kRescueTicks looks for a row nobody has claimed and computes it itself.
+    //    Progress therefore needs ONE resident workgroup, not the first M.
+    for (;;) {
+      if (threadIdx.x < 64) {
+        const uint32_t* fl = p.sync + 32 * (1 + (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7));
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        int c = -1;   // -1: flag seen; >= 0: row to rescue; -2: gave up
+        while (!__builtin_amdgcn_readfirstlane(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          __builtin_amdgcn_s_sleep(8);
+          const uint64_t waited = __builtin_amdgcn_s_memrealtime() - t0;
+          if (waited > kRescueTicks) {
+            const uint32_t sv = lane < p.M ? __hip_atomic_load(st + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+            const uint64_t free_rows = __ballot(sv == 0u);
+            if (free_rows) { c = __builtin_ctzll(free_rows); break; }
+          }
+          if (waited > 100000000ull) {   // 1 s at 100 MHz: report, never hang the GPU
+            if (threadIdx.x == 0) __hip_atomic_fetch_or(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c = -2;
+            break;
+          }
         }
+        if (threadIdx.x == 0) *cmd = c;
       }
+      __syncthreads();
+      const int c = *cmd;
+      __syncthreads();
+      if (c < 0) break;
+      produce(c);
     }
-    __syncthreads();
     asm volatile("" ::: "memory");
-    // 3. x: sc1 loads (served past this CU's L1; the bytes were written through by other CUs)
+    // 4. x: sc1 loads (served past this CU's L1; the bytes were written through by other CUs)
     {
       const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
 #pragma unroll
@@ -399,9 +415,7 @@ __global__ __launch_bounds__(256) void pack_xreg_kernel(u16* __restrict__ packed
 }
 
 int g_stagger = 1;
-int g_norm_dedicated = 0;   // tuning knob (xreg_norm_dedicated): NORM launches with up to this many producer-ONLY workgroups
-                            // in front of the GEMM grid instead of producers that also take GEMM work; measured equal
-                            // at 32 (83.1 vs 83.3 us per layer), worse below (16: 88.1: two rows per producer are not hidden)
+int g_no_producers = 0;   // test hook (xreg_no_producers): the norm-fused launches rely on the rescue path alone
 int g_dbg = 0;
 int g_force_wgs = 0;     // tuning: cap on workgroups per launch (0 = the CU count)
 
@@ -466,9 +480,7 @@ template <typename T, int MB, int KW, int EPI, int NORM = 0>
 int launch_kw(const XregParams& p, int S, hipStream_t stream) {
   const int n_units = EPI ? (p.N >> 5) : (p.N >> 4);     // row groups, or gate/up pairs of them
   const int per_unit = EPI ? 2 : 1;
-  // NORM: dedicated producer workgroups take M of the CUs (one workgroup per CU, all resident)
-  const int n_prod = (NORM && g_norm_dedicated > 0 && n_cus() >= 4 * p.M) ? (g_norm_dedicated < p.M ? g_norm_dedicated : p.M) : 0;
-  const int cap = (g_force_wgs > 0 ? g_force_wgs : n_cus()) - n_prod;
+  const int cap = g_force_wgs > 0 ? g_force_wgs : n_cus();
   int nb = cap / S;
   if (nb < 1) nb = 1;
   if (nb > n_units) nb = n_units;
@@ -481,13 +493,7 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  const dim3 grid((unsigned)(nb + n_prod), (unsigned)S);
-  if constexpr (NORM != 0) {
-    XregParams q = p;
-    q.n_prod = n_prod;
-    gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM><<<grid, 256, lds, stream>>>(q);
-    return check_launch();
-  }
+  const dim3 grid((unsigned)nb, (unsigned)S);
   if constexpr (EPI == 0 && NORM == 0 && MB == 2 && (KW == 32 || KW == 29)) if (g_dbg) {   // ablation variants (tools/bench_gemm_xreg.py OPTS=xreg_dbg=..)
     if (g_dbg == 1) gemm_xreg_kernel<T, MB, KW, 0, 1><<<grid, 256, lds, stream>>>(p);
     else if (g_dbg == 2) gemm_xreg_kernel<T, MB, KW, 0, 2><<<grid, 256, lds, stream>>>(p);
@@ -534,7 +540,7 @@ namespace hx {
 int xreg_set_option(const char* name, int value) {
   if (!strcmp(name, "xreg_stagger")) { g_stagger = value; return HX_OK; }
   if (!strcmp(name, "xreg_wgs")) { g_force_wgs = value; return HX_OK; }
-  if (!strcmp(name, "xreg_norm_dedicated")) { g_norm_dedicated = value; return HX_OK; }
+  if (!strcmp(name, "xreg_no_producers")) { g_no_producers = value; return HX_OK; }
   if (!strcmp(name, "xreg_dbg")) { g_dbg = value; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
@@ -589,8 +595,8 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;
-  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f; p.n_prod = 0;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers ? 2 : 0); p.x_packed = x_fragment_major ? 1 : 0;
+  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
   const int rc = launch_any<0>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
 }
@@ -613,8 +619,8 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
-  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = g_stagger; p.x_packed = x_fragment_major ? 1 : 0;
-  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f; p.n_prod = 0;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers ? 2 : 0); p.x_packed = x_fragment_major ? 1 : 0;
+  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
   return launch_any<1>(p, 1, KW, dtype, (hipStream_t)stream);
 }
 
@@ -652,9 +658,9 @@ extern "C" int hx_norm_linear_decode_xreg(float* partial, void* residual, const 
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x_frag; p.w = packed_weight; p.partial = partial; p.ldx = K; p.act = nullptr;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = g_stagger; p.x_packed = 1;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers ? 2 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
-  p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.n_prod = 0;
+  p.nm_splits = n_splits_in; p.nm_eps = epsilon;
   rc = launch_any<0, 1>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
 }
@@ -673,8 +679,8 @@ extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float*
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
   p.x = x_frag; p.w = packed_gate_up; p.partial = nullptr; p.ldx = K; p.act = act;
-  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = g_stagger; p.x_packed = 1;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers ? 2 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
-  p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.n_prod = 0;
+  p.nm_splits = n_splits_in; p.nm_eps = epsilon;
   return launch_any<1, 1>(p, 1, KW, dtype, (hipStream_t)stream);
 }

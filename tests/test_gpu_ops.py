@@ -410,6 +410,40 @@ def test_norm_fused_in_front_of_xreg_product_is_bit_identical(dt):
     assert not gemm.norm_xreg_supported(33, 4096, 4096, dt)
 
 
+def test_norm_fused_launch_rescues_rows_nobody_produced():
+    """The hand-over must not depend on WHICH workgroups are resident (two processes on one GPU interleave
+    their workgroups per XCD: a producer that is not dispatched yet may sit behind the other launch's
+    waiters).  Test hook xreg_no_producers: no workgroup computes its row up front — after 30 us the
+    waiting workgroups claim the rows themselves.  Same results bit for bit, no give-up."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel import gemm
+    from hydrainfer_amd._C.kernel.norm import add_rms_norm_slabs
+    dt, M, hid, S_in = torch.bfloat16, 32, 4096, 4
+    g = torch.Generator().manual_seed(11)
+    nw = torch.randn(hid, generator=g).to(dt).to(DEV)
+    wq = (torch.randn((3 * hid, hid), generator=g) * 0.03).to(dt).to(DEV)
+    pq = gemm.pack_weight_xreg(wq)
+    slabs = torch.randn((S_in, M, hid), generator=g).to(DEV)
+    h = torch.randn((M, hid), generator=g).to(dt).to(DEV)
+    h1, h2 = h.clone(), h.clone()
+    xf, xf2 = (torch.zeros(gemm.fragment_major_elems(M, hid), dtype=dt, device=DEV) for _ in range(2))
+    a = torch.zeros(gemm.xreg_workspace_floats(M, 3 * hid, hid), dtype=torch.float32, device=DEV)
+    b = torch.zeros_like(a)
+    add_rms_norm_slabs(xf, h1, slabs, S_in, nw, 1e-5, fragment_major=True)
+    gemm.linear_decode_partial_xreg(xf, pq, 3 * hid, a, frag_shape=(M, hid))
+    sync = torch.zeros(gemm.XREG_SYNC_WORDS, dtype=torch.int32, device=DEV)
+    lib = _lib.lib()
+    assert lib.hx_debug_set_option(b"xreg_no_producers", 1) == 0
+    try:
+        gemm.norm_linear_decode_xreg(h2, slabs, S_in, nw, 1e-5, xf2, pq, 3 * hid, b, sync)
+        torch.cuda.synchronize()
+    finally:
+        lib.hx_debug_set_option(b"xreg_no_producers", 0)
+    assert int(sync[1]) == 0 and int(sync[0]) == M
+    assert torch.equal(h1, h2) and torch.equal(a, b)
+    assert torch.equal(gemm.from_fragment_major(xf, M, hid), gemm.from_fragment_major(xf2, M, hid))
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_embed_rms_norm_and_argmax_rows_equal_the_torch_ops(dt):
     """The two step-edge fusions of the decode loop: hx_embed_rms_norm == embedding + rms_norm (which is
