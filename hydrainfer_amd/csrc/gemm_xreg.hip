@@ -17,7 +17,18 @@
 //   * waves start their k-steps at a workgroup-dependent rotation so that the fragments the chip
 //     reads at one instant are spread over all memory channels (in lock-step they would sit
 //     128 KiB apart).
-// K = 4096 needs no K-split at all (one slab); K = 11008 three (was 11).
+// K <= 5120 needs no K-split at all (one slab); K = 11008 takes four (was 11), chosen per (N, K) so
+// that every CU gets a workgroup (xreg_plan).
+// Two extensions of the same kernel finish the operators around the product:
+//   EPI = 1   gate|up + silu*mul: the packed gate and up row groups are interleaved, a workgroup owns
+//             both halves of its columns and writes act = silu(gate) * up (hx_gate_up_silu_xreg);
+//   NORM = 1  the add + RMSNorm that PRODUCES x runs inside the launch: the first M workgroups
+//             compute one row each, publish x write-through and count themselves in; all workgroups
+//             prefetch weights meanwhile, wait on their XCD's flag line, then load x.  Rows are
+//             owned by whoever claims their state word first, and a workgroup that has waited 30 us
+//             claims unstarted rows itself: progress needs ONE resident workgroup (hx_norm_*_xreg).
+// Activations between these launches are FRAGMENT-MAJOR (the order the B operands are loaded in;
+// include/hydra_hip.h): row-major x makes every x load touch 16 cache lines for 16 bytes each.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,7 +46,7 @@ struct XregParams {
   float* partial;       // [S][M][N]
   int64_t ldx;
   int32_t M, N, K;
-  int32_t stagger;
+  int32_t stagger;      // bit 0: rotate the k-steps per workgroup; bit 1: test hook, NORM rows only via the rescue path
   int32_t x_packed;     // x is fragment-major: piece ((ks*MB + mb)*64 + lane) = x[16mb + (lane&15)][32ks + 8(lane>>4) ..+8]
   // NORM = 1: x is produced INSIDE the launch — workgroup r < M first computes row r of
   //   residual += (T) sum of the nm_splits slabs;  x = rms_norm(residual) * nm_weight   (hx_add_rms_norm_slabs)
@@ -43,7 +54,7 @@ struct XregParams {
   const float* nm_partial;   // [nm_splits][M][K]
   void* nm_residual;         // [M][K], in place
   const void* nm_weight;     // [K]
-  uint32_t* sync;            // HX_XREG_SYNC_WORDS zeroed words: counter, error word, one flag line per XCD
+  uint32_t* sync;            // HX_XREG_SYNC_WORDS zeroed words: rows done, error word, one flag line per XCD, row states
   int32_t nm_splits;
   float nm_eps;
   void* act;            // EPI = 1: silu(gate)*up, fragment-major [inter/32][MB][64 lanes][8]
