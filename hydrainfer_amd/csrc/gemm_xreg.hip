@@ -466,9 +466,16 @@ void xreg_plan(int64_t N, int64_t K, int* S, int* KW, bool fewest_splits = false
   };
   int s = s0;
   if (!fewest_splits) {   // the fused gate|up epilogue needs ONE split: it never takes the extra one
-    const int kw1 = kw_of(s0 + 1);
-    const int used = (total_ks + 4 * kw1 - 1) / (4 * kw1);   // splits that hold data
-    if (kw1 > 0 && used == s0 + 1 && (int64_t)used * 4 * kw1 * 100 <= (int64_t)total_ks * 104 && wgs_of(s0) * 5 < n_cus() * 4 && wgs_of(s0 + 1) > wgs_of(s0))
+    // padded k-steps (per cent over the real ones) of a split count: what the padding waves re-read
+    auto waste_pct = [&](int sc) {
+      const int kw = kw_of(sc);
+      if (kw <= 0) return 1000;
+      const int used = (total_ks + 4 * kw - 1) / (4 * kw);
+      return used != sc ? 1000 : (int)(((int64_t)used * 4 * kw * 100) / total_ks) - 100;
+    };
+    const int w0 = waste_pct(s0), w1 = waste_pct(s0 + 1);
+    if (w1 <= 4 && (w0 > 4 ||                                                   // K = 13824: 3 splits pad 11 %, 4 are exact
+                    (wgs_of(s0) * 5 < n_cus() * 4 && wgs_of(s0 + 1) > wgs_of(s0))))   // K = 11008, N = 4096: 192 -> 256 workgroups
       s = s0 + 1;
   }
   static const char* env = getenv("HX_XREG_S");
