@@ -108,16 +108,14 @@ class LlamaForCausalLM:
         self.packed_x: Dict[str, Tensor] = {}
         self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
 
-    def pack_decode_weights(self) -> None:
-        """Builds the packed copies of every decoder-layer weight (once; not during graph capture)."""
+    def pack_decode_weights(self, all_lds_slice: bool = False) -> None:
+        """Builds the packed copies of the decoder-layer weights (once; not during graph capture): the
+        activations-in-registers layout for the projections that run on that kernel at <= 32 rows, the
+        LDS-slice layout for the others (o, layer 0's qkv).  The LDS-slice copies of the former are built
+        on first use only (batches of 33..64 rows, the decode chain: all_lds_slice) — a third copy of a 7B
+        model would be 12 GB that a <= 32-row server never reads."""
         if not (self.use_packed and self.use_hip_gemm and self.dtype in (torch.float16, torch.bfloat16)):
             return
-        for l in range(self.shape.num_hidden_layers):
-            for n in ("wqkv", "wo", "wgu", "wdown"):
-                key = f"l{l}.{n}"
-                w = self.state[key]
-                if key not in self.packed and w.shape[0] % 16 == 0 and w.shape[1] % 256 == 0 and w.stride(1) == 1:
-                    self.packed[key] = hip_gemm.pack_weight(w)
         if self.use_xreg and self._xreg_mlp_ok(32):
             hid, inter = self.shape.hidden_size, self.shape.intermediate_size
             fused = hip_gemm.gate_up_silu_supported(32, inter, hid, self.dtype)
@@ -128,6 +126,17 @@ class LlamaForCausalLM:
                     wq = self.state[f"l{l}.wqkv"]
                     if self.xreg_qkv and l > 0 and wq.stride(1) == 1 and hip_gemm.xreg_supported(32, wq.shape[0], hid, self.dtype):
                         self.packed_x[f"l{l}.wqkv"] = hip_gemm.pack_weight_xreg(wq)
+        for l in range(self.shape.num_hidden_layers):
+            for n in ("wqkv", "wo", "wgu", "wdown"):
+                key = f"l{l}.{n}"
+                if all_lds_slice or key not in self.packed_x:
+                    self._pack_lds_slice(key)
+
+    def _pack_lds_slice(self, key: str) -> Optional[Tensor]:
+        w = self.state[key]
+        if key not in self.packed and w.shape[0] % 16 == 0 and w.shape[1] % 256 == 0 and w.stride(1) == 1:
+            self.packed[key] = hip_gemm.pack_weight(w)
+        return self.packed.get(key)
 
     def _xreg_mlp_ok(self, n: int) -> bool:
         hid, inter = self.shape.hidden_size, self.shape.intermediate_size
@@ -139,8 +148,7 @@ class LlamaForCausalLM:
         """split-K slabs of x @ state[key]^T into ws; packed weights when available."""
         pk = self.packed.get(key)
         if pk is None and self.use_packed and not torch.cuda.is_current_stream_capturing():
-            self.pack_decode_weights()
-            pk = self.packed.get(key)
+            pk = self._pack_lds_slice(key)      # first use of this projection on the LDS-slice kernel
         if pk is not None:
             return hip_gemm.linear_decode_partial_packed(x, pk, self.state[key].shape[0], ws)
         return hip_gemm.linear_decode_partial(x, self.state[key], ws)
@@ -375,8 +383,9 @@ class LlamaForCausalLM:
         if (self.use_hip_gemm and model_params.all_sequences_decode and self.fuse_decode_attention
                 and n <= 64 and h.dtype in (torch.float16, torch.bfloat16)
                 and sh.hidden_size % 256 == 0 and sh.intermediate_size % 256 == 0):
-            if self.use_chain and n <= 32 and not self.packed and not torch.cuda.is_current_stream_capturing():
-                self.pack_decode_weights()
+            if (self.use_chain and n <= 32 and f"l{sh.num_hidden_layers - 1}.wdown" not in self.packed
+                    and not torch.cuda.is_current_stream_capturing()):
+                self.pack_decode_weights(all_lds_slice=True)
             if self.use_chain and n <= 32 and f"l{sh.num_hidden_layers - 1}.wdown" in self.packed and hip_gemm.chain_supported(
                     n, sh.hidden_size, sh.intermediate_size, self.q_size, h.dtype):
                 return self._decode_hidden_chain(h, position_ids, model_params)
