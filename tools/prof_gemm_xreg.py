@@ -8,8 +8,9 @@ the 256 MiB Infinity Cache).
 import csv, glob, json, os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-SHAPES = {"gate_up+silu": (22016, 4096, "<BF16,2,32,1,0>"), "down": (4096, 11008, "<BF16,2,22,0,0>"),
-          "qkv": (12288, 4096, "<BF16,2,32,0,0>")}
+SHAPES = {"gate_up+silu": (22016, 4096, "<BF16,2,32,1,0,0>"), "down": (4096, 11008, "<BF16,2,22,0,0,0>"),
+          "qkv": (12288, 4096, "<BF16,2,32,0,0,0>"),
+          "norm+gate_up+silu": (22016, 4096, "<BF16,2,32,1,0,1>"), "norm+qkv": (12288, 4096, "<BF16,2,32,0,0,1>")}
 M = 32
 
 
@@ -18,15 +19,25 @@ def run():
     from hydrainfer_amd._C.kernel import gemm
     dev, dt = torch.device("cuda:0"), torch.bfloat16
     big = torch.empty(300 * 1024 * 1024, dtype=torch.uint8, device=dev)
+    from hydrainfer_amd._C.kernel import gemm as G
     for name, (N, K, _) in SHAPES.items():
-        fused = name.startswith("gate_up")
+        fused = "gate_up" in name
+        nrm = name.startswith("norm+")
         pk = [gemm.pack_weight_xreg((torch.randn((N, K), device=dev) * 0.02).to(dt), interleave_halves=fused) for _ in range(3)]
         xf = gemm.to_fragment_major(torch.randn((M, K), device=dev).to(dt))
         ws = torch.empty(max(gemm.xreg_workspace_floats(M, N, K), 1), dtype=torch.float32, device=dev)
         act = torch.empty(gemm.fragment_major_elems(M, N // 2), dtype=dt, device=dev)
+        slabs = torch.randn((4, M, K), device=dev)
+        resid = torch.randn((M, K), device=dev).to(dt)
+        nw = torch.randn(K, device=dev).to(dt)
+        sync = torch.zeros((3, G.XREG_SYNC_WORDS), dtype=torch.int32, device=dev)
         for i in range(3):
             big.fill_(i)
-            if fused:
+            if nrm and fused:
+                gemm.norm_gate_up_silu_xreg(resid, slabs, 4, nw, 1e-5, xf, pk[i], N // 2, act, sync[i])
+            elif nrm:
+                gemm.norm_linear_decode_xreg(resid, slabs, 4, nw, 1e-5, xf, pk[i], N, ws, sync[i])
+            elif fused:
                 gemm.gate_up_silu_xreg(xf, pk[i], N // 2, act, frag_shape=(M, K))
             else:
                 gemm.linear_decode_partial_xreg(xf, pk[i], N, ws, frag_shape=(M, K))
@@ -40,6 +51,8 @@ def counters(d, counter):
         for r in csv.DictReader(open(f)):
             if "gemm_xreg_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 key = r["Kernel_Name"].split("gemm_xreg_kernel")[1].split("(")[0].replace("hx::", "").replace(" ", "")
+                if key.count(",") == 4:
+                    key = key[:-1] + ",0>"
                 out.setdefault(key, []).append(float(r["Counter_Value"]))
     return out
 
@@ -57,11 +70,16 @@ def summarize(dir_f, dir_w, out):
         w = statistics.median(wr[cfg]) * 1024
         wbytes = N * K * 2
         xbytes = M * K * 2
-        if name.startswith("gate_up"):
+        if "gate_up" in name:
             out_bytes, what = M * (N // 2) * 2, "act (bf16, fragment-major)"
         else:
             splits = 4 if K == 11008 else 1
             out_bytes, what = splits * M * N * 4, f"{splits} fp32 slab(s)"
+        if name.startswith("norm+"):   # + the residual rows rewritten in place and x (fragment-major, written through)
+            out_bytes += 2 * M * K * 2
+            what += " + residual + x"
+        if cfg not in fe or cfg not in wr:
+            continue
         res["shapes"].append({"name": name, "config": cfg, "N": N, "K": K,
                               "fetch_bytes_corrected": f, "algorithmic_weight_bytes": wbytes,
                               "fetch_over_weights": round(f / wbytes, 4),
