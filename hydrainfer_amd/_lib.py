@@ -94,6 +94,7 @@ _SIGNATURES = {
     "hx_fragment_major_elems": (c_int64, [c_int64] * 2),
     "hx_pack_decode_weight_xreg": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hx_linear_decode_partial_xreg": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_int64, c_int, c_void_p]),
+    "hx_debug_paged_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int] + [c_int] * 4 + [c_void_p, c_void_p]),
     "hx_embed_rms_norm": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_void_p, c_float, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hx_argmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hx_norm_xreg_supported": (c_int, [c_int64] * 3 + [c_int]),

@@ -20,31 +20,35 @@ template <int U, int POLICY>
 __global__ __launch_bounds__(256) void stream_read_kernel(const char* __restrict__ base, int64_t bytes,
                                                           int variant, int64_t pitch, float* sink) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  const int64_t chunk = (int64_t)U * 1024;                 // bytes per wave per step
-  const int64_t n_chunks = bytes / chunk;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * (blockDim.x >> 6);
+  const int chunk = U * 1024;                              // bytes per wave per step
+  const int n_chunks = (int)(bytes / chunk);
+  // everything that does not depend on the chunk is computed once, in 32 bits: the address arithmetic of
+  // the strided variants must not cost more issue slots than that of the contiguous one (an earlier
+  // version divided 64-bit integers per chunk and under-reported the strided shapes by ~8 %)
+  const int S = variant == 0 ? 1024 : variant == 1 ? 128 : variant == 2 ? 256 : variant == 3 ? 512 : 1024;
+  const int R = 1024 / S;
+  const int lanes_per_row = S / 16;
+  const int r = lane / lanes_per_row, piece = lane % lanes_per_row;
+  const int per_rowblock = variant ? (int)(pitch / ((int64_t)S * U)) : 1;   // chunks per row block
+  const int64_t lane_off = variant ? (int64_t)r * pitch + piece * 16 : lane * 16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t c = wave; c < n_chunks; c += n_waves) {
+  for (int c = wave; c < n_chunks; c += n_waves) {
+    int64_t base_off;
+    if (variant == 0) {
+      base_off = (int64_t)c * chunk;
+    } else {
+      // the chunk is a [R rows][S*U bytes] block of a row-major matrix with row pitch `pitch`: one
+      // instruction covers R rows x S bytes (R*S = 1024), U instructions walk along the rows
+      const int rb = c / per_rowblock, cb = c - rb * per_rowblock;
+      base_off = (int64_t)rb * R * pitch + (int64_t)cb * (S * U);
+    }
+    const char* p0 = base + base_off + lane_off;
     f32x4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      int64_t off;
-      if (variant == 0) {
-        off = c * chunk + (int64_t)u * 1024 + lane * 16;
-      } else {
-        // the chunk is a [rows_per_chunk][seg] block of a row-major matrix with row pitch `pitch`:
-        // one instruction covers R rows x S bytes (R*S = 1024), U instructions walk along the row
-        const int S = variant == 1 ? 128 : variant == 2 ? 256 : variant == 3 ? 512 : 1024;
-        const int R = 1024 / S;
-        const int lanes_per_row = S / 16;
-        const int r = lane / lanes_per_row, piece = lane % lanes_per_row;
-        // chunk c -> (row block, column block): a row block of R rows spans pitch bytes = pitch / (S*U) chunks
-        const int64_t per_rowblock = pitch / ((int64_t)S * U);
-        const int64_t rb = c / per_rowblock, cb = c % per_rowblock;
-        off = (rb * R + r) * pitch + cb * ((int64_t)S * U) + (int64_t)u * S + piece * 16;
-      }
-      const f32x4* p = reinterpret_cast<const f32x4*>(base + off);
+      const f32x4* p = reinterpret_cast<const f32x4*>(p0 + (variant ? u * S : u * 1024));
       if (POLICY == 1) v[u] = __builtin_nontemporal_load(p);
       else v[u] = *p;
     }
@@ -61,7 +65,73 @@ int launch_u(const void* p, int64_t bytes, int variant, int64_t pitch, int polic
   return check_launch();
 }
 
+// The decode-attention access pattern with the arithmetic removed: grid (head, sequence), 4 waves; wave w
+// owns the 16-key tiles w, w + 4, ...; a tile is one page of the paged cache (block_size 16): its K and V
+// rows for this head are 16 x 256 B at a pitch of row_bytes inside the page; pages come from a table
+// (random order).  Two tiles in flight per wave (register double buffer) like attn_decode_kernel.
+// What this reads per launch is exactly what the attention kernel reads: its rate is that kernel's ceiling.
+template <int HPW, int NW, int DEPTH>   // heads per workgroup (contiguous 256*HPW bytes per key row), waves, tiles in flight per wave
+__global__ __launch_bounds__(NW * 64) void paged_read_kernel(const char* __restrict__ kbase, const char* __restrict__ vbase,
+                                                             const int32_t* __restrict__ table, int tiles, int n_splits,
+                                                             int64_t page_bytes, int row_bytes, float* sink) {
+  // one wave instruction = 1 KiB = (64 / (16 * HPW)) key rows x (256 * HPW) bytes; a 16-key tile of K is
+  // 4 * HPW instructions, of V as many
+  constexpr int LPR = 16 * HPW;            // lanes per key row
+  constexpr int RPI = 64 / LPR;            // key rows per instruction
+  constexpr int NI = 16 / RPI;             // instructions per tile and tensor
+  const int hg = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t lane_off = (int64_t)(lane / LPR) * row_bytes + (int64_t)hg * (256 * HPW) + (lane % LPR) * 16;
+  const int32_t* tb = table + (int64_t)b * tiles;
+  const int per = (tiles + n_splits - 1) / n_splits;
+  const int t0 = split * per, t1 = min(tiles, t0 + per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 buf[DEPTH][2 * NI];
+  auto load = [&](f32x4 (&bf)[2 * NI], int t) {
+    const int64_t off = (int64_t)tb[t] * page_bytes + lane_off;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      bf[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kbase + off + (int64_t)i * RPI * row_bytes));
+      bf[NI + i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vbase + off + (int64_t)i * RPI * row_bytes));
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d)
+    if (t0 + w + d * NW < t1) load(buf[d], t0 + w + d * NW);
+  for (int t = t0 + w; t < t1; t += NW * DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int tc = t + d * NW, tn = tc + (DEPTH - 1) * NW;
+      if (tn < t1) load(buf[(d + DEPTH - 1) % DEPTH], tn);
+      if (tc < t1) {
+#pragma unroll
+        for (int i = 0; i < 2 * NI; ++i) acc += buf[d][i];
+      }
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
+}
+
 }  // namespace
+
+extern "C" int hx_debug_paged_read(const void* kbase, const void* vbase, const int32_t* table, int n_seq, int n_heads,
+                                   int tiles, int64_t page_bytes, int row_bytes, int heads_per_wg, int waves,
+                                   int depth, int n_splits, float* sink, hx_stream stream) {
+  if (!kbase || !vbase || !table || !sink || n_seq <= 0 || n_heads <= 0 || tiles <= 0 || n_splits <= 0) return HX_ERR_NULL;
+  if (n_heads % heads_per_wg) return HX_ERR_SHAPE;
+  const dim3 grid(n_heads / heads_per_wg, n_seq, n_splits);
+  hipStream_t s = (hipStream_t)stream;
+#define HX_P(HPW, NW, DP)                                                                                          \
+  if (heads_per_wg == HPW && waves == NW && depth == DP) {                                                         \
+    paged_read_kernel<HPW, NW, DP><<<grid, NW * 64, 0, s>>>((const char*)kbase, (const char*)vbase, table, tiles, n_splits, \
+                                                            page_bytes, row_bytes, sink);                          \
+    return check_launch();                                                                                         \
+  }
+  HX_P(1, 4, 2) HX_P(1, 4, 3) HX_P(1, 4, 4) HX_P(1, 8, 2)
+  HX_P(2, 4, 2) HX_P(2, 4, 3) HX_P(4, 4, 2) HX_P(4, 4, 3) HX_P(4, 8, 2) HX_P(2, 8, 2)
+#undef HX_P
+  return HX_ERR_SHAPE;
+}
 
 extern "C" int hx_debug_stream_read(const void* p, int64_t bytes, int variant, int64_t pitch, int unroll,
                                     int policy, int wgs, float* sink, hx_stream stream) {

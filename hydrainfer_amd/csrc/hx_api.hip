@@ -17,6 +17,9 @@ int gemm_set_option(const char* name, int value);
 int fwd_set_option(const char* name, int value);
 int chain_set_option(const char* name, int value);
 int xreg_set_option(const char* name, int value);
+int decode4_set_option(const char* name, int value);
+bool decode4_applies(const AttnParams& p, int batch, int head_dim, int n_cus);
+int launch_attn_decode4(const AttnParams& p, int batch, int dtype, hipStream_t stream);
 bool fwd_supported(int head_dim);
 int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested);
 bool decode_gqa_supported(int head_dim, int group);
@@ -47,6 +50,7 @@ extern "C" int hx_debug_set_option(const char* name, int value) {
   if (rc == HX_ERR_UNSUPPORTED) rc = fwd_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = chain_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = xreg_set_option(name, value);
+  if (rc == HX_ERR_UNSUPPORTED) rc = decode4_set_option(name, value);
   return rc;
 }
 
@@ -69,6 +73,16 @@ namespace {
 
 // decode kernel applies when every sequence contributes exactly one query row and the
 // cache is paged.
+static int device_cus() {
+  static int n = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return n;
+}
+
 bool use_decode(const hx_attn_args* a) {
   return a->block_table != nullptr && a->max_seqlen_q == 1 && a->total_q == a->batch &&
          decode_supported(a->head_dim);
@@ -245,6 +259,8 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
     }
     p.n_splits = splits;
     if (gqa) return launch_attn_decode_gqa(p, a->batch, a->head_dim, a->dtype, s);
+    // four heads per workgroup (1 KiB contiguous per key row) when the grid still fills the chip
+    if (decode4_applies(p, a->batch, a->head_dim, device_cus())) return launch_attn_decode4(p, a->batch, a->dtype, s);
     return launch_attn_decode(p, a->batch, a->head_dim, a->dtype, s);
   }
   return launch_attn_fwd(p, a->batch, a->head_dim, a->max_seqlen_q, a->block_table != nullptr,

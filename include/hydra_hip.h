@@ -391,6 +391,11 @@ int hx_decode_chain(const hx_chain_args* args, hx_stream stream);
  * non-temporal loads.  Reads `bytes` bytes once. */
 int hx_debug_stream_read(const void* p, int64_t bytes, int variant, int64_t pitch, int unroll,
                          int policy, int wgs, float* sink, hx_stream stream);
+/* measurement aid: the decode attention kernel's read pattern (paged, one head's 256 B of every key row) with
+ * no arithmetic — the ceiling that kernel can reach (tools/bench_attn_ceiling.py) */
+int hx_debug_paged_read(const void* kbase, const void* vbase, const int32_t* table, int n_seq, int n_heads,
+                        int tiles, int64_t page_bytes, int row_bytes, int heads_per_wg, int waves, int depth,
+                        int n_splits, float* sink, hx_stream stream);
 
 /* ------------------------------------------------------------------------
  * Cache-block migration between GPUs / processes.

@@ -507,3 +507,33 @@ def test_softcap_with_causal_mask():
                    None, 90, 90, 1 / math.sqrt(D), 20.0, -1, 0, 0)
     ref = ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b, causal=True, softcap=20.0)
     assert_close_t(out.cpu(), ref, 1e-3, 1e-3, what="causal + softcap")
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_decode_four_heads_per_workgroup_experiment(dt):
+    """attn_decode4.hip (experiment, off by default: four heads per workgroup, 1 KiB contiguous per key row, scores
+    on the VALU with DPP row sums): same results as the per-head kernel within the attention tolerance and as the
+    oracle, ragged lengths included."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    from oracle import ops
+    H, D = 32, 128
+    kv_lens = [720, 1, 17, 33, 1040] + [64 + 7 * i for i in range(27)]
+    B = len(kv_lens)
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(B, H, H, D, kv_lens, [1] * B, dt, seed=9)
+    outs = []
+    lib = _lib.lib()
+    try:
+        for v in (0, 1):
+            assert lib.hx_debug_set_option(b"decode_hpw4", v) == 0
+            o = torch.empty_like(q, device=DEV)
+            mha_varlen_fwd(o, q.to(DEV), kc.to(DEV), vc.to(DEV), cu_q.to(DEV), cu_k.to(DEV), bt.to(DEV), cu_b.to(DEV), None,
+                           1, max(kv_lens), 1 / math.sqrt(D), 0.0, -1, 0, 1)
+            outs.append(o.cpu())
+    finally:
+        lib.hx_debug_set_option(b"decode_hpw4", 0)
+    atol, rtol = ATTN_TOL[dt]
+    assert not torch.equal(outs[0], outs[1]) or True      # different summation order: usually not bit-equal
+    assert_close_t(outs[1], outs[0], atol, rtol, what="four-heads kernel vs per-head kernel")
+    ref = ops.paged_attention(q[:3], kc, vc, cu_q[:4], cu_k[:4], bt, cu_b[:4], causal=True)
+    assert_close_t(outs[1][:3], ref, atol, rtol, what="four-heads kernel vs oracle")
