@@ -167,9 +167,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
 // 1 KiB block (row group rg, k-step s) holds, at lane (r = l & 15, g = l >> 4), the 16 bytes
 // W[16 rg + r][32 s + 8 g .. + 8] — exactly one A operand.  A wave reads its (row group, split) as
 // ONE contiguous 32 KiB run, 1 KiB per instruction, straight into the MFMA operand registers: no
-// transpose through LDS, and the access shape that streams fastest on this GPU
-// (tools/bench_stream.py: contiguous 1 KiB per wave instruction 6.6-6.8 TB/s non-temporal at any
-// occupancy, 8 rows x 128 B 4.6-6.2 TB/s depending on the waves per CU).  Same k order, same
+// transpose through LDS (tools/bench_stream.py, corrected: every load shape streams at 6.5-7.0 TB/s when
+// neighbouring waves cover neighbouring bytes; what the packed form saves is the per-wave LDS transpose).  Same k order, same
 // accumulation chains: bit-identical to gemm_skinny_kernel.
 template <typename T, int MB, int R, int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p, const int g_nt_store) {
