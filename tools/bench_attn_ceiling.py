@@ -62,6 +62,14 @@ def attn():
 
 t_a = graph_time(attn, 12)
 print(f"ctx {ctx}: {nbytes / 1e6:.0f} MB per launch; attn_decode_kernel (plain, no fused prologue) {t_a:.1f} us = {nbytes / t_a / 1e6:.2f} TB/s")
+for opt in [o for o in os.environ.get("OPTS", "").split(",") if o]:
+    k, v = opt.split("=")
+    assert l.hx_debug_set_option(k.encode(), int(v)) == 0, opt
+    t_o = graph_time(attn, 12)
+    print(f"  with {opt}: {t_o:.1f} us = {nbytes / t_o / 1e6:.2f} TB/s")
+    l.hx_debug_set_option(k.encode(), 0)
+if os.environ.get("KERNEL_ONLY"):
+    sys.exit(0)
 print("pattern-only reads (heads per workgroup, waves, tiles in flight per wave, KV splits, page order):")
 for hpw, waves, depth, splits in ((1, 4, 2, 1), (1, 4, 3, 1), (1, 4, 4, 1), (1, 8, 2, 1), (2, 4, 2, 1), (2, 4, 2, 2), (2, 4, 3, 2),
                                   (2, 8, 2, 2), (4, 4, 2, 1), (4, 4, 2, 4), (4, 4, 3, 4), (4, 8, 2, 4)):
