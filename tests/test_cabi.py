@@ -88,3 +88,20 @@ def test_op_modules_match_the_reference_stubs():
                    if p.default is inspect.Parameter.empty and p.kind == p.POSITIONAL_OR_KEYWORD]
             assert len(got) == len(params), f"{module}.{name}: {got} vs reference {params}"
     assert not missing, missing
+
+
+def test_xreg_split_plan_is_stable():
+    """The packed layout of hx_pack_decode_weight_xreg depends on the split plan for (N, K): weights packed by one
+    build must be readable by the next.  Pins the plan for the LLaVA-1.5 7B / 13B projections and two small shapes
+    (256 CUs assumed when no device is present; an MI355X has 256)."""
+    l = _lib.lib()
+    want = {(12288, 4096): 1, (22016, 4096): 1, (4096, 11008): 4, (4096, 4096): 1,
+            (15360, 5120): 1, (27648, 5120): 1, (5120, 13824): 4, (48, 64): 1, (64, 2816): 1}
+    for (n, k), s in want.items():
+        assert l.hx_linear_decode_xreg_splits(n, k) == s, (n, k)
+        assert l.hx_linear_decode_xreg_supported(32, n, k) == 1
+        assert l.hx_linear_decode_xreg_workspace_bytes(32, n, k) == s * 32 * n * 4
+    assert l.hx_linear_decode_xreg_supported(33, 4096, 4096) == 0      # more than 32 rows: the LDS-slice kernel
+    assert l.hx_gate_up_silu_xreg_supported(32, 11008, 4096) == 1 and l.hx_gate_up_silu_xreg_supported(32, 13824, 5120) == 1
+    assert l.hx_norm_xreg_supported(32, 12288, 4096, 0) == 1 and l.hx_norm_xreg_supported(32, 4096, 11008, 0) == 0
+    assert l.hx_fragment_major_elems(5, 4096) == 16 * 4096 and l.hx_fragment_major_elems(32, 64) == 32 * 64
