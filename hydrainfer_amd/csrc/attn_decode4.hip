@@ -10,26 +10,31 @@
 //   workgroup — a wave instruction = ONE key row x 1 KiB contiguous (4 heads x 256 B) — the same bytes
 //   stream at 6.3-6.4 TB/s.
 //
-//   * grid = (n_heads / 4, sequence); 4 waves; wave w owns the 16-key tiles w, w + 4, ...
+//   * grid = (n_heads / 4, sequence); 8 waves; wave w owns the 8-key tiles w, w + 8, ...
 //   * lane = (hq = lane >> 4: head 4*blockIdx.x + hq,  c = lane & 15: dims 8c .. 8c+7 of that head).
-//     A tile is 16 K loads + 16 V loads of 16 B per lane (row r of the tile, this lane's 8 dims of its
+//     A tile is 8 K loads + 8 V loads of 16 B per lane (row r of the tile, this lane's 8 dims of its
 //     head): every byte is used by exactly the lane that loaded it — no LDS, no MFMA, no transpose.
 //   * scores: per row an 8-dim partial dot product per lane (packed 2-element dot instructions) and a
 //     4-step DPP butterfly over the 16 lanes of the head; online softmax per head (exp2 domain); P.V is
 //     fp32 FMA on the V rows the lane already holds.  P stays fp32 (as in attn_decode.hip).
-//   * two tiles (64 KiB per wave) in flight: register double buffer, one wave per SIMD.
+//   * two tiles (32 KiB per wave) in flight: register double buffer, two waves per SIMD.
 //   * FUSE: q and the new token's k / v arrive un-rotated (tensors or the fp32 slabs of the qkv GEMM);
 //     RoPE is an exchange with lane c ^ 8 (dims d and d + 64 of one head sit 8 lanes apart), same T
 //     rounding as apply_rotary_pos_emb; the new key / value replace the not-yet-written cache row in
 //     their tile and are appended to the cache by wave 0.
 //   * the four waves' states merge through LDS in wave order.
-// STATUS: correct (tests/test_gpu_attention.py::test_decode_four_heads_per_workgroup_experiment) but NOT faster and
-// therefore off: 64.8 us against 63.7 us for attn_decode.hip at batch 32 x 32 heads x 720 keys.  The read
-// pattern alone would give 59.5 us, but with one wave per SIMD (two 32 KiB tiles = 256 registers) the ~650
-// VALU instructions per tile (conversions, 8-dim dot products, DPP sums, P.V) sit on the critical path —
-// PMC: VALU active 29 % of the wave cycles, waiting 36 % — while the per-head kernel computes QK^T on the MFMA
-// and hides the rest behind four waves per SIMD.  Kept as the measured alternative; eligible launches: no KV
-// split, no fused prologue, grid >= 80 % of the CUs.
+// STATUS: correct (tests/test_gpu_attention.py::test_decode_four_heads_per_workgroup_experiment, plain and fused
+// forms) and OFF (hx_debug_set_option("decode_hpw4", 1) routes eligible launches here).  History of the
+// experiment, batch 32 x 32 heads x 720 keys, against 64.8-65.8 us for attn_decode.hip:
+//   v1  4 waves x 16-key tiles (two 32 KiB tiles = 256 registers, one wave per SIMD): 64.8-66.6 us — the read
+//       pattern alone would give 59.5 us, but the per-tile arithmetic sits on the critical path of the only
+//       wave of a SIMD (PMC: VALU active 29 %, waiting 36 % of the wave cycles); halving the instruction count
+//       changed nothing;
+//   v2  8 waves x 8-key tiles (two waves per SIMD, 170-194 registers), packed fp32 FMAs: 62.8-63.0 us standalone
+//       (-4 %), but +-0 inside the decode step (4.876 vs 4.868 ms): the launch is one 512-thread workgroup per
+//       CU and opens later than 1024 small workgroups do.
+// Both packed dot builtins (v_dot2_f32_f16, v_dot2c_f32_bf16) returned wrong sums in this kernel; plain FMAs.
+// Eligible launches: multi-head, head_dim 128, no KV split, grid >= 80 % of the CUs.
 #include <cstring>
 #include "attn_common.h"
 
@@ -59,8 +64,8 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// 8-element partial dot product in fp32 (the packed v_dot2_f32_f16 builtin returned wrong sums here; plain
-// mixed-precision FMAs cost the same issue slots as the bf16 shift + FMA pairs)
+// 8-element partial dot product in fp32: plain FMAs (both packed dot builtins, v_dot2_f32_f16 and
+// v_dot2c_f32_bf16, returned wrong sums in this kernel — not pursued).
 template <typename T>
 struct Dot2 {
   static __device__ __forceinline__ float dot8(u16x8 a, u16x8 b) {
@@ -70,9 +75,10 @@ struct Dot2 {
     return s;
   }
 };
-
+constexpr int TR = 8;    // key rows per tile (v2: 8-key tiles, 16 KiB per wave and tile: two waves per SIMD fit)
+constexpr int NW4 = 8;   // waves per workgroup
 struct Tile4 {
-  u16x8 k[16], v[16];
+  u16x8 k[TR], v[TR];
 };
 
 template <bool NT>
@@ -87,9 +93,9 @@ __device__ __forceinline__ void load_tile4(Tile4& t, const AttnParams& p, const 
   const u16* kp = kb + (int64_t)page * p.k_block_stride + (int64_t)row0 * p.k_row_stride;
   const u16* vp = vb + (int64_t)page * p.v_block_stride + (int64_t)row0 * p.v_row_stride;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t.k[r] = ld16<true>(kp + (int64_t)min(r, valid - 1) * p.k_row_stride);
+  for (int r = 0; r < TR; ++r) t.k[r] = ld16<true>(kp + (int64_t)min(r, valid - 1) * p.k_row_stride);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t.v[r] = ld16<true>(vp + (int64_t)min(r, valid - 1) * p.v_row_stride);
+  for (int r = 0; r < TR; ++r) t.v[r] = ld16<true>(vp + (int64_t)min(r, valid - 1) * p.v_row_stride);
 }
 
 // identical rounding to norm_rope_act.hip::rotate_pair / attn_decode.hip::rope_pair
@@ -127,43 +133,51 @@ __device__ __forceinline__ u16x8 rope8(u16x8 own, const u16* cs, int c) {
 template <typename T>
 __device__ __forceinline__ void compute_tile4(const Tile4& t, u16x8 q, int valid, float scale_log2, float& m, float& l,
                                               float (&o)[8]) {
-  float s[16];
+  float s[TR];
   float mx = m;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int r = 0; r < TR; ++r) {
     const float d = row16_sum(Dot2<T>::dot8(t.k[r], q));
     s[r] = r < valid ? d * scale_log2 : -INFINITY;
     mx = fmaxf(mx, s[r]);
   }
   const float alpha = fast_exp2(m - mx);
   float ps = 0.f;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 o2[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] *= alpha;
+  for (int e = 0; e < 4; ++e) o2[e] = f32x2{o[2 * e] * alpha, o[2 * e + 1] * alpha};
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int r = 0; r < TR; ++r) {
     const float pr = fast_exp2(s[r] - mx);
     ps += pr;
+    const f32x2 p2 = {pr, pr};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, T::to_float(t.v[r][e]), o[e]);
+    for (int e = 0; e < 4; ++e)   // <2 x float> FMAs: v_pk_fma_f32
+      o2[e] = __builtin_elementwise_fma(p2, f32x2{T::to_float(t.v[r][2 * e]), T::to_float(t.v[r][2 * e + 1])}, o2[e]);
   }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[2 * e] = o2[e][0]; o[2 * e + 1] = o2[e][1]; }
   m = mx;
   l = l * alpha + ps;
 }
 
 template <typename T, bool FUSE>
-__global__ __launch_bounds__(256) void attn_decode4_kernel(const AttnParams p) {
-  __shared__ float s_m[4][4], s_l[4][4];
-  __shared__ float s_o[4][4][D4];
+__global__ __launch_bounds__(NW4 * 64) void attn_decode4_kernel(const AttnParams p) {
+  __shared__ float s_m[NW4][4], s_l[NW4][4];
+  __shared__ float s_o[NW4][4][D4];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hq = lane >> 4, c = lane & 15;
   const int h = 4 * blockIdx.x + hq;              // query head == kv head (group 1)
 
-  const int kv_len = p.cu_k[b + 1] - p.cu_k[b];
+  // FUSE: the new token is the LAST key; it is not read from the cache (its row may not be visible yet) but
+  // enters the softmax from registers after the loop, so the loop covers the kv_len - 1 cached keys
+  const int kv_len = (p.cu_k[b + 1] - p.cu_k[b]) - (FUSE ? 1 : 0);
   const int q_row = p.cu_q[b];
-  const int n_tiles = (kv_len + 15) >> 4;
-  const int tpp = p.block_size >> 4;
+  const int n_tiles = (kv_len + TR - 1) / TR;
+  const int tpp = p.block_size / TR;
   const int32_t* bt = p.block_table + p.cu_block_lens[b];
   // this lane's 16 bytes of a key / value row: head h, dims 8c..
   const u16* kb = reinterpret_cast<const u16*>(p.k) + (int64_t)h * p.k_head_stride + 8 * c;
@@ -174,47 +188,45 @@ __global__ __launch_bounds__(256) void attn_decode4_kernel(const AttnParams p) {
   int my_page = 0, n_my = 0;
   int chunk0 = w;
   auto begin_chunk = [&]() {
-    const int tj = chunk0 + 4 * lane;
+    const int tj = chunk0 + NW4 * lane;
     my_page = (tj < n_tiles) ? bt[tj / tpp] : 0;
-    n_my = min(64, (n_tiles - chunk0 + 3) / 4);   // wave-uniform
-    load_tile4(bufA, p, kb, vb, __builtin_amdgcn_readlane(my_page, 0), (chunk0 % tpp) << 4, kv_len - (chunk0 << 4));
+    n_my = min(64, (n_tiles - chunk0 + NW4 - 1) / NW4);   // wave-uniform
+    load_tile4(bufA, p, kb, vb, __builtin_amdgcn_readlane(my_page, 0), (chunk0 % tpp) * TR, kv_len - chunk0 * TR);
   };
   if (chunk0 < n_tiles) begin_chunk();
 
   // q (and, FUSE, the new token's k / v): this lane's 8 dims of its head
   u16x8 q, kn, vn;
-  const int t_new = (kv_len - 1) >> 4, r_new = (kv_len - 1) & 15;
   if (FUSE) {
-    if (p.qkv_partial) {
-      // straight from the qkv GEMM's fp32 split-K slabs: splits added in order, rounded once to T
-      const float* row = p.qkv_partial + (int64_t)b * p.qkv_row;
-      const int64_t col[3] = {(int64_t)h * D4 + 8 * c, (int64_t)p.n_heads * D4 + (int64_t)h * D4 + 8 * c,
-                              (int64_t)2 * p.n_heads * D4 + (int64_t)h * D4 + 8 * c};
-      u16x8 out3[3];
-#pragma unroll
-      for (int which = 0; which < 3; ++which) {
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(row + col[which]);
-        f32x4 a1 = *reinterpret_cast<const f32x4*>(row + col[which] + 4);
-        for (int s = 1; s < p.qkv_splits; ++s) {
-          a0 += *reinterpret_cast<const f32x4*>(row + col[which] + s * p.qkv_slab_stride);
-          a1 += *reinterpret_cast<const f32x4*>(row + col[which] + 4 + s * p.qkv_slab_stride);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          out3[which][e] = T::from_float(a0[e]);
-          out3[which][4 + e] = T::from_float(a1[e]);
-        }
+    // every wave needs q; only wave 0 needs the new token's k / v (it appends them and adds their term)
+    kn = vn = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    auto slab8 = [&](int64_t col) {   // 8 columns of this sequence's qkv row: splits added in order, rounded once to T
+      const float* src = p.qkv_partial + (int64_t)b * p.qkv_row + col;
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+      for (int s = 1; s < p.qkv_splits; ++s) {
+        a0 += *reinterpret_cast<const f32x4*>(src + s * p.qkv_slab_stride);
+        a1 += *reinterpret_cast<const f32x4*>(src + 4 + s * p.qkv_slab_stride);
       }
-      q = out3[0]; kn = out3[1]; vn = out3[2];
+      u16x8 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { r[e] = T::from_float(a0[e]); r[4 + e] = T::from_float(a1[e]); }
+      return r;
+    };
+    const int64_t hc = (int64_t)h * D4 + 8 * c;
+    if (p.qkv_partial) {
+      q = slab8(hc);
+      if (w == 0) { kn = slab8((int64_t)p.n_heads * D4 + hc); vn = slab8((int64_t)2 * p.n_heads * D4 + hc); }
     } else {
-      q = *reinterpret_cast<const u16x8*>(reinterpret_cast<const u16*>(p.q) + (int64_t)q_row * p.q_row_stride + (int64_t)h * D4 + 8 * c);
-      kn = *reinterpret_cast<const u16x8*>(reinterpret_cast<const u16*>(p.k_new) + (int64_t)b * p.kn_row_stride + (int64_t)h * D4 + 8 * c);
-      vn = *reinterpret_cast<const u16x8*>(reinterpret_cast<const u16*>(p.v_new) + (int64_t)b * p.vn_row_stride + (int64_t)h * D4 + 8 * c);
+      q = *reinterpret_cast<const u16x8*>(reinterpret_cast<const u16*>(p.q) + (int64_t)q_row * p.q_row_stride + hc);
+      if (w == 0) {
+        kn = *reinterpret_cast<const u16x8*>(reinterpret_cast<const u16*>(p.k_new) + (int64_t)b * p.kn_row_stride + hc);
+        vn = *reinterpret_cast<const u16x8*>(reinterpret_cast<const u16*>(p.v_new) + (int64_t)b * p.vn_row_stride + hc);
+      }
     }
     const u16* cs = reinterpret_cast<const u16*>(p.cos_sin) + (int64_t)p.positions[b] * D4;
     q = rope8<T>(q, cs, c);
-    kn = rope8<T>(kn, cs, c);
-    if (w == 0) {   // one writer per head: wave 0 appends the new token to the cache
+    if (w == 0) {   // one writer per head: wave 0 rotates the new key and appends the new token to the cache
+      kn = rope8<T>(kn, cs, c);
       const int slot = p.new_slots[b];
       const int64_t blk = slot / p.block_size, off = slot % p.block_size;
       *reinterpret_cast<u16x8*>(const_cast<u16*>(kb) + blk * p.k_block_stride + off * p.k_row_stride) = kn;
@@ -223,43 +235,41 @@ __global__ __launch_bounds__(256) void attn_decode4_kernel(const AttnParams p) {
   } else {
     q = *reinterpret_cast<const u16x8*>(reinterpret_cast<const u16*>(p.q) + (int64_t)q_row * p.q_row_stride + (int64_t)h * D4 + 8 * c);
   }
-  // the tile holding the new position takes k / v from registers (the cache row may not be visible yet)
-  auto patch = [&](Tile4& t, int tile) {
-    if (FUSE && tile == t_new) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (r == r_new) { t.k[r] = kn; t.v[r] = vn; }
-    }
-  };
-
   float m = HX_NEG_BIG, l = 0.f;
   float o[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
 
-  for (bool first = true; chunk0 < n_tiles; chunk0 += 4 * 64, first = false) {
+  for (bool first = true; chunk0 < n_tiles; chunk0 += NW4 * 64, first = false) {
     if (!first) begin_chunk();
     int j = 0;
     while (j < n_my) {
       if (j + 1 < n_my) {
-        const int t = chunk0 + 4 * (j + 1);
-        load_tile4(bufB, p, kb, vb, __builtin_amdgcn_readlane(my_page, j + 1), (t % tpp) << 4, kv_len - (t << 4));
+        const int t = chunk0 + NW4 * (j + 1);
+        load_tile4(bufB, p, kb, vb, __builtin_amdgcn_readlane(my_page, j + 1), (t % tpp) * TR, kv_len - t * TR);
       }
-      patch(bufA, chunk0 + 4 * j);
-      compute_tile4<T>(bufA, q, kv_len - ((chunk0 + 4 * j) << 4), p.scale_log2, m, l, o);
+      compute_tile4<T>(bufA, q, kv_len - (chunk0 + NW4 * j) * TR, p.scale_log2, m, l, o);
       ++j;
       if (j >= n_my) break;
       if (j + 1 < n_my) {
-        const int t = chunk0 + 4 * (j + 1);
-        load_tile4(bufA, p, kb, vb, __builtin_amdgcn_readlane(my_page, j + 1), (t % tpp) << 4, kv_len - (t << 4));
+        const int t = chunk0 + NW4 * (j + 1);
+        load_tile4(bufA, p, kb, vb, __builtin_amdgcn_readlane(my_page, j + 1), (t % tpp) * TR, kv_len - t * TR);
       }
-      patch(bufB, chunk0 + 4 * j);
-      compute_tile4<T>(bufB, q, kv_len - ((chunk0 + 4 * j) << 4), p.scale_log2, m, l, o);
+      compute_tile4<T>(bufB, q, kv_len - (chunk0 + NW4 * j) * TR, p.scale_log2, m, l, o);
       ++j;
     }
   }
 
-  // merge the four waves' states per head (wave order), normalise, store
+  if (FUSE && w == 0) {   // the new token's key / value, from registers
+    const float sn = row16_sum(Dot2<T>::dot8(kn, q)) * p.scale_log2;
+    const float mx = fmaxf(m, sn);
+    const float alpha = fast_exp2(m - mx), pr = fast_exp2(sn - mx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, T::to_float(vn[e]), o[e] * alpha);
+    l = l * alpha + pr;
+    m = mx;
+  }
+  // merge the waves' states per head (wave order), normalise, store
   if (c == 0) { s_m[w][hq] = m; s_l[w][hq] = l; }
 #pragma unroll
   for (int e = 0; e < 8; ++e) s_o[w][hq][8 * c + e] = o[e];
@@ -267,13 +277,13 @@ __global__ __launch_bounds__(256) void attn_decode4_kernel(const AttnParams p) {
   if (w == 0) {
     float M = HX_NEG_BIG;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) M = fmaxf(M, s_m[k][hq]);
+    for (int k = 0; k < NW4; ++k) M = fmaxf(M, s_m[k][hq]);
     float L = 0.f;
     float O[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) O[e] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NW4; ++k) {
       const float wgt = fast_exp2(s_m[k][hq] - M);
       L = fmaf(s_l[k][hq], wgt, L);
 #pragma unroll
@@ -300,19 +310,23 @@ int decode4_set_option(const char* name, int value) {
 // multi-head (group 1), head_dim 128, one KV split, rows of 4 heads contiguous, and a grid that gives every
 // CU a workgroup (below that the per-head kernel's 4x finer grid wins)
 bool decode4_applies(const AttnParams& p, int batch, int head_dim, int n_cus) {
-  return g_decode4 && !p.k_new && !p.qkv_partial && head_dim == 128 && p.group == 1 && p.n_splits == 1 && p.n_heads % 4 == 0 &&
+  return g_decode4 && head_dim == 128 && p.group == 1 && p.n_splits == 1 && p.n_heads % 4 == 0 &&
          p.k_head_stride == 128 && p.v_head_stride == 128 && p.k_row_stride % 8 == 0 && p.v_row_stride % 8 == 0 &&
          (int64_t)batch * (p.n_heads / 4) * 5 >= (int64_t)n_cus * 4;
 }
 
 int launch_attn_decode4(const AttnParams& p, int batch, int dtype, hipStream_t stream) {
   const dim3 grid(p.n_heads / 4, batch);
-  // the fused-prologue form (FUSE = true) is written but not instantiated: its register allocation spills
-  // (two 32 KiB tiles + the new token's k / v) and the experiment ended before that was worth fixing
-  if (p.k_new || p.qkv_partial) return HX_ERR_UNSUPPORTED;
-  if (dtype == HX_F16) attn_decode4_kernel<F16, false><<<grid, 256, 0, stream>>>(p);
-  else if (dtype == HX_BF16) attn_decode4_kernel<BF16, false><<<grid, 256, 0, stream>>>(p);
-  else return HX_ERR_DTYPE;
+  const bool fuse = p.k_new || p.qkv_partial;
+  if (dtype == HX_F16) {
+    if (fuse) attn_decode4_kernel<F16, true><<<grid, NW4 * 64, 0, stream>>>(p);
+    else attn_decode4_kernel<F16, false><<<grid, NW4 * 64, 0, stream>>>(p);
+  } else if (dtype == HX_BF16) {
+    if (fuse) attn_decode4_kernel<BF16, true><<<grid, NW4 * 64, 0, stream>>>(p);
+    else attn_decode4_kernel<BF16, false><<<grid, NW4 * 64, 0, stream>>>(p);
+  } else {
+    return HX_ERR_DTYPE;
+  }
   return check_launch();
 }
 

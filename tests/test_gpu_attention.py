@@ -537,3 +537,32 @@ def test_decode_four_heads_per_workgroup_experiment(dt):
     assert_close_t(outs[1], outs[0], atol, rtol, what="four-heads kernel vs per-head kernel")
     ref = ops.paged_attention(q[:3], kc, vc, cu_q[:4], cu_k[:4], bt, cu_b[:4], causal=True)
     assert_close_t(outs[1][:3], ref, atol, rtol, what="four-heads kernel vs oracle")
+    # the fused form (RoPE + cache append + attention, the new token from registers): against the three separate ops
+    # with the SAME kernel for the attention — cache bits equal, outputs within the tolerance (the new token's term is
+    # added after the cached keys instead of inside its tile)
+    from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused
+    from hydrainfer_amd._C.kernel.position_embedding import rope_set_kv_cache
+    g = torch.Generator().manual_seed(21)
+    k_new = torch.randn((B, H, D), generator=g).to(dt).to(DEV)
+    v_new = torch.randn((B, H, D), generator=g).to(dt).to(DEV)
+    pos = torch.tensor([l - 1 for l in kv_lens], dtype=torch.int32, device=DEV)
+    cs = ops.build_cos_sin_cache(D, 4096, 1e4, dt).to(DEV)
+    bs = 16
+    slots = torch.tensor([int(bt[int(cu_b[i]) + (l - 1) // bs]) * bs + (l - 1) % bs for i, l in enumerate(kv_lens)],
+                         dtype=torch.int32, device=DEV)
+    try:
+        assert lib.hx_debug_set_option(b"decode_hpw4", 1) == 0
+        dq, dk, dv = q.to(DEV), kc.to(DEV).clone(), vc.to(DEV).clone()
+        o_f = torch.empty_like(dq)
+        decode_attention_fused(o_f, dq, k_new, v_new, dk, dv, pos, cs, slots, cu_q.to(DEV), cu_k.to(DEV), bt.to(DEV),
+                               cu_b.to(DEV), max(kv_lens), 1 / math.sqrt(D), 1)
+        q2, k2, v2 = dq.clone(), kc.to(DEV).clone(), vc.to(DEV).clone()
+        kn2 = k_new.clone()
+        rope_set_kv_cache(q2, kn2, v_new, pos, cs, D, slots, k2, v2)
+        o_u = torch.empty_like(dq)
+        mha_varlen_fwd(o_u, q2, k2, v2, cu_q.to(DEV), cu_k.to(DEV), bt.to(DEV), cu_b.to(DEV), None, 1, max(kv_lens),
+                       1 / math.sqrt(D), 0.0, -1, 0, 1)
+    finally:
+        lib.hx_debug_set_option(b"decode_hpw4", 0)
+    assert torch.equal(dk, k2) and torch.equal(dv, v2)
+    assert_close_t(o_f.cpu(), o_u.cpu(), atol, rtol, what="four-heads kernel: fused vs separate ops")
