@@ -68,6 +68,24 @@ for opt in [o for o in os.environ.get("OPTS", "").split(",") if o]:
     t_o = graph_time(attn, 12)
     print(f"  with {opt}: {t_o:.1f} us = {nbytes / t_o / 1e6:.2f} TB/s")
     l.hx_debug_set_option(k.encode(), 0)
+if os.environ.get("FUSED"):
+    # the variant the decode graph runs: q / k / v from ONE fp32 slab of the qkv GEMM + RoPE + cache append + attention
+    from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused
+    from hydrainfer_amd.model.llama import LLAVA_1_5_7B, build_cos_sin
+    cs = build_cos_sin(LLAVA_1_5_7B, dt, dev)
+    slab = torch.randn((B, 3 * H * D), device=dev)
+    pos = torch.full((B,), ctx - 1, dtype=torch.int32, device=dev)
+    slots = (perm[cu_b[:-1].long() + (ctx - 1) // bs] * bs + (ctx - 1) % bs).to(torch.int32)
+
+    def fused():
+        for i in range(12):
+            decode_attention_fused(out, q, q, q, pool[i % L, 0], pool[i % L, 1], pos, cs, slots, cu_q, cu_k, perm, cu_b, ctx,
+                                   1 / math.sqrt(D), 1, slab, 1)
+    for v in (0, 1, 0, 1):
+        l.hx_debug_set_option(b"decode_hpw4", v)
+        t_f = graph_time(fused, 12)
+        print(f"  fused form, decode_hpw4={v}: {t_f:.1f} us = {nbytes / t_f / 1e6:.2f} TB/s")
+    l.hx_debug_set_option(b"decode_hpw4", 0)
 if os.environ.get("KERNEL_ONLY"):
     sys.exit(0)
 print("pattern-only reads (heads per workgroup, waves, tiles in flight per wave, KV splits, page order):")
