@@ -8,15 +8,22 @@ MI355X: embed -> 32 x [qkv GEMM, (RoPE + set_kv_cache + paged decode attention),
 -> lm_head -> argmax.  Every per-layer launch is libhydra_hip (decode GEMMs: the
 weight-streaming HIP kernel; --lib-gemm switches them to hipBLASLt); prefill GEMMs and lm_head
 are library GEMMs.  The KV
-context starts at the prompt (704 cached tokens) and grows by one per step exactly as in a
-real generation, so K steps cover contexts 705..704+K (K=255 = the whole 256-token
-generation).  Inputs (weights, KV cache, metadata) are resident in HBM before the timed region.
+context starts at the prompt (704 cached tokens) and ends at 959 as in a real 256-token
+generation: K=255 steps walk contexts 705..959 one by one; a shorter run (K < 255) takes K
+contexts evenly spaced over the same 705..959 (`timed_contexts`), so that `value` is the rate of
+the workload the metric names whatever --steps is.  Inputs (weights, KV cache, metadata) are
+resident in HBM before the timed region.
 
-python bench.py [--gpus N --steps K --warmup W]   (N>1: launched by torch.distributed.run)
+python bench.py [--gpus N --steps K --warmup W]
+N>1 without WORLD_SIZE in the environment: this process starts N ranks itself (fresh child
+processes through torch.distributed.run, before anything here touches a GPU) and exits with their
+code; under torch.distributed.run (WORLD_SIZE set) --gpus must equal WORLD_SIZE.
 Prints ONE JSON line on rank 0."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -49,7 +56,66 @@ def parse():
                    help="library GEMMs (hipBLASLt) for decode too, instead of the weight-streaming HIP kernel")
     p.add_argument("--no-fused-attention", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=2)
+    p.add_argument("--no-13b", action="store_true", help="skip the short LLaVA-1.5-13B leg (BASELINE configs[2])")
+    p.add_argument("--steps-13b", type=int, default=20)
+    p.add_argument("--dry-run", action="store_true",
+                   help="launch plumbing only (ranks, rendezvous, barrier, max-over-ranks timing of empty steps): "
+                        "no GPU is touched; the JSON line says dry_run")
     return p.parse_args()
+
+
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` must run N ranks (hydrainfer/cluster/cluster.py:63-79 starts one node
+    per GPU).  Without WORLD_SIZE this process is the launcher: N fresh children via
+    torch.distributed.run, started before this process makes any GPU call (a process that has
+    initialised the GPU must never exec another program; children are spawned, not exec'd), and the
+    launcher exits with their return code.  With WORLD_SIZE set the two must agree."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a line for a "
+                  f"different rank count", file=sys.stderr, flush=True)
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    with socket.socket() as so:      # a free rendezvous port on the loopback
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def timed_contexts(prompt_len, n_generate, steps):
+    """KV lengths of the timed steps.  The generation's decode steps see contexts prompt_len+1 ..
+    prompt_len+n_generate-1 (705..959); fewer steps than that are spread evenly over the same range
+    (both ends included) so that their mean is the generation's mean context."""
+    lo, hi = prompt_len + 1, prompt_len + n_generate - 1
+    if steps >= hi - lo + 1:
+        return list(range(lo, hi + 1))
+    if steps == 1:
+        return [(lo + hi) // 2]
+    return [lo + (k * (hi - lo)) // (steps - 1) for k in range(steps)]
+
+
+def dry_run(args):
+    """Everything of the N-rank contract except the GPU work: rendezvous (gloo), barrier, K empty
+    steps, MAX over ranks, one JSON line on rank 0."""
+    from hydrainfer_amd import parallel
+    ctx = parallel.init_from_env(backend="gloo")
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    ctx.barrier()
+    if ctx.rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "dry_run": True, "value": 0.0, "unit": "tokens/s",
+                          "n_gpus": ctx.world_size, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+                          "roles": parallel.epd_roles(ctx.world_size)}), flush=True)
+    ctx.shutdown()
 
 
 def model_shape(name):
@@ -93,10 +159,11 @@ def copy_ceiling_gbs(dev, nbytes=1 << 30, reps=5):
     return 2 * nbytes / (best * 1e-3) / 1e9
 
 
-def time_attention_kernel(runner, start_len, steps):
+def time_attention_kernel(runner, ctxs):
     """Average duration of the decode-attention launch (the variant the decode graph runs:
-    fused RoPE + cache append + attention) over the same context sequence as the timed region,
-    HIP events on the launch stream (torch's current stream)."""
+    fused RoPE + cache append + attention) over the same context sequence `ctxs` (KV lengths) as
+    the timed region, HIP events on the launch stream (torch's current stream).  MEAN over
+    launches and replays, not the best one."""
     import math
     from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
     sh = runner.model.shape
@@ -132,10 +199,7 @@ def time_attention_kernel(runner, start_len, steps):
             mha_varlen_fwd(out, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
                            ap.cu_blocks_lens, None, 1, runner.max_len, scale, 0.0, -1, 0, 0)
 
-    def rewind():
-        runner.positions.fill_(start_len - 1)
-        runner.kv_lens.fill_(start_len)
-
+    steps = len(ctxs)
     if runner.cfg.use_graph:
         # Issued from Python one by one, a launch that is shorter than the host's ~40 us per call
         # would be timed with the host's gaps in it.  So the launches of the whole context sequence
@@ -145,8 +209,7 @@ def time_attention_kernel(runner, start_len, steps):
         bs = runner.cfg.block_size
         i32 = dict(dtype=torch.int32, device=runner.dev)
         metas = []
-        for s_ in range(steps):
-            ctx_len = start_len + 1 + s_
+        for ctx_len in ctxs:
             pos = ctx_len - 1
             metas.append((torch.full((B,), pos, **i32),
                           torch.tensor([runner.tables[b][pos // bs] * bs + pos % bs for b in range(B)], **i32),
@@ -166,17 +229,19 @@ def time_attention_kernel(runner, start_len, steps):
         with torch.cuda.graph(graph):
             for i, m in enumerate(metas):
                 launch_step(m, i)
-        best = float("inf")
-        for _ in range(3):
+        graph.replay(); torch.cuda.synchronize()             # one untimed replay
+        total, reps = 0.0, 3
+        for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             graph.replay()
             e1.record()
             e1.synchronize()
-            best = min(best, e0.elapsed_time(e1))
-        ms = best / steps
+            total += e0.elapsed_time(e1)
+        ms = total / reps / steps
     else:
         for s in range(steps + 2):
+            runner.set_state(ctxs[max(s - 2, 0)] - 1)
             runner._advance()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -232,7 +297,8 @@ def measure_serving(model, vision, pixels, shape, dtype, dev, batch, n_text, max
     node.executor.image_embed_executor.warmup(pixels, sched.image_budgets)
     warm_library_gemms(lm, sched.token_budgets, batch, vision, pixels, sched.image_budgets)
     cluster = LocalCluster([node])
-    creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16)
+    creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16,
+                                 max_position_embeddings=shape.max_position_embeddings)
     text_hi = min(31999, itid - 1)
     replay(cluster, creator, synthetic_requests(2, n_text, 4, itid, pixels, (min(1000, text_hi - 1), text_hi), 99),
            [0.0, 0.0], dev)
@@ -264,7 +330,8 @@ def build_rank_engine(ctx, model, vision, shape, dtype, dev, batch, n_text, max_
                                  token_budgets=2048, image_budgets=8)
     lm = LlavaLanguageModel(model, image_token_id=image_token_id(shape.vocab_size))
     node = build_node(f"{role}{ctx.rank}", role, lm, vision, shape, dtype, dev, per_req * live, 2 * batch + 2, 576,
-                      sched, rank=ctx.rank, max_blocks_per_seq=per_req, world_size=ctx.world_size)
+                      sched, rank=ctx.rank, max_blocks_per_seq=per_req, world_size=ctx.world_size,
+                      release_prefill_weights=False)   # the replica leg of the same process prefills on every rank
     group = None if ctx.backend == "gloo" else dist.new_group(backend="gloo")
     return RankEngine(ctx.rank, roles, node, group)
 
@@ -291,7 +358,8 @@ def measure_disaggregated(ctx, engine, shape, dev, pixels, batch, n_text, max_to
     ie = engine.node.executor.image_embed_executor
     if ie is not None:      # the vision tower's graphs for 1 .. image budget images
         ie.warmup(pixels, engine.node.batch_scheduler.image_budgets)
-    creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16)
+    creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16,
+                                 max_position_embeddings=shape.max_position_embeddings)
     hi = min(31999, itid - 1)
     vocab_text = (min(1000, hi - 1), hi)
 
@@ -488,13 +556,14 @@ def time_decode_gemms(runner, reps=3):
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
             body()
-        best = float("inf")
+        gr.replay(); torch.cuda.synchronize()
+        total = 0.0
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); gr.replay(); e1.record(); e1.synchronize()
-            best = min(best, e0.elapsed_time(e1))
+            total += e0.elapsed_time(e1)
         w = m.state[f"l0.{key}"]
-        res[name] = {"us": round(best / L * 1e3, 2), "weight_bytes": w.numel() * w.element_size()}
+        res[name] = {"us": round(total / reps / L * 1e3, 2), "weight_bytes": w.numel() * w.element_size()}
     res["_kernels"] = ("gemm_xreg_kernel (activations in registers; gate|up with the silu*mul epilogue, down, qkv of "
                        "layers >= 1" + ("; the gate|up and qkv launches INCLUDE the add+RMSNorm that produces their "
                                         "input (4 slabs in)" if nf else "") +
@@ -664,8 +733,115 @@ def cpu_baseline(shape, dtype, batch, ctx, n_layers):
                       f"{t_full + t_head:.1f}s of CPU work per repetition"}
 
 
+def decode_leg(ctx, model, runner, ctxs, warmup, prompt_len):
+    """Warm-up, then the timed region of the contract: barrier + synchronize on both sides, exactly
+    len(ctxs) decode steps, MAX over ranks.  Contiguous contexts are walked by the step's own advance;
+    a strided schedule repositions the (device-resident) decode state before each step with two tiny
+    fills — they are inside the timed region and count against the result."""
+    state = (runner.positions.clone(), runner.kv_lens.clone(), runner.input_ids.clone())
+
+    def reset():
+        runner.positions.copy_(state[0]); runner.kv_lens.copy_(state[1]); runner.input_ids.copy_(state[2])
+        runner.tokens = []
+    if runner.cfg.use_graph:
+        runner.capture()
+    for _ in range(warmup):
+        runner.step(record=False)
+    reset()
+    contiguous = ctxs == list(range(prompt_len + 1, prompt_len + 1 + len(ctxs)))
+    ctx.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in ctxs:
+        if not contiguous:
+            runner.set_state(c - 1)        # the step's advance makes it c
+        runner.step(record=False)
+    torch.cuda.synchronize()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0, runner.dev)
+    ctx.barrier(); torch.cuda.synchronize()
+    # a norm-fused launch that gave up waiting for its producers leaves an error word: not a measurement
+    if model.handover_failed():
+        print("bench.py: a norm-fused launch gave up waiting for its producer workgroups", file=sys.stderr, flush=True)
+        sys.exit(4)
+    return elapsed
+
+
+def roofline_objects(model, runner, ctxs, ms_per_step, args, model_name, with_gemm=True):
+    """`roofline` (decode attention kernel), `roofline_gemm`, `whole_step` for one timed leg."""
+    B = runner.cfg.batch
+    ctxs_per_step = [[c] * B for c in ctxs]
+    attn_bytes = sum(runner.attention_bytes(c) for c in ctxs_per_step) / len(ctxs)
+    attn_ms = time_attention_kernel(runner, ctxs)
+    attn_gbs = attn_bytes / (attn_ms * 1e-3) / 1e9
+    step_bytes = sum(runner.step_bytes(sum(c)) for c in ctxs_per_step) / len(ctxs)
+    step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic(args, model_name, attn_bytes)
+    roofline = {"bound": "hbm",
+                "kernel": "attn_decode_kernel<BF16,128,4,nt,fused> (qkv split-K reduce + RoPE + cache append "
+                          "+ paged decode attention)" if model.fuse_decode_attention else
+                          "attn_decode_kernel (paged decode attention)",
+                "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": round(attn_ms * 1e3, 2), "timing": "mean over launches and 3 replays, HIP events",
+                "algorithmic_bytes_per_launch": int(attn_bytes)}
+    roofline_gemm = None
+    gemm_t = time_decode_gemms(runner) if with_gemm else None
+    if gemm_t:
+        gemm_kernels = gemm_t.pop("_kernels")
+        wb = sum(v["weight_bytes"] for v in gemm_t.values())
+        us = sum(v["us"] for v in gemm_t.values())
+        roofline_gemm = {"bound": "hbm", "kernel": gemm_kernels + ": qkv + o + gate|up + down of one layer, as the "
+                                                   "decode step launches them",
+                         "achieved": round(wb / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(wb / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "weight_bytes_per_layer": wb, "us_per_layer": round(us, 2),
+                         "per_projection": {k: {"us": v["us"], "GBps": round(v["weight_bytes"] / v["us"] / 1e3, 1)}
+                                            for k, v in gemm_t.items()},
+                         "what": "algorithmic bytes = the weights; HIP events (mean of 3 replays) over one graph "
+                                 "walking all layers' weights (cold), one launch per layer and projection"}
+    whole = {"algorithmic_bytes": int(step_bytes), "achieved_GBps": round(step_gbs, 1),
+             "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4), "weight_bytes": model.weight_bytes(),
+             "weight_bytes_resident": model.weight_bytes_resident()}
+    return roofline, roofline_gemm, whole
+
+
+def ctx_label(ctxs):
+    if len(ctxs) > 1 and ctxs[1] - ctxs[0] == 1:
+        return f"ctx {ctxs[0]}..{ctxs[-1]} (consecutive steps of the generation)"
+    return (f"ctx {ctxs[0]}..{ctxs[-1]} in {len(ctxs)} evenly spaced steps (mean {sum(ctxs) / len(ctxs):.0f}; the "
+            f"generation's 255 decode steps see 705..959, mean 832)")
+
+
+def leg_13b(ctx, args, dtype, dev, rank):
+    """BASELINE configs[2] (LLaVA-1.5-13B, batch 32, decode HBM-roofline run) as a short second leg of the
+    default command: same prompts / prefill / strided contexts, no CPU baseline, no serving."""
+    from hydrainfer_amd.model.llama import LlamaForCausalLM
+    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
+    shape, name = model_shape("13b")
+    prompt_len, n_generate = 704, 256
+    cfg = RunnerConfig(batch=args.batch, prompt_len=prompt_len, n_generate=n_generate, use_graph=not args.no_graph)
+    model = LlamaForCausalLM.random_init(shape, dtype, dev, seed=0)
+    model.use_hip_gemm = not args.lib_gemm
+    model.prepare_decode(max_rows=args.batch, keep_row_major=True)
+    runner = DecodeRunner(model, cfg, seed=rank)
+    prompts = synth_prompts(args.batch, prompt_len, shape.vocab_size, dev)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    img = (torch.randn((args.batch, 576, shape.hidden_size), generator=g, device=dev) * 0.02).to(dtype)
+    runner.prefill(prompts, img, image_token_id(shape.vocab_size))
+    ctxs = timed_contexts(prompt_len, n_generate, min(args.steps_13b, n_generate - 1))
+    elapsed = decode_leg(ctx, model, runner, ctxs, args.warmup, prompt_len)
+    ms = elapsed / len(ctxs) * 1e3
+    roofline, roofline_gemm, whole = roofline_objects(model, runner, ctxs, ms, args, name)
+    return {"workload": f"{name}-shaped random weights, batch {args.batch} decode, paged KV block_size=16, "
+                        f"{ctx_label(ctxs)} (BASELINE configs[2]: 13B batch-32 decode HBM-roofline run)",
+            "value": round(args.batch * len(ctxs) / elapsed, 2), "unit": "tokens/s", "steps": len(ctxs),
+            "ms_per_step": round(ms, 4), "roofline": roofline, "roofline_gemm": roofline_gemm, "whole_step": whole}
+
+
 def main():
     args = parse()
+    launch_ranks_if_needed(args)             # N > 1 without WORLD_SIZE: this process only starts the ranks
+    if args.dry_run:
+        return dry_run(args)
     if os.environ.get("HX_BENCH_WATCHDOG"):      # diagnose hangs: periodic stack dumps
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["HX_BENCH_WATCHDOG"]), repeat=True)
@@ -687,12 +863,16 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     prompt_len, n_generate = 704, 256
     steps = min(args.steps, n_generate - 1)
+    ctxs = timed_contexts(prompt_len, n_generate, steps)
     cfg = RunnerConfig(batch=args.batch, prompt_len=prompt_len, n_generate=n_generate,
                        use_graph=not args.no_graph)
     model = LlamaForCausalLM.random_init(shape, dtype, dev, seed=0)
     model.use_hip_gemm = not args.lib_gemm
     if args.no_fused_attention:
         model.fuse_decode_attention = False
+    # every decode-side weight layout this run can need is built NOW (never in the middle of serving); the
+    # serving / TTFT legs prefill on this GPU, so the row-major tensors stay for the library prefill GEMMs
+    model.prepare_decode(max_rows=args.batch, keep_row_major=True)
     runner = DecodeRunner(model, cfg, seed=rank)
 
     # multi-GPU: exchange IPC handles and map the neighbour's pool NOW — before any hipGraph is
@@ -755,38 +935,12 @@ def main():
         runner.prefill(prompts, img, image_token_id(shape.vocab_size))
         torch.cuda.synchronize()
         ttft_ms = (time.perf_counter() - t0) * 1e3   # prefill of the whole 32-request batch
-    state = (runner.positions.clone(), runner.kv_lens.clone(), runner.input_ids.clone())
 
-    def reset():
-        runner.positions.copy_(state[0]); runner.kv_lens.copy_(state[1]); runner.input_ids.copy_(state[2])
-        runner.tokens = []
-
-    # ---- warmup (untimed): graph capture + W steps, then rewind to the post-prefill state
-    if cfg.use_graph:
-        runner.capture()
-    for _ in range(args.warmup):
-        runner.step(record=False)
-    reset()
-
-    def barrier():
-        ctx.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        runner.step(record=False)
-    torch.cuda.synchronize()
-    elapsed = ctx.max_over_ranks(time.perf_counter() - t0, dev)
-    barrier()
+    # ---- warmup (untimed: graph capture + W steps, state rewound) and the timed region
+    elapsed = decode_leg(ctx, model, runner, ctxs, args.warmup, prompt_len)
     ms_per_step = elapsed / steps * 1e3
     tokens = args.batch * steps * n_gpus
     value = tokens / elapsed
-    # the in-kernel hand-overs of the norm-fused launches report a give-up in word 1 of their area: a
-    # timed run with one is not a valid measurement
-    if getattr(model, "xreg_sync", None) is not None and int(model.xreg_sync[:, :, 1].abs().sum()) != 0:
-        print("bench.py: a norm-fused launch gave up waiting for its producer workgroups", file=sys.stderr, flush=True)
-        sys.exit(4)
 
     ttft = None if args.skip_prefill or args.no_ttft else measure_ttft(runner, prompts, shape, dtype, dev, rank,
                                                                          vision, pixels)
@@ -796,29 +950,11 @@ def main():
     # ---- roofline of the dominant hand-written kernel + whole-step fraction (rank 0)
     out = None
     if rank == 0:
-        ctxs_per_step = [[prompt_len + s + 1] * args.batch for s in range(steps)]
-        attn_bytes = sum(runner.attention_bytes(c) for c in ctxs_per_step) / steps
-        attn_ms = time_attention_kernel(runner, prompt_len, steps)
-        attn_gbs = attn_bytes / (attn_ms * 1e-3) / 1e9
-        step_bytes = sum(runner.step_bytes(sum(c)) for c in ctxs_per_step) / steps
-        step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9
-        mid_ctx = prompt_len + (steps + 1) // 2
-        traffic, traffic_src = measured_traffic(args, model_name, attn_bytes)
-        gemm_t = time_decode_gemms(runner)
-        roofline_gemm = None
-        if gemm_t:
-            gemm_kernels = gemm_t.pop("_kernels")
-            wb = sum(v["weight_bytes"] for v in gemm_t.values())
-            us = sum(v["us"] for v in gemm_t.values())
-            roofline_gemm = {"bound": "hbm", "kernel": gemm_kernels + ": qkv + o + gate|up + down of one layer, as the "
-                                                       "decode step launches them",
-                             "achieved": round(wb / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(wb / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
-                             "weight_bytes_per_layer": wb, "us_per_layer": round(us, 2),
-                             "per_projection": {k: {"us": v["us"], "GBps": round(v["weight_bytes"] / v["us"] / 1e3, 1)}
-                                                for k, v in gemm_t.items()},
-                             "what": "algorithmic bytes = the weights; HIP events over one graph walking all "
-                                     "layers' weights (cold), one launch per layer and projection"}
+        mid_ctx = int(round(sum(ctxs) / len(ctxs)))
+        roofline, roofline_gemm, whole = roofline_objects(model, runner, ctxs, ms_per_step, args, model_name)
+        roofline["measured_copy_ceiling_GBps"] = round(copy_ceiling_gbs(dev), 1)
+        configs_i = {"7b": "configs[1]: LLaVA-1.5-7B bf16, collocated prefill+decode on 1 MI355X",
+                     "13b": "configs[2]: LLaVA-1.5-13B, batch 32, decode HBM-roofline run"}.get(args.model, "smoke shape")
         out = {
             "metric": "decode output tokens/s, LLaVA-1.5-7B image+text requests (576 image + 128 text "
                       "prompt, 256 generated), batch 32 per GPU" if args.model == "7b" else
@@ -827,24 +963,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{model_name}-shaped random weights, batch {args.batch} "
-                                   f"decode, paged KV block_size=16, ctx {prompt_len + 1}..{prompt_len + steps}"
-                                   f" (BASELINE configs[1]: collocated prefill+decode on 1 MI355X)",
+                                   f"decode, paged KV block_size=16, {ctx_label(ctxs)} (BASELINE {configs_i})",
                        "global_batch": args.batch * n_gpus, "prompt_tokens": prompt_len,
                        "generated_tokens": n_generate, "hip_graph": cfg.use_graph,
                        "parallelism": f"replicas x{n_gpus} (independent requests, no data-path collective)"},
-            "roofline": {"bound": "hbm",
-                         "kernel": "attn_decode_kernel<BF16,128,4,nt,fused> (qkv split-K reduce + RoPE + cache append "
-                                   "+ paged decode attention)" if model.fuse_decode_attention else
-                                   "attn_decode_kernel (paged decode attention)",
-                         "achieved": round(attn_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(attn_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_us": round(attn_ms * 1e3, 2),
-                         "measured_copy_ceiling_GBps": round(copy_ceiling_gbs(dev), 1),
-                         "algorithmic_bytes_per_launch": int(attn_bytes)},
+            "roofline": roofline,
             "roofline_gemm": roofline_gemm,
-            "whole_step": {"algorithmic_bytes": int(step_bytes), "achieved_GBps": round(step_gbs, 1),
-                           "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4),
-                           "weight_bytes": model.weight_bytes()},
+            "whole_step": whole,
             "prefill_batch_ms": None if ttft_ms is None else round(ttft_ms, 2),
             "ttft": ttft, "serving": serving, "migration": None,
         }
@@ -882,9 +1007,26 @@ def main():
         stuck = th.is_alive()
         disagg = {"error": "timed out after 240 s"} if stuck else box.get("r")
 
+    # ---- LLaVA-1.5-13B leg (BASELINE configs[2]) in the same line: N = 1, 7B model, default flags only
+    llava_13b = None
+    if world == 1 and args.model == "7b" and not args.no_13b and not stuck:
+        try:
+            del runner, serving
+            engine = vision = None
+            model.release()
+            del model
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            llava_13b = leg_13b(ctx, args, dtype, dev, rank)
+        except SystemExit:
+            raise
+        except Exception as e:      # an extra leg must never cost the headline
+            llava_13b = {"error": repr(e)[:300]}
+
     if rank == 0:
         out["migration"] = migration
         out["disaggregated"] = disagg if engine_error is None else {"error": engine_error}
+        out["llava_13b"] = llava_13b
         print(json.dumps(out), flush=True)
     if stuck:
         sys.stdout.flush()

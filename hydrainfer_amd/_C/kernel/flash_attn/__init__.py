@@ -102,6 +102,7 @@ def mha_varlen_fwd(out: Tensor, q: Tensor, k: Tensor, v: Tensor, cu_seqlens_q: T
     a.softcap = float(softcap)
     a.window_left = int(window_size_left) if local else -1
     a.window_right = int(window_size_right) if local else -1
+    a.flags = _lib.HX_ATTN_LOCAL_WINDOW if local else 0
 
     l = _lib.lib()
     need = l.hx_mha_varlen_fwd_workspace_bytes(ctypes.byref(a))
@@ -154,7 +155,7 @@ def decode_attention_fused(out: Tensor, q: Tensor, k_new: Tensor, v_new: Tensor,
     a.v_block_stride, a.v_row_stride, a.v_head_stride = v.stride(0), v.stride(1), v.stride(2)
     a.softmax_scale, a.causal, a.dtype, a.num_splits = float(softmax_scale), 1, _lib.dtype_code(q), int(num_splits)
     a.workspace, a.workspace_bytes = None, 0
-    a.softcap, a.window_left, a.window_right = 0.0, -1, -1
+    a.softcap, a.window_left, a.window_right, a.flags = 0.0, -1, -1, 0
     fz = _lib.hx_fused_decode_args()
     fz.k_new, fz.v_new = k_new.data_ptr(), v_new.data_ptr()
     fz.k_new_row_stride, fz.v_new_row_stride = k_new.stride(0), v_new.stride(0)

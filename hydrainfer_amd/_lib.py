@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhydra_hip.so")
 
 HX_F32, HX_F16, HX_BF16 = 0, 1, 2
 HX_IPC_HANDLE_BYTES = 64
+HX_ABI_VERSION = 2            # include/hydra_hip.h
+HX_ATTN_LOCAL_WINDOW = 1
 
 _DTYPE = {torch.float32: HX_F32, torch.float16: HX_F16, torch.bfloat16: HX_BF16}
 
@@ -38,7 +40,7 @@ class hx_attn_args(ctypes.Structure):
         ("v_block_stride", c_int64), ("v_row_stride", c_int64), ("v_head_stride", c_int64),
         ("softmax_scale", c_float), ("causal", c_int32), ("dtype", c_int32),
         ("num_splits", c_int32), ("workspace", c_void_p), ("workspace_bytes", c_int64),
-        ("softcap", c_float), ("window_left", c_int32), ("window_right", c_int32), ("reserved", c_int32),
+        ("softcap", c_float), ("window_left", c_int32), ("window_right", c_int32), ("flags", c_int32),
     ]
 
 
@@ -83,9 +85,6 @@ _SIGNATURES = {
     "hx_linear_decode_workspace_bytes": (c_int64, [c_int64] * 3),
     "hx_linear_decode": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_void_p, c_int64, c_int, c_void_p]),
     "hx_linear_decode_partial": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_int, c_void_p]),
-    "hx_debug_stream_read": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "hx_decode_chain_workspace_bytes": (c_int64, [c_int64] * 4),
-    "hx_decode_chain": (c_int, [POINTER(hx_chain_args), c_void_p]),
     "hx_pack_decode_weight": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hx_linear_decode_partial_packed": (c_int, [c_void_p] * 3 + [c_int64] * 5 + [c_int, c_void_p]),
     "hx_linear_decode_xreg_supported": (c_int, [c_int64] * 3),
@@ -94,7 +93,6 @@ _SIGNATURES = {
     "hx_fragment_major_elems": (c_int64, [c_int64] * 2),
     "hx_pack_decode_weight_xreg": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hx_linear_decode_partial_xreg": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_int64, c_int, c_void_p]),
-    "hx_debug_paged_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int] + [c_int] * 4 + [c_void_p, c_void_p]),
     "hx_embed_rms_norm": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_void_p, c_float, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hx_argmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hx_norm_xreg_supported": (c_int, [c_int64] * 3 + [c_int]),
@@ -126,6 +124,15 @@ _SIGNATURES = {
     "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_void_p]),
 }
 
+# Only in a library built with `make EXPERIMENTS=1` (include/hydra_hip_experimental.h): rejected experiments and
+# microbenchmarks.  Bound when present; the product path never calls them.
+_EXPERIMENTAL_SIGNATURES = {
+    "hx_debug_stream_read": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "hx_decode_chain_workspace_bytes": (c_int64, [c_int64] * 4),
+    "hx_decode_chain": (c_int, [POINTER(hx_chain_args), c_void_p]),
+    "hx_debug_paged_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int] + [c_int] * 4 + [c_void_p, c_void_p]),
+}
+
 _lib = None
 
 
@@ -142,8 +149,14 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.hx_abi_version() != 1:
-            raise HydraHipError("libhydra_hip.so ABI version mismatch")
+        for name, (restype, argtypes) in _EXPERIMENTAL_SIGNATURES.items():
+            if hasattr(handle, name):
+                fn = getattr(handle, name)
+                fn.restype = restype
+                fn.argtypes = argtypes
+        if handle.hx_abi_version() != HX_ABI_VERSION:
+            raise HydraHipError(f"libhydra_hip.so ABI version {handle.hx_abi_version()} != {HX_ABI_VERSION} of this binding: "
+                                "rebuild with `make -C hydrainfer_amd/csrc`")
         # A/B runs of whole programs: HX_DEBUG_OPTIONS="decode_small=0,fwd_row_blocks=1"
         for item in filter(None, os.environ.get("HX_DEBUG_OPTIONS", "").split(",")):
             name, _, value = item.partition("=")
@@ -155,6 +168,12 @@ def lib() -> ctypes.CDLL:
 
 def exported_symbols():
     return sorted(_SIGNATURES)
+
+
+def has_experiments() -> bool:
+    """True if libhydra_hip.so was built with `make EXPERIMENTS=1` (decode chain, four-heads decode attention,
+    read-stream probes)."""
+    return hasattr(lib(), "hx_decode_chain")
 
 
 def check(status: int, what: str) -> None:

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
     //    loads and the store drain are not queued behind weight loads — prefetching first cost the whole gain)
     const int flat = blockIdx.y * gridDim.x + blockIdx.x;
     const int n_wg = gridDim.x * gridDim.y;
-    if (flat < p.M && !(p.stagger & 2))   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
+    if (flat < p.M && !(p.stagger & 6))   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
       for (int row = flat; row < p.M; row += n_wg) produce(row);   // several rows only when N is tiny
     // 2. everyone: weight prefetch (independent of x)
 #pragma unroll
@@ -294,12 +294,20 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
         while (!__builtin_amdgcn_readfirstlane(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           __builtin_amdgcn_s_sleep(8);
           const uint64_t waited = __builtin_amdgcn_s_memrealtime() - t0;
-          if (waited > kRescueTicks) {
+          if (waited > kRescueTicks && !(p.stagger & 4)) {
             const uint32_t sv = lane < p.M ? __hip_atomic_load(st + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-            const uint64_t free_rows = __ballot(sv == 0u);
-            if (free_rows) { c = __builtin_ctzll(free_rows); break; }
+            uint64_t free_rows = __ballot(sv == 0u);
+            if (free_rows) {
+              // rescuers spread over the unclaimed rows (workgroup f takes the (f mod n)-th of them): K missing
+              // producers are then rescued side by side, not one after the other through the same lowest row
+              for (int skip = flat % __builtin_popcountll(free_rows); skip > 0; --skip) free_rows &= free_rows - 1;
+              c = __builtin_ctzll(free_rows);
+              break;
+            }
           }
-          if (waited > 100000000ull) {   // 1 s at 100 MHz: report, never hang the GPU
+          // 1 s at 100 MHz: report, never hang the GPU (bit 2 of `stagger`: test hook — no producers, no rescue,
+          // 2 ms bound: every norm-fused launch gives up and must be reported by its caller)
+          if (waited > ((p.stagger & 4) ? 200000ull : 100000000ull)) {
             if (threadIdx.x == 0) __hip_atomic_fetch_or(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             c = -2;
             break;
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(256) void pack_xreg_kernel(u16* __restrict__ packed
 }
 
 int g_stagger = 1;
-int g_no_producers = 0;   // test hook (xreg_no_producers): the norm-fused launches rely on the rescue path alone
+int g_no_producers = 0;   // test hook (xreg_no_producers): 1 = the norm-fused launches rely on the rescue path alone; 2 = no producers and no rescue: every such launch gives up (error word) after 2 ms
 int g_dbg = 0;
 int g_force_wgs = 0;     // tuning: cap on workgroups per launch (0 = the CU count)
 
@@ -613,7 +621,7 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers ? 2 : 0); p.x_packed = x_fragment_major ? 1 : 0;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
   const int rc = launch_any<0>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
@@ -637,7 +645,7 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
-  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers ? 2 : 0); p.x_packed = x_fragment_major ? 1 : 0;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
   return launch_any<1>(p, 1, KW, dtype, (hipStream_t)stream);
 }
@@ -676,7 +684,7 @@ extern "C" int hx_norm_linear_decode_xreg(float* partial, void* residual, const 
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x_frag; p.w = packed_weight; p.partial = partial; p.ldx = K; p.act = nullptr;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers ? 2 : 0); p.x_packed = 1;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
   p.nm_splits = n_splits_in; p.nm_eps = epsilon;
   rc = launch_any<0, 1>(p, S, KW, dtype, (hipStream_t)stream);
@@ -697,7 +705,7 @@ extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float*
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
   p.x = x_frag; p.w = packed_gate_up; p.partial = nullptr; p.ldx = K; p.act = act;
-  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers ? 2 : 0); p.x_packed = 1;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
   p.nm_splits = n_splits_in; p.nm_eps = epsilon;
   return launch_any<1, 1>(p, 1, KW, dtype, (hipStream_t)stream);

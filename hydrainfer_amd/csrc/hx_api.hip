@@ -15,11 +15,13 @@ bool decode_supported(int head_dim);
 int decode_set_option(const char* name, int value);
 int gemm_set_option(const char* name, int value);
 int fwd_set_option(const char* name, int value);
-int chain_set_option(const char* name, int value);
 int xreg_set_option(const char* name, int value);
+#if HX_EXPERIMENTS   // `make EXPERIMENTS=1`: rejected experiments kept measurable (not in the default library)
+int chain_set_option(const char* name, int value);
 int decode4_set_option(const char* name, int value);
 bool decode4_applies(const AttnParams& p, int batch, int head_dim, int n_cus);
 int launch_attn_decode4(const AttnParams& p, int batch, int dtype, hipStream_t stream);
+#endif
 bool fwd_supported(int head_dim);
 int decode_pick_splits(int batch, int n_heads, int max_seqlen_k, int requested);
 bool decode_gqa_supported(int head_dim, int group);
@@ -48,9 +50,11 @@ extern "C" int hx_debug_set_option(const char* name, int value) {
   int rc = decode_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = gemm_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = fwd_set_option(name, value);
-  if (rc == HX_ERR_UNSUPPORTED) rc = chain_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = xreg_set_option(name, value);
+#if HX_EXPERIMENTS
+  if (rc == HX_ERR_UNSUPPORTED) rc = chain_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = decode4_set_option(name, value);
+#endif
   return rc;
 }
 
@@ -129,8 +133,12 @@ int validate(const hx_attn_args* a) {
 
 }  // namespace
 
+static inline bool is_local(const hx_attn_args* a) {
+  return (a->flags & HX_ATTN_LOCAL_WINDOW) && (a->window_left >= 0 || a->window_right >= 0);
+}
+
 extern "C" int64_t hx_mha_varlen_fwd_workspace_bytes(const hx_attn_args* a) {
-  if (validate(a) != HX_OK || !use_decode(a) || a->softcap > 0.f || a->window_left >= 0 || a->window_right >= 0) return 0;
+  if (validate(a) != HX_OK || !use_decode(a) || a->softcap > 0.f || is_local(a)) return 0;
   // the same query serves hx_mha_varlen_fwd and hx_decode_attention_fused, which may pick
   // different kernels (and split counts) for a grouped-query shape: size for the larger
   const int s1 = pick_splits(a, false), s2 = pick_splits(a, true);
@@ -197,14 +205,15 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.xcd_remap = g_fwd_xcd;
   p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
   // flash_api.cpp:93-111
-  p.window_left = a->window_left;
-  p.window_right = a->window_right;
+  if (a->flags & ~HX_ATTN_LOCAL_WINDOW) return HX_ERR_UNSUPPORTED;
+  const bool local = is_local(a);
+  p.window_left = local ? a->window_left : -1;
+  p.window_right = local ? a->window_right : -1;
   p.softcap_scale = 0.f;
   if (a->softcap > 0.f) {
     p.softcap_scale = a->softmax_scale / a->softcap;
     p.scale_log2 = a->softcap * 1.4426950408889634f;
   }
-  const bool local = a->window_left >= 0 || a->window_right >= 0;
   if (local && a->causal) return HX_ERR_UNSUPPORTED;
   if ((local || a->softcap > 0.f) && fused) return HX_ERR_UNSUPPORTED;
   if (local) {   // one-sided windows: the open side reaches the end of the sequence
@@ -259,8 +268,10 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
     }
     p.n_splits = splits;
     if (gqa) return launch_attn_decode_gqa(p, a->batch, a->head_dim, a->dtype, s);
+#if HX_EXPERIMENTS
     // four heads per workgroup (1 KiB contiguous per key row) when the grid still fills the chip
     if (decode4_applies(p, a->batch, a->head_dim, device_cus())) return launch_attn_decode4(p, a->batch, a->dtype, s);
+#endif
     return launch_attn_decode(p, a->batch, a->head_dim, a->dtype, s);
   }
   return launch_attn_fwd(p, a->batch, a->head_dim, a->max_seqlen_q, a->block_table != nullptr,

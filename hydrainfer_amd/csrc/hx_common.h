@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/hydra_hip.h"
+#include "../../include/hydra_hip_experimental.h"   // declarations only; defined in EXPERIMENTS=1 builds
+#ifndef HX_EXPERIMENTS
+#define HX_EXPERIMENTS 0
+#endif
 
 #define HX_WAVE 64
 

@@ -10,6 +10,8 @@ from typing import List, Optional
 
 import torch
 
+from hydrainfer_amd._lib import HydraHipError
+
 from hydrainfer_amd.engine.isa import Fill
 from hydrainfer_amd.engine.parameters_builder import LanguageModelParametersBuilder
 from hydrainfer_amd.engine.rcb import BatchRequest
@@ -146,6 +148,11 @@ class BatchFillExecutor:
             self.image_manager, self.kv_manager, sh.num_hidden_layers, sh.num_attention_heads,
             sh.num_key_value_heads, sh.head_dim, self.language_model.image_token_id, self.dtype, self.device)
         builder.add_batch(batch)
+        if builder.position_ids and max(builder.position_ids) >= sh.max_position_embeddings:
+            # the RoPE / attention kernels index the cos_sin table unchecked (admission normally rejects this:
+            # request_processor.InstructionCreator.max_position_embeddings)
+            raise HydraHipError(f"position {max(builder.position_ids)} outside the rotary table "
+                                f"(max_position_embeddings = {sh.max_position_embeddings})")
         inputs = builder.build_language_model_parameters()
         params = LanguageModelParameters(inputs.attention_params, inputs.all_sequences_decode,
                                          inputs.selected_token_ids_tensor, inputs.image_row_index)

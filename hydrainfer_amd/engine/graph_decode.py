@@ -23,6 +23,7 @@ from typing import Dict, List, Tuple
 import numpy as np
 import torch
 
+from hydrainfer_amd._lib import HydraHipError
 from hydrainfer_amd.layer.causal_attention import AttentionParameters
 from hydrainfer_amd.memory.kv_cache import KVCache
 from hydrainfer_amd.model.llama import LanguageModelParameters
@@ -54,6 +55,10 @@ class GraphedDecoder:
         self.q_cu = torch.arange(0, B + 1, dtype=torch.int32, device=self.dev)
         self.prev_tokens = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.host_tokens = [torch.zeros(B, dtype=torch.int64).pin_memory() for _ in range(2)]
+        # word that is nonzero iff an in-kernel hand-over of that launch gave up waiting (csrc/gemm_xreg.hip): it
+        # travels to the host with the launch's tokens and is checked in fetch()
+        self.host_err = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.launch_has_err = {}
         self.events = [torch.cuda.Event(), torch.cuda.Event()]
         self.launches = 0                  # id of the most recent launch (1-based)
         self.launch_rows = {}              # launch id -> number of live rows
@@ -63,7 +68,7 @@ class GraphedDecoder:
         self.pad_cache = self.kv.allocate_virtual_cache()
         self.kv.realloc(self.pad_cache, 1)
         self.pad_block = self.pad_cache.block_table[0]
-        self.graphs: Dict[Tuple[int, int], Tuple[torch.cuda.CUDAGraph, torch.Tensor]] = {}
+        self.graphs: Dict[Tuple[int, int], tuple] = {}
 
     def fits(self, n_seqs: int, n_blocks: int) -> bool:
         padded = (n_seqs + self.pad_to - 1) // self.pad_to * self.pad_to
@@ -95,9 +100,10 @@ class GraphedDecoder:
         ids, pos = self._views(B)[:2]
         src = self._views(B)[6]
         fed = self.prev_tokens[src.clamp_min(0).long()]
+        self.model.xreg_sync = None
         out = self.model(torch.where(src >= 0, fed, ids), pos, params)
         self.prev_tokens[:B].copy_(out)
-        return out
+        return out, self.model.handover_error_word()
 
     def _capture(self, B: int, bucket: int):
         params = self._params(B, bucket if bucket else 4096)
@@ -112,8 +118,8 @@ class GraphedDecoder:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            out = self._body(B, params)
-        return graph, out
+            out, err = self._body(B, params)
+        return graph, out, err
 
     def _fill(self, rows: List[Tuple[int, int, int, int, List[int]]], B: int) -> int:
         """rows: (token, position, slot, kv_len, block_table) per live sequence; a token < 0 means
@@ -126,7 +132,11 @@ class GraphedDecoder:
         bs = self.kv.block_size
         pad = (0, 0, self.pad_block * bs, 1, [self.pad_block])
         max_pos = self.model.shape.max_position_embeddings
-        assert all(0 <= r[1] < max_pos for r in rows), "position beyond the rotary table (max_position_embeddings)"
+        if not all(0 <= r[1] < max_pos for r in rows):    # the RoPE / attention kernels index cos_sin unchecked
+            raise HydraHipError(f"decode position outside the rotary table (max_position_embeddings = {max_pos})")
+        vocab = self.model.shape.vocab_size
+        if not all(r[0] < vocab for r in rows):           # hx_embed_rms_norm would clamp, torch.embedding raises
+            raise HydraHipError(f"token id outside the vocabulary ({vocab})")
         rows = rows + [pad] * (B - n)
         st[o["ids"]:o["ids"] + B] = [max(r[0], 0) for r in rows]
         st[o["src"]:o["src"] + B] = [-(r[0] + 1) if r[0] < 0 else -1 for r in rows]
@@ -162,11 +172,14 @@ class GraphedDecoder:
         key = (B, self._kv_bucket(B, kv_max))
         if key not in self.graphs:
             self.graphs[key] = self._capture(*key)
-        graph, out = self.graphs[key]
+        graph, out, err = self.graphs[key]
         graph.replay()
         self.launches += 1
         slot = self.launches % 2
         self.host_tokens[slot][:n].copy_(out[:n], non_blocking=True)
+        if err is not None:
+            self.host_err[slot].copy_(err.view(1), non_blocking=True)
+        self.launch_has_err[self.launches] = err is not None
         self.events[slot].record()
         self.launch_rows[self.launches] = n
         return self.launches
@@ -176,7 +189,16 @@ class GraphedDecoder:
         assert launch_id > self.launches - 2, "tokens of an older launch have been overwritten"
         slot = launch_id % 2
         self.events[slot].synchronize()
-        return self.host_tokens[slot][: self.launch_rows.pop(launch_id)].tolist()
+        n = self.launch_rows.pop(launch_id)
+        if self.launch_has_err.pop(launch_id, False) and int(self.host_err[slot][0]) != 0:
+            # a norm-fused launch consumed activations nobody had produced: this step's tokens are garbage.
+            # Later steps run with the add+RMSNorm as separate launches (no in-kernel hand-over).
+            self.model.fuse_norm = False
+            self.graphs.clear()
+            raise HydraHipError(f"decode launch {launch_id}: an in-kernel hand-over (norm-fused GEMM launch) gave up "
+                                "waiting for its producer workgroups; the step's tokens are invalid. Norm fusion is "
+                                "now disabled for this model (fuse_norm = False)")
+        return self.host_tokens[slot][:n].tolist()
 
     def run(self, rows: List[Tuple[int, int, int, int, List[int]]]) -> List[int]:
         return self.fetch(self.launch(rows))

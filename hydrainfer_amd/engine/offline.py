@@ -52,7 +52,8 @@ class OfflineInferenceEngine:
                                max_blocks_per_seq=blocks_per_seq)
         self.cluster = LocalCluster([self.node])
         self.creator = InstructionCreator(image_token_id=language_model.image_token_id,
-                                          n_image_tokens_per_image=self.n_image_tokens, block_size=16, ignore_eos=True)
+                                          n_image_tokens_per_image=self.n_image_tokens, block_size=16, ignore_eos=True,
+                                          max_position_embeddings=shape.max_position_embeddings)
         self.processor = ClipImageProcessor(size=vision_model.shape.image_size)
         if warm_up:
             warm_library_gemms(language_model, token_budgets, max_running_requests)

@@ -23,8 +23,18 @@ _DTYPE_NAMES = {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "f
 def build_node(name: str, node_type: str, language_model, vision_model, lm_shape, dtype: torch.dtype,
                device: torch.device, kv_blocks: int, image_blocks: int, n_image_tokens: int,
                sched: BatchSchedulerConfig, rank: int = 0, graph_decode: bool = True,
-               max_blocks_per_seq: int = 256, world_size: int = 1, eager_migrate: bool = True) -> EPDNode:
+               max_blocks_per_seq: int = 256, world_size: int = 1, eager_migrate: bool = True,
+               release_prefill_weights: Optional[bool] = None) -> EPDNode:
+    """release_prefill_weights (default: this node never prefills, i.e. a "D" node of parallel.epd_roles): keep only
+    the packed decode layouts of the decoder weights — one copy in HBM instead of two."""
     nt = NodeType(node_type)
+    if nt.has_language_model and nt.enable_decode:
+        # every weight layout a decode batch of this node can need is built NOW: before the cache pools are
+        # allocated (it counts against the same HBM) and never in the middle of serving
+        if release_prefill_weights is None:
+            release_prefill_weights = not nt.enable_prefill
+        language_model.language_model.prepare_decode(max_rows=(sched.max_running_requests + 3) // 4 * 4,
+                                                     keep_row_major=not release_prefill_weights)
     # one node of MI355Xs: every rank is a same-host peer, so pulls take the IPC path
     ctx = TokenCacheBlockManagerContext(rank=rank, rank2host={r: "localhost" for r in range(max(world_size, rank + 1))})
     kv = img = None
@@ -63,6 +73,8 @@ def warm_library_gemms(language_model, token_budget: int, max_decode_rows: int =
     rows = sorted(set(list(range(64, token_budget + 1, 64)) + [token_budget + r for r in (1, 8, max_decode_rows)]))
     for name in ("l0.wqkv", "l0.wo", "l0.wgu", "l0.wdown"):
         w = st[name]
+        if w.device.type == "meta":      # decode-only node: no prefill GEMMs to warm
+            continue
         x = torch.zeros((rows[-1], w.shape[1]), dtype=dt, device=dev)
         for m in rows:
             torch.matmul(x[:m], w.t())

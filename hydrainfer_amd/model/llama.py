@@ -107,6 +107,65 @@ class LlamaForCausalLM:
         self.xreg_sync: Optional[Tensor] = None   # [L, 2, XREG_SYNC_WORDS] of the last step (word 1 = wait gave up)
         self.packed_x: Dict[str, Tensor] = {}
         self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
+        # decode-side weight layouts are built ONCE, by prepare_decode (engine build / runner construction), for
+        # the largest decode batch the owner will ever run — never in the middle of serving
+        self.decode_rows_prepared = 0
+        self.decode_only = False                   # row-major decoder weights dropped (D-role node)
+
+    # ------------------------------------------------------------------ decode-side weight layouts
+    def prepare_decode(self, max_rows: int = 64, keep_row_major: bool = True) -> None:
+        """Builds every packed layout a decode batch of <= max_rows rows can need, now (model load, before the
+        KV pool is sized): the activations-in-registers layout for gate|up, down and qkv of layers >= 1 (<= 32
+        rows), the LDS-slice layout for o and layer 0's qkv — and for all four projections when max_rows > 32
+        (batches of 33..64 rows run on that kernel).  keep_row_major=False is for nodes that never prefill
+        (parallel.epd_roles: "D"): the row-major decoder weights — only the library prefill GEMMs read them —
+        are released, ONE copy of the weights stays resident.  Reference: one nn.Linear weight per projection
+        (hydrainfer/model/llama.py:24-27,48-50)."""
+        max_rows = min(int(max_rows), 64)
+        if max_rows > self.decode_rows_prepared and not self.decode_only:
+            self.pack_decode_weights(all_lds_slice=max_rows > 32 or self.use_chain)
+            self.decode_rows_prepared = max_rows
+        if not keep_row_major and not self.decode_only and self._all_packed():
+            for l in range(self.shape.num_hidden_layers):
+                for n in ("wqkv", "wo", "wgu", "wdown"):
+                    w = self.state[f"l{l}.{n}"]
+                    # shape / stride / dtype carrier without storage: anything that tries to read it fails loudly
+                    self.state[f"l{l}.{n}"] = torch.empty_strided(w.shape, w.stride(), dtype=w.dtype, device="meta")
+            self.decode_only = True
+
+    def _all_packed(self) -> bool:
+        return all((f"l{l}.{n}" in self.packed or f"l{l}.{n}" in self.packed_x)
+                   for l in range(self.shape.num_hidden_layers) for n in ("wqkv", "wo", "wgu", "wdown"))
+
+    def weight_bytes_resident(self) -> int:
+        """Bytes of HBM the weights occupy in all their layouts (row-major + packed copies)."""
+        tensors = [v for v in self.state.values() if v.device.type != "meta"]
+        tensors += list(self.packed.values()) + list(self.packed_x.values())
+        return sum(t.numel() * t.element_size() for t in tensors)
+
+    def release(self) -> None:
+        """Drops every weight tensor (bench.py frees the 7B model before its 13B leg)."""
+        self.state, self.packed, self.packed_x = {}, {}, {}
+        self.xreg_sync = self.chain_sync = None
+
+    def handover_failed(self) -> bool:
+        """True if an in-kernel hand-over of the last decode step gave up waiting (word 1 of a norm-fused
+        launch's sync area, HX_CHAIN_SYNC_ERR of a chain launch): that step's activations are garbage.
+        One small D2H sync — callers on the hot path fold the flag into their token copy instead
+        (engine/graph_decode.py)."""
+        bad = False
+        if self.xreg_sync is not None:
+            bad = bool(int(self.xreg_sync[:, :, 1].abs().sum()) != 0)
+        if not bad and self.chain_sync is not None:
+            bad = bool(int(self.chain_sync[:, hip_gemm.SYNC_ERR].abs().sum()) != 0)
+        return bad
+
+    def handover_error_word(self) -> Optional[Tensor]:
+        """int32 scalar tensor on the device, nonzero iff a hand-over of the step just enqueued gave up; None when
+        the step had no in-kernel hand-over.  Enqueued on the current stream (capturable)."""
+        if self.xreg_sync is not None:
+            return self.xreg_sync[:, :, 1].abs().sum().to(torch.int32)
+        return None
 
     def pack_decode_weights(self, all_lds_slice: bool = False) -> None:
         """Builds the packed copies of the decoder-layer weights (once; not during graph capture): the
@@ -147,13 +206,17 @@ class LlamaForCausalLM:
     def _partial(self, x: Tensor, key: str, ws: Tensor) -> int:
         """split-K slabs of x @ state[key]^T into ws; packed weights when available."""
         pk = self.packed.get(key)
-        if pk is None and self.use_packed and not torch.cuda.is_current_stream_capturing():
-            pk = self._pack_lds_slice(key)      # first use of this projection on the LDS-slice kernel
         if pk is not None:
             return hip_gemm.linear_decode_partial_packed(x, pk, self.state[key].shape[0], ws)
+        if self.decode_only:
+            raise RuntimeError(f"decode-only model: no packed layout of {key} for {x.shape[0]} rows (prepare_decode("
+                               f"max_rows={self.decode_rows_prepared}) was called) and the row-major weight is released")
         return hip_gemm.linear_decode_partial(x, self.state[key], ws)
 
     def linear(self, x: Tensor, w: Tensor) -> Tensor:
+        if w.device.type == "meta":
+            raise RuntimeError("decode-only model (prepare_decode(keep_row_major=False)): prefill / row-major GEMMs "
+                               "are not available on this node")
         if self.use_hip_gemm and x.shape[0] <= 64 and hip_gemm.supported(x, w):
             return hip_gemm.linear_decode(x, w)
         return torch.matmul(x, w.t())
@@ -246,12 +309,13 @@ class LlamaForCausalLM:
                    hip_gemm.workspace_floats(n, 2 * inter, hid), hip_gemm.workspace_floats(n, hid, inter))
         ws = torch.empty(ws_n, dtype=torch.float32, device=h.device)
         x = torch.empty_like(h)
-        xreg = self.use_xreg and self._xreg_mlp_ok(n)
-        if xreg and f"l{L - 1}.wdown" not in self.packed_x:
+        if n > self.decode_rows_prepared and not self.decode_only:
             if torch.cuda.is_current_stream_capturing():
-                xreg = False
-            else:
-                self.pack_decode_weights()
+                raise RuntimeError(f"decode batch of {n} rows captured before prepare_decode(max_rows >= {n})")
+            # a caller that never announced its batch size (unit tests, ad-hoc scripts): everything a <= 64-row
+            # batch can need, once; the engine / runners call prepare_decode at build time
+            self.prepare_decode(max_rows=64)
+        xreg = self.use_xreg and self._xreg_mlp_ok(n) and f"l{L - 1}.wdown" in self.packed_x
         qkv_n = q_size + 2 * kv_size
         ws_q = ws          # where the current layer's qkv slabs live
         nf_gu = nf_qkv = False
@@ -383,9 +447,9 @@ class LlamaForCausalLM:
         if (self.use_hip_gemm and model_params.all_sequences_decode and self.fuse_decode_attention
                 and n <= 64 and h.dtype in (torch.float16, torch.bfloat16)
                 and sh.hidden_size % 256 == 0 and sh.intermediate_size % 256 == 0):
-            if (self.use_chain and n <= 32 and f"l{sh.num_hidden_layers - 1}.wdown" not in self.packed
-                    and not torch.cuda.is_current_stream_capturing()):
-                self.pack_decode_weights(all_lds_slice=True)
+            if self.use_chain and n <= 32 and f"l{sh.num_hidden_layers - 1}.wdown" not in self.packed:
+                self.decode_rows_prepared = 0
+                self.prepare_decode(max_rows=64)
             if self.use_chain and n <= 32 and f"l{sh.num_hidden_layers - 1}.wdown" in self.packed and hip_gemm.chain_supported(
                     n, sh.hidden_size, sh.intermediate_size, self.q_size, h.dtype):
                 return self._decode_hidden_chain(h, position_ids, model_params)

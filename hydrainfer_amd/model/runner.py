@@ -61,6 +61,7 @@ class DecodeRunner:
     def __init__(self, model: LlamaForCausalLM, cfg: RunnerConfig, seed: int = 0):
         self.model, self.cfg = model, cfg
         sh, dev, dt = model.shape, model.device, model.dtype
+        model.prepare_decode(max_rows=cfg.batch)      # packed decode layouts now, not inside the first step
         self.dev = dev
         B, bs = cfg.batch, cfg.block_size
         self.max_len = cfg.prompt_len + cfg.n_generate
@@ -240,7 +241,13 @@ class DecodeRunner:
             self.tokens.append(self.input_ids.clone())
 
     def generated(self) -> Tensor:
-        """[n_steps_so_far, B] sampled tokens (one D2H sync, at the end)."""
+        """[n_steps_so_far, B] sampled tokens (one D2H sync, at the end).  Raises if an in-kernel hand-over of the
+        last step gave up (its tokens would be garbage)."""
+        if self.model.handover_failed():
+            self.model.fuse_norm = False
+            self.graph = None
+            raise _lib.HydraHipError("a norm-fused GEMM launch gave up waiting for its producer workgroups: the tokens "
+                                     "of this run are invalid (norm fusion now disabled for this model)")
         return torch.stack(self.tokens).cpu()
 
     # ------------------------------------------------------------------ accounting

@@ -9,10 +9,12 @@ from hydrainfer_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(experimental=False):
+    """hx_* functions declared by include/hydra_hip.h (the product ABI) or, experimental=True, by
+    include/hydra_hip_experimental.h (exported only by `make EXPERIMENTS=1` builds)."""
     names = []
     for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
-        if not hdr.endswith(".h"):
+        if not hdr.endswith(".h") or hdr.endswith("_experimental.h") != experimental:
             continue
         src = open(os.path.join(ROOT, "include", hdr)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
@@ -28,10 +30,23 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in include/ but not exported: {missing}"
 
 
+def test_experiments_are_not_in_the_default_library():
+    """Rejected experiments and microbenchmarks (decode chain, four-heads decode attention, stream probes) ship
+    only in `make EXPERIMENTS=1` builds: either all of hydra_hip_experimental.h is exported or none of it, and the
+    ctypes binding types exactly those names."""
+    exp = _declared(experimental=True)
+    assert exp == sorted(_lib._EXPERIMENTAL_SIGNATURES) and len(exp) >= 4
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    present = [n for n in exp if hasattr(handle, n)]
+    assert present in ([], exp), present
+    assert _lib.has_experiments() == bool(present)
+    assert not set(exp) & set(_declared())
+
+
 def test_python_binding_covers_the_header():
     assert sorted(_lib.exported_symbols()) == _declared()
     lib = _lib.lib()
-    assert lib.hx_abi_version() == 1
+    assert lib.hx_abi_version() == _lib.HX_ABI_VERSION == 2
     assert lib.hx_strerror(0) == b"ok"
     assert b"data type" in lib.hx_strerror(-1)
 

@@ -9,7 +9,11 @@ import torch
 
 from hydrainfer_amd._C.kernel import gemm as gemm_mod
 
-pytestmark = pytest.mark.gpu
+from hydrainfer_amd import _lib
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not (_lib.has_experiments() if __import__("os").path.exists(_lib.LIB_PATH) else False),
+                                 reason="decode_chain.hip is only in `make EXPERIMENTS=1` builds of libhydra_hip.so")]
 DEV = "cuda:0"
 
 
