@@ -45,6 +45,9 @@ def parse():
     p.add_argument("--batch", type=int, default=32)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--executor", default=os.environ.get("HX_DECODE_EXECUTOR", "graph"), choices=["graph", "plan", "plan-nochain"],
+                   help="replay of the decode step: one hipGraph, or a launch plan (native launch loop; 'plan' chains the "
+                        "five launches of every layer without the AQL barrier bit, dependencies taken inside the kernels)")
     p.add_argument("--skip-prefill", action="store_true",
                    help="decode against the randn-filled cache instead of a real prefill")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -818,7 +821,8 @@ def leg_13b(ctx, args, dtype, dev, rank):
     from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
     shape, name = model_shape("13b")
     prompt_len, n_generate = 704, 256
-    cfg = RunnerConfig(batch=args.batch, prompt_len=prompt_len, n_generate=n_generate, use_graph=not args.no_graph)
+    cfg = RunnerConfig(batch=args.batch, prompt_len=prompt_len, n_generate=n_generate, use_graph=not args.no_graph,
+                       executor=args.executor)
     model = LlamaForCausalLM.random_init(shape, dtype, dev, seed=0)
     model.use_hip_gemm = not args.lib_gemm
     model.prepare_decode(max_rows=args.batch, keep_row_major=True)
@@ -865,7 +869,7 @@ def main():
     steps = min(args.steps, n_generate - 1)
     ctxs = timed_contexts(prompt_len, n_generate, steps)
     cfg = RunnerConfig(batch=args.batch, prompt_len=prompt_len, n_generate=n_generate,
-                       use_graph=not args.no_graph)
+                       use_graph=not args.no_graph, executor=args.executor)
     model = LlamaForCausalLM.random_init(shape, dtype, dev, seed=0)
     model.use_hip_gemm = not args.lib_gemm
     if args.no_fused_attention:
@@ -965,7 +969,8 @@ def main():
             "config": {"workload": f"{model_name}-shaped random weights, batch {args.batch} "
                                    f"decode, paged KV block_size=16, {ctx_label(ctxs)} (BASELINE {configs_i})",
                        "global_batch": args.batch * n_gpus, "prompt_tokens": prompt_len,
-                       "generated_tokens": n_generate, "hip_graph": cfg.use_graph,
+                       "generated_tokens": n_generate, "hip_graph": cfg.use_graph and cfg.executor == "graph",
+                       "step_executor": cfg.executor if cfg.use_graph else "eager",
                        "parallelism": f"replicas x{n_gpus} (independent requests, no data-path collective)"},
             "roofline": roofline,
             "roofline_gemm": roofline_gemm,

@@ -68,6 +68,7 @@ class hx_chain_args(ctypes.Structure):
 
 HX_CHAIN_SYNC_WORDS, HX_CHAIN_SYNC_ERR = 18432, 480
 HX_XREG_SYNC_WORDS = 512
+HX_PLAN_SYNC_BYTES_PER_LAUNCH = 2048
 
 _SIGNATURES = {
     "hx_abi_version": (c_int, []),
@@ -122,6 +123,12 @@ _SIGNATURES = {
     "hx_moe_unpermute": (c_int, [c_void_p] * 4 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_moe_sum_out": (c_int, [c_void_p] * 2 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_void_p]),
+    "hx_plan_begin": (c_int, [POINTER(c_void_p), c_void_p, c_int64, c_void_p, c_int]),
+    "hx_plan_end": (c_int, [c_void_p]),
+    "hx_plan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
+    "hx_plan_launch": (c_int, [c_void_p, c_void_p]),
+    "hx_plan_destroy": (c_int, [c_void_p]),
+    "hx_memset_zero": (c_int, [c_void_p, c_int64, c_void_p]),
 }
 
 # Only in a library built with `make EXPERIMENTS=1` (include/hydra_hip_experimental.h): rejected experiments and
@@ -215,3 +222,11 @@ def require_gpu(*tensors: torch.Tensor) -> None:
 
 def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def memset_zero(t: torch.Tensor) -> None:
+    """t.zero_() as a launch the library knows about: recordable in a launch plan, capturable in a hipGraph."""
+    require_gpu(t)
+    if not t.is_contiguous():
+        raise HydraHipError("memset_zero: contiguous tensors only")
+    check(lib().hx_memset_zero(t.data_ptr(), t.numel() * t.element_size(), current_stream()), "memset_zero")

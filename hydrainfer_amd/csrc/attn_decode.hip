@@ -237,15 +237,20 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
       // the splits of column d in order and rounds once to T (the projection's output
       // rounding); the three rows are shared through LDS so every slab element is read once
       // per workgroup.
-      const float* row = p.qkv_partial + (int64_t)b * p.qkv_row;
+      // Launch chain: the K/V stream above is already in flight; only now does this workgroup need its
+      // predecessor (the qkv projection).  The slabs are read with sc1 loads: coherent with the write-through
+      // stores of a producer that may still have been running when this kernel was dispatched.
+      chain_wait(p.chain);
+      const chain_rsrc_t slabs = chain_rsrc(p.qkv_partial);
+      const int64_t row = (int64_t)b * p.qkv_row;
       const int64_t col0[3] = {(int64_t)h * D, (int64_t)p.n_heads * D + (int64_t)hk * D,
                                (int64_t)p.n_heads * D + (int64_t)(p.n_heads / p.group) * D + (int64_t)hk * D};
       if (threadIdx.x < D) {
 #pragma unroll
         for (int which = 0; which < 3; ++which) {
-          const float* src = row + col0[which] + threadIdx.x;
-          float acc = src[0];
-          for (int s = 1; s < p.qkv_splits; ++s) acc += src[s * p.qkv_slab_stride];
+          const int64_t src = row + col0[which] + threadIdx.x;
+          float acc = chain_load_f32(slabs, (uint32_t)(src * 4));
+          for (int s = 1; s < p.qkv_splits; ++s) acc += chain_load_f32(slabs, (uint32_t)((src + s * p.qkv_slab_stride) * 4));
           s_qkv[which][threadIdx.x] = T::from_float(acc);
         }
       }
@@ -369,8 +374,9 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
     }
     if (p.n_splits == 1) {
       const float r = (L > 0.f) ? O / L : 0.f;
-      reinterpret_cast<u16*>(p.out)[(int64_t)q_row * p.o_row_stride + (int64_t)h * D + d] =
-          T::from_float(r);
+      const int64_t oi = (int64_t)q_row * p.o_row_stride + (int64_t)h * D + d;
+      if (FUSE) chain_store_b16(chain_rsrc(p.out), (uint32_t)(oi * 2), T::from_float(r));   // write-through: read by the next launch of a chain
+      else reinterpret_cast<u16*>(p.out)[oi] = T::from_float(r);
     } else {
       const int64_t idx = ((int64_t)b * p.n_heads + h) * p.n_splits + split;
       p.ws_o[idx * D + d] = O;
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
       }
     }
   }
+  if (FUSE) chain_signal(p.chain);
 }
 
 // one workgroup of D threads per (head, sequence)
@@ -414,19 +421,26 @@ int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
   const int64_t pairs = (int64_t)batch * p.n_heads;
   const bool wide = pairs >= g_decode_small_lo && pairs <= g_decode_small_hi && p.n_splits == 1;
   if (p.k_new || p.qkv_partial) {
-    if (wide) attn_decode_kernel<T, D, 8, true, true><<<grid, 512, 0, stream>>>(p);
-    else attn_decode_kernel<T, D, 4, true, true><<<grid, 256, 0, stream>>>(p);
+    // chain-capable when the qkv slabs are its input and it writes the final output itself (no split + combine)
+    AttnParams pc = p;
+    uint32_t flags = 0;
+    const bool chain = p.qkv_partial && p.n_splits == 1;
+    if (chain) pc.chain = chain_next(grid.x * grid.y * grid.z, &flags);
+    if (wide) (chain ? hx::launcher_chained(attn_decode_kernel<T, D, 8, true, true>, grid, 512, 0, stream, flags)
+                     : hx::launcher(attn_decode_kernel<T, D, 8, true, true>, grid, 512, 0, stream))(pc);
+    else (chain ? hx::launcher_chained(attn_decode_kernel<T, D, 4, true, true>, grid, 256, 0, stream, flags)
+                : hx::launcher(attn_decode_kernel<T, D, 4, true, true>, grid, 256, 0, stream))(pc);
   } else if (g_decode_waves == 8 || wide) {
-    if (g_decode_nt) attn_decode_kernel<T, D, 8, true, false><<<grid, 512, 0, stream>>>(p);
-    else attn_decode_kernel<T, D, 8, false, false><<<grid, 512, 0, stream>>>(p);
+    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 8, true, false>, grid, 512, 0, stream)(p);
+    else hx::launcher(attn_decode_kernel<T, D, 8, false, false>, grid, 512, 0, stream)(p);
   } else {
-    if (g_decode_nt) attn_decode_kernel<T, D, 4, true, false><<<grid, 256, 0, stream>>>(p);
-    else attn_decode_kernel<T, D, 4, false, false><<<grid, 256, 0, stream>>>(p);
+    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 4, true, false>, grid, 256, 0, stream)(p);
+    else hx::launcher(attn_decode_kernel<T, D, 4, false, false>, grid, 256, 0, stream)(p);
   }
   int rc = check_launch();
   if (rc) return rc;
   if (p.n_splits > 1) {
-    attn_decode_combine_kernel<T, D><<<dim3(p.n_heads, batch), D, 0, stream>>>(p);
+    hx::launcher(attn_decode_combine_kernel<T, D>, dim3(p.n_heads, batch), D, 0, stream)(p);
     rc = check_launch();
   }
   return rc;
@@ -450,7 +464,7 @@ bool decode_supported(int head_dim) { return head_dim == 64 || head_dim == 128 |
 int launch_decode_combine(const AttnParams& p, int batch, int head_dim, int dtype, hipStream_t stream) {
   const dim3 grid(p.n_heads, batch);
 #define HX_COMBINE_CASE(TT, DD) \
-  case DD: attn_decode_combine_kernel<TT, DD><<<grid, DD, 0, stream>>>(p); break;
+  case DD: hx::launcher(attn_decode_combine_kernel<TT, DD>, grid, DD, 0, stream)(p); break;
   if (dtype == HX_F16) {
     switch (head_dim) { HX_COMBINE_CASE(F16, 64) HX_COMBINE_CASE(F16, 128) HX_COMBINE_CASE(F16, 256) default: return HX_ERR_SHAPE; }
   } else if (dtype == HX_BF16) {

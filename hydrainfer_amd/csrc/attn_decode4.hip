@@ -319,11 +319,11 @@ int launch_attn_decode4(const AttnParams& p, int batch, int dtype, hipStream_t s
   const dim3 grid(p.n_heads / 4, batch);
   const bool fuse = p.k_new || p.qkv_partial;
   if (dtype == HX_F16) {
-    if (fuse) attn_decode4_kernel<F16, true><<<grid, NW4 * 64, 0, stream>>>(p);
-    else attn_decode4_kernel<F16, false><<<grid, NW4 * 64, 0, stream>>>(p);
+    if (fuse) hx::launcher(attn_decode4_kernel<F16, true>, grid, NW4 * 64, 0, stream)(p);
+    else hx::launcher(attn_decode4_kernel<F16, false>, grid, NW4 * 64, 0, stream)(p);
   } else if (dtype == HX_BF16) {
-    if (fuse) attn_decode4_kernel<BF16, true><<<grid, NW4 * 64, 0, stream>>>(p);
-    else attn_decode4_kernel<BF16, false><<<grid, NW4 * 64, 0, stream>>>(p);
+    if (fuse) hx::launcher(attn_decode4_kernel<BF16, true>, grid, NW4 * 64, 0, stream)(p);
+    else hx::launcher(attn_decode4_kernel<BF16, false>, grid, NW4 * 64, 0, stream)(p);
   } else {
     return HX_ERR_DTYPE;
   }

@@ -237,7 +237,7 @@ int launch_gqa(const AttnParams& p, int batch, int dtype, hipStream_t stream) {
     if (e != hipSuccess) return hip_rc(e);
   }
   dim3 grid(p.n_heads / p.group, batch, p.n_splits);
-  attn_decode_gqa_kernel<T, D><<<grid, NW * 64, lds, stream>>>(p);
+  hx::launcher(attn_decode_gqa_kernel<T, D>, grid, NW * 64, lds, stream)(p);
   int rc = check_launch();
   if (rc || p.n_splits == 1) return rc;
   return launch_decode_combine(p, batch, D, dtype, stream);

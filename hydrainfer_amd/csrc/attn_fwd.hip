@@ -609,7 +609,7 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  attn_fwd32_kernel<T, D, PAGED><<<grid, 256, lds, stream>>>(p);
+  hx::launcher(attn_fwd32_kernel<T, D, PAGED>, grid, 256, lds, stream)(p);
   return check_launch();
 }
 
@@ -627,7 +627,7 @@ int launch_fwd_cfg(const AttnParams& p, int batch, int max_seqlen_q, hipStream_t
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  attn_fwd_kernel<T, D, PAGED, QR, KU><<<grid, 256, lds, stream>>>(p);
+  hx::launcher(attn_fwd_kernel<T, D, PAGED, QR, KU>, grid, 256, lds, stream)(p);
   return check_launch();
 }
 

@@ -77,7 +77,7 @@ int launch_scatter(const int32_t* slot_ids, const void* s0, const void* s1, void
       const int vpr = (int)(row_bytes / 16);
       dim3 grid((vpr + 255) / 256, (unsigned)nt);
       const int64_t epv = 16 / es;
-      scatter_rows_vec16<NCACHE><<<grid, 256, 0, stream>>>(
+      hx::launcher(scatter_rows_vec16<NCACHE>, grid, 256, 0, stream)(
           sl, (const uint4*)((const char*)s0 + t0 * s0_stride * es),
           NCACHE == 2 ? (const uint4*)((const char*)s1 + t0 * s1_stride * es) : nullptr,
           (uint4*)d0, (uint4*)d1, s0_stride / epv, s1_stride / epv, d0_bstride / epv,
@@ -86,13 +86,13 @@ int launch_scatter(const int32_t* slot_ids, const void* s0, const void* s1, void
       dim3 grid((unsigned)((row_elems + 255) / 256 > 64 ? 64 : (row_elems + 255) / 256),
                 (unsigned)nt);
       if (es == 2) {
-        scatter_rows_elem<uint16_t, NCACHE><<<grid, 256, 0, stream>>>(
+        hx::launcher(scatter_rows_elem<uint16_t, NCACHE>, grid, 256, 0, stream)(
             sl, (const uint16_t*)s0 + t0 * s0_stride,
             NCACHE == 2 ? (const uint16_t*)s1 + t0 * s1_stride : nullptr, (uint16_t*)d0,
             (uint16_t*)d1, s0_stride, s1_stride, d0_bstride, d1_bstride, (int)row_elems,
             (int)block_size);
       } else {
-        scatter_rows_elem<uint32_t, NCACHE><<<grid, 256, 0, stream>>>(
+        hx::launcher(scatter_rows_elem<uint32_t, NCACHE>, grid, 256, 0, stream)(
             sl, (const uint32_t*)s0 + t0 * s0_stride,
             NCACHE == 2 ? (const uint32_t*)s1 + t0 * s1_stride : nullptr, (uint32_t*)d0,
             (uint32_t*)d1, s0_stride, s1_stride, d0_bstride, d1_bstride, (int)row_elems,
@@ -182,7 +182,7 @@ extern "C" int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* 
       !cu_block_lens)
     return HX_ERR_NULL;
   if (batch <= 0 || block_size <= 0) return HX_ERR_SHAPE;
-  decode_advance_kernel<<<1, 256, 0, (hipStream_t)stream>>>(positions, kv_lens, cu_seqlens_k,
+  hx::launcher(decode_advance_kernel, 1, 256, 0, (hipStream_t)stream)(positions, kv_lens, cu_seqlens_k,
                                                             new_cache_slots, block_table,
                                                             cu_block_lens, batch, block_size);
   return hx::check_launch();

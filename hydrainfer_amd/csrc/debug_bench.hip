@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const char* __restrict
 
 template <int U>
 int launch_u(const void* p, int64_t bytes, int variant, int64_t pitch, int policy, int wgs, float* sink, hipStream_t s) {
-  if (policy) stream_read_kernel<U, 1><<<wgs, 256, 0, s>>>((const char*)p, bytes, variant, pitch, sink);
-  else stream_read_kernel<U, 0><<<wgs, 256, 0, s>>>((const char*)p, bytes, variant, pitch, sink);
+  if (policy) hx::launcher(stream_read_kernel<U, 1>, wgs, 256, 0, s)((const char*)p, bytes, variant, pitch, sink);
+  else hx::launcher(stream_read_kernel<U, 0>, wgs, 256, 0, s)((const char*)p, bytes, variant, pitch, sink);
   return check_launch();
 }
 
@@ -123,7 +123,7 @@ extern "C" int hx_debug_paged_read(const void* kbase, const void* vbase, const i
   hipStream_t s = (hipStream_t)stream;
 #define HX_P(HPW, NW, DP)                                                                                          \
   if (heads_per_wg == HPW && waves == NW && depth == DP) {                                                         \
-    paged_read_kernel<HPW, NW, DP><<<grid, NW * 64, 0, s>>>((const char*)kbase, (const char*)vbase, table, tiles, n_splits, \
+    hx::launcher(paged_read_kernel<HPW, NW, DP>, grid, NW * 64, 0, s)((const char*)kbase, (const char*)vbase, table, tiles, n_splits, \
                                                             page_bytes, row_bytes, sink);                          \
     return check_launch();                                                                                         \
   }

@@ -685,8 +685,8 @@ extern "C" int hx_decode_chain(const hx_chain_args* a, hx_stream stream) {
     n_cu = prop.multiProcessorCount;
   }
   const int grid = total < 2 * n_cu ? total : 2 * n_cu;
-  if (a->dtype == HX_F16) decode_chain_kernel<F16><<<grid, kThreads, kLdsBytes, s>>>(p);
-  else decode_chain_kernel<BF16><<<grid, kThreads, kLdsBytes, s>>>(p);
+  if (a->dtype == HX_F16) hx::launcher(decode_chain_kernel<F16>, grid, kThreads, kLdsBytes, s)(p);
+  else hx::launcher(decode_chain_kernel<BF16>, grid, kThreads, kLdsBytes, s)(p);
   int rc = check_launch();
   if (rc) return rc;
   return a->qkv_n ? p.desc[D_QKV].n_splits : 0;

@@ -36,6 +36,7 @@ struct GemmParams {
   int32_t ks_per_split;  // k-steps (of 32) per split, multiple of 8
   int32_t n_splits;
   int32_t packed;        // w is in fragment order (hx_pack_decode_weight)
+  ChainLink chain;       // launch chain (packed kernel only; zeros otherwise): x is the predecessor's output
 };
 
 constexpr int kChunk = 16;       // k-steps per register buffer (16 KiB of W per wave)
@@ -188,7 +189,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
   constexpr int kCpr = kMaxKs * 4;
   constexpr int XPT = MB * 16 * kCpr / kThreads;
   u16x8 xr[XPT];
-  {
+  // in a launch chain x is the output of a launch that may still be running: it is read AFTER the weights have
+  // been requested and the predecessor's done flag has been seen (below); otherwise first, as always
+  const bool x_late = p.chain.wait != nullptr;
+  if (!x_late) {
     const u16* xb = reinterpret_cast<const u16*>(p.x) + (int64_t)ks0 * 32;
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {
@@ -219,6 +223,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
   load(buf[0], 0);
   load(buf[1], 1);
   __builtin_amdgcn_sched_barrier(0);
+  if (x_late) {
+    chain_wait(p.chain);
+    const chain_rsrc_t xrs = chain_rsrc(p.x);
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+      const int i = threadIdx.x + j * kThreads;
+      const int row = i / kCpr, ch = i % kCpr;
+      const bool ok = row < p.M && ch * 8 < KR;
+      xr[j] = __builtin_bit_cast(u16x8, chain_load_b128(xrs, (uint32_t)((((int64_t)(ok ? row : 0) * p.ldx + (int64_t)ks0 * 32 + (ok ? ch * 8 : 0))) * 2)));
+    }
+  }
 #pragma unroll
   for (int j = 0; j < XPT; ++j) {
     const int i = threadIdx.x + j * kThreads;
@@ -259,14 +274,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
       for (int mb = 0; mb < MB; ++mb) {
         const int m = mb * 16 + c;
         if (m < p.M && rg < n_rg_all && !((DBG & 2) && acc[mb][0] != 123.25f)) {   // bit 1: ablation, no stores
-          f32x4* dst = reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g);
-          if (g_nt_store & 1) __builtin_nontemporal_store(acc[mb], dst);
+          const int64_t di = ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g;
+          f32x4* dst = reinterpret_cast<f32x4*>(p.partial + di);
+          if (p.chain.signal) chain_store_b128(chain_rsrc(p.partial), (uint32_t)(di * 4), __builtin_bit_cast(u32x4, acc[mb]));   // write-through: a chained consumer reads it
+          else if (g_nt_store & 1) __builtin_nontemporal_store(acc[mb], dst);
           else *dst = acc[mb];
         }
         acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
+  chain_signal(p.chain);
 }
 
 // fragment (rg, s) of split = s / kMaxKs lives at KiB index ks0 * n_rg + rg * nks + (s - ks0)
@@ -341,11 +359,14 @@ int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
       if (e != hipSuccess) return hip_rc(e);
     }
     if (MB == 2 && (g_slab_nt >> 1)) {   // ablation variants (tools/gemm_ablate.py), batch 17..32 only
-      if ((g_slab_nt >> 1) == 1) gemm_packed_kernel<T, MB, R, NW, 2><<<grid, NW * 64, plds, stream>>>(p, g_slab_nt & 1);
-      else gemm_packed_kernel<T, MB, R, NW, 14><<<grid, NW * 64, plds, stream>>>(p, g_slab_nt & 1);
+      if ((g_slab_nt >> 1) == 1) hx::launcher(gemm_packed_kernel<T, MB, R, NW, 2>, grid, NW * 64, plds, stream)(p, g_slab_nt & 1);
+      else hx::launcher(gemm_packed_kernel<T, MB, R, NW, 14>, grid, NW * 64, plds, stream)(p, g_slab_nt & 1);
       return check_launch();
     }
-    gemm_packed_kernel<T, MB, R, NW><<<grid, NW * 64, plds, stream>>>(p, g_slab_nt & 1);
+    GemmParams pc = p;
+    uint32_t flags = 0;
+    pc.chain = chain_next(grid.x * grid.y, &flags);      // zeros outside a chained plan recording
+    hx::launcher_chained(gemm_packed_kernel<T, MB, R, NW>, grid, NW * 64, plds, stream, flags)(pc, g_slab_nt & 1);
     return check_launch();
   }
   const size_t lds = (size_t)MB * 16 * kRS + (size_t)NW * 2048;   // x slice + per-wave transpose images
@@ -354,7 +375,7 @@ int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  gemm_skinny_kernel<T, MB, R, NW><<<grid, NW * 64, lds, stream>>>(p, g_slab_nt);
+  hx::launcher(gemm_skinny_kernel<T, MB, R, NW>, grid, NW * 64, lds, stream)(p, g_slab_nt);
   return check_launch();
 }
 
@@ -421,6 +442,7 @@ int launch_gemm_skinny(const void* x, const void* w, float* partial, int64_t M, 
   if (!gemm_skinny_supported(M, N, K, ldx, ldw)) return HX_ERR_SHAPE;
   if (!aligned16(x) || !aligned16(w) || !aligned16(partial)) return HX_ERR_STRIDE;
   GemmParams p;
+  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x; p.w = w; p.partial = partial; p.ldx = ldx; p.ldw = ldw;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.ks_per_split = kMaxKs;
@@ -445,9 +467,9 @@ int launch_slab_reduce(const float* partial, void* out, int64_t M, int64_t N, in
   const int64_t mn = M * N;
   const unsigned blocks = (unsigned)((mn / 4 + 255) / 256);
   if (dtype == HX_F16)
-    slab_reduce_kernel<F16><<<blocks, 256, 0, stream>>>(partial, (u16*)out, mn, n_splits, N, ldo);
+    hx::launcher(slab_reduce_kernel<F16>, blocks, 256, 0, stream)(partial, (u16*)out, mn, n_splits, N, ldo);
   else if (dtype == HX_BF16)
-    slab_reduce_kernel<BF16><<<blocks, 256, 0, stream>>>(partial, (u16*)out, mn, n_splits, N, ldo);
+    hx::launcher(slab_reduce_kernel<BF16>, blocks, 256, 0, stream)(partial, (u16*)out, mn, n_splits, N, ldo);
   else
     return HX_ERR_DTYPE;
   return check_launch();
@@ -499,7 +521,7 @@ extern "C" int hx_pack_decode_weight(void* packed, const void* weight, int64_t N
   if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
   if (!aligned16(packed) || !aligned16(weight)) return HX_ERR_STRIDE;
   const int64_t n_pieces = N * K / 8;
-  pack_weight_kernel<<<(unsigned)((n_pieces + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+  hx::launcher(pack_weight_kernel, (unsigned)((n_pieces + 255) / 256), 256, 0, (hipStream_t)stream)(
       (u16*)packed, (const u16*)weight, n_pieces, (int)(K >> 5), (int)(N >> 4), ldw);
   return check_launch();
 }

@@ -58,6 +58,8 @@ struct XregParams {
   int32_t nm_splits;
   float nm_eps;
   void* act;            // EPI = 1: silu(gate)*up, fragment-major [inter/32][MB][64 lanes][8]
+  ChainLink chain;      // launch chain (hx_common.h): x resp. the slabs / residual of the NORM form come from the
+                        // predecessor launch; the slabs / act written here go to the successor
 };
 
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
@@ -89,7 +91,10 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
   const int nvec = hidden / 8;
   uint32_t claimed = 1;
   if (tid == 0) claimed = __hip_atomic_exchange(state + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  u16x8* res_v = reinterpret_cast<u16x8*>(residual + (int64_t)row * hidden);
+  // the slabs and the residual stream are handed over between launches that may overlap (launch chain): sc1 loads
+  // (coherent across the XCDs' L2s) and write-through stores, always — they are a few KiB per row
+  const rsrc_t res_rs = make_rsrc(residual + (int64_t)row * hidden);
+  const rsrc_t par_rs = make_rsrc(partial);
   const u16x8* w_v = reinterpret_cast<const u16x8*>(weight);
   const rsrc_t xrs = make_rsrc(x_frag);
   float x[2 * MAXV][8];
@@ -100,7 +105,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
       const int i = min(tid + 256 * v + 512 * j, nvec - 1);
-      rr[v * MAXV + j] = res_v[i];
+      rr[v * MAXV + j] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (uint32_t)i * 16, 0, 16));
       ww[v * MAXV + j] = w_v[i];
     }
 #pragma unroll
@@ -111,7 +116,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
       if (i < nvec) {
         // slab pieces: all loads of a batch of 6 splits before the first add, adds in split order
         // (norm_rope_act.hip slab_sum8)
-        const float* pp = partial + (int64_t)row * hidden + i * 8;
+        const uint32_t pp = (uint32_t)(((int64_t)row * hidden + i * 8) * 4);   // byte offset into the slabs
         constexpr int kB = 6;
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
         for (int s0 = 0; s0 < n_splits; s0 += kB) {
@@ -119,8 +124,8 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
 #pragma unroll
           for (int k = 0; k < kB; ++k) {
             const int sp = min(s0 + k, n_splits - 1);
-            pa[k] = *reinterpret_cast<const f32x4*>(pp + sp * slab_stride);
-            pb[k] = *reinterpret_cast<const f32x4*>(pp + sp * slab_stride + 4);
+            pa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(par_rs, pp + (uint32_t)(sp * slab_stride * 4), 0, 16));
+            pb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(par_rs, pp + (uint32_t)(sp * slab_stride * 4) + 16, 0, 16));
           }
 #pragma unroll
           for (int k = 0; k < kB; ++k) {
@@ -160,7 +165,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
       for (int j = 0; j < MAXV; ++j) {
         const int i = tid + 256 * v + 512 * j;
         if (i < nvec) {
-          res_v[i] = hh[v * MAXV + j];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, hh[v * MAXV + j]), res_rs, (uint32_t)i * 16, 0, 16);
           const u16x8 w = ww[v * MAXV + j];
           u16x8 o;
 #pragma unroll
@@ -275,8 +280,13 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
     //    loads and the store drain are not queued behind weight loads — prefetching first cost the whole gain)
     const int flat = blockIdx.y * gridDim.x + blockIdx.x;
     const int n_wg = gridDim.x * gridDim.y;
-    if (flat < p.M && !(p.stagger & 6))   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
+    // launch chain: the slabs and the residual are the predecessor launch's output — a workgroup that computes a row
+    // first waits for that launch's done flag (the others never need it: the x flag below implies it)
+    bool pred_seen = p.chain.wait == nullptr;
+    if (flat < p.M && !(p.stagger & 6)) {   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
+      if (!pred_seen) { chain_wait(p.chain); pred_seen = true; }
       for (int row = flat; row < p.M; row += n_wg) produce(row);   // several rows only when N is tiny
+    }
     // 2. everyone: weight prefetch (independent of x)
 #pragma unroll
     for (int q = 0; q < NBUF; ++q) load_buf(rg_of(0), q);
@@ -319,6 +329,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       const int c = *cmd;
       __syncthreads();
       if (c < 0) break;
+      if (!pred_seen) { chain_wait(p.chain); pred_seen = true; }
       produce(c);
     }
     asm volatile("" ::: "memory");
@@ -336,6 +347,27 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
           xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
               ok ? xrs : zrs, ok ? (uint32_t)((ks * MB + mb) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, 16));
         }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  } else if (p.chain.wait != nullptr && p.x_packed) {
+    // launch chain: x is the predecessor launch's output.  All weight buffers first (32 KiB per wave in flight),
+    // then its done flag, then x with sc1 loads
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) load_buf(rg_of(0), q);
+    __builtin_amdgcn_sched_barrier(0);
+    chain_wait(p.chain);
+    {
+      const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
+#pragma unroll
+      for (int t = 0; t < KW; ++t) {
+        const int r = rot(t);
+        const bool ok = r < kw;
+        const int ks = min(ks0 + w * KW + r, total_ks - 1);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
+              ok ? xrs : zrs, ok ? (uint32_t)((ks * MB + mb) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, 16));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -394,7 +426,11 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       const int i = pr / MB, mb = pr - i * MB;
       const f32x4 s = tile_sum(i, mb);
       const int m = mb * 16 + c;
-      if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg_of(i) << 4) + 4 * g) = s;
+      if (m < p.M) {
+        const int64_t di = ((int64_t)split * p.M + m) * p.N + (rg_of(i) << 4) + 4 * g;
+        if (p.chain.signal) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, s), make_rsrc(p.partial), (uint32_t)(di * 4), 0, 16);
+        else *reinterpret_cast<f32x4*>(p.partial + di) = s;
+      }
     }
   } else {
     for (int pr = w; pr < (G >> 1) * MB; pr += 4) {
@@ -406,10 +442,12 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
         r[e] = T::from_float(round_to<T>(silu_f32(round_to<T>(gt[e]))) * round_to<T>(up[e]));
       // act[m = 16mb + c][k = 16j + 4g + e], j = pair index: piece ((k/32)*MB + mb)*64 + ((k%32)/8)*16 + c, element k%8
       const int k = 16 * (b + ip * nb) + 4 * g;
-      u16* dst = reinterpret_cast<u16*>(p.act) + ((((int64_t)(k >> 5) * MB + mb) * 64 + ((k & 31) >> 3) * 16 + c) << 3) + (k & 7);
-      *reinterpret_cast<u16x4*>(dst) = r;
+      const int64_t ai = ((((int64_t)(k >> 5) * MB + mb) * 64 + ((k & 31) >> 3) * 16 + c) << 3) + (k & 7);
+      if (p.chain.signal) chain_store_b64(make_rsrc(p.act), (uint32_t)(ai * 2), __builtin_bit_cast(u32x2, r));
+      else *reinterpret_cast<u16x4*>(reinterpret_cast<u16*>(p.act) + ai) = r;
     }
   }
+  chain_signal(p.chain);
 }
 
 // output piece i (16 bytes) of the packed tensor <- its source in the row-major weight
@@ -521,12 +559,19 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
   }
   const dim3 grid((unsigned)nb, (unsigned)S);
   if constexpr (EPI == 0 && NORM == 0 && MB == 2 && (KW == 32 || KW == 29)) if (g_dbg) {   // ablation variants (tools/bench_gemm_xreg.py OPTS=xreg_dbg=..)
-    if (g_dbg == 1) gemm_xreg_kernel<T, MB, KW, 0, 1><<<grid, 256, lds, stream>>>(p);
-    else if (g_dbg == 2) gemm_xreg_kernel<T, MB, KW, 0, 2><<<grid, 256, lds, stream>>>(p);
-    else gemm_xreg_kernel<T, MB, KW, 0, 3><<<grid, 256, lds, stream>>>(p);
+    if (g_dbg == 1) hx::launcher(gemm_xreg_kernel<T, MB, KW, 0, 1>, grid, 256, lds, stream)(p);
+    else if (g_dbg == 2) hx::launcher(gemm_xreg_kernel<T, MB, KW, 0, 2>, grid, 256, lds, stream)(p);
+    else hx::launcher(gemm_xreg_kernel<T, MB, KW, 0, 3>, grid, 256, lds, stream)(p);
     return check_launch();
   }
-  gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM><<<grid, 256, lds, stream>>>(p);
+  if (NORM || p.x_packed) {   // chain-capable: its input is handed over with sc1 loads (fragment-major x / the NORM form)
+    XregParams pc = p;
+    uint32_t flags = 0;
+    pc.chain = chain_next((uint32_t)(nb * S), &flags);      // zeros outside a chained plan recording
+    hx::launcher_chained(gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>, grid, 256, lds, stream, flags)(pc);
+  } else {
+    hx::launcher(gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>, grid, 256, lds, stream)(p);
+  }
   return check_launch();
 }
 
@@ -604,7 +649,7 @@ extern "C" int hx_pack_decode_weight_xreg(void* packed, const void* weight, int6
   xreg_plan(N, K, &S, &KW, interleave_halves != 0);
   if (KW <= 0) return HX_ERR_SHAPE;
   const int64_t n_pieces = N * K / 8;
-  pack_xreg_kernel<<<(unsigned)((n_pieces + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+  hx::launcher(pack_xreg_kernel, (unsigned)((n_pieces + 255) / 256), 256, 0, (hipStream_t)stream)(
       (u16*)packed, (const u16*)weight, n_pieces, (int)(K >> 5), (int)(N >> 4), ldw, 4 * KW, interleave_halves ? 1 : 0);
   return check_launch();
 }
@@ -620,6 +665,7 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   int S, KW;
   xreg_plan(N, K, &S, &KW);
   XregParams p;
+  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
@@ -644,6 +690,7 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   int S, KW;
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
+  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
@@ -683,6 +730,7 @@ extern "C" int hx_norm_linear_decode_xreg(float* partial, void* residual, const 
   int S, KW;
   xreg_plan(N, K, &S, &KW);
   XregParams p;
+  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x_frag; p.w = packed_weight; p.partial = partial; p.ldx = K; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
@@ -704,6 +752,7 @@ extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float*
   int S, KW;
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
+  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x_frag; p.w = packed_gate_up; p.partial = nullptr; p.ldx = K; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;

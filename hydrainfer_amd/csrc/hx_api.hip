@@ -179,6 +179,7 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   if (a->total_q == 0) return HX_OK;
 
   AttnParams p;
+  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.out = a->out;
   p.q = a->q;
   p.k = a->k;

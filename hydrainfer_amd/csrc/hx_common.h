@@ -1,7 +1,11 @@
 // hx_common.h — shared device/host helpers for libhydra_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+#include <memory>
+#include <tuple>
+#include <utility>
 #include "../../include/hydra_hip.h"
 #include "../../include/hydra_hip_experimental.h"   // declarations only; defined in EXPERIMENTS=1 builds
 #ifndef HX_EXPERIMENTS
@@ -30,6 +34,81 @@ inline int hip_rc(hipError_t e) {
     return HX_ERR_HIP;
   }
   return HX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel launches.  Every launch of the library goes through hx::launcher(kernel, grid, block, lds, stream)(args...)
+// instead of kernel<<<...>>>(args...): outside a recording it is the same hipLaunchKernel call; while a launch plan is
+// being recorded on this thread (hx_plan_begin .. hx_plan_end, csrc/launch_plan.hip) the launch is appended to the
+// plan — kernel, geometry and a private copy of its arguments — and NOT executed; hx_plan_launch replays the list.
+//
+// Why the library has its own replay mechanism next to hipGraph: a captured hipGraph always puts the AQL barrier
+// bit between consecutive kernels, so a kernel's workgroups are dispatched only after its predecessor has drained
+// completely (~2 us of idle HBM plus the ramp, five times per decoder layer).  A plan can launch a kernel with
+// hipExtAnyOrderLaunch (barrier bit cleared: the command processor dispatches its workgroups, in queue order, as
+// soon as the predecessor's LAST workgroup has been dispatched, i.e. while that one is still running); the data
+// dependency is then taken inside the kernel (ChainLink below): weight / KV prefetch first, then wait for the
+// predecessor's done flag, then consume its output.  Measured: tools/probes/probe_chain2.hip, DESIGN.md §6d.
+// ---------------------------------------------------------------------------------------------------------
+struct ChainLink {
+  const uint32_t* wait;    // sync area of the predecessor launch (nullptr: nothing to wait for)
+  uint32_t* signal;        // sync area of this launch (nullptr: nobody waits for it)
+  uint32_t* err;           // word set to 1 if a wait gives up (1 s): the step's results are invalid
+  uint32_t signal_total;   // workgroups of this launch
+  uint32_t reserved;
+};
+constexpr int kChainWords = 512;        // per launch: 8 arrival-count lines + 8 flag lines of 32 words (one pair per XCD)
+constexpr int kChainFlagWord = 256;
+
+struct ArgHolderBase {
+  virtual ~ArgHolderBase() = default;
+  virtual void** argv() = 0;
+};
+template <typename... P>
+struct ArgHolder final : ArgHolderBase {
+  std::tuple<P...> t;
+  void* ptrs[sizeof...(P) ? sizeof...(P) : 1];
+  explicit ArgHolder(const P&... a) : t(a...) { fill(std::index_sequence_for<P...>{}); }
+  template <size_t... I> void fill(std::index_sequence<I...>) { ((ptrs[I] = (void*)&std::get<I>(t)), ...); }
+  void** argv() override { return ptrs; }
+};
+
+struct PlanRecorder;
+PlanRecorder* recording();       // the plan being recorded on this thread, or nullptr
+void record_launch(PlanRecorder* r, const void* func, dim3 grid, dim3 block, size_t lds, uint32_t flags,
+                   std::unique_ptr<ArgHolderBase> args, bool chained);
+// Next link of the launch chain being recorded (zeros outside a chained recording).  *flags gets
+// hipExtAnyOrderLaunch when the launch has a predecessor to wait for.
+ChainLink chain_next(uint32_t n_workgroups, uint32_t* flags);
+
+template <typename... P>
+struct Launcher {
+  void (*kernel)(P...);
+  dim3 grid, block;
+  size_t lds;
+  hipStream_t stream;
+  uint32_t flags;
+  bool chained;
+  void operator()(P... a) const {
+    if (PlanRecorder* r = recording()) {
+      record_launch(r, (const void*)kernel, grid, block, lds, flags,
+                    std::unique_ptr<ArgHolderBase>(new ArgHolder<P...>(a...)), chained);
+      return;
+    }
+    void* argv[sizeof...(P) ? sizeof...(P) : 1] = {(void*)&a...};
+    (void)hipLaunchKernel((const void*)kernel, grid, block, argv, lds, stream);   // errors: hipGetLastError (check_launch)
+  }
+};
+// a launch that takes no part in a chain (it ends one: its successor is launched in stream order again)
+template <typename... P>
+inline Launcher<P...> launcher(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t stream) {
+  return Launcher<P...>{kernel, grid, block, lds, stream, 0u, false};
+}
+// a launch whose kernel implements the ChainLink protocol (flags from chain_next)
+template <typename... P>
+inline Launcher<P...> launcher_chained(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                                       uint32_t flags) {
+  return Launcher<P...>{kernel, grid, block, lds, stream, flags, true};
 }
 
 inline int64_t dtype_size(int dtype) {
@@ -105,6 +184,82 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Device side of a launch chain (see ChainLink).  Protocol of a chained kernel:
+//   1. issue every load that does not depend on the predecessor (weights, KV pages, block tables);
+//   2. chain_wait(link)  — all threads; the first wave polls this XCD's flag line of the predecessor's area;
+//   3. read the predecessor's output with chain_load* (sc1: served past the CU's L1 and coherent across the XCDs'
+//      L2s), write its own output with chain_store* (sc1: written through);
+//   4. chain_signal(link) — all threads: drain the stores, then thread 0 counts the workgroup in on its XCD's
+//      line; whoever sees all of them arrived raises the eight flag lines.
+// Progress: a chained kernel's workgroups are dispatched only after ALL of its predecessor's have been (one
+// in-order queue), so a waiter never holds a resource its producer still needs.  A wait is bounded (1 s of the
+// 100 MHz clock): on give-up the error word is set and the kernel continues — never a hung GPU; the host
+// checks the word with the step's tokens.
+// ---------------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t chain_rsrc_t;
+__device__ __forceinline__ chain_rsrc_t chain_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+constexpr int kSc1 = 16;   // aux bit of the buffer intrinsics on gfx94x/gfx950: sc1 (agent-coherent, write-through)
+__device__ __forceinline__ u32x4 chain_load_b128(chain_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kSc1));
+}
+__device__ __forceinline__ void chain_store_b128(chain_rsrc_t r, uint32_t byte_off, u32x4 v) {
+  typedef unsigned int bu32x4_ __attribute__((__vector_size__(16)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4_, v), r, byte_off, 0, kSc1);
+}
+__device__ __forceinline__ void chain_store_b64(chain_rsrc_t r, uint32_t byte_off, u32x2 v) {
+  typedef unsigned int bu32x2_ __attribute__((__vector_size__(8)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bu32x2_, v), r, byte_off, 0, kSc1);
+}
+__device__ __forceinline__ void chain_store_b16(chain_rsrc_t r, uint32_t byte_off, u16 v) {
+  __builtin_amdgcn_raw_buffer_store_b16((short)v, r, byte_off, 0, kSc1);
+}
+__device__ __forceinline__ float chain_load_f32(chain_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, kSc1));
+}
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7; }   // HW_REG_XCC_ID
+
+__device__ __forceinline__ void chain_wait(const ChainLink& ch) {
+  if (ch.wait) {
+    if (threadIdx.x < 64) {
+      const uint32_t* fl = ch.wait + kChainFlagWord + 32 * xcc_id();
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+      while (!__builtin_amdgcn_readfirstlane(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {   // 1 s: report, never hang
+          if (threadIdx.x == 0) __hip_atomic_fetch_or(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void chain_signal(const ChainLink& ch) {
+  if (ch.signal) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached memory
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // the add returns (its old value is consumed) before the eight counts are read, so the workgroup whose add
+      // completes last is certain to read the full total
+      const uint32_t old = __hip_atomic_fetch_add(ch.signal + 32 * xcc_id(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(old) : "memory");   // the returned value is waited for here; nothing below moves above
+      uint32_t sum = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += __hip_atomic_load(ch.signal + 32 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sum == ch.signal_total) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          __hip_atomic_store(ch.signal + kChainFlagWord + 32 * i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 }  // namespace hx

@@ -71,7 +71,7 @@ int launch_copy(const int32_t* src_tbl, const int32_t* dst_tbl, int64_t n_pairs,
     // staging buffers are indexed by absolute pair index: shift their base per chunk
     const char* s = (const char*)src + (src_staging ? p0 * block_bytes : 0);
     char* d = (char*)dst + (dst_staging ? p0 * block_bytes : 0);
-    gather_copy_blocks<<<dim3(gx, (unsigned)np, (unsigned)n_planes), 256, 0, stream>>>(
+    hx::launcher(gather_copy_blocks, dim3(gx, (unsigned)np, (unsigned)n_planes), 256, 0, stream)(
         tbl, s, d, src_plane_bytes, dst_plane_bytes, block_bytes, src_staging ? 1 : 0,
         dst_staging ? 1 : 0);
     int rc = check_launch();

@@ -301,7 +301,7 @@ extern "C" int hx_topk_softmax(const float* gating_logits, float* topk_weights,
     return HX_ERR_SHAPE;
   if (n_tokens == 0) return HX_OK;
   if (!gating_logits || !topk_weights || !topk_indices) return HX_ERR_NULL;
-  topk_softmax_kernel<<<(unsigned)((n_tokens + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+  hx::launcher(topk_softmax_kernel, (unsigned)((n_tokens + 3) / 4), 256, 0, (hipStream_t)stream)(
       gating_logits, topk_weights, topk_indices, n_tokens, (int)n_experts, (int)topk);
   return check_launch();
 }
@@ -319,7 +319,7 @@ extern "C" int hx_grouped_topk_sigmoid(const float* gating_logits, const float* 
   if (n_tokens == 0) return HX_OK;
   if (!gating_logits || !correction_bias || !topk_weights || !topk_indices) return HX_ERR_NULL;
   const size_t lds = (size_t)4 * 2 * n_experts * sizeof(float);
-  grouped_topk_sigmoid_kernel<<<(unsigned)((n_tokens + 3) / 4), 256, lds, (hipStream_t)stream>>>(
+  hx::launcher(grouped_topk_sigmoid_kernel, (unsigned)((n_tokens + 3) / 4), 256, lds, (hipStream_t)stream)(
       gating_logits, correction_bias, topk_weights, topk_indices, n_tokens, (int)n_experts,
       (int)n_groups, (int)topk_group, (int)topk);
   return check_launch();
@@ -348,14 +348,14 @@ extern "C" int hx_moe_row_id_map_from_indices(const int32_t* topk_indices, int32
   int32_t* vals_out = (int32_t*)(ws + 2 * seg);
   void* temp = ws + 3 * seg;
   size_t temp_bytes = sort_temp_bytes(n);
-  iota_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(vals_in, n);
+  hx::launcher(iota_kernel, (unsigned)((n + 255) / 256), 256, 0, s)(vals_in, n);
   int rc = check_launch();
   if (rc) return rc;
   // stable LSD radix sort == cub::DeviceRadixSort::SortPairs (permutation_index_kernel.cu:39-53)
   rc = hip_rc(rocprim::radix_sort_pairs(temp, temp_bytes, topk_indices, keys_out, vals_in, vals_out,
                                         (size_t)n, 0, 32, s));
   if (rc) return rc;
-  row_id_map_from_sorted_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(vals_out, row_id_map,
+  hx::launcher(row_id_map_from_sorted_kernel, (unsigned)((n + 255) / 256), 256, 0, s)(vals_out, row_id_map,
                                                                           n_tokens, (int)topk);
   return check_launch();
 }
@@ -369,10 +369,10 @@ extern "C" int hx_moe_row_id_map_from_mask(const uint8_t* routing_map, int32_t* 
   if (workspace_bytes < n_experts * 4) return HX_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   int32_t* counts = (int32_t*)workspace;
-  mask_count_kernel<<<(unsigned)n_experts, 256, 0, s>>>(routing_map, counts, n_tokens, (int)n_experts);
+  hx::launcher(mask_count_kernel, (unsigned)n_experts, 256, 0, s)(routing_map, counts, n_tokens, (int)n_experts);
   int rc = check_launch();
   if (rc) return rc;
-  mask_assign_kernel<<<(unsigned)n_experts, 256, 0, s>>>(routing_map, counts, row_id_map, n_tokens,
+  hx::launcher(mask_assign_kernel, (unsigned)n_experts, 256, 0, s)(routing_map, counts, row_id_map, n_tokens,
                                                        (int)n_experts);
   return check_launch();
 }
@@ -388,14 +388,14 @@ extern "C" int hx_moe_permute(const void* tokens, void* permuted, const int32_t*
   hipStream_t s = (hipStream_t)stream;
   const int64_t row_bytes = dim * es;
   if (row_bytes % 16 == 0 && aligned16(tokens) && aligned16(permuted)) {
-    permute_kernel<uint4><<<(unsigned)n_tokens, 256, 0, s>>>((const uint4*)tokens, (uint4*)permuted,
+    hx::launcher(permute_kernel<uint4>, (unsigned)n_tokens, 256, 0, s)((const uint4*)tokens, (uint4*)permuted,
                                                             row_id_map, n_tokens, (int)n_rows,
                                                             row_bytes / 16);
   } else if (es == 2) {
-    permute_kernel<uint16_t><<<(unsigned)n_tokens, 256, 0, s>>>(
+    hx::launcher(permute_kernel<uint16_t>, (unsigned)n_tokens, 256, 0, s)(
         (const uint16_t*)tokens, (uint16_t*)permuted, row_id_map, n_tokens, (int)n_rows, dim);
   } else {
-    permute_kernel<uint32_t><<<(unsigned)n_tokens, 256, 0, s>>>(
+    hx::launcher(permute_kernel<uint32_t>, (unsigned)n_tokens, 256, 0, s)(
         (const uint32_t*)tokens, (uint32_t*)permuted, row_id_map, n_tokens, (int)n_rows, dim);
   }
   return check_launch();
@@ -410,16 +410,16 @@ extern "C" int hx_moe_unpermute(const void* permuted, void* out, const int32_t* 
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case HX_F32:
-      unpermute_kernel<F32><<<(unsigned)n_tokens, 256, 0, s>>>(
+      hx::launcher(unpermute_kernel<F32>, (unsigned)n_tokens, 256, 0, s)(
           (const float*)permuted, (float*)out, row_id_map, (const float*)probs, n_tokens,
           (int)n_rows, dim);
       break;
     case HX_F16:
-      unpermute_kernel<F16><<<(unsigned)n_tokens, 256, 0, s>>>(
+      hx::launcher(unpermute_kernel<F16>, (unsigned)n_tokens, 256, 0, s)(
           (const u16*)permuted, (u16*)out, row_id_map, (const u16*)probs, n_tokens, (int)n_rows, dim);
       break;
     case HX_BF16:
-      unpermute_kernel<BF16><<<(unsigned)n_tokens, 256, 0, s>>>(
+      hx::launcher(unpermute_kernel<BF16>, (unsigned)n_tokens, 256, 0, s)(
           (const u16*)permuted, (u16*)out, row_id_map, (const u16*)probs, n_tokens, (int)n_rows, dim);
       break;
     default: return HX_ERR_DTYPE;
@@ -435,13 +435,13 @@ extern "C" int hx_moe_sum_out(const void* in, void* out, int64_t n_tokens, int64
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case HX_F32:
-      sum_out_kernel<F32><<<(unsigned)n_tokens, 256, 0, s>>>((const float*)in, (float*)out, (int)topk, dim);
+      hx::launcher(sum_out_kernel<F32>, (unsigned)n_tokens, 256, 0, s)((const float*)in, (float*)out, (int)topk, dim);
       break;
     case HX_F16:
-      sum_out_kernel<F16><<<(unsigned)n_tokens, 256, 0, s>>>((const u16*)in, (u16*)out, (int)topk, dim);
+      hx::launcher(sum_out_kernel<F16>, (unsigned)n_tokens, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim);
       break;
     case HX_BF16:
-      sum_out_kernel<BF16><<<(unsigned)n_tokens, 256, 0, s>>>((const u16*)in, (u16*)out, (int)topk, dim);
+      hx::launcher(sum_out_kernel<BF16>, (unsigned)n_tokens, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim);
       break;
     default: return HX_ERR_DTYPE;
   }

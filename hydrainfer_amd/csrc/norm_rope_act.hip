@@ -126,19 +126,19 @@ int launch_rms(void* out, void* residual, const void* input, const void* weight,
                    (!ADD || aligned16(residual));
   dim3 grid((unsigned)rows);
   if (vec && hidden / N <= 256 * 1) {
-    rms_norm_vec_kernel<T, 1, ADD><<<grid, 256, 0, stream>>>((S*)out, (S*)residual,
+    hx::launcher(rms_norm_vec_kernel<T, 1, ADD>, grid, 256, 0, stream)((S*)out, (S*)residual,
                                                             (const S*)input, (const S*)weight,
                                                             eps, (int)hidden);
   } else if (vec && hidden / N <= 256 * 2) {
-    rms_norm_vec_kernel<T, 2, ADD><<<grid, 256, 0, stream>>>((S*)out, (S*)residual,
+    hx::launcher(rms_norm_vec_kernel<T, 2, ADD>, grid, 256, 0, stream)((S*)out, (S*)residual,
                                                             (const S*)input, (const S*)weight,
                                                             eps, (int)hidden);
   } else if (vec && hidden / N <= 256 * 4) {
-    rms_norm_vec_kernel<T, 4, ADD><<<grid, 256, 0, stream>>>((S*)out, (S*)residual,
+    hx::launcher(rms_norm_vec_kernel<T, 4, ADD>, grid, 256, 0, stream)((S*)out, (S*)residual,
                                                             (const S*)input, (const S*)weight,
                                                             eps, (int)hidden);
   } else {
-    rms_norm_generic_kernel<T, ADD><<<grid, 256, 0, stream>>>((S*)out, (S*)residual,
+    hx::launcher(rms_norm_generic_kernel<T, ADD>, grid, 256, 0, stream)((S*)out, (S*)residual,
                                                              (const S*)input, (const S*)weight,
                                                              eps, hidden);
   }
@@ -419,12 +419,12 @@ int launch_rope(void* q, void* k, const int32_t* positions, const void* cos_sin,
                    aligned16(k) && aligned16(cos_sin);
   dim3 grid((unsigned)n_tokens);
   if (vec) {
-    rope_neox_vec_kernel<T><<<grid, 256, 0, stream>>>((S*)q, (S*)k, positions, (const S*)cos_sin,
+    hx::launcher(rope_neox_vec_kernel<T>, grid, 256, 0, stream)((S*)q, (S*)k, positions, (const S*)cos_sin,
                                                      (int)n_heads, (int)n_kv_heads,
                                                      (int)head_dim, (int)rotary_dim, q_stride,
                                                      k_stride);
   } else {
-    rope_kernel<T><<<grid, 256, 0, stream>>>((S*)q, (S*)k, positions, (const S*)cos_sin,
+    hx::launcher(rope_kernel<T>, grid, 256, 0, stream)((S*)q, (S*)k, positions, (const S*)cos_sin,
                                             (int)n_heads, (int)n_kv_heads, (int)head_dim,
                                             (int)rotary_dim, q_stride, k_stride, interleaved);
   }
@@ -616,12 +616,12 @@ int launch_silu(void* out, const void* gate, const void* up, int64_t rows, int64
       const int nvec = (int)(n / N);
       int gx = (nvec + 255) / 256;
       if (gx > 64) gx = 64;
-      silu_vec_kernel<T, MUL><<<dim3(gx, (unsigned)nr), 256, 0, stream>>>(o, g, u, nvec,
+      hx::launcher(silu_vec_kernel<T, MUL>, dim3(gx, (unsigned)nr), 256, 0, stream)(o, g, u, nvec,
                                                                          gate_stride, up_stride, n);
     } else {
       int64_t gx = (n + 255) / 256;
       if (gx > 64) gx = 64;
-      silu_elem_kernel<T, MUL><<<dim3((unsigned)gx, (unsigned)nr), 256, 0, stream>>>(
+      hx::launcher(silu_elem_kernel<T, MUL>, dim3((unsigned)gx, (unsigned)nr), 256, 0, stream)(
           o, g, u, n, gate_stride, up_stride, n);
     }
     int rc = check_launch();
@@ -748,7 +748,7 @@ extern "C" int hx_rope_set_kv_cache(void* query, void* key, const void* value,
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)n_tokens);
 #define HX_RC(TT)                                                                              \
-  rope_cache_neox_vec_kernel<TT><<<grid, 256, 0, s>>>(                                         \
+  hx::launcher(rope_cache_neox_vec_kernel<TT>, grid, 256, 0, s)(                                         \
       (TT::storage*)query, (TT::storage*)key, (const TT::storage*)value, positions,            \
       (const TT::storage*)cos_sin, slot_ids, (TT::storage*)key_cache,                          \
       (TT::storage*)value_cache, (int)n_heads, (int)n_kv_heads, (int)head_dim, (int)rotary_dim, \
@@ -787,7 +787,7 @@ extern "C" int hx_add_rms_norm_slabs_ex(void* out, void* residual, const float* 
   // 512 threads: one 8-element vector (and its n_splits fp32 slab pieces) per thread up to
   // hidden = 4096 — the kernel is latency-bound on 32 rows, so more loads in flight per row win
 #define HX_L(TT, MV)                                                                             \
-  add_rms_norm_slab_kernel<TT, MV, 512><<<grid, 512, 0, s>>>((u16*)out, (u16*)residual, partial, \
+  hx::launcher(add_rms_norm_slab_kernel<TT, MV, 512>, grid, 512, 0, s)((u16*)out, (u16*)residual, partial, \
                                                             n_splits, stride, (const u16*)weight, \
                                                             epsilon, (int)hidden, frag_mb)
   const int mv = (int)((hidden / 8 + 511) / 512);
@@ -823,9 +823,9 @@ extern "C" int hx_silu_and_mul_slabs_ex(void* out, const float* partial, int32_t
   dim3 grid(gx, (unsigned)rows);
   const int64_t stride = rows * 2 * inter;
   if (dtype == HX_F16)
-    silu_mul_slab_kernel<F16><<<grid, 256, 0, s>>>((u16*)out, partial, n_splits, stride, (int)inter, frag_mb);
+    hx::launcher(silu_mul_slab_kernel<F16>, grid, 256, 0, s)((u16*)out, partial, n_splits, stride, (int)inter, frag_mb);
   else if (dtype == HX_BF16)
-    silu_mul_slab_kernel<BF16><<<grid, 256, 0, s>>>((u16*)out, partial, n_splits, stride, (int)inter, frag_mb);
+    hx::launcher(silu_mul_slab_kernel<BF16>, grid, 256, 0, s)((u16*)out, partial, n_splits, stride, (int)inter, frag_mb);
   else
     return HX_ERR_DTYPE;
   return check_launch();
@@ -843,7 +843,7 @@ extern "C" int hx_embed_rms_norm(void* h_out, void* x_out, const void* ids, int 
   hipStream_t s = (hipStream_t)stream;
   const int mv = (int)((hidden / 8 + 255) / 256);
 #define HX_L(TT, MV)                                                                                      \
-  embed_rms_norm_kernel<TT, MV><<<(unsigned)rows, 256, 0, s>>>((u16*)h_out, (u16*)x_out, ids, ids_are_int64, \
+  hx::launcher(embed_rms_norm_kernel<TT, MV>, (unsigned)rows, 256, 0, s)((u16*)h_out, (u16*)x_out, ids, ids_are_int64, \
                                                                (const u16*)table, (const u16*)weight, epsilon,  \
                                                                (int)hidden, vocab)
   if (dtype == HX_F16) {
@@ -861,8 +861,8 @@ extern "C" int hx_argmax_rows(int64_t* out, const void* logits, int64_t rows, in
   if (rows == 0) return HX_OK;
   if (!out || !logits) return HX_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == HX_F16) argmax_rows_kernel<F16><<<(unsigned)rows, 1024, 0, s>>>(out, (const u16*)logits, (int)n, ld);
-  else if (dtype == HX_BF16) argmax_rows_kernel<BF16><<<(unsigned)rows, 1024, 0, s>>>(out, (const u16*)logits, (int)n, ld);
+  if (dtype == HX_F16) hx::launcher(argmax_rows_kernel<F16>, (unsigned)rows, 1024, 0, s)(out, (const u16*)logits, (int)n, ld);
+  else if (dtype == HX_BF16) hx::launcher(argmax_rows_kernel<BF16>, (unsigned)rows, 1024, 0, s)(out, (const u16*)logits, (int)n, ld);
   else return HX_ERR_DTYPE;
   return check_launch();
 }

@@ -25,6 +25,7 @@ from hydrainfer_amd._C.kernel.position_embedding import rope_set_kv_cache
 from hydrainfer_amd.layer.causal_attention import AttentionParameters
 from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
 from hydrainfer_amd._C.kernel import gemm as hip_gemm
+from hydrainfer_amd import _lib, launch_plan
 
 
 @dataclass
@@ -328,8 +329,9 @@ class LlamaForCausalLM:
             nf_qkv = (self.fuse_norm and f"l{L - 1}.wqkv" in self.packed_x
                       and hip_gemm.norm_xreg_supported(n, qkv_n, hid, h.dtype))
             if nf_gu or nf_qkv:
-                # one zeroed hand-over area per fused launch of this step (a memset node when captured)
-                sync = torch.zeros((L, 2, hip_gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=h.device)
+                # one zeroed hand-over area per fused launch of this step (a memset node when captured / recorded)
+                sync = torch.empty((L, 2, hip_gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=h.device)
+                _lib.memset_zero(sync)
                 self.xreg_sync = sync
             if nf_qkv:   # the fused launch reads the down slabs (ws) while it writes the qkv slab
                 ws_q = torch.empty(max(hip_gemm.xreg_workspace_floats(n, qkv_n, hid), hip_gemm.workspace_floats(n, qkv_n, hid)),
@@ -501,8 +503,15 @@ class LlamaForCausalLM:
         return x
 
     def forward_logits(self, input_ids_or_embeds, position_ids, model_params) -> Tensor:
-        return torch.matmul(self.forward_hidden(input_ids_or_embeds, position_ids, model_params),
-                            self.state["lm_head"].t())
+        x = self.forward_hidden(input_ids_or_embeds, position_ids, model_params)
+        w = self.state["lm_head"]
+        if launch_plan.current() is None:
+            return torch.matmul(x, w.t())
+        # a launch plan is being recorded: the library GEMM is a host-side step of the plan between two native
+        # launch segments, writing into a buffer of the plan's pool
+        logits = torch.empty((x.shape[0], w.shape[0]), dtype=x.dtype, device=x.device)
+        launch_plan.host_op(lambda: torch.matmul(x, w.t(), out=logits))
+        return logits
 
     def forward(self, input_ids_or_embeds, position_ids, model_params) -> Tensor:
         """Returns sampled token ids (greedy), like the reference model."""

@@ -17,7 +17,7 @@ from typing import List, Optional
 import torch
 from torch import Tensor
 
-from hydrainfer_amd import _lib
+from hydrainfer_amd import _lib, launch_plan
 from hydrainfer_amd.layer.causal_attention import AttentionParameters, AttentionParametersBuilder
 from hydrainfer_amd.memory.block_allocator import BlockAllocator
 from hydrainfer_amd.memory.kv_cache import KVCache
@@ -55,6 +55,11 @@ class RunnerConfig:
     block_size: int = 16
     prefill_token_budget: int = 4096
     use_graph: bool = True
+    # how a decode step is replayed when use_graph: "graph" = one captured hipGraph; "plan" = a launch plan
+    # (hydrainfer_amd/launch_plan.py): the same launches issued by a native loop, the five kernels of every layer
+    # chained without the AQL barrier bit (dependencies taken inside the kernels); "plan-nochain" = the plan with
+    # ordinary stream-ordered launches (A/B reference)
+    executor: str = "graph"
 
 
 class DecodeRunner:
@@ -209,7 +214,7 @@ class DecodeRunner:
         finally:
             self.model.sample_out = None
         if nxt.data_ptr() != self.input_ids.data_ptr():
-            self.input_ids.copy_(nxt)
+            launch_plan.host_op(lambda: self.input_ids.copy_(nxt))
 
     def capture(self) -> None:
         """Warm up on a side stream, then capture one decode step into a hipGraph.  Decode
@@ -223,11 +228,17 @@ class DecodeRunner:
                 self._step_body()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         self.positions.copy_(saved[0]); self.kv_lens.copy_(saved[1]); self.input_ids.copy_(saved[2])
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._step_body()
-        self.graph = graph
-        self.positions.copy_(saved[0]); self.kv_lens.copy_(saved[1]); self.input_ids.copy_(saved[2])
+        if self.cfg.executor in ("plan", "plan-nochain"):
+            plan = launch_plan.LaunchPlan(self.dev, chain=self.cfg.executor == "plan",
+                                          max_chained_launches=8 * self.model.shape.num_hidden_layers + 16)
+            plan.capture(self._step_body)       # records, runs nothing: the decode state is untouched
+            self.graph = plan
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._step_body()
+            self.graph = graph
+            self.positions.copy_(saved[0]); self.kv_lens.copy_(saved[1]); self.input_ids.copy_(saved[2])
         torch.cuda.synchronize(self.dev)
 
     def step(self, record: bool = True) -> None:
@@ -243,7 +254,7 @@ class DecodeRunner:
     def generated(self) -> Tensor:
         """[n_steps_so_far, B] sampled tokens (one D2H sync, at the end).  Raises if an in-kernel hand-over of the
         last step gave up (its tokens would be garbage)."""
-        if self.model.handover_failed():
+        if self.model.handover_failed() or (isinstance(self.graph, launch_plan.LaunchPlan) and self.graph.failed()):
             self.model.fuse_norm = False
             self.graph = None
             raise _lib.HydraHipError("a norm-fused GEMM launch gave up waiting for its producer workgroups: the tokens "

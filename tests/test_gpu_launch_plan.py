@@ -1,0 +1,78 @@
+"""-m gpu: launch plans (hydrainfer_amd/launch_plan.py, csrc/launch_plan.hip).  A decode step replayed from a plan —
+with the five launches of every layer CHAINED (no AQL barrier bit between them; each kernel prefetches, then waits
+inside the kernel for its predecessor's done flag, then reads that kernel's output with sc1 loads) — must produce
+exactly the tokens and the KV pool of the same step replayed from a hipGraph (stream-ordered launches of the same
+kernels): the chain changes when workgroups start, never what they compute."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _run(executor, dt, shape, batch, steps, seed=3, prompt=40):
+    from hydrainfer_amd.model.llama import LlamaForCausalLM
+    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
+    model = LlamaForCausalLM.random_init(shape, dt, DEV, seed=seed)
+    r = DecodeRunner(model, RunnerConfig(batch=batch, prompt_len=prompt, n_generate=steps + 8, use_graph=True,
+                                         executor=executor), seed=seed + 1)
+    g = torch.Generator().manual_seed(0)
+    r.prefill(torch.randint(5, shape.vocab_size - 1, (batch, prompt), generator=g).to(DEV))
+    for _ in range(steps):
+        r.step()
+    torch.cuda.synchronize()
+    return r, r.generated(), r.pool.clone()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("batch", [32, 5])
+def test_chained_plan_equals_graph(dt, batch):
+    """3 layers of 7B width (the benchmark's launch shapes), 24 steps over the same buffers."""
+    from hydrainfer_amd import launch_plan
+    from hydrainfer_amd.model.llama import LlamaShape
+    sh = LlamaShape(4096, 11008, 3, 32, 32, 128, 32064)
+    outs = {}
+    for ex in ("graph", "plan-nochain", "plan"):
+        r, toks, pool = _run(ex, dt, sh, batch, 24)
+        outs[ex] = (toks, pool)
+        if ex != "graph":
+            plan = r.graph
+            assert isinstance(plan, launch_plan.LaunchPlan) and not plan.failed()
+            # advance + memset + embed + 5 per layer (layer 0: + its own qkv launch) + final norm | lm_head | argmax
+            assert plan.n_launches == 3 + 5 * sh.num_hidden_layers + 1 + 1 + 1
+            # all launches of the layers but the first of the chain run without the barrier bit
+            assert plan.n_any_order == (5 * sh.num_hidden_layers if ex == "plan" else 0)
+        del r
+    for ex in ("plan-nochain", "plan"):
+        assert torch.equal(outs["graph"][0], outs[ex][0]), f"{ex}: sampled tokens differ from the hipGraph run"
+        assert torch.equal(outs["graph"][1], outs[ex][1]), f"{ex}: KV pool differs from the hipGraph run"
+
+
+def test_chained_plan_small_and_13b_widths():
+    from hydrainfer_amd.model.llama import LlamaShape
+    for sh, batch in ((LlamaShape(1024, 2816, 3, 8, 8, 128, 2048), 7), (LlamaShape(5120, 13824, 2, 40, 40, 128, 32064), 32)):
+        a = _run("graph", torch.bfloat16, sh, batch, 12)
+        b = _run("plan", torch.bfloat16, sh, batch, 12)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert b[0].graph.n_any_order > 0 and not b[0].graph.failed()
+
+
+def test_plan_buffers_survive_other_allocations():
+    """The plan's launches hold raw pointers into its private memory pool: allocating and freeing around replays
+    must not disturb them."""
+    from hydrainfer_amd.model.llama import LlamaShape
+    sh = LlamaShape(1024, 2816, 2, 8, 8, 128, 2048)
+    ref = _run("graph", torch.float16, sh, 8, 10)
+    from hydrainfer_amd.model.llama import LlamaForCausalLM
+    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
+    model = LlamaForCausalLM.random_init(sh, torch.float16, DEV, seed=3)
+    r = DecodeRunner(model, RunnerConfig(batch=8, prompt_len=40, n_generate=18, use_graph=True, executor="plan"), seed=4)
+    g = torch.Generator().manual_seed(0)
+    r.prefill(torch.randint(5, sh.vocab_size - 1, (8, 40), generator=g).to(DEV))
+    for i in range(10):
+        junk = [torch.full((1 << 20,), float(i), device=DEV) for _ in range(8)]     # churn the caching allocator
+        r.step()
+        del junk
+        torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    assert torch.equal(r.generated(), ref[1]) and torch.equal(r.pool, ref[2])
