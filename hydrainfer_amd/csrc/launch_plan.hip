@@ -145,17 +145,21 @@ extern "C" int hx_plan_destroy(hx_plan* plan) {
   return HX_OK;
 }
 
-// memset(p, 0, bytes) on the stream — recordable (a torch.zeros inside a recorded region would run once, at
-// recording time, and never again)
+namespace {
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, int64_t n_words) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_words) p[i] = 0u;
+}
+}  // namespace
+
+// memset(p, 0, bytes) on the stream as a KERNEL of this library: recordable in a plan (a torch.zeros inside a
+// recorded region would run once, at recording time, and never again) and a plain kernel node under hipGraph
+// capture (a captured hipMemsetAsync node was seen to leave garbage from the second replay on).  4-byte granularity.
 extern "C" int hx_memset_zero(void* p, int64_t bytes, hx_stream stream) {
   if (!p || bytes < 0) return HX_ERR_NULL;
   if (bytes == 0) return HX_OK;
-  if (PlanRecorder* r = t_recording) {
-    PlanItem it;
-    it.kind = 1; it.func = nullptr; it.lds = 0; it.flags = 0; it.chained = false; it.ptr = p; it.bytes = (size_t)bytes;
-    r->prev_signal = nullptr;
-    r->items.push_back(std::move(it));
-    return HX_OK;
-  }
-  return hip_rc(hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream));
+  if ((bytes & 3) || (reinterpret_cast<uintptr_t>(p) & 3u)) return HX_ERR_STRIDE;
+  const int64_t n = bytes >> 2;
+  hx::launcher(zero_kernel, (unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream)((uint32_t*)p, n);
+  return check_launch();
 }
