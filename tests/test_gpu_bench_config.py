@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 # stated tolerance, bf16: logits (|logit| ~ 3) within 1.5e-1 of the fp32-accumulating oracle, greedy tokens
-# identical wherever the oracle's top-1 margin exceeds 2 x that; KV pool within one bf16 ulp of the oracle's
+# identical wherever the oracle's top-1 margin exceeds 2 x that; KV pool within two bf16 ulps of the oracle's
 LOGIT_TOL = 1.5e-1
-KV_RTOL, KV_ATOL = 2.0 ** -7, 2e-3      # one bf16 ulp (relative 2^-8 .. 2^-7) of the projections' round-off
+KV_RTOL, KV_ATOL = 2.0 ** -6, 4e-3      # two bf16 ulps (one of the projection's accumulation order, one of RoPE's T arithmetic on it)
 
 
 def _build(batch=32, prompt_len=40, n_generate=12, layers=2, seed=3):
