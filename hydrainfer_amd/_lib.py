@@ -68,7 +68,7 @@ class hx_chain_args(ctypes.Structure):
 
 HX_CHAIN_SYNC_WORDS, HX_CHAIN_SYNC_ERR = 18432, 480
 HX_XREG_SYNC_WORDS = 512
-HX_PLAN_SYNC_BYTES_PER_LAUNCH = 2048
+HX_PLAN_SYNC_BYTES_PER_LAUNCH = 4096
 
 _SIGNATURES = {
     "hx_abi_version": (c_int, []),

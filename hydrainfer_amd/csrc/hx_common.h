@@ -57,8 +57,12 @@ struct ChainLink {
   uint32_t signal_total;   // workgroups of this launch
   uint32_t reserved;
 };
-constexpr int kChainWords = 512;        // per launch: 8 arrival-count lines + 8 flag lines of 32 words (one pair per XCD)
-constexpr int kChainFlagWord = 256;
+// sync area of one chained launch, in 32-word (128-byte) lines: 16 arrival-count shards (workgroup id mod 16), one
+// line counting completed shards, 8 flag lines (one per XCD, polled by that XCD's waiters)
+constexpr int kChainShards = 16;
+constexpr int kChainTopWord = 32 * kChainShards;
+constexpr int kChainFlagWord = kChainTopWord + 32;
+constexpr int kChainWords = 1024;
 
 struct ArgHolderBase {
   virtual ~ArgHolderBase() = default;
@@ -192,8 +196,8 @@ __device__ __forceinline__ float wave_max(float v) {
 //   2. chain_wait(link)  — all threads; the first wave polls this XCD's flag line of the predecessor's area;
 //   3. read the predecessor's output with chain_load* (sc1: served past the CU's L1 and coherent across the XCDs'
 //      L2s), write its own output with chain_store* (sc1: written through);
-//   4. chain_signal(link) — all threads: drain the stores, then thread 0 counts the workgroup in on its XCD's
-//      line; whoever sees all of them arrived raises the eight flag lines.
+//   4. chain_signal(link) — all threads: drain the stores, then thread 0 counts the workgroup in on its shard of the
+//      arrival counter; the workgroup that completes the last shard raises the eight flag lines.
 // Progress: a chained kernel's workgroups are dispatched only after ALL of its predecessor's have been (one
 // in-order queue), so a waiter never holds a resource its producer still needs.  A wait is bounded (1 s of the
 // 100 MHz clock): on give-up the error word is set and the kernel continues — never a hung GPU; the host
@@ -246,17 +250,19 @@ __device__ __forceinline__ void chain_signal(const ChainLink& ch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached memory
     __syncthreads();
     if (threadIdx.x == 0) {
-      // the add returns (its old value is consumed) before the eight counts are read, so the workgroup whose add
-      // completes last is certain to read the full total
-      const uint32_t old = __hip_atomic_fetch_add(ch.signal + 32 * xcc_id(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("" ::"v"(old) : "memory");   // the returned value is waited for here; nothing below moves above
-      uint32_t sum = 0u;
+      // ONE memory-side operation per workgroup (1024 workgroups reading eight count lines each cost the decode
+      // attention launch 10 us): the arrival counter is sharded by workgroup id, so every shard knows its own total;
+      // whoever completes a shard counts it in on the top line, whoever completes that raises the eight flags
+      const uint32_t id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const uint32_t shard = id & (kChainShards - 1);
+      const uint32_t expect = (ch.signal_total + (kChainShards - 1) - shard) / kChainShards;
+      if (__hip_atomic_fetch_add(ch.signal + 32 * shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == expect) {
+        const uint32_t n_shards = ch.signal_total < (uint32_t)kChainShards ? ch.signal_total : (uint32_t)kChainShards;
+        if (__hip_atomic_fetch_add(ch.signal + kChainTopWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == n_shards) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sum += __hip_atomic_load(ch.signal + 32 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (sum == ch.signal_total) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          __hip_atomic_store(ch.signal + kChainFlagWord + 32 * i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int i = 0; i < 8; ++i)
+            __hip_atomic_store(ch.signal + kChainFlagWord + 32 * i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }

@@ -163,3 +163,6 @@ extern "C" int hx_memset_zero(void* p, int64_t bytes, hx_stream stream) {
   hx::launcher(zero_kernel, (unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream)((uint32_t*)p, n);
   return check_launch();
 }
+
+static_assert(HX_PLAN_SYNC_BYTES_PER_LAUNCH == hx::kChainWords * 4, "header and kernel disagree on the size of a link area");
+static_assert(hx::kChainFlagWord + 8 * 32 <= hx::kChainWords, "link area too small for its lines");

@@ -409,7 +409,7 @@ int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_
  * One recording per thread at a time; a plan may be replayed from any thread, one replay in flight per plan.
  * ---------------------------------------------------------------------- */
 typedef struct hx_plan hx_plan;
-#define HX_PLAN_SYNC_BYTES_PER_LAUNCH 2048
+#define HX_PLAN_SYNC_BYTES_PER_LAUNCH 4096
 int hx_plan_begin(hx_plan** plan, void* sync, int64_t sync_bytes, uint32_t* error_word, int chain);
 int hx_plan_end(hx_plan* plan);
 int hx_plan_info(const hx_plan* plan, int32_t* n_launches, int32_t* n_any_order, int64_t* sync_bytes_used);
