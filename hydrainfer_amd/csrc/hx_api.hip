@@ -16,6 +16,7 @@ int decode_set_option(const char* name, int value);
 int gemm_set_option(const char* name, int value);
 int fwd_set_option(const char* name, int value);
 int xreg_set_option(const char* name, int value);
+int plan_set_option(const char* name, int value);
 #if HX_EXPERIMENTS   // `make EXPERIMENTS=1`: rejected experiments kept measurable (not in the default library)
 int chain_set_option(const char* name, int value);
 int decode4_set_option(const char* name, int value);
@@ -51,6 +52,7 @@ extern "C" int hx_debug_set_option(const char* name, int value) {
   if (rc == HX_ERR_UNSUPPORTED) rc = gemm_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = fwd_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = xreg_set_option(name, value);
+  if (rc == HX_ERR_UNSUPPORTED) rc = plan_set_option(name, value);
 #if HX_EXPERIMENTS
   if (rc == HX_ERR_UNSUPPORTED) rc = chain_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = decode4_set_option(name, value);

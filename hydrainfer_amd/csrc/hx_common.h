@@ -55,13 +55,15 @@ struct ChainLink {
   uint32_t* signal;        // sync area of this launch (nullptr: nobody waits for it)
   uint32_t* err;           // word set to 1 if a wait gives up (1 s): the step's results are invalid
   uint32_t signal_total;   // workgroups of this launch
-  uint32_t reserved;
+  uint32_t opts;           // bit 0: diagnostic time stamps into the link area (hx_debug_set_option("chain_stamps", 1))
 };
 // sync area of one chained launch, in 32-word (128-byte) lines: 16 arrival-count shards (workgroup id mod 16), one
 // line counting completed shards, 8 flag lines (one per XCD, polled by that XCD's waiters)
 constexpr int kChainShards = 16;
 constexpr int kChainTopWord = 32 * kChainShards;
 constexpr int kChainFlagWord = kChainTopWord + 32;
+constexpr int kChainStampWord = kChainFlagWord + 8 * 32;   // 4 x uint64 (100 MHz clock): workgroup 0 at its wait, workgroup
+                                                           // 0 past its wait, the flag raiser at the end, workgroup 0 at its signal
 constexpr int kChainWords = 1024;
 
 struct ArgHolderBase {
@@ -227,7 +229,14 @@ __device__ __forceinline__ float chain_load_f32(chain_rsrc_t r, uint32_t byte_of
 }
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7; }   // HW_REG_XCC_ID
 
+__device__ __forceinline__ void chain_stamp(const ChainLink& ch, int which, bool only_wg0) {
+  if ((ch.opts & 1u) && ch.signal && threadIdx.x == 0 &&
+      (!only_wg0 || (blockIdx.x | blockIdx.y | blockIdx.z) == 0))
+    reinterpret_cast<unsigned long long*>(ch.signal + kChainStampWord)[which] = __builtin_amdgcn_s_memrealtime();
+}
+
 __device__ __forceinline__ void chain_wait(const ChainLink& ch) {
+  chain_stamp(ch, 0, true);
   if (ch.wait) {
     if (threadIdx.x < 64) {
       const uint32_t* fl = ch.wait + kChainFlagWord + 32 * xcc_id();
@@ -242,6 +251,7 @@ __device__ __forceinline__ void chain_wait(const ChainLink& ch) {
     }
     __syncthreads();
   }
+  chain_stamp(ch, 1, true);
   asm volatile("" ::: "memory");
 }
 
@@ -249,6 +259,7 @@ __device__ __forceinline__ void chain_signal(const ChainLink& ch) {
   if (ch.signal) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached memory
     __syncthreads();
+    chain_stamp(ch, 3, true);
     if (threadIdx.x == 0) {
       // ONE memory-side operation per workgroup (1024 workgroups reading eight count lines each cost the decode
       // attention launch 10 us): the arrival counter is sharded by workgroup id, so every shard knows its own total;
@@ -262,6 +273,7 @@ __device__ __forceinline__ void chain_signal(const ChainLink& ch) {
 #pragma unroll
           for (int i = 0; i < 8; ++i)
             __hip_atomic_store(ch.signal + kChainFlagWord + 32 * i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          chain_stamp(ch, 2, false);
         }
       }
     }

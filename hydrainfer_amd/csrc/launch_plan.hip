@@ -45,6 +45,12 @@ struct PlanRecorder {
 };
 
 static thread_local PlanRecorder* t_recording = nullptr;
+static int g_chain_stamps = 0;   // diagnostic (hx_debug_set_option("chain_stamps", 1)): links recorded from now on carry time stamps
+
+int plan_set_option(const char* name, int value) {
+  if (!strcmp(name, "chain_stamps")) { g_chain_stamps = value ? 1 : 0; return HX_OK; }
+  return HX_ERR_UNSUPPORTED;
+}
 
 PlanRecorder* recording() { return t_recording; }
 
@@ -72,6 +78,7 @@ ChainLink chain_next(uint32_t n_workgroups, uint32_t* flags) {
   lk.signal = r->sync + r->used_words;
   lk.err = r->err;
   lk.signal_total = n_workgroups;
+  lk.opts = g_chain_stamps ? 1u : 0u;
   r->used_words += kChainWords;
   r->prev_signal = lk.signal;
   if (lk.wait) *flags = hipExtAnyOrderLaunch;
