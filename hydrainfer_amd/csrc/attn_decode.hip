@@ -187,6 +187,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int hk = h / p.group;
+  const uint32_t chain_peeked = FUSE ? chain_peek(p.chain) : 1u;   // the predecessor's flag, requested before anything else
 
   const int kv_len = p.cu_k[b + 1] - p.cu_k[b];
   const int q_row = p.cu_q[b];
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
       // Launch chain: the K/V stream above is already in flight; only now does this workgroup need its
       // predecessor (the qkv projection).  The slabs are read with sc1 loads: coherent with the write-through
       // stores of a producer that may still have been running when this kernel was dispatched.
-      chain_wait(p.chain);
+      chain_wait(p.chain, chain_peeked);
       const chain_rsrc_t slabs = chain_rsrc(p.qkv_partial);
       const int64_t row = (int64_t)b * p.qkv_row;
       const int64_t col0[3] = {(int64_t)h * D, (int64_t)p.n_heads * D + (int64_t)hk * D,

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
   // in a launch chain x is the output of a launch that may still be running: it is read AFTER the weights have
   // been requested and the predecessor's done flag has been seen (below); otherwise first, as always
   const bool x_late = p.chain.wait != nullptr;
+  const uint32_t chain_peeked = chain_peek(p.chain);
   if (!x_late) {
     const u16* xb = reinterpret_cast<const u16*>(p.x) + (int64_t)ks0 * 32;
 #pragma unroll
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
   load(buf[1], 1);
   __builtin_amdgcn_sched_barrier(0);
   if (x_late) {
-    chain_wait(p.chain);
+    chain_wait(p.chain, chain_peeked);
     const chain_rsrc_t xrs = chain_rsrc(p.x);
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int split = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
+  const uint32_t chain_peeked = chain_peek(p.chain);   // the predecessor's flag, requested before anything else
   const int total_ks = p.K >> 5;
   const int n_rg = p.N >> 4;
   const int ks0 = split * P;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
     // first waits for that launch's done flag (the others never need it: the x flag below implies it)
     bool pred_seen = p.chain.wait == nullptr;
     if (flat < p.M && !(p.stagger & 6)) {   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
-      if (!pred_seen) { chain_wait(p.chain); pred_seen = true; }
+      if (!pred_seen) { chain_wait(p.chain, chain_peeked); pred_seen = true; }
       for (int row = flat; row < p.M; row += n_wg) produce(row);   // several rows only when N is tiny
     }
     // 2. everyone: weight prefetch (independent of x)
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
 #pragma unroll
     for (int q = 0; q < NBUF; ++q) load_buf(rg_of(0), q);
     __builtin_amdgcn_sched_barrier(0);
-    chain_wait(p.chain);
+    chain_wait(p.chain, chain_peeked);
     {
       const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
 #pragma unroll

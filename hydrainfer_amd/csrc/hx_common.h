@@ -235,10 +235,22 @@ __device__ __forceinline__ void chain_stamp(const ChainLink& ch, int which, bool
     reinterpret_cast<unsigned long long*>(ch.signal + kChainStampWord)[which] = __builtin_amdgcn_s_memrealtime();
 }
 
-__device__ __forceinline__ void chain_wait(const ChainLink& ch) {
+// First thing in a chained kernel (all threads): request the predecessor's flag BEFORE any prefetch load is issued.
+// Loads return in order, so this one comes back after one round trip (~1 us) however many prefetch loads queue up
+// behind it; in the common case — the predecessor had already finished when this workgroup was dispatched — the
+// later chain_wait then costs nothing (measured: polled only after the prefetch had been issued, the first flag
+// load came back behind 32 KiB of HBM loads, 2.2 us per launch on the critical path).
+__device__ __forceinline__ uint32_t chain_peek(const ChainLink& ch) {
+  uint32_t v = 1u;
+  if (ch.wait && threadIdx.x < 64)
+    v = __hip_atomic_load(ch.wait + kChainFlagWord + 32 * xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+
+__device__ __forceinline__ void chain_wait(const ChainLink& ch, uint32_t peeked = 0u) {
   chain_stamp(ch, 0, true);
   if (ch.wait) {
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 64 && !__builtin_amdgcn_readfirstlane(peeked)) {
       const uint32_t* fl = ch.wait + kChainFlagWord + 32 * xcc_id();
       const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
       while (!__builtin_amdgcn_readfirstlane(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
