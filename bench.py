@@ -511,9 +511,8 @@ def time_decode_gemms(runner, reps=3):
     rnd = lambda *s_: torch.randn(s_, device=dev, generator=g).to(dt)
     x_h, x_q, x_i = rnd(B, sh.hidden_size), rnd(B, m.q_size), rnd(B, sh.intermediate_size)
     shapes = {"qkv": ("wqkv", x_h), "o": ("wo", x_q), "gate_up": ("wgu", x_h), "down": ("wdown", x_i)}
-    ws = torch.empty(max([hip_gemm.workspace_floats(B, m.state[f"l0.{k}"].shape[0], m.state[f"l0.{k}"].shape[1])
-                          for k, _ in shapes.values()] + [hip_gemm.short_workspace_floats(B, sh.hidden_size, m.q_size)]),
-                     dtype=torch.float32, device=dev)
+    ws = torch.empty(max(hip_gemm.workspace_floats(B, m.state[f"l0.{k}"].shape[0], m.state[f"l0.{k}"].shape[1])
+                         for k, _ in shapes.values()), dtype=torch.float32, device=dev)
     L = sh.num_hidden_layers
     res = {}
     hid, inter = sh.hidden_size, sh.intermediate_size
@@ -548,8 +547,6 @@ def time_decode_gemms(runner, reps=3):
                 return hip_gemm.norm_linear_decode_xreg(resid, slabs_in, 4, nw, 1e-5, xf_s, m.packed_x[full],
                                                         m.state[full].shape[0], ws_q, sync[l])
             return hip_gemm.linear_decode_partial_xreg(xf_h, m.packed_x[full], m.state[full].shape[0], ws, frag_shape=(B, hid))
-        if name == "o" and m.o_short and B <= 32 and full in m.packed:
-            return hip_gemm.linear_decode_partial_packed_short(x, m.packed[full], hid, ws)
         return m._partial(x, full, ws)
 
     for name, (key, x) in shapes.items():

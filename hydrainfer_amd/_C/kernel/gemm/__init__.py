@@ -141,27 +141,6 @@ def pack_weight(weight: Tensor) -> Tensor:
     return packed
 
 
-def short_workspace_floats(M: int, N: int, K: int) -> int:
-    return _lib.lib().hx_linear_decode_short_workspace_bytes(M, N, K) // 4
-
-
-def linear_decode_partial_packed_short(x: Tensor, packed: Tensor, N: int, partial: Tensor) -> int:
-    """linear_decode_partial_packed in 512-k splits (K / 512 slabs; M <= 32): the small-workgroup form for a launch
-    chained behind a kernel that is still draining (the o projection behind the decode attention)."""
-    _lib.require_gpu(x, packed, partial)
-    M, K = x.shape
-    if packed.numel() != N * K or packed.dtype != x.dtype or not packed.is_contiguous() or x.stride(1) != 1:
-        raise _lib.HydraHipError("linear_decode_partial_packed_short: packed must be pack_weight(weight [N, K]) of x's dtype")
-    if partial.dtype != torch.float32 or not partial.is_contiguous():
-        raise _lib.HydraHipError("linear_decode_partial_packed_short: partial must be contiguous float32")
-    rc = _lib.lib().hx_linear_decode_partial_packed_short(partial.data_ptr(), x.data_ptr(), packed.data_ptr(), M, N, K,
-                                                          x.stride(0), partial.numel() * 4, _lib.dtype_code(x),
-                                                          _lib.current_stream())
-    if rc < 0:
-        _lib.check(rc, "linear_decode_partial_packed_short")
-    return rc
-
-
 def linear_decode_partial_packed(x: Tensor, packed: Tensor, N: int, partial: Tensor) -> int:
     """As linear_decode_partial with `packed` = pack_weight(weight [N, K])."""
     _lib.require_gpu(x, packed, partial)

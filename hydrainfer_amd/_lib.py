@@ -88,8 +88,6 @@ _SIGNATURES = {
     "hx_linear_decode_partial": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_int, c_void_p]),
     "hx_pack_decode_weight": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hx_linear_decode_partial_packed": (c_int, [c_void_p] * 3 + [c_int64] * 5 + [c_int, c_void_p]),
-    "hx_linear_decode_short_workspace_bytes": (c_int64, [c_int64] * 3),
-    "hx_linear_decode_partial_packed_short": (c_int, [c_void_p] * 3 + [c_int64] * 5 + [c_int, c_void_p]),
     "hx_linear_decode_xreg_supported": (c_int, [c_int64] * 3),
     "hx_linear_decode_xreg_splits": (c_int, [c_int64] * 2),
     "hx_linear_decode_xreg_workspace_bytes": (c_int64, [c_int64] * 3),

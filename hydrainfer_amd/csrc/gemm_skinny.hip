@@ -288,88 +288,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
   chain_signal(p.chain);
 }
 
-// The packed product in SHORT splits (16 k-steps = 512 k per workgroup instead of 1024), for a launch that follows a
-// kernel which is still draining (launch chain: the o projection behind the decode attention).  What it is built
-// for is to get INTO the machine early: 4 waves of <= 128 registers and 33 KiB of LDS, so a workgroup fits next to
-// three of the four decode-attention workgroups of a CU as soon as the first one leaves (the 1024-k kernel above
-// needs 274 registers per wave and 66 KiB: it enters when a CU is three quarters empty).  A wave's whole share — one
-// 16-row group x 16 k-steps = 16 KiB — is requested up front into 64 registers; then the predecessor's done flag,
-// the x slice (32 KiB) into LDS, 16 x MB MFMAs, one store.  Most workgroups have their weights in registers when the
-// predecessor ends.  Twice the slabs of the 1024-k kernel (S = K / 512): the consumer adds them in order.
-// Reads the SAME packed layout (hx_pack_decode_weight): a 512-k split is one half of a (1024-k split, row group) run.
-constexpr int kShortKs = 16;
-constexpr int kShortRS = kShortKs * 64 + 32;
-template <typename T, int MB>
-__global__ __launch_bounds__(256, 4) void gemm_packed_short_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 4, c = lane & 15;
-  const uint32_t chain_peeked = chain_peek(p.chain);
-  const int split = blockIdx.y;
-  const int total_ks = p.K >> 5;
-  const int ks0 = split * kShortKs;
-  const int nks = min(kShortKs, total_ks - ks0);
-  const int n_rg_all = p.N >> 4;
-  const int rg_real = blockIdx.x * 4 + w;
-  const int rg = min(rg_real, n_rg_all - 1);
-  // fragment (1024-k split sb, row group, k-step j) at KiB index sb * 32 * n_rg + rg * nks_b + j
-  const int sb = ks0 / kMaxKs, jo = ks0 % kMaxKs;
-  const int nks_b = min(kMaxKs, total_ks - sb * kMaxKs);
-  const u16* wp = reinterpret_cast<const u16*>(p.w) + 8 * lane +
-                  ((int64_t)sb * kMaxKs * n_rg_all + (int64_t)rg * nks_b + jo) * 512;
-  u16x8 wf[kShortKs];
-#pragma unroll
-  for (int j = 0; j < kShortKs; ++j)
-    wf[j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(wp + (int64_t)min(j, nks - 1) * 512));
-  __builtin_amdgcn_sched_barrier(0);
-  chain_wait(p.chain, chain_peeked);
-  constexpr int kCpr = kShortKs * 4;                  // 16-byte pieces per x row of the slice
-  constexpr int XPT = MB * 16 * kCpr / 256;
-  const bool sc1 = p.chain.wait != nullptr;
-  const chain_rsrc_t xrs = chain_rsrc(p.x);
-  u16x8 xr[XPT];
-#pragma unroll
-  for (int j = 0; j < XPT; ++j) {
-    const int i = threadIdx.x + j * 256;
-    const int row = i / kCpr, ch = i % kCpr;
-    const bool ok = row < p.M && ch * 8 < (nks << 5);
-    const int64_t off = (int64_t)(ok ? row : 0) * p.ldx + (int64_t)ks0 * 32 + (ok ? ch * 8 : 0);
-    if (sc1) xr[j] = __builtin_bit_cast(u16x8, chain_load_b128(xrs, (uint32_t)(off * 2)));
-    else xr[j] = *reinterpret_cast<const u16x8*>(reinterpret_cast<const u16*>(p.x) + off);
-  }
-#pragma unroll
-  for (int j = 0; j < XPT; ++j) {
-    const int i = threadIdx.x + j * 256;
-    const int row = i / kCpr, ch = i % kCpr;
-    const bool ok = row < p.M && ch * 8 < (nks << 5);
-    *reinterpret_cast<u16x8*>(smem + row * kShortRS + ch * 16) = ok ? xr[j] : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  }
-  __syncthreads();
-  const char* xl = smem + c * kShortRS + g * 16;
-  f32x4 acc[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < kShortKs; ++j) {
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const u16x8 xf = *reinterpret_cast<const u16x8*>(xl + mb * 16 * kShortRS + j * 64);
-      acc[mb] = Mfma<T>::mma(wf[j], xf, acc[mb]);
-    }
-  }
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int m = mb * 16 + c;
-    if (m < p.M && rg_real < n_rg_all) {
-      const int64_t di = ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g;
-      if (p.chain.signal) chain_store_b128(chain_rsrc(p.partial), (uint32_t)(di * 4), __builtin_bit_cast(u32x4, acc[mb]));
-      else *reinterpret_cast<f32x4*>(p.partial + di) = acc[mb];
-    }
-  }
-  chain_signal(p.chain);
-}
-
 // fragment (rg, s) of split = s / kMaxKs lives at KiB index ks0 * n_rg + rg * nks + (s - ks0)
 // (ks0 = split * kMaxKs, nks = k-steps of that split); inside it lane l holds
 // W[16 rg + (l & 15)][32 s + 8 (l >> 4) .. + 8]
@@ -594,45 +512,6 @@ extern "C" int hx_linear_decode_partial(float* partial, const void* x, const voi
   int rc = launch_gemm_skinny(x, weight, partial, M, N, K, ldx, ldw, dtype, (hipStream_t)stream);
   if (rc) return rc;
   return gemm_skinny_splits(K);
-}
-
-// ---- short splits (see gemm_packed_short_kernel) ---------------------------------------------------
-static int short_splits(int64_t K) { return (int)(((K >> 5) + kShortKs - 1) / kShortKs); }
-
-template <typename T, int MB>
-static int launch_short(const GemmParams& p, hipStream_t stream) {
-  const int n_rg = p.N >> 4;
-  const dim3 grid((unsigned)((n_rg + 3) / 4), (unsigned)short_splits(p.K));
-  const size_t lds = (size_t)MB * 16 * kShortRS;
-  GemmParams pc = p;
-  uint32_t flags = 0;
-  pc.chain = chain_next(grid.x * grid.y, &flags);
-  hx::launcher_chained(gemm_packed_short_kernel<T, MB>, grid, 256, lds, stream, flags)(pc);
-  return check_launch();
-}
-
-extern "C" int64_t hx_linear_decode_short_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (int64_t)short_splits(K) * M * N * (int64_t)sizeof(float);
-}
-
-extern "C" int hx_linear_decode_partial_packed_short(float* partial, const void* x, const void* packed_weight,
-                                                     int64_t M, int64_t N, int64_t K, int64_t ldx,
-                                                     int64_t partial_bytes, int dtype, hx_stream stream) {
-  if (M <= 0 || N <= 0 || K <= 0) return HX_ERR_SHAPE;
-  if (!partial || !x || !packed_weight) return HX_ERR_NULL;
-  if (M > 32 || !gemm_skinny_supported(M, N, K, ldx, K)) return HX_ERR_SHAPE;
-  if (!aligned16(x) || !aligned16(packed_weight) || !aligned16(partial)) return HX_ERR_STRIDE;
-  if (partial_bytes < hx_linear_decode_short_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
-  GemmParams p;
-  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
-  p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.ldw = K;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.ks_per_split = kShortKs; p.n_splits = short_splits(K); p.packed = 1;
-  int rc;
-  if (dtype == HX_F16) rc = M <= 16 ? launch_short<F16, 1>(p, (hipStream_t)stream) : launch_short<F16, 2>(p, (hipStream_t)stream);
-  else if (dtype == HX_BF16) rc = M <= 16 ? launch_short<BF16, 1>(p, (hipStream_t)stream) : launch_short<BF16, 2>(p, (hipStream_t)stream);
-  else return HX_ERR_DTYPE;
-  return rc ? rc : short_splits(K);
 }
 
 // ---- packed weights ----------------------------------------------------------------------------

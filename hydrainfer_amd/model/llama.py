@@ -104,9 +104,6 @@ class LlamaForCausalLM:
         # the two add+norm launches of a layer run INSIDE the gate|up and qkv launches (the first 32
         # workgroups produce x while all prefetch weights; in-kernel hand-over): 5 launches per layer
         self.fuse_norm = os.environ.get("HX_FUSE_NORM", "1") == "1"
-        # the o projection of <= 32-row decode batches in 512-k splits (small workgroups that enter the machine while
-        # the decode attention launch drains: csrc/gemm_skinny.hip gemm_packed_short_kernel)
-        self.o_short = os.environ.get("HX_O_SHORT", "1") == "1"
         self.sample_out: Optional[Tensor] = None   # int64 [rows]: forward() writes the sampled ids here (decode loops)
         self.xreg_sync: Optional[Tensor] = None   # [L, 2, XREG_SYNC_WORDS] of the last step (word 1 = wait gave up)
         self.packed_x: Dict[str, Tensor] = {}
@@ -309,9 +306,7 @@ class LlamaForCausalLM:
         H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
         q_size, kv_size, inter, hid = self.q_size, self.kv_size, sh.intermediate_size, sh.hidden_size
         eps, L = sh.rms_norm_eps, sh.num_hidden_layers
-        o_short = self.o_short and n <= 32 and f"l{L - 1}.wo" in self.packed
         ws_n = max(hip_gemm.workspace_floats(n, q_size + 2 * kv_size, hid), hip_gemm.workspace_floats(n, hid, q_size),
-                   hip_gemm.short_workspace_floats(n, hid, q_size) if o_short else 0,
                    hip_gemm.workspace_floats(n, 2 * inter, hid), hip_gemm.workspace_floats(n, hid, inter))
         ws = torch.empty(ws_n, dtype=torch.float32, device=h.device)
         x = torch.empty_like(h)
@@ -361,10 +356,7 @@ class LlamaForCausalLM:
                                    ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
                                    ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws_q, s_qkv)
             s_qkv = None
-            if o_short:
-                s_o = hip_gemm.linear_decode_partial_packed_short(o.view(n, q_size), self.packed[f"l{l}.wo"], hid, ws)
-            else:
-                s_o = self._partial(o.view(n, q_size), f"l{l}.wo", ws)
+            s_o = self._partial(o.view(n, q_size), f"l{l}.wo", ws)
             if xreg:
                 # fragment-major activations from here to the down projection
                 pgu, pdn = self.packed_x[f"l{l}.wgu"], self.packed_x[f"l{l}.wdown"]

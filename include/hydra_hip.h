@@ -167,14 +167,6 @@ int hx_pack_decode_weight(void* packed, const void* weight, int64_t N, int64_t K
 int hx_linear_decode_partial_packed(float* partial, const void* x, const void* packed_weight,
                                     int64_t M, int64_t N, int64_t K, int64_t ldx,
                                     int64_t partial_bytes, int dtype, hx_stream stream);
-/* The packed product in SHORT splits (512 k per workgroup, S = K / 512 slabs; M <= 32): small workgroups (4 waves of
- * <= 128 registers, 33 KiB LDS) that enter the machine next to a kernel that is still draining and request their
- * whole weight share up front — the form for a launch chained behind the decode attention (the o projection).
- * Same packed weight as hx_linear_decode_partial_packed; same products, summed in twice as many slabs. */
-int64_t hx_linear_decode_short_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int hx_linear_decode_partial_packed_short(float* partial, const void* x, const void* packed_weight,
-                                          int64_t M, int64_t N, int64_t K, int64_t ldx,
-                                          int64_t partial_bytes, int dtype, hx_stream stream);
 /* Step-edge fusions of a decode loop (extensions, bit-identical to the ops they replace).
  * hx_embed_rms_norm: h_out[r] = table[ids[r]] (torch.nn.functional.embedding; ids int32 or int64, out-of-range
  * ids clamp) and x_out[r] = rms_norm(h_out[r]) * weight, one launch (hydrainfer/model/llama.py:80-83 + layer/norm.py).

@@ -471,32 +471,3 @@ def test_embed_rms_norm_and_argmax_rows_equal_the_torch_ops(dt):
         assert torch.equal(argmax_rows(logits), torch.argmax(logits, dim=-1))
         view = logits[:, : n - 3]                     # row stride != n, unaligned tail
         assert torch.equal(argmax_rows(view), torch.argmax(view, dim=-1))
-
-
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-def test_short_split_packed_gemm_matches_the_1024k_kernel(dt):
-    """hx_linear_decode_partial_packed_short (512-k splits, small workgroups for a launch chained behind the decode
-    attention) == hx_linear_decode_partial_packed up to fp32 summation order: the slab sums of both agree with an fp64
-    product of the same operands to fp32 round-off, every slab count is K / 512, and rows >= M are never written."""
-    from hydrainfer_amd._C.kernel import gemm
-    for (M, N, K) in ((32, 4096, 4096), (5, 5120, 5120), (17, 64, 768), (1, 4096, 4096), (32, 48, 256)):
-        g = torch.Generator().manual_seed(M * 7 + K)
-        x = torch.randn((M, K), generator=g).to(dt).to(DEV)
-        w = (torch.randn((N, K), generator=g) * 0.05).to(dt).to(DEV)
-        pk = gemm.pack_weight(w)
-        a = torch.full((gemm.workspace_floats(M, N, K),), float("nan"), dtype=torch.float32, device=DEV)
-        b = torch.full((gemm.short_workspace_floats(M, N, K) + M * N,), float("nan"), dtype=torch.float32, device=DEV)
-        sa = gemm.linear_decode_partial_packed(x, pk, N, a)
-        sb = gemm.linear_decode_partial_packed_short(x, pk, N, b)
-        assert sb == (K + 511) // 512 and sa == (K + 1023) // 1024
-        ya = a[: sa * M * N].view(sa, M, N).sum(0)
-        yb = b[: sb * M * N].view(sb, M, N).sum(0)
-        assert torch.isnan(b[sb * M * N:]).all()                      # nothing written past the slabs
-        ref = (x.double() @ w.double().t()).float()
-        tol = 2e-4 * (K ** 0.5)
-        assert (ya - ref).abs().max().item() <= tol and (yb - ref).abs().max().item() <= tol
-        assert (ya - yb).abs().max().item() <= tol
-    with pytest.raises(Exception):
-        gemm.linear_decode_partial_packed_short(torch.zeros((33, 256), dtype=dt, device=DEV),
-                                                gemm.pack_weight(torch.zeros((16, 256), dtype=dt, device=DEV)), 16,
-                                                torch.zeros(33 * 16, dtype=torch.float32, device=DEV))
