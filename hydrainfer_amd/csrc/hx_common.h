@@ -55,7 +55,8 @@ struct ChainLink {
   uint32_t* signal;        // sync area of this launch (nullptr: nobody waits for it)
   uint32_t* err;           // word set to 1 if a wait gives up (1 s): the step's results are invalid
   uint32_t signal_total;   // workgroups of this launch
-  uint32_t opts;           // bit 0: diagnostic time stamps into the link area (hx_debug_set_option("chain_stamps", 1))
+  uint32_t opts;           // diagnostics (hx_debug_set_option("chain_stamps", v)): bit 0 time stamps of workgroup 0 and of the
+                           // flag raiser into the link area; bit 1 earliest / latest workgroup entry (one atomic pair per workgroup)
 };
 // sync area of one chained launch, in 32-word (128-byte) lines: 16 arrival-count shards (workgroup id mod 16), one
 // line counting completed shards, 8 flag lines (one per XCD, polled by that XCD's waiters)
@@ -241,6 +242,12 @@ __device__ __forceinline__ void chain_stamp(const ChainLink& ch, int which, bool
 // later chain_wait then costs nothing (measured: polled only after the prefetch had been issued, the first flag
 // load came back behind 32 KiB of HBM loads, 2.2 us per launch on the critical path).
 __device__ __forceinline__ uint32_t chain_peek(const ChainLink& ch) {
+  if ((ch.opts & 2u) && ch.signal && threadIdx.x == 0) {   // diagnostic: first / last workgroup entry of this launch
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(ch.signal + kChainStampWord);
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    atomicMax(st + 4, ~t);      // earliest entry, complemented (the area starts zeroed)
+    atomicMax(st + 5, t);       // latest entry
+  }
   uint32_t v = 1u;
   if (ch.wait && threadIdx.x < 64)
     v = __hip_atomic_load(ch.wait + kChainFlagWord + 32 * xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

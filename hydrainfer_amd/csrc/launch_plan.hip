@@ -48,7 +48,7 @@ static thread_local PlanRecorder* t_recording = nullptr;
 static int g_chain_stamps = 0;   // diagnostic (hx_debug_set_option("chain_stamps", 1)): links recorded from now on carry time stamps
 
 int plan_set_option(const char* name, int value) {
-  if (!strcmp(name, "chain_stamps")) { g_chain_stamps = value ? 1 : 0; return HX_OK; }
+  if (!strcmp(name, "chain_stamps")) { g_chain_stamps = value & 3; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 
@@ -78,7 +78,7 @@ ChainLink chain_next(uint32_t n_workgroups, uint32_t* flags) {
   lk.signal = r->sync + r->used_words;
   lk.err = r->err;
   lk.signal_total = n_workgroups;
-  lk.opts = g_chain_stamps ? 1u : 0u;
+  lk.opts = (uint32_t)g_chain_stamps;
   r->used_words += kChainWords;
   r->prev_signal = lk.signal;
   if (lk.wait) *flags = hipExtAnyOrderLaunch;

@@ -18,7 +18,7 @@ from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
 dev = torch.device("cuda:0")
 shape = LLAVA_1_5_13B if len(sys.argv) > 1 and sys.argv[1] == "13b" else LLAVA_1_5_7B
 ctx = int(sys.argv[2]) if len(sys.argv) > 2 else 832
-assert _lib.lib().hx_debug_set_option(b"chain_stamps", 1) == 0
+assert _lib.lib().hx_debug_set_option(b"chain_stamps", 3) == 0
 model = LlamaForCausalLM.random_init(shape, torch.bfloat16, dev, seed=0)
 r = DecodeRunner(model, RunnerConfig(batch=32, prompt_len=704, n_generate=256, use_graph=True, executor="plan"), seed=0)
 r.set_state(ctx - 1, torch.randint(5, 30000, (32,), device=dev))
@@ -35,23 +35,23 @@ stamp0 = 16 * 32 + 32 + 8 * 32
 names = ["attention", "o proj", "norm+gate|up+silu", "down", "norm+qkv"]
 rows = []
 for i in range(n):
-    st = sync[i * W + stamp0: i * W + stamp0 + 8].view(np.uint64)
-    rows.append([int(x) for x in st])      # wait entry (wg0), past wait (wg0), end (flag raiser), wg0 at signal
+    st = sync[i * W + stamp0: i * W + stamp0 + 12].view(np.uint64)
+    rows.append([int(x) for x in st[:4]] + [int(~st[4] & np.uint64(0xFFFFFFFFFFFFFFFF)), int(st[5])])   # + first / last workgroup entry
 L = shape.num_hidden_layers
-print(f"{'launch':28s} {'wg0 at wait':>12s} {'wg0 past wait':>14s} {'wg0 done':>10s} {'end':>8s}   (us after the predecessor's end)")
+print(f"{'launch':28s} {'first wg in':>12s} {'last wg in':>11s} {'wg0 at wait':>12s} {'wg0 past wait':>14s} {'wg0 done':>10s} {'end':>8s}   (us after the predecessor's end)")
 per = {k: [] for k in names}
 for i in range(1, n):
     prev_end = rows[i - 1][2]
-    a, b, e, s0 = rows[i]
+    a, b, e, s0, f_in, l_in = rows[i]
     name = names[(i - 1) % 5]
     layer = (i - 1) // 5
-    vals = [(x - prev_end) / 100.0 for x in (a, b, s0, e)]
+    vals = [(x - prev_end) / 100.0 for x in (f_in, l_in, a, b, s0, e)]
     per[name].append(vals)
     if L // 2 <= layer < L // 2 + 2:
-        print(f"L{layer:02d} {name:24s} {vals[0]:12.2f} {vals[1]:14.2f} {vals[2]:10.2f} {vals[3]:8.2f}")
+        print(f"L{layer:02d} {name:24s} " + " ".join(f"{v:12.2f}" for v in vals))
 print("\nmean over all layers:")
 for k in names:
     v = np.array(per[k])
-    print(f"    {k:24s} {v[:, 0].mean():12.2f} {v[:, 1].mean():14.2f} {v[:, 2].mean():10.2f} {v[:, 3].mean():8.2f}")
+    print(f"    {k:24s} " + " ".join(f"{v[:, j].mean():12.2f}" for j in range(6)))
 tot = (rows[n - 1][2] - rows[0][2]) / 100.0
 print(f"\nchain from layer 0's qkv end to the last down projection's end: {tot:.1f} us = {tot / L:.2f} us per layer")
