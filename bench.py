@@ -45,7 +45,7 @@ def parse():
     p.add_argument("--batch", type=int, default=32)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     p.add_argument("--no-graph", action="store_true")
-    p.add_argument("--executor", default=os.environ.get("HX_DECODE_EXECUTOR", "graph"), choices=["graph", "plan", "plan-nochain"],
+    p.add_argument("--executor", default=os.environ.get("HX_DECODE_EXECUTOR", "plan"), choices=["graph", "plan", "plan-nochain"],
                    help="replay of the decode step: one hipGraph, or a launch plan (native launch loop; 'plan' chains the "
                         "five launches of every layer without the AQL barrier bit, dependencies taken inside the kernels)")
     p.add_argument("--skip-prefill", action="store_true",
@@ -92,14 +92,17 @@ def launch_ranks_if_needed(args):
 
 def timed_contexts(prompt_len, n_generate, steps):
     """KV lengths of the timed steps.  The generation's decode steps see contexts prompt_len+1 ..
-    prompt_len+n_generate-1 (705..959); fewer steps than that are spread evenly over the same range
-    (both ends included) so that their mean is the generation's mean context."""
+    prompt_len+n_generate-1 (705..959); fewer steps than that sample the same range at a FIXED spacing, centred,
+    so that their mean is the generation's mean context (832) and the step's own device-side advance
+    (hx_decode_advance with that stride) walks them — no extra launch in the timed region."""
     lo, hi = prompt_len + 1, prompt_len + n_generate - 1
     if steps >= hi - lo + 1:
         return list(range(lo, hi + 1))
     if steps == 1:
         return [(lo + hi) // 2]
-    return [lo + (k * (hi - lo)) // (steps - 1) for k in range(steps)]
+    stride = (hi - lo) // (steps - 1)
+    first = lo + ((hi - lo) - stride * (steps - 1)) // 2
+    return [first + k * stride for k in range(steps)]
 
 
 def dry_run(args):
@@ -244,7 +247,7 @@ def time_attention_kernel(runner, ctxs):
         ms = total / reps / steps
     else:
         for s in range(steps + 2):
-            runner.set_state(ctxs[max(s - 2, 0)] - 1)
+            runner.set_state(ctxs[max(s - 2, 0)] - runner.cfg.advance_stride)
             runner._advance()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -738,32 +741,33 @@ def cpu_baseline(shape, dtype, batch, ctx, n_layers):
 
 def decode_leg(ctx, model, runner, ctxs, warmup, prompt_len):
     """Warm-up, then the timed region of the contract: barrier + synchronize on both sides, exactly
-    len(ctxs) decode steps, MAX over ranks.  Contiguous contexts are walked by the step's own advance;
-    a strided schedule repositions the (device-resident) decode state before each step with two tiny
-    fills — they are inside the timed region and count against the result."""
-    state = (runner.positions.clone(), runner.kv_lens.clone(), runner.input_ids.clone())
-
-    def reset():
-        runner.positions.copy_(state[0]); runner.kv_lens.copy_(state[1]); runner.input_ids.copy_(state[2])
-        runner.tokens = []
+    len(ctxs) decode steps, MAX over ranks.  The contexts are equally spaced: the step's own device-side advance
+    moves the decode state from one to the next (stride 1 = the generation itself), so the timed region is
+    nothing but the K steps."""
+    stride = ctxs[1] - ctxs[0] if len(ctxs) > 1 else 1
+    assert all(b - a == stride for a, b in zip(ctxs, ctxs[1:])), "timed contexts must be equally spaced"
+    runner.cfg.advance_stride = stride
+    ids = runner.input_ids.clone()
     if runner.cfg.use_graph:
+        runner.set_state(ctxs[0] - stride, ids)
         runner.capture()
     for _ in range(warmup):
+        runner.set_state(ctxs[0] - stride, ids)
         runner.step(record=False)
-    reset()
-    contiguous = ctxs == list(range(prompt_len + 1, prompt_len + 1 + len(ctxs)))
+    runner.set_state(ctxs[0] - stride, ids)      # the first step's advance makes it ctxs[0]
     ctx.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for c in ctxs:
-        if not contiguous:
-            runner.set_state(c - 1)        # the step's advance makes it c
+    for _ in ctxs:
         runner.step(record=False)
     torch.cuda.synchronize()
     elapsed = ctx.max_over_ranks(time.perf_counter() - t0, runner.dev)
     ctx.barrier(); torch.cuda.synchronize()
-    # a norm-fused launch that gave up waiting for its producers leaves an error word: not a measurement
-    if model.handover_failed():
-        print("bench.py: a norm-fused launch gave up waiting for its producer workgroups", file=sys.stderr, flush=True)
+    assert int(runner.kv_lens[0]) == ctxs[-1], "the timed steps did not walk the announced contexts"
+    # an in-kernel hand-over that gave up waiting leaves an error word: not a measurement
+    from hydrainfer_amd import launch_plan
+    if model.handover_failed() or (isinstance(runner.graph, launch_plan.LaunchPlan) and runner.graph.failed()):
+        print("bench.py: an in-kernel hand-over (norm-fused launch / launch chain) gave up waiting for its producer",
+              file=sys.stderr, flush=True)
         sys.exit(4)
     return elapsed
 
@@ -810,8 +814,8 @@ def roofline_objects(model, runner, ctxs, ms_per_step, args, model_name, with_ge
 def ctx_label(ctxs):
     if len(ctxs) > 1 and ctxs[1] - ctxs[0] == 1:
         return f"ctx {ctxs[0]}..{ctxs[-1]} (consecutive steps of the generation)"
-    return (f"ctx {ctxs[0]}..{ctxs[-1]} in {len(ctxs)} evenly spaced steps (mean {sum(ctxs) / len(ctxs):.0f}; the "
-            f"generation's 255 decode steps see 705..959, mean 832)")
+    return (f"ctx {ctxs[0]}..{ctxs[-1]} in {len(ctxs)} steps {ctxs[1] - ctxs[0] if len(ctxs) > 1 else 0} apart (mean "
+            f"{sum(ctxs) / len(ctxs):.0f}; the generation's 255 decode steps see 705..959, mean 832)")
 
 
 def leg_13b(ctx, args, dtype, dev, rank):

@@ -122,7 +122,9 @@ _SIGNATURES = {
     "hx_moe_permute": (c_int, [c_void_p] * 3 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_moe_unpermute": (c_int, [c_void_p] * 4 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_moe_sum_out": (c_int, [c_void_p] * 2 + [c_int64] * 3 + [c_int, c_void_p]),
-    "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_void_p]),
+    "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_int32, c_void_p]),
+    "hx_decode_feed_ids": (c_int, [c_void_p] * 4 + [c_int32, c_void_p]),
+    "hx_collect_errors": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     "hx_plan_begin": (c_int, [POINTER(c_void_p), c_void_p, c_int64, c_void_p, c_int]),
     "hx_plan_end": (c_int, [c_void_p]),
     "hx_plan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),

@@ -182,7 +182,11 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   __shared__ __attribute__((aligned(16))) char s_k[NW][KLds<D>::BYTES];
   __shared__ __attribute__((aligned(16))) u16 s_qkv[FUSE ? 3 : 1][FUSE ? D : 8];
 
-  const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
+  // head of this workgroup: blockIdx.x rotated by rot * sequence.  Workgroup (x, y) runs on XCD (x + 32 y) mod 8, and
+  // head h reads bytes [256 h, 256 h + 256) of every 8 KiB key row: unrotated, XCD c serves exactly the heads
+  // == c (mod 8), i.e. one fixed residue of the address bits 8..10, for the whole launch
+  const int b = blockIdx.y, split = blockIdx.z;
+  const int h = p.xcd_remap ? (int)((blockIdx.x + (unsigned)p.xcd_remap * blockIdx.y) % gridDim.x) : (int)blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
@@ -412,6 +416,7 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const AttnParams
 // (sequence, head) pair counts for which one 8-wave workgroup per pair replaces key splits + combine
 int g_decode_small_lo = 160, g_decode_small_hi = 576;
 int g_decode_waves = 4;  // tuning knobs (hx_debug_set_option)
+int g_decode_rot = 0;  // head rotation per sequence (see attn_decode_kernel): 0 = off
 int g_decode_nt = 1;   // K/V are read once: non-temporal loads measured +4 % (profiles/r1_attn_decode_variants.txt)
 
 template <typename T, int D>
@@ -424,6 +429,7 @@ int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
   if (p.k_new || p.qkv_partial) {
     // chain-capable when the qkv slabs are its input and it writes the final output itself (no split + combine)
     AttnParams pc = p;
+    pc.xcd_remap = g_decode_rot;
     uint32_t flags = 0;
     const bool chain = p.qkv_partial && p.n_splits == 1;
     if (chain) pc.chain = chain_next(grid.x * grid.y * grid.z, &flags);
@@ -454,6 +460,7 @@ namespace hx {
 int decode_set_option(const char* name, int value) {
   if (!strcmp(name, "decode_waves")) { g_decode_waves = (value == 8) ? 8 : 4; return HX_OK; }
   if (!strcmp(name, "decode_nt")) { g_decode_nt = value ? 1 : 0; return HX_OK; }
+  if (!strcmp(name, "decode_rot")) { g_decode_rot = value; return HX_OK; }
   if (!strcmp(name, "decode_small_lo")) { g_decode_small_lo = value; return HX_OK; }
   if (!strcmp(name, "decode_small_hi")) { g_decode_small_hi = value; return HX_OK; }
   return HX_ERR_UNSUPPORTED;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(
     int32_t* __restrict__ positions, int32_t* __restrict__ kv_lens,
     int32_t* __restrict__ cu_seqlens_k, int32_t* __restrict__ new_cache_slots,
     const int32_t* __restrict__ block_table, const int32_t* __restrict__ cu_block_lens,
-    int32_t batch, int32_t block_size) {
+    int32_t batch, int32_t block_size, int32_t stride) {
   __shared__ int32_t scan[256];
   int32_t carry = 0;
   if (threadIdx.x == 0) cu_seqlens_k[0] = 0;
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(
     const int b = base + threadIdx.x;
     int32_t len = 0;
     if (b < batch) {
-      const int32_t pos = positions[b] + 1;
+      const int32_t pos = positions[b] + stride;
       positions[b] = pos;
-      len = kv_lens[b] + 1;
+      len = kv_lens[b] + stride;
       kv_lens[b] = len;
       const int32_t page = block_table[cu_block_lens[b] + pos / block_size];
       new_cache_slots[b] = page * block_size + pos % block_size;
@@ -177,13 +177,51 @@ extern "C" int hx_set_image_cache(const int32_t* slot_ids, const void* image_tok
 extern "C" int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_k,
                                  int32_t* new_cache_slots, const int32_t* block_table,
                                  const int32_t* cu_block_lens, int32_t batch, int32_t block_size,
-                                 hx_stream stream) {
+                                 int32_t stride, hx_stream stream) {
   if (!positions || !kv_lens || !cu_seqlens_k || !new_cache_slots || !block_table ||
       !cu_block_lens)
     return HX_ERR_NULL;
-  if (batch <= 0 || block_size <= 0) return HX_ERR_SHAPE;
+  if (batch <= 0 || block_size <= 0 || stride < 1) return HX_ERR_SHAPE;
   hx::launcher(decode_advance_kernel, 1, 256, 0, (hipStream_t)stream)(positions, kv_lens, cu_seqlens_k,
                                                             new_cache_slots, block_table,
-                                                            cu_block_lens, batch, block_size);
+                                                            cu_block_lens, batch, block_size, stride);
+  return hx::check_launch();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void decode_feed_ids_kernel(int64_t* __restrict__ out, const int32_t* __restrict__ ids,
+                                                              const int32_t* __restrict__ src,
+                                                              const int64_t* __restrict__ prev, int32_t n) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < n) {
+    const int32_t s = src[r];
+    out[r] = s >= 0 ? prev[s] : (int64_t)ids[r];
+  }
+}
+
+__global__ __launch_bounds__(64) void collect_errors_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ areas,
+                                                            int32_t n_areas, int64_t stride_words, int32_t word,
+                                                            const uint32_t* __restrict__ extra) {
+  uint32_t v = 0;
+  for (int i = threadIdx.x; i < n_areas; i += 64) v |= areas[(int64_t)i * stride_words + word];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
+  if (threadIdx.x == 0) out[0] = v | (extra ? extra[0] : 0u);
+}
+}  // namespace
+
+extern "C" int hx_decode_feed_ids(int64_t* out, const int32_t* ids, const int32_t* src, const int64_t* prev,
+                                  int32_t n, hx_stream stream) {
+  if (!out || !ids || !src || !prev) return HX_ERR_NULL;
+  if (n <= 0) return HX_ERR_SHAPE;
+  hx::launcher(decode_feed_ids_kernel, (unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream)(out, ids, src, prev, n);
+  return hx::check_launch();
+}
+
+extern "C" int hx_collect_errors(uint32_t* out, const uint32_t* areas, int32_t n_areas, int64_t stride_words,
+                                 int32_t word, const uint32_t* extra, hx_stream stream) {
+  if (!out || (n_areas > 0 && !areas)) return HX_ERR_NULL;
+  if (n_areas < 0 || stride_words < 0 || word < 0) return HX_ERR_SHAPE;
+  hx::launcher(collect_errors_kernel, 1, 64, 0, (hipStream_t)stream)(out, areas, n_areas, stride_words, word, extra);
   return hx::check_launch();
 }

@@ -275,6 +275,18 @@ __device__ __forceinline__ void chain_wait(const ChainLink& ch, uint32_t peeked 
 }
 
 __device__ __forceinline__ void chain_signal(const ChainLink& ch) {
+  if ((ch.opts & 2u) && ch.signal && threadIdx.x == 0) {   // diagnostic: histogram of workgroup END times, 2 us buckets
+    // relative to the launch's earliest workgroup entry (words kChainStampWord + 16 .. + 79)
+    const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long first = ~__hip_atomic_load(reinterpret_cast<unsigned long long*>(ch.signal + kChainStampWord) + 4,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long b = (t - first) / 200ull;
+    if (b > 63ull) b = 63ull;
+    atomicAdd(ch.signal + kChainStampWord + 16 + (int)b, 1u);
+    // ... and the summed end time (us) per blockIdx.x and per blockIdx.y (both mod 32): who finishes late?
+    atomicAdd(ch.signal + kChainStampWord + 80 + (blockIdx.x & 31), (uint32_t)((t - first) / 100ull));
+    atomicAdd(ch.signal + kChainStampWord + 112 + (blockIdx.y & 31), (uint32_t)((t - first) / 100ull));
+  }
   if (ch.signal) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached memory
     __syncthreads();

@@ -18,11 +18,13 @@ from the host-written id or from `prev_tokens[src_row]` (the previous launch's s
 static buffer the graph itself updates at its end), so the host can build and enqueue launch N+1
 while launch N is still running and read N's tokens afterwards (`launch` / `fetch`).  The host work
 of a step (scheduler, tables, staging) no longer leaves the GPU idle."""
+import os
 from typing import Dict, List, Tuple
 
 import numpy as np
 import torch
 
+from hydrainfer_amd import _lib, launch_plan
 from hydrainfer_amd._lib import HydraHipError
 from hydrainfer_amd.layer.causal_attention import AttentionParameters
 from hydrainfer_amd.memory.kv_cache import KVCache
@@ -31,7 +33,10 @@ from hydrainfer_amd.model.llama import LanguageModelParameters
 
 class GraphedDecoder:
     def __init__(self, language_model, kv_cache_block_manager, max_batch: int = 64,
-                 max_blocks_per_seq: int = 256, pad_to: int = 4):
+                 max_blocks_per_seq: int = 256, pad_to: int = 4, executor: str = None):
+        # how a captured step is replayed: "plan" = a launch plan (hydrainfer_amd/launch_plan.py: native launch loop,
+        # the five launches of every layer chained without the AQL barrier bit), "graph" = a hipGraph
+        self.executor = executor or os.environ.get("HX_DECODE_EXECUTOR", "plan")
         self.lm = language_model                       # LlavaLanguageModel
         self.model = language_model.language_model     # LlamaForCausalLM
         self.kv = kv_cache_block_manager
@@ -53,7 +58,7 @@ class GraphedDecoder:
         self.copy_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.fills = 0
         self.q_cu = torch.arange(0, B + 1, dtype=torch.int32, device=self.dev)
-        self.prev_tokens = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.prev_tokens = torch.zeros(B, dtype=torch.int64, device=self.dev)   # the previous launch's samples
         self.host_tokens = [torch.zeros(B, dtype=torch.int64).pin_memory() for _ in range(2)]
         # word that is nonzero iff an in-kernel hand-over of that launch gave up waiting (csrc/gemm_xreg.hip): it
         # travels to the host with the launch's tokens and is checked in fetch()
@@ -97,13 +102,37 @@ class GraphedDecoder:
         return LanguageModelParameters(attention_params=attn, all_sequences_decode=True)
 
     def _body(self, B: int, params):
+        """One decode step as library launches only (+ the lm_head GEMM): recordable in a launch plan."""
         ids, pos = self._views(B)[:2]
         src = self._views(B)[6]
-        fed = self.prev_tokens[src.clamp_min(0).long()]
+        lib = _lib.lib()
+        fed = torch.empty(B, dtype=torch.int64, device=self.dev)
+        _lib.check(lib.hx_decode_feed_ids(fed.data_ptr(), ids.data_ptr(), src.data_ptr(), self.prev_tokens.data_ptr(), B,
+                                          _lib.current_stream()), "decode_feed_ids")
         self.model.xreg_sync = None
-        out = self.model(torch.where(src >= 0, fed, ids), pos, params)
-        self.prev_tokens[:B].copy_(out)
-        return out, self.model.handover_error_word()
+        # the greedy sampler writes straight into prev_tokens: this launch's feed (above) has read it, the next
+        # launch's feed and the D2H copy of the tokens read it after this launch, in stream order
+        out = self.prev_tokens[:B]
+        self.model.sample_out = out
+        try:
+            res = self.model(fed, pos, params)
+        finally:
+            self.model.sample_out = None
+        if res.data_ptr() != out.data_ptr():
+            launch_plan.host_op(lambda: out.copy_(res))
+        # give-up words of the step's in-kernel hand-overs (norm-fused launches, launch chain) -> one word
+        err = None
+        sync = self.model.xreg_sync
+        plan = launch_plan.current()
+        plan_err = plan.error_word if plan is not None and plan.chain else None
+        if sync is not None or plan_err is not None:
+            err = torch.empty(1, dtype=torch.int32, device=self.dev)
+            n_areas = sync.numel() // sync.shape[-1] if sync is not None else 0
+            _lib.check(lib.hx_collect_errors(err.data_ptr(), sync.data_ptr() if sync is not None else None, n_areas,
+                                             sync.shape[-1] if sync is not None else 0, 1,
+                                             plan_err.data_ptr() if plan_err is not None else None,
+                                             _lib.current_stream()), "collect_errors")
+        return out, err
 
     def _capture(self, B: int, bucket: int):
         params = self._params(B, bucket if bucket else 4096)
@@ -116,9 +145,14 @@ class GraphedDecoder:
                 self._body(B, params)
             self.prev_tokens.copy_(saved)
         torch.cuda.current_stream(self.dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out, err = self._body(B, params)
+        if self.executor == "plan":
+            graph = launch_plan.LaunchPlan(self.dev, chain=True,
+                                           max_chained_launches=8 * self.model.shape.num_hidden_layers + 16)
+            out, err = graph.capture(lambda: self._body(B, params))
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out, err = self._body(B, params)
         return graph, out, err
 
     def _fill(self, rows: List[Tuple[int, int, int, int, List[int]]], B: int) -> int:
@@ -194,10 +228,14 @@ class GraphedDecoder:
             # a norm-fused launch consumed activations nobody had produced: this step's tokens are garbage.
             # Later steps run with the add+RMSNorm as separate launches (no in-kernel hand-over).
             self.model.fuse_norm = False
+            self.executor = "graph"
+            for g in self.graphs.values():
+                if isinstance(g[0], launch_plan.LaunchPlan):
+                    g[0].error_word.zero_()
             self.graphs.clear()
-            raise HydraHipError(f"decode launch {launch_id}: an in-kernel hand-over (norm-fused GEMM launch) gave up "
-                                "waiting for its producer workgroups; the step's tokens are invalid. Norm fusion is "
-                                "now disabled for this model (fuse_norm = False)")
+            raise HydraHipError(f"decode launch {launch_id}: an in-kernel hand-over (norm-fused GEMM launch or launch "
+                                "chain) gave up waiting for its producer; the step's tokens are invalid. Later steps run "
+                                "with separate norm launches from stream-ordered hipGraphs (fuse_norm = False)")
         return self.host_tokens[slot][:n].tolist()
 
     def run(self, rows: List[Tuple[int, int, int, int, List[int]]]) -> List[int]:

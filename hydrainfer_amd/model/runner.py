@@ -60,6 +60,8 @@ class RunnerConfig:
     # chained without the AQL barrier bit (dependencies taken inside the kernels); "plan-nochain" = the plan with
     # ordinary stream-ordered launches (A/B reference)
     executor: str = "graph"
+    advance_stride: int = 1      # tokens a decode step moves the contexts forward (1 = a real generation; bench.py
+                                 # samples the generation's contexts at a fixed spacing when it times fewer steps)
 
 
 class DecodeRunner:
@@ -204,7 +206,7 @@ class DecodeRunner:
         _lib.check(_lib.lib().hx_decode_advance(
             self.positions.data_ptr(), self.kv_lens.data_ptr(), self.cu_k.data_ptr(),
             self.slots.data_ptr(), self.block_table.data_ptr(), self.cu_block_lens.data_ptr(),
-            self.cfg.batch, self.cfg.block_size, _lib.current_stream()), "decode_advance")
+            self.cfg.batch, self.cfg.block_size, self.cfg.advance_stride, _lib.current_stream()), "decode_advance")
 
     def _step_body(self) -> None:
         self._advance()

@@ -379,14 +379,24 @@ int hx_unpack_blocks(const int32_t* table_host, int64_t n_pairs, const void* sta
  * Decode-step metadata advance: device-resident equivalent of one
  * AttentionParametersBuilder pass for an all-decode batch
  * (hydrainfer/layer/causal_attention.py:147-168).  For every sequence b:
- *   positions[b] += 1; kv_len[b] += 1; cu_seqlens_k = prefix-sum(kv_len);
+ *   positions[b] += stride; kv_len[b] += stride; cu_seqlens_k = prefix-sum(kv_len);
  *   new_cache_slots[b] = block_table[cu_block_lens[b] + pos/bs]*bs + pos%bs.
- * Lets a whole decode step live inside one hipGraph.
+ * stride = 1 is the reference's step; a benchmark that samples the generation's contexts at a fixed spacing
+ * uses a larger one.  Lets a whole decode step live inside one hipGraph / launch plan.
+ * hx_decode_feed_ids: the step's input ids with one step of look-ahead (engine/graph_decode.py): row r takes the
+ * token the PREVIOUS launch sampled for row src[r] (prev, int64, still on the device) when src[r] >= 0, else the
+ * host-written ids[r].  hx_collect_errors: out[0] = OR over i < n_areas of areas[i * stride_words + word], OR
+ * extra[0] if given — the give-up words of a step's in-kernel hand-overs folded into ONE word that travels to the
+ * host with the step's tokens.
  * ---------------------------------------------------------------------- */
 int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_k,
                       int32_t* new_cache_slots, const int32_t* block_table,
                       const int32_t* cu_block_lens, int32_t batch, int32_t block_size,
-                      hx_stream stream);
+                      int32_t stride, hx_stream stream);
+int hx_decode_feed_ids(int64_t* out, const int32_t* ids, const int32_t* src, const int64_t* prev,
+                       int32_t n, hx_stream stream);
+int hx_collect_errors(uint32_t* out, const uint32_t* areas, int32_t n_areas, int64_t stride_words,
+                      int32_t word, const uint32_t* extra, hx_stream stream);
 
 /* ------------------------------------------------------------------------
  * Launch plans: record the launches of a fixed sequence of hx_* calls once, replay them with one

@@ -45,8 +45,10 @@ def test_timed_contexts_cover_the_generation():
     full = bench.timed_contexts(704, 256, 255)
     assert full == list(range(705, 960))                       # the 255 decode steps of a 256-token generation
     assert bench.timed_contexts(704, 256, 400) == full
-    for k in (2, 5, 20, 64, 128):
+    for k in (2, 5, 20, 40, 64, 128):
         c = bench.timed_contexts(704, 256, k)
-        assert len(c) == k and c[0] == 705 and c[-1] == 959 and c == sorted(c)
+        assert len(c) == k and 705 <= c[0] and c[-1] <= 959
+        assert len({b - a for a, b in zip(c, c[1:])}) == 1 and c[1] > c[0]     # one fixed spacing: the step's own advance
         assert abs(sum(c) / k - 832) <= 1.0                     # same mean context as the whole generation
+        assert c[-1] - c[0] >= 228                              # ... and at least 90 % of its range
     assert bench.timed_contexts(704, 256, 1) == [832]

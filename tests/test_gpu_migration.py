@@ -112,7 +112,7 @@ def test_decode_advance_matches_builder():
     bt = torch.tensor(tables, dtype=torch.int32, device=DEV)
     cub = torch.tensor(cu_b, dtype=torch.int32, device=DEV)
     _lib.check(_lib.lib().hx_decode_advance(pos.data_ptr(), kvl.data_ptr(), cu_k.data_ptr(),
-                                            slots.data_ptr(), bt.data_ptr(), cub.data_ptr(), B, bs,
+                                            slots.data_ptr(), bt.data_ptr(), cub.data_ptr(), B, bs, 1,
                                             _lib.current_stream()), "decode_advance")
     torch.cuda.synchronize()
     want_slots = [tcm.v2p(tables[cu_b[i]:cu_b[i + 1]], [lens[i]], bs)[0] for i in range(B)]

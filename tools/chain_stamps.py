@@ -53,5 +53,15 @@ print("\nmean over all layers:")
 for k in names:
     v = np.array(per[k])
     print(f"    {k:24s} " + " ".join(f"{v[:, j].mean():12.2f}" for j in range(6)))
+print("\nworkgroup end times of one middle layer's launches (count per 2-us bucket after the launch's first workgroup entry):")
+for i in range(1 + 5 * (L // 2), 1 + 5 * (L // 2) + 5):
+    h = sync[i * W + stamp0 + 16: i * W + stamp0 + 80]
+    nz = [(2 * j, int(c)) for j, c in enumerate(h) if c]
+    print(f"    {names[(i - 1) % 5]:20s} " + " ".join(f"{t}:{c}" for t, c in nz))
+i = 1 + 5 * (L // 2)
+hx_ = sync[i * W + stamp0 + 80: i * W + stamp0 + 112].astype(np.float64) / 32
+hy_ = sync[i * W + stamp0 + 112: i * W + stamp0 + 144].astype(np.float64) / 32
+print("attention, mean end time (us) by head   :", " ".join(f"{v:.0f}" for v in hx_))
+print("attention, mean end time (us) by sequence:", " ".join(f"{v:.0f}" for v in hy_))
 tot = (rows[n - 1][2] - rows[0][2]) / 100.0
 print(f"\nchain from layer 0's qkv end to the last down projection's end: {tot:.1f} us = {tot / L:.2f} us per layer")
