@@ -171,7 +171,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
 // transpose through LDS (tools/bench_stream.py, corrected: every load shape streams at 6.5-7.0 TB/s when
 // neighbouring waves cover neighbouring bytes; what the packed form saves is the per-wave LDS transpose).  Same k order, same
 // accumulation chains: bit-identical to gemm_skinny_kernel.
-template <typename T, int MB, int R, int NW, int DBG = 0>
+// XLATE (launch chain, the predecessor's flag has to be waited for): x is read after the weights have been requested —
+// a template parameter, not a branch: loads behind a branch make hipcc fall back to vmcnt(0) at the join, which
+// serialises the x round trip in front of the weight stream (+1.5 us on the o projection, measured)
+template <typename T, int MB, int R, int NW, int DBG = 0, bool XLATE = false>
 __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p, const int g_nt_store) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kThreads = NW * 64;
@@ -191,9 +194,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
   u16x8 xr[XPT];
   // in a launch chain x is the output of a launch that may still be running: it is read AFTER the weights have
   // been requested and the predecessor's done flag has been seen (below); otherwise first, as always
-  const bool x_late = p.chain.wait != nullptr;
-  const uint32_t chain_peeked = chain_peek(p.chain);
-  if (!x_late) {
+  constexpr bool x_late = XLATE;
+  const uint32_t chain_peeked = XLATE ? chain_peek(p.chain) : 1u;
+  if constexpr (!x_late) {
     const u16* xb = reinterpret_cast<const u16*>(p.x) + (int64_t)ks0 * 32;
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
   load(buf[0], 0);
   load(buf[1], 1);
   __builtin_amdgcn_sched_barrier(0);
-  if (x_late) {
+  if constexpr (x_late) {
     chain_wait(p.chain, chain_peeked);
     const chain_rsrc_t xrs = chain_rsrc(p.x);
 #pragma unroll
@@ -367,7 +370,16 @@ int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
     GemmParams pc = p;
     uint32_t flags = 0;
     pc.chain = chain_next(grid.x * grid.y, &flags);      // zeros outside a chained plan recording
-    hx::launcher_chained(gemm_packed_kernel<T, MB, R, NW>, grid, NW * 64, plds, stream, flags)(pc, g_slab_nt & 1);
+    if (pc.chain.wait) {
+      if (plds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_packed_kernel<T, MB, R, NW, 0, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+        if (e != hipSuccess) return hip_rc(e);
+      }
+      hx::launcher_chained(gemm_packed_kernel<T, MB, R, NW, 0, true>, grid, NW * 64, plds, stream, flags)(pc, g_slab_nt & 1);
+    } else {
+      hx::launcher_chained(gemm_packed_kernel<T, MB, R, NW>, grid, NW * 64, plds, stream, flags)(pc, g_slab_nt & 1);
+    }
     return check_launch();
   }
   const size_t lds = (size_t)MB * 16 * kRS + (size_t)NW * 2048;   // x slice + per-wave transpose images

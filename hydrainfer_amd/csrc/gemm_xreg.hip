@@ -186,7 +186,9 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
 // 16-row groups interleaved (group 2j = gate rows 16j.., group 2j+1 = up rows 16j..); a workgroup
 // takes whole pairs and writes act = silu(gate) * up with the rounding of hx_silu_and_mul_slabs on the
 // one-slab result (sum -> T, silu -> T, product -> T), fragment-major for the down projection.
-template <typename T, int MB, int KW, int EPI = 0, int DBG = 0, int NORM = 0>
+// XLATE (NORM = 0 in a launch chain): x is the predecessor launch's output and is read after its done flag — a template
+// parameter, not a branch around the prologue loads (hipcc's vmcnt bookkeeping is exact only in straight-line code)
+template <typename T, int MB, int KW, int EPI = 0, int DBG = 0, int NORM = 0, bool XLATE = false>
 __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = (KW + 7) / 8;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int split = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
-  const uint32_t chain_peeked = chain_peek(p.chain);   // the predecessor's flag, requested before anything else
+  const uint32_t chain_peeked = (NORM || XLATE) ? chain_peek(p.chain) : 1u;   // the predecessor's flag, requested before anything else
   const int total_ks = p.K >> 5;
   const int n_rg = p.N >> 4;
   const int ks0 = split * P;
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-  } else if (p.chain.wait != nullptr && p.x_packed) {
+  } else if constexpr (XLATE) {
     // launch chain: x is the predecessor launch's output.  All weight buffers first (32 KiB per wave in flight),
     // then its done flag, then x with sc1 loads
 #pragma unroll
@@ -569,6 +571,17 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
     XregParams pc = p;
     uint32_t flags = 0;
     pc.chain = chain_next((uint32_t)(nb * S), &flags);      // zeros outside a chained plan recording
+    if constexpr (NORM == 0) {
+      if (pc.chain.wait) {
+        if (lds > 48 * 1024) {
+          hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_kernel<T, MB, KW, EPI, 0, 0, true>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (e != hipSuccess) return hip_rc(e);
+        }
+        hx::launcher_chained(gemm_xreg_kernel<T, MB, KW, EPI, 0, 0, true>, grid, 256, lds, stream, flags)(pc);
+        return check_launch();
+      }
+    }
     hx::launcher_chained(gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>, grid, 256, lds, stream, flags)(pc);
   } else {
     hx::launcher(gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>, grid, 256, lds, stream)(p);

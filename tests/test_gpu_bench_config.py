@@ -103,46 +103,53 @@ def test_benchmarked_decode_configuration_matches_oracle():
 
 def test_handover_give_up_is_loud_in_runner_and_engine():
     """Test hook xreg_no_producers = 2: the norm-fused launches get no producers and no rescue, so every one of them
-    gives up (2 ms bound under the hook) and leaves its error word.  The runner must refuse to hand out that run's
-    tokens, the engine's graph decoder must raise from fetch() and switch the model to separate norm launches."""
+    gives up (2 ms bound under the hook) and leaves its error word.  (The hook is a launch argument: it has to be set
+    when the step is captured / recorded.)  The runner must refuse to hand out that run's tokens, the engine's
+    decoder must raise from fetch(), switch the model to separate norm launches and keep serving."""
     from hydrainfer_amd import _lib
     lib = _lib.lib()
-    shape, model, runner = _build(batch=8, prompt_len=24, n_generate=8, layers=2, seed=5)
-    g = torch.Generator().manual_seed(1)
-    runner.prefill(torch.randint(5, 32000, (8, 24), generator=g).to(DEV))
-    runner.step(); torch.cuda.synchronize()
-    assert not model.handover_failed()
-    try:
-        assert lib.hx_debug_set_option(b"xreg_no_producers", 2) == 0
-        runner.step(); torch.cuda.synchronize()
-    finally:
-        lib.hx_debug_set_option(b"xreg_no_producers", 0)
-    assert model.handover_failed()
-    with pytest.raises(_lib.HydraHipError, match="gave up"):
-        runner.generated()
-    assert model.fuse_norm is False
+    for executor in ("graph", "plan"):
+        from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
+        from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
+        shape = LlamaShape(4096, 11008, 2, 32, 32, 128, 32064)
+        model = LlamaForCausalLM.random_init(shape, torch.bfloat16, DEV, seed=5)
+        runner = DecodeRunner(model, RunnerConfig(batch=8, prompt_len=24, n_generate=8, use_graph=True, executor=executor), seed=6)
+        g = torch.Generator().manual_seed(1)
+        runner.prefill(torch.randint(5, 32000, (8, 24), generator=g).to(DEV))
+        try:
+            assert lib.hx_debug_set_option(b"xreg_no_producers", 2) == 0
+            runner.step(); torch.cuda.synchronize()        # captures / records under the hook, then replays once
+        finally:
+            lib.hx_debug_set_option(b"xreg_no_producers", 0)
+        assert model.handover_failed()
+        with pytest.raises(_lib.HydraHipError, match="gave up"):
+            runner.generated()
+        assert model.fuse_norm is False
+        del runner, model
 
-    # ---- engine path: GraphedDecoder.fetch
+    # ---- engine path: GraphedDecoder.fetch (its default executor)
     from hydrainfer_amd.engine.graph_decode import GraphedDecoder
     from hydrainfer_amd.memory.token_cache_manger import (TokenCacheBlockManager, TokenCacheBlockManagerConfig,
                                                           TokenCacheBlockManagerContext)
+    from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
     from hydrainfer_amd.model.llava import LlavaLanguageModel
-    model.fuse_norm = True
+    shape = LlamaShape(4096, 11008, 2, 32, 32, 128, 32064)
+    model = LlamaForCausalLM.random_init(shape, torch.bfloat16, DEV, seed=5)
     kv = TokenCacheBlockManager(TokenCacheBlockManagerConfig(
         n_layers=shape.num_hidden_layers, n_tokens=2, n_blocks=64, block_size=16, n_heads=shape.num_key_value_heads,
         head_size=shape.head_dim, dtype="bf16", device=str(DEV)), TokenCacheBlockManagerContext(rank=0, rank2host={0: "localhost"}))
     dec = GraphedDecoder(LlavaLanguageModel(model, image_token_id=32000), kv, max_batch=8, max_blocks_per_seq=4)
     vc = kv.allocate_virtual_cache()
     kv.realloc(vc, 3)
-    rows = [(17, 0, vc.block_table[0] * 16, 1, list(vc.block_table))]
-    assert len(dec.run(rows)) == 1                                   # healthy launch
+    row0 = (17, 0, vc.block_table[0] * 16, 1, list(vc.block_table))
+    row1 = (23, 1, vc.block_table[0] * 16 + 1, 2, list(vc.block_table))
     try:
         assert lib.hx_debug_set_option(b"xreg_no_producers", 2) == 0
-        lid = dec.launch([(23, 1, vc.block_table[0] * 16 + 1, 2, list(vc.block_table))])
+        lid = dec.launch([row0])                      # first launch of this batch size: captured under the hook
         torch.cuda.synchronize()
     finally:
         lib.hx_debug_set_option(b"xreg_no_producers", 0)
     with pytest.raises(_lib.HydraHipError, match="hand-over"):
         dec.fetch(lid)
-    assert model.fuse_norm is False and not dec.graphs
-    assert len(dec.run([(23, 1, vc.block_table[0] * 16 + 1, 2, list(vc.block_table))])) == 1   # recaptured without fusion
+    assert model.fuse_norm is False and not dec.graphs and dec.executor == "graph"
+    assert len(dec.run([row0])) == 1 and len(dec.run([row1])) == 1      # recaptured without fusion: serving goes on
