@@ -68,7 +68,6 @@ class hx_chain_args(ctypes.Structure):
 
 HX_CHAIN_SYNC_WORDS, HX_CHAIN_SYNC_ERR = 18432, 480
 HX_XREG_SYNC_WORDS = 512
-HX_PLAN_SYNC_BYTES_PER_LAUNCH = 4096
 
 _SIGNATURES = {
     "hx_abi_version": (c_int, []),
@@ -125,9 +124,9 @@ _SIGNATURES = {
     "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_int32, c_void_p]),
     "hx_decode_feed_ids": (c_int, [c_void_p] * 4 + [c_int32, c_void_p]),
     "hx_collect_errors": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
-    "hx_plan_begin": (c_int, [POINTER(c_void_p), c_void_p, c_int64, c_void_p, c_int]),
+    "hx_plan_begin": (c_int, [POINTER(c_void_p)]),
     "hx_plan_end": (c_int, [c_void_p]),
-    "hx_plan_info": (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
+    "hx_plan_size": (c_int, [c_void_p]),
     "hx_plan_launch": (c_int, [c_void_p, c_void_p]),
     "hx_plan_destroy": (c_int, [c_void_p]),
     "hx_memset_zero": (c_int, [c_void_p, c_int64, c_void_p]),

@@ -81,9 +81,6 @@ struct AttnParams {
   int32_t qkv_splits;
   int64_t qkv_slab_stride;  // batch * row length
   int64_t qkv_row;          // (n_heads + 2*n_kv_heads) * D
-  // launch chain (fused decode kernel only; zeros otherwise): wait for the qkv projection's launch before the slabs
-  // are read, signal the o projection's launch when the output rows are written (hx_common.h ChainLink)
-  ChainLink chain;
 };
 
 }  // namespace hx

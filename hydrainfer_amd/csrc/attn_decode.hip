@@ -182,16 +182,11 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   __shared__ __attribute__((aligned(16))) char s_k[NW][KLds<D>::BYTES];
   __shared__ __attribute__((aligned(16))) u16 s_qkv[FUSE ? 3 : 1][FUSE ? D : 8];
 
-  // head of this workgroup: blockIdx.x rotated by rot * sequence.  Workgroup (x, y) runs on XCD (x + 32 y) mod 8, and
-  // head h reads bytes [256 h, 256 h + 256) of every 8 KiB key row: unrotated, XCD c serves exactly the heads
-  // == c (mod 8), i.e. one fixed residue of the address bits 8..10, for the whole launch
-  const int b = blockIdx.y, split = blockIdx.z;
-  const int h = p.xcd_remap ? (int)((blockIdx.x + (unsigned)p.xcd_remap * blockIdx.y) % gridDim.x) : (int)blockIdx.x;
+  const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int hk = h / p.group;
-  const uint32_t chain_peeked = FUSE ? chain_peek(p.chain) : 1u;   // the predecessor's flag, requested before anything else
 
   const int kv_len = p.cu_k[b + 1] - p.cu_k[b];
   const int q_row = p.cu_q[b];
@@ -242,20 +237,15 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
       // the splits of column d in order and rounds once to T (the projection's output
       // rounding); the three rows are shared through LDS so every slab element is read once
       // per workgroup.
-      // Launch chain: the K/V stream above is already in flight; only now does this workgroup need its
-      // predecessor (the qkv projection).  The slabs are read with sc1 loads: coherent with the write-through
-      // stores of a producer that may still have been running when this kernel was dispatched.
-      chain_wait(p.chain, chain_peeked);
-      const chain_rsrc_t slabs = chain_rsrc(p.qkv_partial);
-      const int64_t row = (int64_t)b * p.qkv_row;
+      const float* row = p.qkv_partial + (int64_t)b * p.qkv_row;
       const int64_t col0[3] = {(int64_t)h * D, (int64_t)p.n_heads * D + (int64_t)hk * D,
                                (int64_t)p.n_heads * D + (int64_t)(p.n_heads / p.group) * D + (int64_t)hk * D};
       if (threadIdx.x < D) {
 #pragma unroll
         for (int which = 0; which < 3; ++which) {
-          const int64_t src = row + col0[which] + threadIdx.x;
-          float acc = chain_load_f32(slabs, (uint32_t)(src * 4));
-          for (int s = 1; s < p.qkv_splits; ++s) acc += chain_load_f32(slabs, (uint32_t)((src + s * p.qkv_slab_stride) * 4));
+          const float* src = row + col0[which] + threadIdx.x;
+          float acc = src[0];
+          for (int s = 1; s < p.qkv_splits; ++s) acc += src[s * p.qkv_slab_stride];
           s_qkv[which][threadIdx.x] = T::from_float(acc);
         }
       }
@@ -379,9 +369,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
     }
     if (p.n_splits == 1) {
       const float r = (L > 0.f) ? O / L : 0.f;
-      const int64_t oi = (int64_t)q_row * p.o_row_stride + (int64_t)h * D + d;
-      if (FUSE) chain_store_b16(chain_rsrc(p.out), (uint32_t)(oi * 2), T::from_float(r));   // write-through: read by the next launch of a chain
-      else reinterpret_cast<u16*>(p.out)[oi] = T::from_float(r);
+      reinterpret_cast<u16*>(p.out)[(int64_t)q_row * p.o_row_stride + (int64_t)h * D + d] =
+          T::from_float(r);
     } else {
       const int64_t idx = ((int64_t)b * p.n_heads + h) * p.n_splits + split;
       p.ws_o[idx * D + d] = O;
@@ -391,7 +380,6 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
       }
     }
   }
-  if (FUSE) chain_signal(p.chain);
 }
 
 // one workgroup of D threads per (head, sequence)
@@ -416,7 +404,6 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const AttnParams
 // (sequence, head) pair counts for which one 8-wave workgroup per pair replaces key splits + combine
 int g_decode_small_lo = 160, g_decode_small_hi = 576;
 int g_decode_waves = 4;  // tuning knobs (hx_debug_set_option)
-int g_decode_rot = 0;  // head rotation per sequence (see attn_decode_kernel): 0 = off
 int g_decode_nt = 1;   // K/V are read once: non-temporal loads measured +4 % (profiles/r1_attn_decode_variants.txt)
 
 template <typename T, int D>
@@ -427,16 +414,8 @@ int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
   const int64_t pairs = (int64_t)batch * p.n_heads;
   const bool wide = pairs >= g_decode_small_lo && pairs <= g_decode_small_hi && p.n_splits == 1;
   if (p.k_new || p.qkv_partial) {
-    // chain-capable when the qkv slabs are its input and it writes the final output itself (no split + combine)
-    AttnParams pc = p;
-    pc.xcd_remap = g_decode_rot;
-    uint32_t flags = 0;
-    const bool chain = p.qkv_partial && p.n_splits == 1;
-    if (chain) pc.chain = chain_next(grid.x * grid.y * grid.z, &flags);
-    if (wide) (chain ? hx::launcher_chained(attn_decode_kernel<T, D, 8, true, true>, grid, 512, 0, stream, flags)
-                     : hx::launcher(attn_decode_kernel<T, D, 8, true, true>, grid, 512, 0, stream))(pc);
-    else (chain ? hx::launcher_chained(attn_decode_kernel<T, D, 4, true, true>, grid, 256, 0, stream, flags)
-                : hx::launcher(attn_decode_kernel<T, D, 4, true, true>, grid, 256, 0, stream))(pc);
+    if (wide) hx::launcher(attn_decode_kernel<T, D, 8, true, true>, grid, 512, 0, stream)(p);
+    else hx::launcher(attn_decode_kernel<T, D, 4, true, true>, grid, 256, 0, stream)(p);
   } else if (g_decode_waves == 8 || wide) {
     if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 8, true, false>, grid, 512, 0, stream)(p);
     else hx::launcher(attn_decode_kernel<T, D, 8, false, false>, grid, 512, 0, stream)(p);
@@ -460,7 +439,6 @@ namespace hx {
 int decode_set_option(const char* name, int value) {
   if (!strcmp(name, "decode_waves")) { g_decode_waves = (value == 8) ? 8 : 4; return HX_OK; }
   if (!strcmp(name, "decode_nt")) { g_decode_nt = value ? 1 : 0; return HX_OK; }
-  if (!strcmp(name, "decode_rot")) { g_decode_rot = value; return HX_OK; }
   if (!strcmp(name, "decode_small_lo")) { g_decode_small_lo = value; return HX_OK; }
   if (!strcmp(name, "decode_small_hi")) { g_decode_small_hi = value; return HX_OK; }
   return HX_ERR_UNSUPPORTED;

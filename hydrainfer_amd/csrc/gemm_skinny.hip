@@ -36,7 +36,6 @@ struct GemmParams {
   int32_t ks_per_split;  // k-steps (of 32) per split, multiple of 8
   int32_t n_splits;
   int32_t packed;        // w is in fragment order (hx_pack_decode_weight)
-  ChainLink chain;       // launch chain (packed kernel only; zeros otherwise): x is the predecessor's output
 };
 
 constexpr int kChunk = 16;       // k-steps per register buffer (16 KiB of W per wave)
@@ -171,10 +170,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
 // transpose through LDS (tools/bench_stream.py, corrected: every load shape streams at 6.5-7.0 TB/s when
 // neighbouring waves cover neighbouring bytes; what the packed form saves is the per-wave LDS transpose).  Same k order, same
 // accumulation chains: bit-identical to gemm_skinny_kernel.
-// XLATE (launch chain, the predecessor's flag has to be waited for): x is read after the weights have been requested —
-// a template parameter, not a branch: loads behind a branch make hipcc fall back to vmcnt(0) at the join, which
-// serialises the x round trip in front of the weight stream (+1.5 us on the o projection, measured)
-template <typename T, int MB, int R, int NW, int DBG = 0, bool XLATE = false>
+template <typename T, int MB, int R, int NW, int DBG = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p, const int g_nt_store) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kThreads = NW * 64;
@@ -192,11 +188,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
   constexpr int kCpr = kMaxKs * 4;
   constexpr int XPT = MB * 16 * kCpr / kThreads;
   u16x8 xr[XPT];
-  // in a launch chain x is the output of a launch that may still be running: it is read AFTER the weights have
-  // been requested and the predecessor's done flag has been seen (below); otherwise first, as always
-  constexpr bool x_late = XLATE;
-  const uint32_t chain_peeked = XLATE ? chain_peek(p.chain) : 1u;
-  if constexpr (!x_late) {
+  {
     const u16* xb = reinterpret_cast<const u16*>(p.x) + (int64_t)ks0 * 32;
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {
@@ -227,17 +219,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
   load(buf[0], 0);
   load(buf[1], 1);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (x_late) {
-    chain_wait(p.chain, chain_peeked);
-    const chain_rsrc_t xrs = chain_rsrc(p.x);
-#pragma unroll
-    for (int j = 0; j < XPT; ++j) {
-      const int i = threadIdx.x + j * kThreads;
-      const int row = i / kCpr, ch = i % kCpr;
-      const bool ok = row < p.M && ch * 8 < KR;
-      xr[j] = __builtin_bit_cast(u16x8, chain_load_b128(xrs, (uint32_t)((((int64_t)(ok ? row : 0) * p.ldx + (int64_t)ks0 * 32 + (ok ? ch * 8 : 0))) * 2)));
-    }
-  }
 #pragma unroll
   for (int j = 0; j < XPT; ++j) {
     const int i = threadIdx.x + j * kThreads;
@@ -278,17 +259,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p
       for (int mb = 0; mb < MB; ++mb) {
         const int m = mb * 16 + c;
         if (m < p.M && rg < n_rg_all && !((DBG & 2) && acc[mb][0] != 123.25f)) {   // bit 1: ablation, no stores
-          const int64_t di = ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g;
-          f32x4* dst = reinterpret_cast<f32x4*>(p.partial + di);
-          if (p.chain.signal) chain_store_b128(chain_rsrc(p.partial), (uint32_t)(di * 4), __builtin_bit_cast(u32x4, acc[mb]));   // write-through: a chained consumer reads it
-          else if (g_nt_store & 1) __builtin_nontemporal_store(acc[mb], dst);
+          f32x4* dst = reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg << 4) + 4 * g);
+          if (g_nt_store & 1) __builtin_nontemporal_store(acc[mb], dst);
           else *dst = acc[mb];
         }
         acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
-  chain_signal(p.chain);
 }
 
 // fragment (rg, s) of split = s / kMaxKs lives at KiB index ks0 * n_rg + rg * nks + (s - ks0)
@@ -367,19 +345,7 @@ int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
       else hx::launcher(gemm_packed_kernel<T, MB, R, NW, 14>, grid, NW * 64, plds, stream)(p, g_slab_nt & 1);
       return check_launch();
     }
-    GemmParams pc = p;
-    uint32_t flags = 0;
-    pc.chain = chain_next(grid.x * grid.y, &flags);      // zeros outside a chained plan recording
-    if (pc.chain.wait) {
-      if (plds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_packed_kernel<T, MB, R, NW, 0, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-        if (e != hipSuccess) return hip_rc(e);
-      }
-      hx::launcher_chained(gemm_packed_kernel<T, MB, R, NW, 0, true>, grid, NW * 64, plds, stream, flags)(pc, g_slab_nt & 1);
-    } else {
-      hx::launcher_chained(gemm_packed_kernel<T, MB, R, NW>, grid, NW * 64, plds, stream, flags)(pc, g_slab_nt & 1);
-    }
+    hx::launcher(gemm_packed_kernel<T, MB, R, NW>, grid, NW * 64, plds, stream)(p, g_slab_nt & 1);
     return check_launch();
   }
   const size_t lds = (size_t)MB * 16 * kRS + (size_t)NW * 2048;   // x slice + per-wave transpose images
@@ -455,7 +421,6 @@ int launch_gemm_skinny(const void* x, const void* w, float* partial, int64_t M, 
   if (!gemm_skinny_supported(M, N, K, ldx, ldw)) return HX_ERR_SHAPE;
   if (!aligned16(x) || !aligned16(w) || !aligned16(partial)) return HX_ERR_STRIDE;
   GemmParams p;
-  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x; p.w = w; p.partial = partial; p.ldx = ldx; p.ldw = ldw;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.ks_per_split = kMaxKs;

@@ -58,8 +58,6 @@ struct XregParams {
   int32_t nm_splits;
   float nm_eps;
   void* act;            // EPI = 1: silu(gate)*up, fragment-major [inter/32][MB][64 lanes][8]
-  ChainLink chain;      // launch chain (hx_common.h): x resp. the slabs / residual of the NORM form come from the
-                        // predecessor launch; the slabs / act written here go to the successor
 };
 
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
@@ -91,10 +89,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
   const int nvec = hidden / 8;
   uint32_t claimed = 1;
   if (tid == 0) claimed = __hip_atomic_exchange(state + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // the slabs and the residual stream are handed over between launches that may overlap (launch chain): sc1 loads
-  // (coherent across the XCDs' L2s) and write-through stores, always — they are a few KiB per row
-  const rsrc_t res_rs = make_rsrc(residual + (int64_t)row * hidden);
-  const rsrc_t par_rs = make_rsrc(partial);
+  u16x8* res_v = reinterpret_cast<u16x8*>(residual + (int64_t)row * hidden);
   const u16x8* w_v = reinterpret_cast<const u16x8*>(weight);
   const rsrc_t xrs = make_rsrc(x_frag);
   float x[2 * MAXV][8];
@@ -105,7 +100,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
       const int i = min(tid + 256 * v + 512 * j, nvec - 1);
-      rr[v * MAXV + j] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(res_rs, (uint32_t)i * 16, 0, 16));
+      rr[v * MAXV + j] = res_v[i];
       ww[v * MAXV + j] = w_v[i];
     }
 #pragma unroll
@@ -116,7 +111,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
       if (i < nvec) {
         // slab pieces: all loads of a batch of 6 splits before the first add, adds in split order
         // (norm_rope_act.hip slab_sum8)
-        const uint32_t pp = (uint32_t)(((int64_t)row * hidden + i * 8) * 4);   // byte offset into the slabs
+        const float* pp = partial + (int64_t)row * hidden + i * 8;
         constexpr int kB = 6;
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
         for (int s0 = 0; s0 < n_splits; s0 += kB) {
@@ -124,8 +119,8 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
 #pragma unroll
           for (int k = 0; k < kB; ++k) {
             const int sp = min(s0 + k, n_splits - 1);
-            pa[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(par_rs, pp + (uint32_t)(sp * slab_stride * 4), 0, 16));
-            pb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(par_rs, pp + (uint32_t)(sp * slab_stride * 4) + 16, 0, 16));
+            pa[k] = *reinterpret_cast<const f32x4*>(pp + sp * slab_stride);
+            pb[k] = *reinterpret_cast<const f32x4*>(pp + sp * slab_stride + 4);
           }
 #pragma unroll
           for (int k = 0; k < kB; ++k) {
@@ -165,7 +160,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
       for (int j = 0; j < MAXV; ++j) {
         const int i = tid + 256 * v + 512 * j;
         if (i < nvec) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, hh[v * MAXV + j]), res_rs, (uint32_t)i * 16, 0, 16);
+          res_v[i] = hh[v * MAXV + j];
           const u16x8 w = ww[v * MAXV + j];
           u16x8 o;
 #pragma unroll
@@ -186,9 +181,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
 // 16-row groups interleaved (group 2j = gate rows 16j.., group 2j+1 = up rows 16j..); a workgroup
 // takes whole pairs and writes act = silu(gate) * up with the rounding of hx_silu_and_mul_slabs on the
 // one-slab result (sum -> T, silu -> T, product -> T), fragment-major for the down projection.
-// XLATE (NORM = 0 in a launch chain): x is the predecessor launch's output and is read after its done flag — a template
-// parameter, not a branch around the prologue loads (hipcc's vmcnt bookkeeping is exact only in straight-line code)
-template <typename T, int MB, int KW, int EPI = 0, int DBG = 0, int NORM = 0, bool XLATE = false>
+template <typename T, int MB, int KW, int EPI = 0, int DBG = 0, int NORM = 0>
 __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = (KW + 7) / 8;
@@ -197,7 +190,6 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int split = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
-  const uint32_t chain_peeked = (NORM || XLATE) ? chain_peek(p.chain) : 1u;   // the predecessor's flag, requested before anything else
   const int total_ks = p.K >> 5;
   const int n_rg = p.N >> 4;
   const int ks0 = split * P;
@@ -283,13 +275,8 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
     //    loads and the store drain are not queued behind weight loads — prefetching first cost the whole gain)
     const int flat = blockIdx.y * gridDim.x + blockIdx.x;
     const int n_wg = gridDim.x * gridDim.y;
-    // launch chain: the slabs and the residual are the predecessor launch's output — a workgroup that computes a row
-    // first waits for that launch's done flag (the others never need it: the x flag below implies it)
-    bool pred_seen = p.chain.wait == nullptr;
-    if (flat < p.M && !(p.stagger & 6)) {   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
-      if (!pred_seen) { chain_wait(p.chain, chain_peeked); pred_seen = true; }
+    if (flat < p.M && !(p.stagger & 6))   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
       for (int row = flat; row < p.M; row += n_wg) produce(row);   // several rows only when N is tiny
-    }
     // 2. everyone: weight prefetch (independent of x)
 #pragma unroll
     for (int q = 0; q < NBUF; ++q) load_buf(rg_of(0), q);
@@ -332,7 +319,6 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       const int c = *cmd;
       __syncthreads();
       if (c < 0) break;
-      if (!pred_seen) { chain_wait(p.chain); pred_seen = true; }
       produce(c);
     }
     asm volatile("" ::: "memory");
@@ -350,27 +336,6 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
           xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
               ok ? xrs : zrs, ok ? (uint32_t)((ks * MB + mb) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, 16));
         }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  } else if constexpr (XLATE) {
-    // launch chain: x is the predecessor launch's output.  All weight buffers first (32 KiB per wave in flight),
-    // then its done flag, then x with sc1 loads
-#pragma unroll
-    for (int q = 0; q < NBUF; ++q) load_buf(rg_of(0), q);
-    __builtin_amdgcn_sched_barrier(0);
-    chain_wait(p.chain, chain_peeked);
-    {
-      const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
-#pragma unroll
-      for (int t = 0; t < KW; ++t) {
-        const int r = rot(t);
-        const bool ok = r < kw;
-        const int ks = min(ks0 + w * KW + r, total_ks - 1);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-          xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
-              ok ? xrs : zrs, ok ? (uint32_t)((ks * MB + mb) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, 16));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -429,11 +394,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       const int i = pr / MB, mb = pr - i * MB;
       const f32x4 s = tile_sum(i, mb);
       const int m = mb * 16 + c;
-      if (m < p.M) {
-        const int64_t di = ((int64_t)split * p.M + m) * p.N + (rg_of(i) << 4) + 4 * g;
-        if (p.chain.signal) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, s), make_rsrc(p.partial), (uint32_t)(di * 4), 0, 16);
-        else *reinterpret_cast<f32x4*>(p.partial + di) = s;
-      }
+      if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg_of(i) << 4) + 4 * g) = s;
     }
   } else {
     for (int pr = w; pr < (G >> 1) * MB; pr += 4) {
@@ -445,12 +406,10 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
         r[e] = T::from_float(round_to<T>(silu_f32(round_to<T>(gt[e]))) * round_to<T>(up[e]));
       // act[m = 16mb + c][k = 16j + 4g + e], j = pair index: piece ((k/32)*MB + mb)*64 + ((k%32)/8)*16 + c, element k%8
       const int k = 16 * (b + ip * nb) + 4 * g;
-      const int64_t ai = ((((int64_t)(k >> 5) * MB + mb) * 64 + ((k & 31) >> 3) * 16 + c) << 3) + (k & 7);
-      if (p.chain.signal) chain_store_b64(make_rsrc(p.act), (uint32_t)(ai * 2), __builtin_bit_cast(u32x2, r));
-      else *reinterpret_cast<u16x4*>(reinterpret_cast<u16*>(p.act) + ai) = r;
+      u16* dst = reinterpret_cast<u16*>(p.act) + ((((int64_t)(k >> 5) * MB + mb) * 64 + ((k & 31) >> 3) * 16 + c) << 3) + (k & 7);
+      *reinterpret_cast<u16x4*>(dst) = r;
     }
   }
-  chain_signal(p.chain);
 }
 
 // output piece i (16 bytes) of the packed tensor <- its source in the row-major weight
@@ -567,25 +526,7 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
     else hx::launcher(gemm_xreg_kernel<T, MB, KW, 0, 3>, grid, 256, lds, stream)(p);
     return check_launch();
   }
-  if (NORM || p.x_packed) {   // chain-capable: its input is handed over with sc1 loads (fragment-major x / the NORM form)
-    XregParams pc = p;
-    uint32_t flags = 0;
-    pc.chain = chain_next((uint32_t)(nb * S), &flags);      // zeros outside a chained plan recording
-    if constexpr (NORM == 0) {
-      if (pc.chain.wait) {
-        if (lds > 48 * 1024) {
-          hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_kernel<T, MB, KW, EPI, 0, 0, true>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          if (e != hipSuccess) return hip_rc(e);
-        }
-        hx::launcher_chained(gemm_xreg_kernel<T, MB, KW, EPI, 0, 0, true>, grid, 256, lds, stream, flags)(pc);
-        return check_launch();
-      }
-    }
-    hx::launcher_chained(gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>, grid, 256, lds, stream, flags)(pc);
-  } else {
-    hx::launcher(gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>, grid, 256, lds, stream)(p);
-  }
+  hx::launcher(gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>, grid, 256, lds, stream)(p);
   return check_launch();
 }
 
@@ -679,7 +620,6 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   int S, KW;
   xreg_plan(N, K, &S, &KW);
   XregParams p;
-  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
@@ -704,7 +644,6 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   int S, KW;
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
-  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
@@ -744,7 +683,6 @@ extern "C" int hx_norm_linear_decode_xreg(float* partial, void* residual, const 
   int S, KW;
   xreg_plan(N, K, &S, &KW);
   XregParams p;
-  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x_frag; p.w = packed_weight; p.partial = partial; p.ldx = K; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
@@ -766,7 +704,6 @@ extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float*
   int S, KW;
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
-  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.x = x_frag; p.w = packed_gate_up; p.partial = nullptr; p.ldx = K; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;

@@ -16,7 +16,6 @@ int decode_set_option(const char* name, int value);
 int gemm_set_option(const char* name, int value);
 int fwd_set_option(const char* name, int value);
 int xreg_set_option(const char* name, int value);
-int plan_set_option(const char* name, int value);
 #if HX_EXPERIMENTS   // `make EXPERIMENTS=1`: rejected experiments kept measurable (not in the default library)
 int chain_set_option(const char* name, int value);
 int decode4_set_option(const char* name, int value);
@@ -52,7 +51,6 @@ extern "C" int hx_debug_set_option(const char* name, int value) {
   if (rc == HX_ERR_UNSUPPORTED) rc = gemm_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = fwd_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = xreg_set_option(name, value);
-  if (rc == HX_ERR_UNSUPPORTED) rc = plan_set_option(name, value);
 #if HX_EXPERIMENTS
   if (rc == HX_ERR_UNSUPPORTED) rc = chain_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = decode4_set_option(name, value);
@@ -181,7 +179,6 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   if (a->total_q == 0) return HX_OK;
 
   AttnParams p;
-  p.chain = ChainLink{nullptr, nullptr, nullptr, 0u, 0u};
   p.out = a->out;
   p.q = a->q;
   p.k = a->k;

@@ -34,8 +34,8 @@ from hydrainfer_amd.model.llama import LanguageModelParameters
 class GraphedDecoder:
     def __init__(self, language_model, kv_cache_block_manager, max_batch: int = 64,
                  max_blocks_per_seq: int = 256, pad_to: int = 4, executor: str = None):
-        # how a captured step is replayed: "plan" = a launch plan (hydrainfer_amd/launch_plan.py: native launch loop,
-        # the five launches of every layer chained without the AQL barrier bit), "graph" = a hipGraph
+        # how a captured step is replayed: "plan" = a launch plan (hydrainfer_amd/launch_plan.py: the step's launches
+        # issued in stream order by a native loop), "graph" = a hipGraph
         self.executor = executor or os.environ.get("HX_DECODE_EXECUTOR", "plan")
         self.lm = language_model                       # LlavaLanguageModel
         self.model = language_model.language_model     # LlamaForCausalLM
@@ -120,18 +120,13 @@ class GraphedDecoder:
             self.model.sample_out = None
         if res.data_ptr() != out.data_ptr():
             launch_plan.host_op(lambda: out.copy_(res))
-        # give-up words of the step's in-kernel hand-overs (norm-fused launches, launch chain) -> one word
+        # give-up words of the step's in-kernel hand-overs (norm-fused launches) -> one word
         err = None
         sync = self.model.xreg_sync
-        plan = launch_plan.current()
-        plan_err = plan.error_word if plan is not None and plan.chain else None
-        if sync is not None or plan_err is not None:
+        if sync is not None:
             err = torch.empty(1, dtype=torch.int32, device=self.dev)
-            n_areas = sync.numel() // sync.shape[-1] if sync is not None else 0
-            _lib.check(lib.hx_collect_errors(err.data_ptr(), sync.data_ptr() if sync is not None else None, n_areas,
-                                             sync.shape[-1] if sync is not None else 0, 1,
-                                             plan_err.data_ptr() if plan_err is not None else None,
-                                             _lib.current_stream()), "collect_errors")
+            _lib.check(lib.hx_collect_errors(err.data_ptr(), sync.data_ptr(), sync.numel() // sync.shape[-1],
+                                             sync.shape[-1], 1, None, _lib.current_stream()), "collect_errors")
         return out, err
 
     def _capture(self, B: int, bucket: int):
@@ -146,8 +141,7 @@ class GraphedDecoder:
             self.prev_tokens.copy_(saved)
         torch.cuda.current_stream(self.dev).wait_stream(side)
         if self.executor == "plan":
-            graph = launch_plan.LaunchPlan(self.dev, chain=True,
-                                           max_chained_launches=8 * self.model.shape.num_hidden_layers + 16)
+            graph = launch_plan.LaunchPlan(self.dev)
             out, err = graph.capture(lambda: self._body(B, params))
         else:
             graph = torch.cuda.CUDAGraph()
@@ -228,14 +222,10 @@ class GraphedDecoder:
             # a norm-fused launch consumed activations nobody had produced: this step's tokens are garbage.
             # Later steps run with the add+RMSNorm as separate launches (no in-kernel hand-over).
             self.model.fuse_norm = False
-            self.executor = "graph"
-            for g in self.graphs.values():
-                if isinstance(g[0], launch_plan.LaunchPlan):
-                    g[0].error_word.zero_()
             self.graphs.clear()
-            raise HydraHipError(f"decode launch {launch_id}: an in-kernel hand-over (norm-fused GEMM launch or launch "
-                                "chain) gave up waiting for its producer; the step's tokens are invalid. Later steps run "
-                                "with separate norm launches from stream-ordered hipGraphs (fuse_norm = False)")
+            raise HydraHipError(f"decode launch {launch_id}: an in-kernel hand-over (norm-fused GEMM launch) gave up "
+                                "waiting for its producer workgroups; the step's tokens are invalid. Later steps run "
+                                "with the add+RMSNorm as separate launches (fuse_norm = False)")
         return self.host_tokens[slot][:n].tolist()
 
     def run(self, rows: List[Tuple[int, int, int, int, List[int]]]) -> List[int]:

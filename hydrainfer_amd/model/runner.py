@@ -56,10 +56,8 @@ class RunnerConfig:
     prefill_token_budget: int = 4096
     use_graph: bool = True
     # how a decode step is replayed when use_graph: "graph" = one captured hipGraph; "plan" = a launch plan
-    # (hydrainfer_amd/launch_plan.py): the same launches issued by a native loop, the five kernels of every layer
-    # chained without the AQL barrier bit (dependencies taken inside the kernels); "plan-nochain" = the plan with
-    # ordinary stream-ordered launches (A/B reference)
-    executor: str = "graph"
+    # (hydrainfer_amd/launch_plan.py): the same launches, in the same stream order, issued by a native loop
+    executor: str = "plan"
     advance_stride: int = 1      # tokens a decode step moves the contexts forward (1 = a real generation; bench.py
                                  # samples the generation's contexts at a fixed spacing when it times fewer steps)
 
@@ -230,9 +228,8 @@ class DecodeRunner:
                 self._step_body()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         self.positions.copy_(saved[0]); self.kv_lens.copy_(saved[1]); self.input_ids.copy_(saved[2])
-        if self.cfg.executor in ("plan", "plan-nochain"):
-            plan = launch_plan.LaunchPlan(self.dev, chain=self.cfg.executor == "plan",
-                                          max_chained_launches=8 * self.model.shape.num_hidden_layers + 16)
+        if self.cfg.executor == "plan":
+            plan = launch_plan.LaunchPlan(self.dev)
             plan.capture(self._step_body)       # records, runs nothing: the decode state is untouched
             self.graph = plan
         else:
@@ -256,7 +253,7 @@ class DecodeRunner:
     def generated(self) -> Tensor:
         """[n_steps_so_far, B] sampled tokens (one D2H sync, at the end).  Raises if an in-kernel hand-over of the
         last step gave up (its tokens would be garbage)."""
-        if self.model.handover_failed() or (isinstance(self.graph, launch_plan.LaunchPlan) and self.graph.failed()):
+        if self.model.handover_failed():
             self.model.fuse_norm = False
             self.graph = None
             raise _lib.HydraHipError("a norm-fused GEMM launch gave up waiting for its producer workgroups: the tokens "

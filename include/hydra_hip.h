@@ -21,7 +21,8 @@ extern "C" {
 #endif
 
 /* 2: hx_attn_args.flags (was `reserved`) gates the local-window fields — a zero-filled tail of the struct means
- * "no softcap, no window"; hx_decode_weight / hx_linear_decode_ex; experiments moved to hydra_hip_experimental.h */
+ * "no softcap, no window"; launch plans; hx_decode_advance takes a stride; experiments moved to
+ * hydra_hip_experimental.h */
 #define HX_ABI_VERSION 2
 
 typedef enum hx_dtype {
@@ -401,31 +402,19 @@ int hx_collect_errors(uint32_t* out, const uint32_t* areas, int32_t n_areas, int
 /* ------------------------------------------------------------------------
  * Launch plans: record the launches of a fixed sequence of hx_* calls once, replay them with one
  * native loop — the role of the hipGraph in the reference's unfinished
- * hydrainfer/model_runner/cuda_graph_model_runner.py:1-72, plus what a captured hipGraph cannot express on this
- * hardware: LAUNCH CHAINS.  Between hx_plan_begin and hx_plan_end every hx_* entry point called on the recording
- * thread appends its kernel launches (and hx_memset_zero) to the plan instead of executing them; nothing runs, no
- * stream is touched.  hx_plan_launch replays them on a stream, in order, with the recorded arguments (pointers are
- * recorded by value: the buffers must stay allocated and in place, like a graph's).
- * chain != 0: consecutive launches of chain-capable kernels — the five launches of a decode layer: the fused decode
- * attention, hx_linear_decode_partial_packed, hx_norm_gate_up_silu_xreg, hx_linear_decode_partial_xreg,
- * hx_norm_linear_decode_xreg — are linked: the later one is launched with the AQL barrier bit cleared
- * (hipExtAnyOrderLaunch: its workgroups are dispatched while its predecessor drains), prefetches its weights / KV
- * pages, and waits INSIDE the kernel for the predecessor's done flag before it reads that kernel's output (sc1
- * loads / write-through stores on the activations they hand over).  Results are bit-identical to the unchained
- * launches.  `sync`: device memory, 128-byte aligned, HX_PLAN_SYNC_BYTES_PER_LAUNCH per chained launch; the plan
- * zeroes what it uses at the start of every replay.  `error_word`: one device word, non-zero after a replay iff an
- * in-kernel wait gave up (1 s bound; the results of that replay are invalid) — the caller clears and checks it.
- * hx_plan_end returns HX_ERR_WORKSPACE if `sync` was too small (the launches beyond it were recorded unchained).
- * One recording per thread at a time; a plan may be replayed from any thread, one replay in flight per plan.
+ * hydrainfer/model_runner/cuda_graph_model_runner.py:1-72.  Between hx_plan_begin and hx_plan_end every hx_* entry
+ * point called on the recording thread appends its kernel launches (hx_memset_zero included) to the plan instead of
+ * executing them; nothing runs, no stream is touched.  hx_plan_launch issues them on a stream, in order, with the
+ * recorded arguments (pointers are recorded by value: the buffers must stay allocated and in place, like a graph's).
+ * One recording per thread at a time; a plan may be replayed from any thread.  hx_plan_size: recorded launches.
  * ---------------------------------------------------------------------- */
 typedef struct hx_plan hx_plan;
-#define HX_PLAN_SYNC_BYTES_PER_LAUNCH 4096
-int hx_plan_begin(hx_plan** plan, void* sync, int64_t sync_bytes, uint32_t* error_word, int chain);
+int hx_plan_begin(hx_plan** plan);
 int hx_plan_end(hx_plan* plan);
-int hx_plan_info(const hx_plan* plan, int32_t* n_launches, int32_t* n_any_order, int64_t* sync_bytes_used);
+int hx_plan_size(const hx_plan* plan);
 int hx_plan_launch(const hx_plan* plan, hx_stream stream);
 int hx_plan_destroy(hx_plan* plan);
-/* memset(p, 0, bytes) on the stream; recordable in a plan (and capturable in a hipGraph). */
+/* memset(p, 0, bytes) on the stream as a kernel launch; recordable in a plan, capturable in a hipGraph. */
 int hx_memset_zero(void* p, int64_t bytes, hx_stream stream);
 
 /* ------------------------------------------------------------------------

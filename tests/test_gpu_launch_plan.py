@@ -1,8 +1,6 @@
-"""-m gpu: launch plans (hydrainfer_amd/launch_plan.py, csrc/launch_plan.hip).  A decode step replayed from a plan —
-with the five launches of every layer CHAINED (no AQL barrier bit between them; each kernel prefetches, then waits
-inside the kernel for its predecessor's done flag, then reads that kernel's output with sc1 loads) — must produce
-exactly the tokens and the KV pool of the same step replayed from a hipGraph (stream-ordered launches of the same
-kernels): the chain changes when workgroups start, never what they compute."""
+"""-m gpu: launch plans (hydrainfer_amd/launch_plan.py, csrc/launch_plan.hip).  A decode step replayed from a plan — the
+step's launches recorded once and issued by a native loop, the lm_head GEMM as a host-side step in between — must
+produce exactly the tokens and the KV pool of the same step replayed from a captured hipGraph."""
 import pytest
 import torch
 
@@ -26,48 +24,43 @@ def _run(executor, dt, shape, batch, steps, seed=3, prompt=40):
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("batch", [32, 5])
-def test_chained_plan_equals_graph(dt, batch):
+def test_plan_equals_graph(dt, batch):
     """3 layers of 7B width (the benchmark's launch shapes), 24 steps over the same buffers."""
     from hydrainfer_amd import launch_plan
     from hydrainfer_amd.model.llama import LlamaShape
     sh = LlamaShape(4096, 11008, 3, 32, 32, 128, 32064)
     outs = {}
-    for ex in ("graph", "plan-nochain", "plan"):
+    for ex in ("graph", "plan"):
         r, toks, pool = _run(ex, dt, sh, batch, 24)
         outs[ex] = (toks, pool)
-        if ex != "graph":
+        if ex == "plan":
             plan = r.graph
-            assert isinstance(plan, launch_plan.LaunchPlan) and not plan.failed()
+            assert isinstance(plan, launch_plan.LaunchPlan)
             # advance, embed + norm, memset of the hand-over areas, layer 0's qkv, 5 per layer (attention, o, norm +
             # gate|up, down, norm + next qkv resp. the final norm), argmax; the lm_head GEMM is a host-side step
-            L = sh.num_hidden_layers
-            assert plan.n_launches == 5 * L + 5
-            # the chain runs from layer 0's qkv (its head, launched in stream order) to the last layer's down
-            # projection: every launch in between goes out without the barrier bit
-            assert plan.n_any_order == (5 * L - 1 if ex == "plan" else 0)
+            assert plan.n_launches == 5 * sh.num_hidden_layers + 5
+            assert sum(1 for it in plan.items if callable(it)) == 1
         del r
-    for ex in ("plan-nochain", "plan"):
-        assert torch.equal(outs["graph"][0], outs[ex][0]), f"{ex}: sampled tokens differ from the hipGraph run"
-        assert torch.equal(outs["graph"][1], outs[ex][1]), f"{ex}: KV pool differs from the hipGraph run"
+    assert torch.equal(outs["graph"][0], outs["plan"][0]), "sampled tokens differ from the hipGraph run"
+    assert torch.equal(outs["graph"][1], outs["plan"][1]), "KV pool differs from the hipGraph run"
 
 
-def test_chained_plan_small_and_13b_widths():
+def test_plan_small_and_13b_widths():
     from hydrainfer_amd.model.llama import LlamaShape
-    for sh, batch in ((LlamaShape(1024, 2816, 3, 8, 8, 128, 2048), 7), (LlamaShape(5120, 13824, 2, 40, 40, 128, 32064), 32)):
+    for sh, batch in ((LlamaShape(1024, 2816, 3, 8, 8, 128, 2048), 7), (LlamaShape(5120, 13824, 2, 40, 40, 128, 32064), 32),
+                      (LlamaShape(1024, 2816, 2, 8, 8, 128, 2048), 40)):      # 40 rows: the 8-launch LDS-slice layer
         a = _run("graph", torch.bfloat16, sh, batch, 12)
         b = _run("plan", torch.bfloat16, sh, batch, 12)
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-        assert b[0].graph.n_any_order > 0 and not b[0].graph.failed()
 
 
 def test_plan_buffers_survive_other_allocations():
     """The plan's launches hold raw pointers into its private memory pool: allocating and freeing around replays
     must not disturb them."""
-    from hydrainfer_amd.model.llama import LlamaShape
+    from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
+    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
     sh = LlamaShape(1024, 2816, 2, 8, 8, 128, 2048)
     ref = _run("graph", torch.float16, sh, 8, 10)
-    from hydrainfer_amd.model.llama import LlamaForCausalLM
-    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
     model = LlamaForCausalLM.random_init(sh, torch.float16, DEV, seed=3)
     r = DecodeRunner(model, RunnerConfig(batch=8, prompt_len=40, n_generate=18, use_graph=True, executor="plan"), seed=4)
     g = torch.Generator().manual_seed(0)
@@ -79,3 +72,18 @@ def test_plan_buffers_survive_other_allocations():
         torch.cuda.empty_cache()
     torch.cuda.synchronize()
     assert torch.equal(r.generated(), ref[1]) and torch.equal(r.pool, ref[2])
+
+
+def test_recording_is_per_thread_and_exclusive():
+    from hydrainfer_amd import _lib, launch_plan
+    plan = launch_plan.LaunchPlan(DEV)
+    x = torch.ones(64, dtype=torch.int32, device=DEV)
+
+    def body():
+        with pytest.raises(_lib.HydraHipError):
+            launch_plan.LaunchPlan(DEV).capture(lambda: None)      # one recording per thread
+        _lib.memset_zero(x)
+    plan.capture(body)
+    assert int(x.sum()) == 64                                      # recorded, not executed
+    plan.replay(); torch.cuda.synchronize()
+    assert int(x.sum()) == 0 and plan.n_launches == 1

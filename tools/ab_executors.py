@@ -15,7 +15,7 @@ rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 stride = 254 // (K - 1)
 first = 705 + (254 - stride * (K - 1)) // 2
 model = LlamaForCausalLM.random_init(shape, torch.bfloat16, dev, seed=0)
-execs = [e for e in os.environ.get("EXECS", "graph,plan-nochain,plan").split(",")]
+execs = [e for e in os.environ.get("EXECS", "graph,plan").split(",")]
 runners = {}
 base = None
 names = []
