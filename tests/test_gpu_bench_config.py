@@ -151,5 +151,5 @@ def test_handover_give_up_is_loud_in_runner_and_engine():
         lib.hx_debug_set_option(b"xreg_no_producers", 0)
     with pytest.raises(_lib.HydraHipError, match="hand-over"):
         dec.fetch(lid)
-    assert model.fuse_norm is False and not dec.graphs and dec.executor == "graph"
+    assert model.fuse_norm is False and not dec.graphs
     assert len(dec.run([row0])) == 1 and len(dec.run([row1])) == 1      # recaptured without fusion: serving goes on
