@@ -300,3 +300,51 @@ def norm_gate_up_silu_xreg(residual: Tensor, slabs_in: Tensor, n_splits_in: int,
                                                     packed_gate_up.data_ptr(), M, inter, K, sync.data_ptr(),
                                                     _lib.dtype_code(residual), _lib.current_stream()),
                "norm_gate_up_silu_xreg")
+
+
+# ------------------------------------------------------------------------------------------------
+# the single-entry form (include/hydra_hip.h hx_decode_weight / hx_linear_decode_ex): describe the weight once, the
+# library picks the layout for the largest decode batch it has to serve, packs, and dispatches
+# ------------------------------------------------------------------------------------------------
+class DecodeWeight:
+    """A [N, K] linear weight packed for decode batches of <= max_rows rows.  .layout is "xreg" or "lds_slice";
+    .interleaved tells whether a gate|up weight was packed for the fused silu*mul epilogue."""
+
+    def __init__(self, weight: Tensor, max_rows: int = 32, gate_up: bool = False):
+        _lib.require_gpu(weight)
+        if weight.dim() != 2 or weight.stride(1) != 1 or weight.dtype not in (torch.float16, torch.bfloat16):
+            raise _lib.HydraHipError("DecodeWeight: fp16 / bf16 [N, K] with contiguous rows")
+        N, K = weight.shape
+        self.desc = _lib.hx_decode_weight()
+        _lib.check(_lib.lib().hx_decode_weight_plan(ctypes.byref(self.desc), N, K, _lib.dtype_code(weight), int(max_rows),
+                                                    _lib.HX_DW_GATE_UP if gate_up else 0), "decode_weight_plan")
+        self.packed = torch.empty(N * K, dtype=weight.dtype, device=weight.device)
+        _lib.check(_lib.lib().hx_decode_weight_pack(ctypes.byref(self.desc), self.packed.data_ptr(), weight.data_ptr(),
+                                                    weight.stride(0), _lib.current_stream()), "decode_weight_pack")
+        self.N, self.K, self.max_rows = N, K, int(max_rows)
+
+    @property
+    def layout(self) -> str:
+        return "xreg" if self.desc.layout == _lib.HX_DW_XREG else "lds_slice"
+
+    @property
+    def interleaved(self) -> bool:
+        return bool(self.desc.flags & _lib.HX_DW_GATE_UP)
+
+    def workspace_floats(self, M: int) -> int:
+        return _lib.lib().hx_linear_decode_ex_workspace_bytes(ctypes.byref(self.desc), M) // 4
+
+
+def linear_decode_ex(x: Tensor, w: DecodeWeight, partial: Tensor, frag_shape=None) -> int:
+    """fp32 slabs [n_slabs, M, N] of x @ W^T through the one dispatching entry; returns n_slabs."""
+    _lib.require_gpu(x, partial)
+    M, K, ldx, fm = _x_args(x, frag_shape)
+    if K != w.K or x.dtype != w.packed.dtype:
+        raise _lib.HydraHipError("linear_decode_ex: x does not match the packed weight")
+    if partial.dtype != torch.float32 or not partial.is_contiguous():
+        raise _lib.HydraHipError("linear_decode_ex: partial must be contiguous float32")
+    rc = _lib.lib().hx_linear_decode_ex(partial.data_ptr(), partial.numel() * 4, x.data_ptr(), ldx, fm, ctypes.byref(w.desc),
+                                        M, _lib.current_stream())
+    if rc < 0:
+        _lib.check(rc, "linear_decode_ex")
+    return rc

@@ -53,6 +53,14 @@ class hx_fused_decode_args(ctypes.Structure):
     ]
 
 
+class hx_decode_weight(ctypes.Structure):
+    _fields_ = [("packed", c_void_p), ("N", c_int64), ("K", c_int64), ("dtype", c_int32), ("layout", c_int32),
+                ("flags", c_int32), ("max_rows", c_int32)]
+
+
+HX_DW_LDS_SLICE, HX_DW_XREG, HX_DW_GATE_UP = 0, 1, 1
+
+
 class hx_chain_args(ctypes.Structure):
     _fields_ = [
         ("M", c_int32), ("hidden", c_int32), ("inter", c_int32), ("q_size", c_int32),
@@ -124,6 +132,10 @@ _SIGNATURES = {
     "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_int32, c_void_p]),
     "hx_decode_feed_ids": (c_int, [c_void_p] * 4 + [c_int32, c_void_p]),
     "hx_collect_errors": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
+    "hx_decode_weight_plan": (c_int, [POINTER(hx_decode_weight), c_int64, c_int64, c_int, c_int, c_int]),
+    "hx_decode_weight_pack": (c_int, [POINTER(hx_decode_weight), c_void_p, c_void_p, c_int64, c_void_p]),
+    "hx_linear_decode_ex_workspace_bytes": (c_int64, [POINTER(hx_decode_weight), c_int64]),
+    "hx_linear_decode_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, POINTER(hx_decode_weight), c_int64, c_void_p]),
     "hx_plan_begin": (c_int, [POINTER(c_void_p)]),
     "hx_plan_end": (c_int, [c_void_p]),
     "hx_plan_size": (c_int, [c_void_p]),

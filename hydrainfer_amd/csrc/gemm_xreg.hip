@@ -710,3 +710,57 @@ extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float*
   p.nm_splits = n_splits_in; p.nm_eps = epsilon;
   return launch_any<1, 1>(p, 1, KW, dtype, (hipStream_t)stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// One entry for the decode-batch linear layer (include/hydra_hip.h "hx_decode_weight"): the caller describes the
+// weight once, the library chooses the layout (activations-in-registers for <= 32 rows when the shape allows it,
+// LDS-slice otherwise), packs it, and hx_linear_decode_ex dispatches on the descriptor.
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int hx_decode_weight_plan(hx_decode_weight* w, int64_t N, int64_t K, int dtype, int max_rows, int flags) {
+  if (!w) return HX_ERR_NULL;
+  if (N <= 0 || K <= 0 || max_rows <= 0 || max_rows > 64) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (flags & ~HX_DW_GATE_UP) return HX_ERR_UNSUPPORTED;
+  w->packed = nullptr;
+  w->N = N; w->K = K; w->dtype = dtype; w->flags = flags; w->max_rows = max_rows;
+  const bool xreg = max_rows <= 32 && hx_linear_decode_xreg_supported(max_rows, N, K) == 1;
+  if (!xreg && (N % 16 || K % 256)) return HX_ERR_SHAPE;
+  if ((flags & HX_DW_GATE_UP) && (!xreg || N % 32)) w->flags &= ~HX_DW_GATE_UP;   // no fused epilogue on this layout: halves stay in order
+  w->layout = xreg ? HX_DW_XREG : HX_DW_LDS_SLICE;
+  return HX_OK;
+}
+
+extern "C" int hx_decode_weight_pack(hx_decode_weight* w, void* packed, const void* weight, int64_t ldw, hx_stream stream) {
+  if (!w || !packed || !weight) return HX_ERR_NULL;
+  int rc;
+  if (w->layout == HX_DW_XREG) {
+    const int inter = (w->flags & HX_DW_GATE_UP) && hx_gate_up_silu_xreg_supported(w->max_rows, w->N / 2, w->K) == 1;
+    if (!inter) w->flags &= ~HX_DW_GATE_UP;
+    rc = hx_pack_decode_weight_xreg(packed, weight, w->N, w->K, ldw, inter, w->dtype, stream);
+  } else if (w->layout == HX_DW_LDS_SLICE) {
+    rc = hx_pack_decode_weight(packed, weight, w->N, w->K, ldw, w->dtype, stream);
+  } else {
+    return HX_ERR_UNSUPPORTED;
+  }
+  if (rc == HX_OK) w->packed = packed;
+  return rc;
+}
+
+extern "C" int64_t hx_linear_decode_ex_workspace_bytes(const hx_decode_weight* w, int64_t M) {
+  if (!w || M <= 0) return 0;
+  return w->layout == HX_DW_XREG ? hx_linear_decode_xreg_workspace_bytes(M, w->N, w->K)
+                                 : hx_linear_decode_workspace_bytes(M, w->N, w->K);
+}
+
+extern "C" int hx_linear_decode_ex(float* partial, int64_t partial_bytes, const void* x, int64_t ldx,
+                                   int x_fragment_major, const hx_decode_weight* w, int64_t M, hx_stream stream) {
+  if (!w || !w->packed) return HX_ERR_NULL;
+  if (M > w->max_rows) return HX_ERR_SHAPE;
+  if (w->layout == HX_DW_XREG) {
+    if (w->flags & HX_DW_GATE_UP) return HX_ERR_UNSUPPORTED;   // interleaved halves: hx_gate_up_silu_xreg consumes this packing
+    return hx_linear_decode_partial_xreg(partial, x, w->packed, M, w->N, w->K, ldx, x_fragment_major, partial_bytes,
+                                         w->dtype, stream);
+  }
+  if (x_fragment_major) return HX_ERR_STRIDE;                  // the LDS-slice kernel stages row-major x
+  return hx_linear_decode_partial_packed(partial, x, w->packed, M, w->N, w->K, ldx, partial_bytes, w->dtype, stream);
+}

@@ -107,6 +107,8 @@ class LlamaForCausalLM:
         self.sample_out: Optional[Tensor] = None   # int64 [rows]: forward() writes the sampled ids here (decode loops)
         self.xreg_sync: Optional[Tensor] = None   # [L, 2, XREG_SYNC_WORDS] of the last step (word 1 = wait gave up)
         self.packed_x: Dict[str, Tensor] = {}
+        self.dw: Dict[str, "hip_gemm.DecodeWeight"] = {}       # descriptors of the packed copies (xreg layout)
+        self.dw_lds: Dict[str, "hip_gemm.DecodeWeight"] = {}   # ... (LDS-slice layout)
         self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
         # decode-side weight layouts are built ONCE, by prepare_decode (engine build / runner construction), for
         # the largest decode batch the owner will ever run — never in the middle of serving
@@ -146,7 +148,7 @@ class LlamaForCausalLM:
 
     def release(self) -> None:
         """Drops every weight tensor (bench.py frees the 7B model before its 13B leg)."""
-        self.state, self.packed, self.packed_x = {}, {}, {}
+        self.state, self.packed, self.packed_x, self.dw, self.dw_lds = {}, {}, {}, {}, {}
         self.xreg_sync = self.chain_sync = None
 
     def handover_failed(self) -> bool:
@@ -169,23 +171,26 @@ class LlamaForCausalLM:
         return None
 
     def pack_decode_weights(self, all_lds_slice: bool = False) -> None:
-        """Builds the packed copies of the decoder-layer weights (once; not during graph capture): the
-        activations-in-registers layout for the projections that run on that kernel at <= 32 rows, the
-        LDS-slice layout for the others (o, layer 0's qkv).  The LDS-slice copies of the former are built
-        on first use only (batches of 33..64 rows, the decode chain: all_lds_slice) — a third copy of a 7B
-        model would be 12 GB that a <= 32-row server never reads."""
+        """Builds the packed copies of the decoder-layer weights (prepare_decode calls this; never during a capture)
+        through the library's one decode-weight entry (hx_decode_weight_plan / _pack, gemm.DecodeWeight): planned for
+        <= 32 rows it picks the activations-in-registers layout where the shape allows it (gate|up with its halves
+        interleaved for the fused silu*mul epilogue), planned for 64 rows the LDS-slice layout.  o and layer 0's qkv
+        always take the LDS-slice layout (o: at 33 MB the x broadcast of the other kernel would dominate; layer 0's
+        qkv: its x comes row-major from the embedding launch); the LDS-slice copies of the other projections are
+        built only when batches of 33..64 rows (or the experimental decode chain) are announced: all_lds_slice."""
         if not (self.use_packed and self.use_hip_gemm and self.dtype in (torch.float16, torch.bfloat16)):
             return
         if self.use_xreg and self._xreg_mlp_ok(32):
-            hid, inter = self.shape.hidden_size, self.shape.intermediate_size
-            fused = hip_gemm.gate_up_silu_supported(32, inter, hid, self.dtype)
             for l in range(self.shape.num_hidden_layers):
                 if f"l{l}.wgu" not in self.packed_x:
-                    self.packed_x[f"l{l}.wgu"] = hip_gemm.pack_weight_xreg(self.state[f"l{l}.wgu"], interleave_halves=fused)
-                    self.packed_x[f"l{l}.wdown"] = hip_gemm.pack_weight_xreg(self.state[f"l{l}.wdown"])
+                    for n, gu in (("wgu", True), ("wdown", False)):
+                        dw = hip_gemm.DecodeWeight(self.state[f"l{l}.{n}"], max_rows=32, gate_up=gu)
+                        assert dw.layout == "xreg"
+                        self.dw[f"l{l}.{n}"], self.packed_x[f"l{l}.{n}"] = dw, dw.packed
                     wq = self.state[f"l{l}.wqkv"]
-                    if self.xreg_qkv and l > 0 and wq.stride(1) == 1 and hip_gemm.xreg_supported(32, wq.shape[0], hid, self.dtype):
-                        self.packed_x[f"l{l}.wqkv"] = hip_gemm.pack_weight_xreg(wq)
+                    if self.xreg_qkv and l > 0 and wq.stride(1) == 1 and hip_gemm.xreg_supported(32, wq.shape[0], wq.shape[1], self.dtype):
+                        dw = hip_gemm.DecodeWeight(wq, max_rows=32)
+                        self.dw[f"l{l}.wqkv"], self.packed_x[f"l{l}.wqkv"] = dw, dw.packed
         for l in range(self.shape.num_hidden_layers):
             for n in ("wqkv", "wo", "wgu", "wdown"):
                 key = f"l{l}.{n}"
@@ -195,7 +200,9 @@ class LlamaForCausalLM:
     def _pack_lds_slice(self, key: str) -> Optional[Tensor]:
         w = self.state[key]
         if key not in self.packed and w.shape[0] % 16 == 0 and w.shape[1] % 256 == 0 and w.stride(1) == 1:
-            self.packed[key] = hip_gemm.pack_weight(w)
+            dw = hip_gemm.DecodeWeight(w, max_rows=64)          # 33..64 rows: always the LDS-slice layout
+            assert dw.layout == "lds_slice"
+            self.dw_lds[key], self.packed[key] = dw, dw.packed
         return self.packed.get(key)
 
     def _xreg_mlp_ok(self, n: int) -> bool:
@@ -206,9 +213,9 @@ class LlamaForCausalLM:
 
     def _partial(self, x: Tensor, key: str, ws: Tensor) -> int:
         """split-K slabs of x @ state[key]^T into ws; packed weights when available."""
-        pk = self.packed.get(key)
-        if pk is not None:
-            return hip_gemm.linear_decode_partial_packed(x, pk, self.state[key].shape[0], ws)
+        dw = self.dw_lds.get(key)
+        if dw is not None:
+            return hip_gemm.linear_decode_ex(x, dw, ws)
         if self.decode_only:
             raise RuntimeError(f"decode-only model: no packed layout of {key} for {x.shape[0]} rows (prepare_decode("
                                f"max_rows={self.decode_rows_prepared}) was called) and the row-major weight is released")
@@ -346,8 +353,7 @@ class LlamaForCausalLM:
             kc, vc = ap.kv_cache.get_kv_cache()
             if s_qkv is None:
                 if xreg and f"l{l}.wqkv" in self.packed_x:
-                    s_qkv = hip_gemm.linear_decode_partial_xreg(xf, self.packed_x[f"l{l}.wqkv"], qkv_n, ws_q,
-                                                                frag_shape=(n, hid))
+                    s_qkv = hip_gemm.linear_decode_ex(xf, self.dw[f"l{l}.wqkv"], ws_q, frag_shape=(n, hid))
                 else:
                     s_qkv = self._partial(x, f"l{l}.wqkv", ws_q)
             o = torch.empty((n, H, D), dtype=h.dtype, device=h.device)
@@ -371,7 +377,7 @@ class LlamaForCausalLM:
                     else:
                         s_gu = hip_gemm.linear_decode_partial_xreg(xf, pgu, 2 * inter, ws, frag_shape=(n, hid))
                         a_f = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype, fragment_major=True)
-                s_dn = hip_gemm.linear_decode_partial_xreg(a_f, pdn, hid, ws, frag_shape=(n, inter))
+                s_dn = hip_gemm.linear_decode_ex(a_f, self.dw[f"l{l}.wdown"], ws, frag_shape=(n, inter))
             else:
                 add_rms_norm_slabs(x, h, ws, s_o, st[f"l{l}.norm2"], eps)
                 s_gu = self._partial(x, f"l{l}.wgu", ws)

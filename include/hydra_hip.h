@@ -151,6 +151,35 @@ int64_t hx_linear_decode_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int hx_linear_decode(void* out, const void* x, const void* weight, int64_t M, int64_t N,
                      int64_t K, int64_t ldx, int64_t ldw, int64_t ldo, void* workspace,
                      int64_t workspace_bytes, int dtype, hx_stream stream);
+/* ONE ENTRY for the decode-batch linear layer with pre-packed weights (what a maintainer binds; the layout-specific
+ * entry points further down are what it dispatches to and what the fused decode layer of hydrainfer_amd/model uses).
+ *   hx_decode_weight w;
+ *   hx_decode_weight_plan(&w, N, K, dtype, max_rows, flags);      // host only: picks the layout for batches <= max_rows
+ *   hx_decode_weight_pack(&w, packed_dev, weight, ldw, stream);   // once, at model load; packed_dev: N*K elements
+ *   n_slabs = hx_linear_decode_ex(partial, bytes, x, ldx, 0, &w, M, stream);          // every step: partial[s][M][N] fp32
+ * followed by a slab consumer (hx_add_rms_norm_slabs, hx_silu_and_mul_slabs, hx_decode_attention_fused, or a plain
+ * sum).  layout: activations-in-registers (HX_DW_XREG: max_rows <= 32 and hx_linear_decode_xreg_supported) else
+ * LDS-slice (HX_DW_LDS_SLICE: N % 16 == 0, K % 256 == 0, max_rows <= 64).  HX_DW_GATE_UP marks a [gate; up] weight:
+ * on the XREG layout its halves are interleaved for hx_gate_up_silu_xreg / hx_norm_gate_up_silu_xreg (flag kept in
+ * w->flags; hx_linear_decode_ex refuses such a packing), otherwise the flag is cleared and the rows stay in order.
+ * x may be fragment-major (see hx_linear_decode_partial_xreg) on the XREG layout only.
+ * Replaces: torch.nn.functional.linear of hydrainfer/model/llama.py:24-27,48-50 at decode batch sizes. */
+typedef struct hx_decode_weight {
+  const void* packed;   /* device, N*K elements; set by hx_decode_weight_pack */
+  int64_t N, K;
+  int32_t dtype;        /* HX_F16 | HX_BF16 */
+  int32_t layout;       /* HX_DW_* chosen by hx_decode_weight_plan */
+  int32_t flags;
+  int32_t max_rows;
+} hx_decode_weight;
+#define HX_DW_LDS_SLICE 0
+#define HX_DW_XREG 1
+#define HX_DW_GATE_UP 1
+int hx_decode_weight_plan(hx_decode_weight* w, int64_t N, int64_t K, int dtype, int max_rows, int flags);
+int hx_decode_weight_pack(hx_decode_weight* w, void* packed, const void* weight, int64_t ldw, hx_stream stream);
+int64_t hx_linear_decode_ex_workspace_bytes(const hx_decode_weight* w, int64_t M);
+int hx_linear_decode_ex(float* partial, int64_t partial_bytes, const void* x, int64_t ldx, int x_fragment_major,
+                        const hx_decode_weight* w, int64_t M, hx_stream stream);
 /* Same GEMM, but the fp32 split-K slabs partial[s][M][N] are left for a fused consumer.
  * Returns the number of slabs (>= 1) or a negative hx_status. */
 int hx_linear_decode_partial(float* partial, const void* x, const void* weight, int64_t M,

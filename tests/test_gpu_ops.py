@@ -471,3 +471,42 @@ def test_embed_rms_norm_and_argmax_rows_equal_the_torch_ops(dt):
         assert torch.equal(argmax_rows(logits), torch.argmax(logits, dim=-1))
         view = logits[:, : n - 3]                     # row stride != n, unaligned tail
         assert torch.equal(argmax_rows(view), torch.argmax(view, dim=-1))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_single_entry_decode_linear_dispatches_to_the_layout_kernels(dt):
+    """hx_decode_weight_plan / _pack / hx_linear_decode_ex (the one entry a maintainer binds) pick the layout for the
+    announced batch size and give the layout-specific kernels' results bit for bit."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel import gemm
+    g = torch.Generator().manual_seed(3)
+    for (N, K, M) in ((4096, 4096, 32), (4096, 11008, 7), (768, 256, 20)):
+        w = (torch.randn((N, K), generator=g) * 0.05).to(dt).to(DEV)
+        x = torch.randn((M, K), generator=g).to(dt).to(DEV)
+        # <= 32 rows: activations in registers
+        dw = gemm.DecodeWeight(w, max_rows=32)
+        assert dw.layout == "xreg" and not dw.interleaved and torch.equal(dw.packed, gemm.pack_weight_xreg(w))
+        a = torch.zeros(dw.workspace_floats(M), dtype=torch.float32, device=DEV)
+        b = torch.zeros_like(a)
+        assert gemm.linear_decode_ex(x, dw, a) == gemm.linear_decode_partial_xreg(x, dw.packed, N, b) and torch.equal(a, b)
+        xf = gemm.to_fragment_major(x)
+        a.zero_()
+        gemm.linear_decode_ex(xf, dw, a, frag_shape=(M, K))
+        assert torch.equal(a, b)
+        # up to 64 rows: the LDS-slice layout
+        dl = gemm.DecodeWeight(w, max_rows=64)
+        assert dl.layout == "lds_slice" and torch.equal(dl.packed, gemm.pack_weight(w))
+        a2 = torch.zeros(dl.workspace_floats(M), dtype=torch.float32, device=DEV)
+        b2 = torch.zeros_like(a2)
+        assert gemm.linear_decode_ex(x, dl, a2) == gemm.linear_decode_partial_packed(x, dl.packed, N, b2) and torch.equal(a2, b2)
+        with pytest.raises(_lib.HydraHipError):
+            gemm.linear_decode_ex(xf, dl, a2, frag_shape=(M, K))        # fragment-major x only on the XREG layout
+    # a gate|up weight: interleaved for the fused epilogue, and refused by the plain product
+    wgu = (torch.randn((2 * 11008, 4096), generator=g) * 0.05).to(dt).to(DEV)
+    dgu = gemm.DecodeWeight(wgu, max_rows=32, gate_up=True)
+    assert dgu.layout == "xreg" and dgu.interleaved and torch.equal(dgu.packed, gemm.pack_weight_xreg(wgu, interleave_halves=True))
+    with pytest.raises(_lib.HydraHipError):
+        gemm.linear_decode_ex(torch.zeros((4, 4096), dtype=dt, device=DEV), dgu, torch.zeros(4 * 22016, dtype=torch.float32, device=DEV))
+    assert not gemm.DecodeWeight(wgu, max_rows=64, gate_up=True).interleaved
+    with pytest.raises(_lib.HydraHipError):
+        gemm.DecodeWeight(wgu, max_rows=65)
