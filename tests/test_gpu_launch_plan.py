@@ -80,8 +80,10 @@ def test_recording_is_per_thread_and_exclusive():
     x = torch.ones(64, dtype=torch.int32, device=DEV)
 
     def body():
-        with pytest.raises(_lib.HydraHipError):
-            launch_plan.LaunchPlan(DEV).capture(lambda: None)      # one recording per thread
+        import ctypes
+        h = ctypes.c_void_p()
+        assert _lib.lib().hx_plan_begin(ctypes.byref(h)) == -5     # HX_ERR_UNSUPPORTED: one recording per thread
+        assert launch_plan.current() is plan
         _lib.memset_zero(x)
     plan.capture(body)
     assert int(x.sum()) == 64                                      # recorded, not executed
