@@ -8,6 +8,8 @@ MI355X redesign of the data path:
            block_migration.cpp:222-244).
   * rccl : pack kernel -> ONE send/recv of the packed buffer -> unpack kernel, instead of one
            P2POp per (block, layer, k/v) view (communication.py:57-74)."""
+import os
+import time
 from dataclasses import dataclass
 from typing import Dict, Literal, Optional
 
@@ -17,6 +19,11 @@ from torch import Tensor
 
 from hydrainfer_amd._C.data_transfer import block_migration
 from hydrainfer_amd.memory.token_cache import VirtualTokenCache
+
+
+class MigrationTimeout(RuntimeError):
+    """The peer of a send/recv block transfer did not take part within the bound (it died, or never got the
+    request): the caller's rank must fail loudly — a fresh process is started on retry, nothing is re-exec'd."""
 
 
 class CommunicationBackend:
@@ -48,11 +55,32 @@ class RCCLBackend(CommunicationBackend):
     reused across calls."""
 
     def __init__(self, migrate_stream: Optional["torch.cuda.Stream"], cache: Tensor,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, timeout_s: Optional[float] = None):
         self.migrate_stream = migrate_stream
         self.cache = cache
         self.group = group
         self._staging: Optional[Tensor] = None
+        # a transfer whose peer never shows up must not hang the rank (the reference's batch_isend_irecv +
+        # req.wait(), hydrainfer/memory/communication.py:66-74, waits for ever)
+        self.timeout_s = float(os.environ.get("HX_MIGRATE_TIMEOUT_S", "120")) if timeout_s is None else timeout_s
+
+    def _bounded_wait(self, work, what: str, peer: int) -> None:
+        """RCCL: poll the work's completion (it is stream-ordered; wait() would only enqueue a stream wait).  gloo
+        (CPU protocol tests): its wait takes the bound itself; its is_completed() stays False until waited on."""
+        try:
+            if dist.get_backend(self.group) == "gloo":
+                from datetime import timedelta
+                work.wait(timeout=timedelta(seconds=self.timeout_s))
+                return
+            deadline = time.monotonic() + self.timeout_s
+            while not work.is_completed():
+                if time.monotonic() > deadline:
+                    raise TimeoutError("not completed")
+                time.sleep(0.0005)
+            work.wait()        # completed: surfaces a transport error, if any, as an exception
+        except (RuntimeError, TimeoutError) as e:
+            raise MigrationTimeout(f"{what} rank {peer}: no progress within {self.timeout_s:.0f} s or transport error "
+                                   f"({str(e)[:120]}) — peer dead or never asked to take part in the transfer") from e
 
     def _staging_for(self, n_blocks: int) -> Tensor:
         L, T, _, bs, H, D = self.cache.shape
@@ -71,9 +99,9 @@ class RCCLBackend(CommunicationBackend):
         with ctx:
             if is_send:
                 block_migration.pack_blocks(table, self.cache, staging)
-                dist.send(staging, dst=peer, group=self.group)
+                self._bounded_wait(dist.isend(staging, dst=peer, group=self.group), "send to", peer)
             else:
-                dist.recv(staging, src=peer, group=self.group)
+                self._bounded_wait(dist.irecv(staging, src=peer, group=self.group), "recv from", peer)
                 block_migration.unpack_blocks(table, staging, self.cache)
 
 
