@@ -148,11 +148,12 @@ class BatchFillExecutor:
             self.image_manager, self.kv_manager, sh.num_hidden_layers, sh.num_attention_heads,
             sh.num_key_value_heads, sh.head_dim, self.language_model.image_token_id, self.dtype, self.device)
         builder.add_batch(batch)
-        if builder.position_ids and max(builder.position_ids) >= sh.max_position_embeddings:
+        max_pos = getattr(sh, "max_position_embeddings", None)
+        if max_pos is not None and builder.position_ids and max(builder.position_ids) >= max_pos:
             # the RoPE / attention kernels index the cos_sin table unchecked (admission normally rejects this:
             # request_processor.InstructionCreator.max_position_embeddings)
             raise HydraHipError(f"position {max(builder.position_ids)} outside the rotary table "
-                                f"(max_position_embeddings = {sh.max_position_embeddings})")
+                                f"(max_position_embeddings = {max_pos})")
         inputs = builder.build_language_model_parameters()
         params = LanguageModelParameters(inputs.attention_params, inputs.all_sequences_decode,
                                          inputs.selected_token_ids_tensor, inputs.image_row_index)
