@@ -438,25 +438,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   // tile and cache (a 16-key group never straddles a page: block_size % 16 == 0), the chunks are
   // immediate offsets from it.  (With a chunk index spread over rows the address arithmetic —
   // a page lookup and two 64-bit multiplies per chunk — was most of the tile's instructions.)
-  const int st_row = 16 * (threadIdx.x >> 6) + ((threadIdx.x >> 2) & 15);
+  // K and V use DIFFERENT lane -> (row, chunk) maps inside the 16-key group, chosen for their LDS images: the V image
+  // (row stride 2D + 64 B = 16 banks mod 64) takes 4 rows x 4 chunks per 16 lanes without a bank conflict, the K image
+  // (2D + 16 B = 4 banks mod 64: conflict-free for the fragment READS, which are 4x as frequent) needs 16 different
+  // rows per 16 lanes — with the V map its stores hit every bank four times (round 2 PMC: 15.8 % of the LDS cycles
+  // were bank conflicts).  Both rows lie in the same 16-key group, hence on the same page.
+  const int st_row = 16 * (threadIdx.x >> 6) + ((threadIdx.x >> 2) & 15);     // V
   const int st_q4 = threadIdx.x & 3;
-  int page_next = 0;      // page of my key in the tile that will be loaded next
+  const int st_rowk = 16 * (threadIdx.x >> 6) + (threadIdx.x & 15);           // K
+  const int st_q4k = (threadIdx.x >> 4) & 3;
+  int page_next = 0;      // page of my keys in the tile that will be loaded next
   auto lookup_page = [&](int t) {
     if (PAGED) page_next = bt[page_slot(min(t * KT + st_row, kv_len - 1), p.block_size, p.block_shift)];
   };
   u16x8 kreg[NL], vreg[NL];
   auto load_tile = [&](int t) {
     const int key = min(t * KT + st_row, kv_len - 1);
+    // the K row's key is clamped into the page that was looked up (the page of the V row's key)
+    const int keyk = min(t * KT + st_rowk, kv_len - 1);
     int64_t ko, vo;
     if (PAGED) {
       const int row = page_row(key, p.block_size, p.block_shift);
-      ko = (int64_t)page_next * p.k_block_stride + (int64_t)row * p.k_row_stride;
+      const int slot_v = page_slot(key, p.block_size, p.block_shift);
+      const int rowk = page_slot(keyk, p.block_size, p.block_shift) == slot_v ? page_row(keyk, p.block_size, p.block_shift) : row;
+      ko = (int64_t)page_next * p.k_block_stride + (int64_t)rowk * p.k_row_stride;
       vo = (int64_t)page_next * p.v_block_stride + (int64_t)row * p.v_row_stride;
     } else {
-      ko = (int64_t)(k_start + key) * p.k_row_stride;
+      ko = (int64_t)(k_start + keyk) * p.k_row_stride;
       vo = (int64_t)(k_start + key) * p.v_row_stride;
     }
-    const u16* kp = kbase + ko + 8 * st_q4;
+    const u16* kp = kbase + ko + 8 * st_q4k;
     const u16* vp = vbase + vo + 8 * st_q4;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
     }
   };
   auto store_tile = [&](int buf) {
-    char* kd = kbuf + buf * KTILE + st_row * RSK + 16 * st_q4;
+    char* kd = kbuf + buf * KTILE + st_rowk * RSK + 16 * st_q4k;
     char* vd = vbuf + buf * VTILE + st_row * RSV + 16 * st_q4;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
