@@ -199,6 +199,14 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   const int G = EPI ? 2 * (((n_rg >> 1) - b + nb - 1) / nb) : (n_rg - b + nb - 1) / nb;
   auto rg_of = [&](int i) { return EPI ? 2 * (b + (i >> 1) * nb) + (i & 1) : b + i * nb; };
   const int j0 = (p.stagger & 1) ? (int)(((unsigned)b * 7u + (unsigned)w * 3u) % (unsigned)KW) : 0;
+  // bit 3 of `stagger` (hx_debug_set_option("xreg_timeline", 1); NORM launches only): the first and the last workgroup
+  // of the grid write 100 MHz time stamps of their phases into words 384.. of the sync area (tools/xreg_timeline.py)
+  const int flat_id = blockIdx.y * gridDim.x + blockIdx.x;
+  auto stamp = [&](int k) {
+    if (NORM && (p.stagger & 8) && threadIdx.x == 0 && (flat_id == 0 || flat_id == (int)(gridDim.x * gridDim.y) - 1))
+      reinterpret_cast<unsigned long long*>(p.sync + 384 + (flat_id ? 32 : 0))[k] = __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
 
   // k-step of slot t: rot(t) = (j0 + t) mod KW; slots whose k-step is past the wave's range are
   // padding: x fragment zero, weight address clamped to a valid fragment
@@ -277,7 +285,10 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
     const int n_wg = gridDim.x * gridDim.y;
     if (flat < p.M && !(p.stagger & 6))   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
       for (int row = flat; row < p.M; row += n_wg) produce(row);   // several rows only when N is tiny
-    // 2. everyone: weight prefetch (independent of x)
+    stamp(1);
+    // 2. everyone: weight prefetch (independent of x).  (Round 3, tools/xreg_timeline.py: a producer sees the flag 3 us
+    //    later than the others — its first poll returns behind its own prefetch, loads return in order — but letting it
+    //    poll first and request its weights afterwards only moves the wait: its first row group ends at 15 us either way.)
 #pragma unroll
     for (int q = 0; q < NBUF; ++q) load_buf(rg_of(0), q);
     __builtin_amdgcn_sched_barrier(0);
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       if (c < 0) break;
       produce(c);
     }
+    stamp(2);
     asm volatile("" ::: "memory");
     // 4. x: sc1 loads (served past this CU's L1; the bytes were written through by other CUs)
     {
@@ -376,8 +388,9 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  for (int i = 0; i < G - 1; ++i) row_group(i, std::true_type{});
+  for (int i = 0; i < G - 1; ++i) { row_group(i, std::true_type{}); if (i < 6) stamp(3 + i); }
   row_group(G - 1, std::false_type{});
+  stamp(10);
   if ((DBG & 2) && acc[0][0] != 123.25f) return;   // ablation: no reduction, no stores
   __syncthreads();
 
@@ -410,6 +423,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       *reinterpret_cast<u16x4*>(dst) = r;
     }
   }
+  stamp(11);
 }
 
 // output piece i (16 bytes) of the packed tensor <- its source in the row-major weight
@@ -436,6 +450,7 @@ __global__ __launch_bounds__(256) void pack_xreg_kernel(u16* __restrict__ packed
 int g_stagger = 1;
 int g_no_producers = 0;   // test hook (xreg_no_producers): 1 = the norm-fused launches rely on the rescue path alone; 2 = no producers and no rescue: every such launch gives up (error word) after 2 ms
 int g_dbg = 0;
+int g_timeline = 0;      // diagnostic (xreg_timeline): phase time stamps of the NORM launches into their sync areas
 int g_force_wgs = 0;     // tuning: cap on workgroups per launch (0 = the CU count)
 
 constexpr int kKwSet[] = {4, 8, 16, 20, 22, 27, 29, 32, 40};
@@ -565,6 +580,7 @@ bool xreg_ok(int64_t M, int64_t N, int64_t K) {
 namespace hx {
 int xreg_set_option(const char* name, int value) {
   if (!strcmp(name, "xreg_stagger")) { g_stagger = value; return HX_OK; }
+  if (!strcmp(name, "xreg_timeline")) { g_timeline = value ? 1 : 0; return HX_OK; }
   if (!strcmp(name, "xreg_wgs")) { g_force_wgs = value; return HX_OK; }
   if (!strcmp(name, "xreg_no_producers")) { g_no_producers = value; return HX_OK; }
   if (!strcmp(name, "xreg_dbg")) { g_dbg = value; return HX_OK; }
@@ -621,7 +637,7 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = x_fragment_major ? 1 : 0;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
   const int rc = launch_any<0>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
@@ -645,7 +661,7 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
-  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = x_fragment_major ? 1 : 0;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
   return launch_any<1>(p, 1, KW, dtype, (hipStream_t)stream);
 }
@@ -684,7 +700,7 @@ extern "C" int hx_norm_linear_decode_xreg(float* partial, void* residual, const 
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x_frag; p.w = packed_weight; p.partial = partial; p.ldx = K; p.act = nullptr;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = 1;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
   p.nm_splits = n_splits_in; p.nm_eps = epsilon;
   rc = launch_any<0, 1>(p, S, KW, dtype, (hipStream_t)stream);
@@ -705,7 +721,7 @@ extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float*
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
   p.x = x_frag; p.w = packed_gate_up; p.partial = nullptr; p.ldx = K; p.act = act;
-  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0); p.x_packed = 1;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
   p.nm_splits = n_splits_in; p.nm_eps = epsilon;
   return launch_any<1, 1>(p, 1, KW, dtype, (hipStream_t)stream);
