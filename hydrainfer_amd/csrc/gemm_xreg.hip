@@ -189,7 +189,12 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int split = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
+  // Work is numbered from the END of the grid: row groups (pairs) are dealt round-robin, so the workgroups that go
+  // short in the last, partial round are the FIRST ones of the grid — in a NORM launch the producers of x, which start
+  // their own row groups ~3 us after everybody else (tools/xreg_timeline.py: with a full share they were the launch's
+  // tail, 32.3 us against ~28 for the others in the 7B gate|up launch).  The same numbering in every form of the
+  // kernel: the k-step rotation (stagger) follows it, and with it the summation order of a row group.
+  const int split = blockIdx.y, nb = gridDim.x, b = nb - 1 - (int)blockIdx.x;
   const int total_ks = p.K >> 5;
   const int n_rg = p.N >> 4;
   const int ks0 = split * P;
@@ -527,7 +532,8 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
   if (nb > n_units) nb = n_units;
   int G = (n_units + nb - 1) / nb;
   if (G * per_unit > kMaxG) G = kMaxG / per_unit;
-  nb = (n_units + G - 1) / G;                 // same depth, no idle tail workgroups
+  // (one workgroup per CU even when the last round is partial: its short shares go to the first workgroups of the
+  // grid, which are the late starters of a NORM launch — see the kernel)
   const size_t lds = (size_t)G * per_unit * 4 * MB * 1024;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>,
