@@ -62,7 +62,10 @@ def add_rms_norm_slabs(out: Tensor, residual: Tensor, partial: Tensor, n_splits:
 
 def embed_rms_norm(ids: Tensor, table: Tensor, weight: Tensor, epsilon: float):
     """Extension: (h, x) with h = table[ids], x = rms_norm(h) * weight — one launch, bit-identical to
-    torch.nn.functional.embedding + rms_norm.  ids int32 / int64 [rows]; fp16 / bf16; hidden % 8 == 0, <= 8192."""
+    torch.nn.functional.embedding + rms_norm for ids inside the vocabulary.  ids int32 / int64 [rows]; fp16 / bf16;
+    hidden % 8 == 0, <= 8192.  DIVERGENCE from torch: an id outside [0, vocab) is CLAMPED by the kernel where
+    torch.nn.functional.embedding (the reference path) raises — callers validate host-provided ids themselves
+    (engine/graph_decode.py does, before the launch); ids produced by hx_argmax_rows are in range by construction."""
     _lib.require_gpu(ids, table, weight)
     if ids.dim() != 1 or ids.dtype not in (torch.int32, torch.int64) or not ids.is_contiguous():
         raise _lib.HydraHipError("embed_rms_norm: ids must be contiguous int32 / int64 [rows]")
