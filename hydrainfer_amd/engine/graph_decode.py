@@ -34,9 +34,13 @@ from hydrainfer_amd.model.llama import LanguageModelParameters
 class GraphedDecoder:
     def __init__(self, language_model, kv_cache_block_manager, max_batch: int = 64,
                  max_blocks_per_seq: int = 256, pad_to: int = 4, executor: str = None):
-        # how a captured step is replayed: "plan" = a launch plan (hydrainfer_amd/launch_plan.py: the step's launches
-        # issued in stream order by a native loop), "graph" = a hipGraph
-        self.executor = executor or os.environ.get("HX_DECODE_EXECUTOR", "plan")
+        # how a captured step is replayed: "graph" = a hipGraph (default here), "plan" = a launch plan
+        # (hydrainfer_amd/launch_plan.py: the step's launches issued in stream order by a native loop).  The plan costs
+        # ~0.65 ms of HOST time per 7B step (170 launches x 3.8 us) where a graph launch costs ~0.1: irrelevant for a
+        # GPU-bound decode loop (model/runner.py, where the plan is 0.5-1 % faster), but the engine's one thread also
+        # schedules, stages and runs eager prefill steps — at 16 req/s Poisson the plan measured TPOT p50 7.7 ms and
+        # TTFT p50 84 ms against 6.5 / 51 for the graph (tools/bench_engine.py, round 3)
+        self.executor = executor or os.environ.get("HX_ENGINE_EXECUTOR", "graph")
         self.lm = language_model                       # LlavaLanguageModel
         self.model = language_model.language_model     # LlamaForCausalLM
         self.kv = kv_cache_block_manager

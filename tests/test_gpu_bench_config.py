@@ -138,7 +138,7 @@ def test_handover_give_up_is_loud_in_runner_and_engine():
     kv = TokenCacheBlockManager(TokenCacheBlockManagerConfig(
         n_layers=shape.num_hidden_layers, n_tokens=2, n_blocks=64, block_size=16, n_heads=shape.num_key_value_heads,
         head_size=shape.head_dim, dtype="bf16", device=str(DEV)), TokenCacheBlockManagerContext(rank=0, rank2host={0: "localhost"}))
-    dec = GraphedDecoder(LlavaLanguageModel(model, image_token_id=32000), kv, max_batch=8, max_blocks_per_seq=4)
+    dec = GraphedDecoder(LlavaLanguageModel(model, image_token_id=32000), kv, max_batch=8, max_blocks_per_seq=4, executor="plan")
     vc = kv.allocate_virtual_cache()
     kv.realloc(vc, 3)
     row0 = (17, 0, vc.block_table[0] * 16, 1, list(vc.block_table))

@@ -89,3 +89,43 @@ def test_recording_is_per_thread_and_exclusive():
     assert int(x.sum()) == 64                                      # recorded, not executed
     plan.replay(); torch.cuda.synchronize()
     assert int(x.sum()) == 0 and plan.n_launches == 1
+
+
+def test_engine_decoder_plan_equals_graph_with_lookahead():
+    """engine/graph_decode.GraphedDecoder with either executor: the same launches (look-ahead input ids taken from the
+    previous launch's samples on the device, padded batch, error word) give the same tokens, step after step."""
+    from hydrainfer_amd.engine.graph_decode import GraphedDecoder
+    from hydrainfer_amd.memory.token_cache_manger import (TokenCacheBlockManager, TokenCacheBlockManagerConfig,
+                                                          TokenCacheBlockManagerContext)
+    from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
+    from hydrainfer_amd.model.llava import LlavaLanguageModel
+    shape = LlamaShape(1024, 2816, 2, 8, 8, 128, 2048)
+    outs = {}
+    for ex in ("graph", "plan"):
+        model = LlamaForCausalLM.random_init(shape, torch.bfloat16, DEV, seed=7)
+        kv = TokenCacheBlockManager(TokenCacheBlockManagerConfig(
+            n_layers=shape.num_hidden_layers, n_tokens=2, n_blocks=64, block_size=16, n_heads=shape.num_key_value_heads,
+            head_size=shape.head_dim, dtype="bf16", device=str(DEV)), TokenCacheBlockManagerContext(rank=0, rank2host={0: "localhost"}))
+        dec = GraphedDecoder(LlavaLanguageModel(model, image_token_id=2047), kv, max_batch=8, max_blocks_per_seq=4, executor=ex)
+        caches = []
+        for _ in range(5):
+            vc = kv.allocate_virtual_cache()
+            kv.realloc(vc, 40)
+            caches.append(vc)
+        toks = []
+        first = [11, 22, 33, 44, 55]
+        pending = None
+        for step in range(12):
+            rows = []
+            for r, vc in enumerate(caches):
+                tok = first[r] if step == 0 else -(r + 1)          # step > 0: "the sample of row r of the previous launch"
+                rows.append((tok, step, vc.block_table[step // 16] * 16 + step % 16, step + 1, list(vc.block_table)))
+            lid = dec.launch(rows)                                  # enqueued before the previous launch's tokens are read
+            if pending is not None:
+                toks.append(dec.fetch(pending))
+            pending = lid
+        toks.append(dec.fetch(pending))
+        outs[ex] = toks
+        del dec, kv, model
+    assert outs["graph"] == outs["plan"]
+    assert len(outs["plan"]) == 12 and all(len(t) == 5 for t in outs["plan"])
