@@ -112,15 +112,69 @@ __global__ __launch_bounds__(NW * 64) void paged_read_kernel(const char* __restr
   if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
 }
 
+// The same bytes with HG adjacent heads served by DIFFERENT waves of one workgroup (wave w: head hg*HG + w % HG, tile
+// phase w / HG), every wave instruction still 4 key rows x 256 B like attn_decode_kernel: do waves of one CU that ask
+// for neighbouring 256-byte pieces of the same key rows at about the same time stream faster than workgroups
+// scattered over the chip?  row_bytes == 256 asks for head-major pages ([page][head][16 rows][256 B]: one head's piece
+// of a page contiguous).  Measured (ctx 832, 436 MB): 1 head x 4 phases 68.5 us, 4 x 4 67.4, 2 x 8 67.4; head-major
+// pages 66.5 / 66.1 / 65.9 — 1-3 %, not worth a cache-layout change.
+template <int HG, int NP>
+__global__ __launch_bounds__(HG * NP * 64) void paged_read_hg_kernel(const char* __restrict__ kbase, const char* __restrict__ vbase,
+                                                                     const int32_t* __restrict__ table, int tiles,
+                                                                     int64_t page_bytes, int row_bytes, float* sink) {
+  const int hgrp = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int head = hgrp * HG + (w % HG), ph = w / HG;
+  const int64_t head_bytes = row_bytes == 256 ? 16 * 256 : 256;
+  const int64_t lane_off = (int64_t)(lane >> 4) * row_bytes + (int64_t)head * head_bytes + (lane & 15) * 16;
+  const int32_t* tb = table + (int64_t)b * tiles;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 buf[2][8];
+  auto load = [&](f32x4 (&bf)[8], int t) {
+    const int64_t off = (int64_t)tb[t] * page_bytes + lane_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kbase + off + (int64_t)i * 4 * row_bytes));
+      bf[4 + i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vbase + off + (int64_t)i * 4 * row_bytes));
+    }
+  };
+  if (ph < tiles) load(buf[0], ph);
+  for (int t = ph; t < tiles; t += 2 * NP) {
+    if (t + NP < tiles) load(buf[1], t + NP);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += buf[0][i];
+    if (t + NP < tiles) {
+      if (t + 2 * NP < tiles) load(buf[0], t + 2 * NP);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += buf[1][i];
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
+}
+
 }  // namespace
 
 extern "C" int hx_debug_paged_read(const void* kbase, const void* vbase, const int32_t* table, int n_seq, int n_heads,
                                    int tiles, int64_t page_bytes, int row_bytes, int heads_per_wg, int waves,
                                    int depth, int n_splits, float* sink, hx_stream stream) {
   if (!kbase || !vbase || !table || !sink || n_seq <= 0 || n_heads <= 0 || tiles <= 0 || n_splits <= 0) return HX_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (heads_per_wg < 0) {       // -HG: HG adjacent heads by different waves of one workgroup, `waves` / HG tile phases each
+    const int HG = -heads_per_wg;
+    if (n_heads % HG || n_splits != 1) return HX_ERR_SHAPE;
+    const dim3 g2(n_heads / HG, n_seq);
+#define HX_PH(HGv, NPv)                                                                                              \
+    if (HG == HGv && waves == HGv * NPv) {                                                                           \
+      hx::launcher(paged_read_hg_kernel<HGv, NPv>, g2, HGv * NPv * 64, 0, s)((const char*)kbase, (const char*)vbase, table, tiles, \
+                                                                           page_bytes, row_bytes, sink);             \
+      return check_launch();                                                                                         \
+    }
+    HX_PH(4, 4) HX_PH(2, 4) HX_PH(4, 2) HX_PH(8, 2) HX_PH(2, 8) HX_PH(1, 4) HX_PH(2, 2) HX_PH(4, 1)
+#undef HX_PH
+    return HX_ERR_SHAPE;
+  }
   if (n_heads % heads_per_wg) return HX_ERR_SHAPE;
   const dim3 grid(n_heads / heads_per_wg, n_seq, n_splits);
-  hipStream_t s = (hipStream_t)stream;
 #define HX_P(HPW, NW, DP)                                                                                          \
   if (heads_per_wg == HPW && waves == NW && depth == DP) {                                                         \
     hx::launcher(paged_read_kernel<HPW, NW, DP>, grid, NW * 64, 0, s)((const char*)kbase, (const char*)vbase, table, tiles, n_splits, \

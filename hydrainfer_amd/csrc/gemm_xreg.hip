@@ -339,7 +339,10 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
     }
     stamp(2);
     asm volatile("" ::: "memory");
-    // 4. x: sc1 loads (served past this CU's L1; the bytes were written through by other CUs)
+    // 4. x: sc1 loads (served past this CU's L1 and the XCD's L2; the bytes were written through by other CUs).
+    //    Round 3 measured what that costs — 256 CUs x 256 KiB = 67 MB over the XCD links: with sc0 loads (L2 hits; sound
+    //    only by the argument that a kernel's start invalidates the L2) or with no x loads at all the first row group
+    //    ends ~1 us earlier (12.7 -> 11.5 us, tools/xreg_timeline.py) and the decode step does not move: not taken.
     {
       const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
 #pragma unroll

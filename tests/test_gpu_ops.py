@@ -373,7 +373,9 @@ def test_norm_fused_in_front_of_xreg_product_is_bit_identical(dt):
     workgroups of the GEMM grid, in-kernel hand-over) == hx_add_rms_norm_slabs_ex followed by the product:
     residual, x and the outputs bit for bit; the hand-over areas report no give-up.  Includes shapes with
     fewer workgroups than rows (every producer workgroup takes several rows) and many back-to-back launches
-    on the SAME buffers with changing inputs (a stale copy of x in any cache would show)."""
+    on the SAME buffers with changing inputs; between the fused launches an ordinary launch re-reads the same x
+    buffer from every CU, so that every L2 (and L1) holds the OLD x when the next fused launch rewrites it — a
+    consumer served by a stale line would show."""
     from hydrainfer_amd._C.kernel import gemm
     from hydrainfer_amd._C.kernel.norm import add_rms_norm_slabs
     for (M, hid, inter, S_in) in ((32, 4096, 11008, 4), (7, 4096, 11008, 3), (17, 5120, 13824, 4), (32, 256, 512, 1),
@@ -386,8 +388,8 @@ def test_norm_fused_in_front_of_xreg_product_is_bit_identical(dt):
         pq, pg = gemm.pack_weight_xreg(wq), gemm.pack_weight_xreg(wgu, interleave_halves=True)
         xf, xf2 = (torch.zeros(gemm.fragment_major_elems(M, hid), dtype=dt, device=DEV) for _ in range(2))
         a = torch.zeros(gemm.xreg_workspace_floats(M, 3 * hid, hid), dtype=torch.float32, device=DEV)
-        b = torch.zeros_like(a)
-        act1, act2 = (torch.zeros(gemm.fragment_major_elems(M, inter), dtype=dt, device=DEV) for _ in range(2))
+        b, c = torch.zeros_like(a), torch.zeros_like(a)
+        act1, act2, act3 = (torch.zeros(gemm.fragment_major_elems(M, inter), dtype=dt, device=DEV) for _ in range(3))
         n_it = 40 if hid == 4096 and M == 32 else 3
         sync = torch.zeros((2 * n_it, gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=DEV)
         for it in range(n_it):
@@ -399,10 +401,14 @@ def test_norm_fused_in_front_of_xreg_product_is_bit_identical(dt):
             s2 = gemm.norm_linear_decode_xreg(h2, slabs, S_in, nw, 1e-5, xf2, pq, 3 * hid, b, sync[2 * it])
             assert s == s2 and torch.equal(h1, h2) and torch.equal(a, b), f"qkv it={it} M={M} hid={hid}"
             assert torch.equal(gemm.from_fragment_major(xf, M, hid), gemm.from_fragment_major(xf2, M, hid))
+            gemm.linear_decode_partial_xreg(xf2, pq, 3 * hid, c, frag_shape=(M, hid))     # every CU caches this x
+            assert torch.equal(a, c)
             add_rms_norm_slabs(xf, h3, slabs, S_in, nw, 1e-5, fragment_major=True)
             gemm.gate_up_silu_xreg(xf, pg, inter, act1, frag_shape=(M, hid))
             gemm.norm_gate_up_silu_xreg(h4, slabs, S_in, nw, 1e-5, xf2, pg, inter, act2, sync[2 * it + 1])
             assert torch.equal(h3, h4), f"gate|up residual it={it}"
+            gemm.gate_up_silu_xreg(xf2, pg, inter, act3, frag_shape=(M, hid))                 # ... and this one
+            assert torch.equal(act1, act3)
             assert torch.equal(gemm.from_fragment_major(act1, M, inter), gemm.from_fragment_major(act2, M, inter)), f"act it={it}"
         assert int(sync[:, 1].abs().sum()) == 0          # no workgroup gave up waiting
         assert (sync[:, 0] == M).all()                   # every launch counted each of its M rows in exactly once

@@ -40,7 +40,7 @@ def graph_time(fn, n, reps=7):
 ident = torch.arange(n_blocks, dtype=torch.int32, device=dev)
 
 
-def reads(hpw=1, waves=4, depth=2, splits=1, table=None):
+def reads(hpw=1, waves=4, depth=2, splits=1, table=None, row_bytes=row_bytes):
     tb = perm if table is None else table
     for i in range(12):
         _lib.check(l.hx_debug_paged_read(pool[i % L, 0].data_ptr(), pool[i % L, 1].data_ptr(), tb.data_ptr(), B, H, tiles,
@@ -94,3 +94,9 @@ for hpw, waves, depth, splits in ((1, 4, 2, 1), (1, 4, 3, 1), (1, 4, 4, 1), (1, 
     for name, tb in (("random", None), ("sequential", ident)):
         t = graph_time(lambda: reads(hpw, waves, depth, splits, tb), 12)
         print(f"  hpw {hpw} waves {waves} depth {depth} splits {splits} {name:10s}: {t:6.1f} us = {nbytes / t / 1e6:.2f} TB/s", flush=True)
+
+print("adjacent heads by different waves of one workgroup (heads per workgroup, tile phases per head; 4 rows x 256 B per instruction):")
+for hg, npf in ((1, 4), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 2), (2, 8)):
+    for name, rb in (("token-major pages", row_bytes), ("head-major pages", 256)):
+        t = graph_time(lambda: reads(-hg, hg * npf, 2, 1, None, rb), 12)
+        print(f"  heads {hg} x phases {npf} ({hg * npf} waves, {32 // hg * 32} workgroups) {name:18s}: {t:6.1f} us = {nbytes / t / 1e6:.2f} TB/s", flush=True)
