@@ -23,6 +23,7 @@
 //   * P is rounded to T before P.V exactly like the reference kernel
 //     (flash_fwd_kernel.h:878); accumulation is fp32.
 #include <cstring>
+#include <type_traits>
 #include "attn_common.h"
 
 namespace {
@@ -343,7 +344,9 @@ template <> struct Mfma32<BF16> {
 // two workgroups per CU (LDS: 2 x 74 KiB): registers + accumulator registers must stay within 256,
 // or one wave per SIMD runs with nothing to hide its latencies behind (measured: 0.8 waves per SIMD
 // on average and 80 us for 4 x 704 tokens with the default bound)
-template <typename T, int D, bool PAGED>
+// ABL (EXPERIMENTS builds, fwd_ablate option; timing only, wrong results): 1 no softmax arithmetic, 2 no P V product,
+// 4 no Q K product, 8 no tile staging and no barrier after the first tile, 16 no barrier, 32 no tile loads / LDS stores, 128 no tile loads (LDS stores of stale registers kept)
+template <typename T, int D, bool PAGED, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) {
   constexpr int KS = D / 16;         // QK k-steps
   constexpr int NDB = D / 32;        // 32-dim output blocks
@@ -362,6 +365,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   // inside an XCD's contiguous id range the head is the fastest index — so an XCD starts with the
   // longest tiles of ALL its heads and sequences, not with every tile of its first head
   // (4 x 704 tokens: 49 -> see tools/bench_attn_prefill32.py).
+  // the per-sequence index arrays through the scalar cache (uniform indices; as vector loads each was a ~1 us round
+  // trip in a chain of five before the first K / V request could be formed)
+  typedef __attribute__((address_space(4))) const int32_t c_i32;
+  c_i32* cu_q_s = (c_i32*)p.cu_q;
+  c_i32* cu_k_s = (c_i32*)p.cu_k;
   int mblk = -1, h, b = 0;
   {
     const int gx = gridDim.x, gy = gridDim.y;
@@ -381,20 +389,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
     // sequence's longest tile) of its sequences, then rank 1, ...  (Rank-major over ALL sequences
     // spreads the tiles of one (sequence, head) so far apart in time that they stop sharing K / V
     // in L2: 32 x 704 tokens ran 1.5x slower that way.)
+    // (the group's five offsets are requested together and kept: with a load inside the rank loop the decode was a
+    // chain of up to 24 scalar round trips, ~2 us in front of every workgroup's first request for K / V)
     for (int g0 = 0; g0 < p.batch && mblk < 0; g0 += 4) {
-      const int g1 = min(g0 + 4, p.batch);
-      int max_tiles = 0, group_tiles = 0;
-      for (int i = g0; i < g1; ++i) {
-        const int tiles = (p.cu_q[i + 1] - p.cu_q[i] + TQ - 1) / TQ;
-        max_tiles = max(max_tiles, tiles);
-        group_tiles += tiles;
+      int cq[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) cq[i] = cu_q_s[min(g0 + i, p.batch)];
+      int tl[4], max_tiles = 0, group_tiles = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tl[i] = (cq[i + 1] - cq[i] + TQ - 1) / TQ;          // 0 past the last sequence (its offsets repeat)
+        max_tiles = max(max_tiles, tl[i]);
+        group_tiles += tl[i];
       }
       if (slot >= group_tiles) { slot -= group_tiles; continue; }
       for (int rank = 0; rank < max_tiles && mblk < 0; ++rank) {
-        for (int i = g0; i < g1; ++i) {
-          const int tiles = (p.cu_q[i + 1] - p.cu_q[i] + TQ - 1) / TQ;
-          if (tiles > rank) {
-            if (slot == 0) { b = i; mblk = tiles - 1 - rank; break; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (mblk < 0 && tl[i] > rank) {
+            if (slot == 0) { b = g0 + i; mblk = tl[i] - 1 - rank; }
             --slot;
           }
         }
@@ -406,10 +419,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, hi = lane >> 5;
   const int hk = h / p.group;
-  const int q_start = p.cu_q[b];
-  const int q_len = p.cu_q[b + 1] - q_start;
-  const int k_start = p.cu_k[b];
-  const int kv_len = p.cu_k[b + 1] - k_start;
+  b = __builtin_amdgcn_readfirstlane(b);
+// (priority of this workgroup's waves: see below)
+  const int q_start = cu_q_s[b];
+  const int q_len = cu_q_s[b + 1] - q_start;
+  const int k_start = cu_k_s[b];
+  const int kv_len = cu_k_s[b + 1] - k_start;
   const int q_row0_wg = mblk * TQ;
   if (q_row0_wg >= q_len) return;
   const int q_row0 = q_row0_wg + w * 32;
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   char* vbuf = smem + 2 * KTILE;
   const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
   const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
-  const int32_t* bt = PAGED ? p.block_table + p.cu_block_lens[b] : nullptr;
+  const int32_t* bt = PAGED ? p.block_table + ((c_i32*)p.cu_block_lens)[b] : nullptr;
 
   u16x8 qf[KS];
   {
@@ -433,57 +448,71 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + TQ - 1, q_len - 1) + shift) : kv_len - 1;
   const int n_tiles = (last_key_wg >= 0) ? last_key_wg / KT + 1 : 0;
 
-  // ---- cooperative tile staging.  Thread (gq = tid >> 6, r = (tid >> 2) & 15, q4 = tid & 3) owns key
-  // 16 gq + r of the tile and its 16-byte chunks q4 + 4 j: ONE page id and ONE row address per
-  // tile and cache (a 16-key group never straddles a page: block_size % 16 == 0), the chunks are
-  // immediate offsets from it.  (With a chunk index spread over rows the address arithmetic —
-  // a page lookup and two 64-bit multiplies per chunk — was most of the tile's instructions.)
-  // K and V use DIFFERENT lane -> (row, chunk) maps inside the 16-key group, chosen for their LDS images: the V image
-  // (row stride 2D + 64 B = 16 banks mod 64) takes 4 rows x 4 chunks per 16 lanes without a bank conflict, the K image
-  // (2D + 16 B = 4 banks mod 64: conflict-free for the fragment READS, which are 4x as frequent) needs 16 different
-  // rows per 16 lanes — with the V map its stores hit every bank four times (round 2 PMC: 15.8 % of the LDS cycles
-  // were bank conflicts).  Both rows lie in the same 16-key group, hence on the same page.
-  const int st_row = 16 * (threadIdx.x >> 6) + ((threadIdx.x >> 2) & 15);     // V
-  const int st_q4 = threadIdx.x & 3;
-  const int st_rowk = 16 * (threadIdx.x >> 6) + (threadIdx.x & 15);           // K
-  const int st_q4k = (threadIdx.x >> 4) & 3;
-  int page_next = 0;      // page of my keys in the tile that will be loaded next
+  // ---- cooperative tile staging.  Wave w stages the tile's keys 16 w .. 16 w + 15 (a 16-key group never straddles a
+  // page: block_size % 16 == 0), instruction j its rows RPI j .. RPI j + RPI - 1: D / 8 lanes per row, the whole row of
+  // K (and of V) contiguous (D = 128: sixteen lanes, 256 bytes, four rows per instruction).  Every cache line is touched by ONE instruction (round 3 PMC with 64-byte pieces of 16 rows
+  // per instruction: 17 % of the L1's cycles were stalls on a line already in flight), and the LDS stores of sixteen
+  // lanes are one contiguous row piece: no bank conflicts in either image whatever its row stride.
+  constexpr int RPI = 64 / LPR;         // rows per instruction
+  static_assert(NL * RPI == 16, "a wave stages one 16-key group");
+  const int st_r4 = lane / LPR;         // row RPI j + st_r4 of the wave's group
+  const int st_ch = lane % LPR;         // 16-byte chunk of the row
+  // Page of my keys in the tile that will be requested next.  A wave's threads stage ONE 16-key group (st_row and
+  // st_rowk lie in 16 w .. 16 w + 15), hence one page: the table entry is read through the SCALAR cache.  As a vector
+  // load its answer came back behind every tile load in flight (loads return in order) — each request for a tile began
+  // with a wait for ALL earlier ones, and a second tile in flight bought nothing.
+  c_i32* bt_s = (c_i32*)bt;
+  int page_next = 0;
   auto lookup_page = [&](int t) {
-    if (PAGED) page_next = bt[page_slot(min(t * KT + st_row, kv_len - 1), p.block_size, p.block_shift)];
+    if (PAGED) page_next = bt_s[__builtin_amdgcn_readfirstlane(page_slot(min(t * KT + 16 * w, kv_len - 1), p.block_size, p.block_shift))];
   };
-  u16x8 kreg[NL], vreg[NL];
-  auto load_tile = [&](int t) {
-    const int key = min(t * KT + st_row, kv_len - 1);
-    // the K row's key is clamped into the page that was looked up (the page of the V row's key)
-    const int keyk = min(t * KT + st_rowk, kv_len - 1);
-    int64_t ko, vo;
+  // Two register sets: the tile after next is requested while this tile is computed (with one set the request for
+  // tile t+1 had ONE tile of arithmetic, ~1 us, to come back before the barrier needed it; with everything but the
+  // staging removed the launch still took 29 of its 47 us — tools/ablate_attn_prefill32.py)
+  u16x8 kreg[2][NL], vreg[2][NL];
+#ifndef HX_FWD32_PF
+#define HX_FWD32_PF 1
+#endif
+  constexpr int PF = HX_FWD32_PF;      // tiles a request runs ahead of its use (measured: 1 -> 43.5 us, 2 -> 45.4 us on 4 x 704)
+  // Addresses: a wave-uniform part per tile (page and first row of the wave's 16-key group: scalar arithmetic) plus a
+  // per-thread part that changes only where the group runs past the last key (rows are clamped to it).  Per tile and
+  // thread that is two min / multiply / add — the general form (page slot and page row of the thread's own key, with a
+  // runtime branch on the block size being a power of two, for K and V) was ~100 instructions and ~20 branches.
+  const int last_key = kv_len - 1;
+  auto load_tile = [&](int t, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    const int g0 = min(t * KT + 16 * w, last_key);      // first key of the wave's group, clamped: uniform
+    const int r_max = last_key - g0;                     // rows of the group that exist (>= 0)
+    int64_t kb, vb;
     if (PAGED) {
-      const int row = page_row(key, p.block_size, p.block_shift);
-      const int slot_v = page_slot(key, p.block_size, p.block_shift);
-      const int rowk = page_slot(keyk, p.block_size, p.block_shift) == slot_v ? page_row(keyk, p.block_size, p.block_shift) : row;
-      ko = (int64_t)page_next * p.k_block_stride + (int64_t)rowk * p.k_row_stride;
-      vo = (int64_t)page_next * p.v_block_stride + (int64_t)row * p.v_row_stride;
+      const int rowg = page_row(g0, p.block_size, p.block_shift);
+      kb = (int64_t)page_next * p.k_block_stride + (int64_t)rowg * p.k_row_stride;
+      vb = (int64_t)page_next * p.v_block_stride + (int64_t)rowg * p.v_row_stride;
     } else {
-      ko = (int64_t)(k_start + keyk) * p.k_row_stride;
-      vo = (int64_t)(k_start + key) * p.v_row_stride;
+      kb = (int64_t)(k_start + g0) * p.k_row_stride;
+      vb = (int64_t)(k_start + g0) * p.v_row_stride;
     }
-    const u16* kp = kbase + ko + 8 * st_q4k;
-    const u16* vp = vbase + vo + 8 * st_q4;
+    const u16* kp = kbase + kb + 8 * st_ch;
+    const u16* vp = vbase + vb + 8 * st_ch;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      kreg[j] = *reinterpret_cast<const u16x8*>(kp + 32 * j);
-      vreg[j] = *reinterpret_cast<const u16x8*>(vp + 32 * j);
+      const uint32_t r = (uint32_t)min(RPI * j + st_r4, r_max);    // rows past the last key repeat it
+      kreg[SET][j] = *reinterpret_cast<const u16x8*>(kp + r * (uint32_t)p.k_row_stride);
+      vreg[SET][j] = *reinterpret_cast<const u16x8*>(vp + r * (uint32_t)p.v_row_stride);
     }
   };
-  auto store_tile = [&](int buf) {
-    char* kd = kbuf + buf * KTILE + st_rowk * RSK + 16 * st_q4k;
-    char* vd = vbuf + buf * VTILE + st_row * RSV + 16 * st_q4;
+  auto store_tile = [&](int buf, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    char* kd = kbuf + buf * KTILE + (16 * w + st_r4) * RSK + 16 * st_ch;
+    char* vd = vbuf + buf * VTILE + (16 * w + st_r4) * RSV + 16 * st_ch;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      *reinterpret_cast<u16x8*>(kd + 64 * j) = kreg[j];
-      *reinterpret_cast<u16x8*>(vd + 64 * j) = vreg[j];
+      *reinterpret_cast<u16x8*>(kd + RPI * j * RSK) = kreg[SET][j];
+      *reinterpret_cast<u16x8*>(vd + RPI * j * RSV) = vreg[SET][j];
     }
   };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
 
   f32x16 acc[NDB];
 #pragma unroll
@@ -492,24 +521,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   float m = HX_NEG_BIG, l = 0.f;
 
+  // (loads past the last tile repeat it: a branch around a load makes every later wait a wait for ALL loads)
+  const int t_last = max(n_tiles - 1, 0);
   if (n_tiles > 0) {
     lookup_page(0);
-    load_tile(0);
-    lookup_page(1);
-    store_tile(0);
+    load_tile(0, Set0{});
+    lookup_page(min(1, t_last));
+    store_tile(0, Set0{});
+    if (PF == 2) {
+      load_tile(min(1, t_last), Set1{});
+      lookup_page(min(2, t_last));
+    }
   }
+  // The two workgroups of a CU at DIFFERENT priorities.  At equal priority two waves of a SIMD that happen to be in
+  // the same phase slow each other equally and stay in phase — MFMA burst against MFMA burst, softmax against softmax
+  // — and a tile costs its MFMA plus its VALU time (4 x 704: 1.8 us per tile and pair of workgroups with the staging
+  // removed = 2 x (1024 + ~1100) cycles; PMC: a VALU instruction co-executes in 28 % of the MFMA cycles).  With one
+  // workgroup always issuing first, the other fills what it leaves: its MFMAs under the first one's softmax and the
+  // other way round.  Which of the two: the parity of the hardware wave slot of wave 0 (two resident workgroups whose
+  // first waves share a SIMD sit in different slots there; otherwise both may get the same priority — no loss).
+  // Only when workgroups queue for the CUs (more than two per CU in the launch): of two workgroups that start together
+  // and have nobody waiting for their slot, the favoured one finishes early and the other runs its last tiles alone
+  // (one round of 512 equal workgroups, 2048 new tokens of 4096: 128 us without, 135 us with priorities).
+  uint32_t* prio_flag = reinterpret_cast<uint32_t*>(smem + 2 * KTILE + 2 * VTILE);
+  const bool queued = p.wg_priority != 0;
+  if (queued && threadIdx.x == 0) *prio_flag = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1;     // HW_ID.wave_id
   __syncthreads();
+  if (queued && *prio_flag) __builtin_amdgcn_s_setprio(3);
 
   // transposed-read lane address inside a 4-row x 32-dim block: lane 4q + pp of each 16-lane group
   // supplies row q, dims 16 half + 4 pp .. + 3 (half = which 16 of the 32 dims this group takes)
   const int tr_q = (lane & 15) >> 2, tr_pp = lane & 3, tr_half = (lane >> 4) & 1;
   const int tr_off = (4 * hi + tr_q) * RSV + (16 * tr_half + 4 * tr_pp) * 2;
 
-  for (int t = 0; t < n_tiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < n_tiles) {
-      load_tile(t + 1);                          // in flight under this tile's MFMAs
-      lookup_page(t + 2);                        // (clamped to the last key) for the next iteration
+  auto tile_step = [&](int t, auto par_tag) {
+    constexpr int PAR = decltype(par_tag)::value;       // t & 1: this tile's LDS image and the register set that is free
+    const int cur = (ABL & 8) ? 0 : PAR;
+    if (!(ABL & (8 | 32 | 128))) {
+      load_tile(min(t + PF, t_last), std::integral_constant<int, PF == 2 ? PAR : 1 - PAR>{});   // PF tiles ahead
     }
     if (t * KT <= last_key_wave) {
       const char* kt = kbuf + cur * KTILE;
@@ -524,6 +573,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
         // under sub-tile 0's MFMAs: no MFMA waits for a read issued just before it
         const char* krd = kt + c * RSK + 16 * hi;
         u16x8 kfa[KS], kfb[KS];
+        if (ABL & 4) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[0][r] = 0.01f * (r + lane); s[1][r] = 0.02f * (r + t); }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kfa[ks] = *reinterpret_cast<const u16x8*>(krd + 32 * ks);
 #pragma unroll
@@ -533,9 +586,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) s[1] = Mfma32<T>::mma(kfb[ks], qf[ks], s[1]);
+        // keep that order: left alone the scheduler issues read, wait, MFMA, read, wait, MFMA (fewest registers)
+        __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, KS, 0);
+        }
       }
       const bool interior = t * KT + KT - 1 <= min(kv_len - 1, p.causal ? q_row0 + shift : kv_len - 1);
       float mx = HX_NEG_BIG;
+      u16x8 pf[2][2];
+      if (ABL & 1) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pf[u][r >> 3][r & 7] = T::from_float(s[u][r]);
+        l += 1.f;
+      } else {
       if (interior) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -552,26 +622,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
           }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m, mx * p.scale_log2);
-      const float alpha = fast_exp2(m - m_new);
-      m = m_new;
-      float ps = 0.f;
-      u16x8 pf[2][2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = fast_exp2(fmaf(s[u][r], p.scale_log2, -m_new));
-          ps += e;
-          pf[u][r >> 3][r & 7] = T::from_float(e);
-        }
-      l = l * alpha + ps;
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+      // Lazy running maximum: a row keeps its reference m until a score exceeds it by more than 2^8 (the exponentials
+      // then stay below 256: exact in fp32, eight mantissa bits as ever in T) — with the exact maximum as reference some
+      // row of the 32 moved in nearly every tile and all 64 accumulator registers were rescaled every time (PMC: 33
+      // v_pk_mul per wave and tile).  O = acc / l is unchanged in exact arithmetic: both carry the same factor.
+      const float m_cand = fmaxf(m, mx * p.scale_log2);
+      const bool grow = m_cand > m + 8.0f;
+      float m_new = m;
+      if (__builtin_amdgcn_ballot_w64(grow)) {
+        m_new = grow ? m_cand : m;
+        const float alpha = fast_exp2(m - m_new);      // 1 for the rows that keep their reference
+        l *= alpha;
 #pragma unroll
         for (int i = 0; i < NDB; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        m = m_new;
       }
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 ps2 = {0.f, 0.f};
+      const f32x2 sc2 = {p.scale_log2, p.scale_log2}, mn2 = {-m_new, -m_new};
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 x = f32x2{s[u][r], s[u][r + 1]} * sc2 + mn2;      // v_pk_fma_f32
+          const f32x2 e = {fast_exp2(x[0]), fast_exp2(x[1])};
+          ps2 += e;                                                      // v_pk_add_f32
+          pf[u][r >> 3][r & 7] = T::from_float(e[0]);
+          pf[u][r >> 3][(r & 7) + 1] = T::from_float(e[1]);
+        }
+      l += ps2[0] + ps2[1];
+      }
+      if (ABL & 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) acc[0][u * 2 + k2] += __builtin_bit_cast(float, (uint32_t)pf[u][k2][0] << 16);
+      } else
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -588,8 +676,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
           }
         }
     }
-    if (t + 1 < n_tiles) store_tile(cur ^ 1);
-    __syncthreads();    // tile t+1 visible; everyone is done with tile t's image
+    if (!(ABL & 8)) {
+      // the table entry for the next request HERE, in front of the barrier's wait: a scalar load shares its counter with
+      // the LDS reads and returns out of order — while one is outstanding every LDS read is waited for singly
+      if (!(ABL & (32 | 128))) lookup_page(min(t + PF + 1, t_last));
+      if (!(ABL & 32) && t + 1 < n_tiles) store_tile(cur ^ 1, std::integral_constant<int, 1 - PAR>{});   // tile t+1, requested one tile ago
+      if (!(ABL & 16)) __syncthreads();    // tile t+1 visible; everyone is done with tile t's image
+    }
+  };
+  for (int t = 0; t < n_tiles; t += 2) {
+    tile_step(t, Set0{});
+    if (t + 1 < n_tiles) tile_step(t + 1, Set1{});
   }
 
   // epilogue: O[query c][dim 32 db + 8 (r >> 2) + 4 hi + (r & 3)] = acc[db][r] / L
@@ -610,17 +707,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   }
 }
 
+int fwd_n_cus() {
+  static int n = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return n;
+}
+
+int g_fwd_ablate = 0;   // EXPERIMENTS builds: timing ablations of attn_fwd32_kernel (wrong results)
+
 template <typename T, int D, bool PAGED>
 int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
-  const size_t lds = 2 * 64 * ((2 * D + 16) + (2 * D + 64));
+  const size_t lds = 2 * 64 * ((2 * D + 16) + (2 * D + 64)) + 16;      // K / V images + the workgroup's priority flag
   dim3 grid((unsigned)(p.total_q / 128 + batch), p.n_heads, 1);
+  AttnParams pp = p;
+  pp.wg_priority = (p.total_q / 128) * (int64_t)p.n_heads > 2 * (int64_t)fwd_n_cus() ? 1 : 0;   // more than two workgroups per CU
   if (p.total_q == 0) return HX_OK;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32_kernel<T, D, PAGED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  hx::launcher(attn_fwd32_kernel<T, D, PAGED>, grid, 256, lds, stream)(p);
+#if HX_EXPERIMENTS
+  if constexpr (D == 128 && PAGED && std::is_same<T, BF16>::value) {
+    switch (g_fwd_ablate) {
+#define HX_ABL(n) case n: hx::launcher(attn_fwd32_kernel<T, D, PAGED, n>, grid, 256, lds, stream)(pp); return check_launch();
+      HX_ABL(1) HX_ABL(2) HX_ABL(4) HX_ABL(8) HX_ABL(3) HX_ABL(5) HX_ABL(6) HX_ABL(7) HX_ABL(9) HX_ABL(15) HX_ABL(16) HX_ABL(32) HX_ABL(48) HX_ABL(128) HX_ABL(144)
+#undef HX_ABL
+      default: break;
+    }
+  }
+#endif
+  hx::launcher(attn_fwd32_kernel<T, D, PAGED>, grid, 256, lds, stream)(pp);
   return check_launch();
 }
 
@@ -687,6 +808,7 @@ int fwd_set_option(const char* name, int value) {
   if (!strcmp(name, "fwd_row_blocks")) { g_fwd_rows = value; return HX_OK; }
   if (!strcmp(name, "fwd_key_units")) { g_fwd_keys = value; return HX_OK; }
   if (!strcmp(name, "fwd_mfma32")) { g_fwd_mfma32 = value ? 1 : 0; return HX_OK; }
+  if (!strcmp(name, "fwd_ablate")) { g_fwd_ablate = value; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 

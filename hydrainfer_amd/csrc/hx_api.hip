@@ -203,6 +203,7 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.block_shift = (p.block_size & (p.block_size - 1)) == 0 ? __builtin_ctz((unsigned)p.block_size) : -1;
   p.causal = a->causal;
   p.xcd_remap = g_fwd_xcd;
+  p.wg_priority = 0;
   p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
   // flash_api.cpp:93-111
   if (a->flags & ~HX_ATTN_LOCAL_WINDOW) return HX_ERR_UNSUPPORTED;

@@ -21,7 +21,13 @@ base = None
 names = []
 for i, ex in enumerate(execs):
     names.append(f"{ex}#{i}")
+from hydrainfer_amd import _lib
 for name, ex in zip(names, execs):
+    # "plan:decode_hpw4=1": library options (hx_debug_set_option) in force while THIS runner's launches are recorded
+    ex, *opts = ex.split(":")
+    opts = [(o.split("=")[0].encode(), int(o.split("=")[1])) for o in opts]
+    for k, v in opts:
+        assert _lib.lib().hx_debug_set_option(k, v) == 0, k
     r = DecodeRunner(model, RunnerConfig(batch=32, prompt_len=704, n_generate=256, use_graph=True, executor=ex,
                                          advance_stride=stride), seed=0)
     if base is None:
@@ -33,6 +39,8 @@ for name, ex in zip(names, execs):
             ap.kv_cache = bp.kv_cache
     r.set_state(first - stride, torch.randint(5, 30000, (32,), device=dev))
     r.capture()
+    for k, v in opts:
+        _lib.lib().hx_debug_set_option(k, 0)
     runners[name] = r
 execs = names
 res = {ex: [] for ex in execs}
