@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   constexpr int KTILE = KT * RSK, VTILE = KT * RSV;
   constexpr int TQ = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2][KT][RSK] | V[2][KT][RSV]
+  if (ABL == 256) return;                                        // the launch alone
 
   // Workgroup -> (sequence, query tile, head).  Compact grid (x = tile slots, y = heads) as in the
   // kernel above, with two differences that matter for the causal tail: slots are ordered by tile
@@ -435,12 +436,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
   const int32_t* bt = PAGED ? p.block_table + ((c_i32*)p.cu_block_lens)[b] : nullptr;
 
+  // Staging map of a wave (Q here, K / V tiles below, O at the end): instruction j takes rows RPI j .. RPI j + RPI - 1
+  // of the wave's block, D / 8 lanes per row — the whole row contiguous.
+  constexpr int RPI = 64 / LPR;         // rows per instruction
+  const int st_r4 = lane / LPR;         // row RPI j + st_r4
+  const int st_ch = lane % LPR;         // 16-byte chunk of the row
+  // Q: whole rows into a wave-private LDS block (the second K / V images are idle until tile 1 is stored, after the
+  // barrier below), the B-operand fragments out of it.  Loaded straight into the fragment layout every instruction
+  // took 32 bytes of each of 32 rows: 7 us of the 4 x 704 launch (37.0 -> 30.1 us with constants instead).
   u16x8 qf[KS];
   {
-    const int qr = min(q_row0 + c, q_len - 1);
-    const u16* qp = reinterpret_cast<const u16*>(p.q) + (int64_t)(q_start + qr) * p.q_row_stride + (int64_t)h * D + 8 * hi;
+    constexpr int RSO = 2 * D + 16;
+    char* qb = (w < 2 ? kbuf + KTILE : vbuf + VTILE) + (w & 1) * 32 * RSO;
+    const u16* qbase = reinterpret_cast<const u16*>(p.q) + (int64_t)h * D + 8 * st_ch;
+    u16x8 qrow[32 / RPI];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qp + 16 * ks);
+    for (int j = 0; j < 32 / RPI; ++j) {
+      const int qr = min(q_row0 + RPI * j + st_r4, q_len - 1);
+      if (ABL == 512) qrow[j] = u16x8{(u16)(0x3c00 + lane), 0x3800, 0x3400, 0x3000, 0x2c00, 0x2800, (u16)(0x2400 + j), 0x2000};
+      else qrow[j] = *reinterpret_cast<const u16x8*>(qbase + (int64_t)(q_start + qr) * p.q_row_stride);
+    }
+#pragma unroll
+    for (int j = 0; j < 32 / RPI; ++j) *reinterpret_cast<u16x8*>(qb + (RPI * j + st_r4) * RSO + 16 * st_ch) = qrow[j];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qb + c * RSO + (16 * ks + 8 * hi) * 2);
   }
   const int shift = kv_len - q_len;
   const int limit_c = p.causal ? min(kv_len - 1, q_row0 + c + shift) : kv_len - 1;
@@ -453,10 +472,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   // K (and of V) contiguous (D = 128: sixteen lanes, 256 bytes, four rows per instruction).  Every cache line is touched by ONE instruction (round 3 PMC with 64-byte pieces of 16 rows
   // per instruction: 17 % of the L1's cycles were stalls on a line already in flight), and the LDS stores of sixteen
   // lanes are one contiguous row piece: no bank conflicts in either image whatever its row stride.
-  constexpr int RPI = 64 / LPR;         // rows per instruction
   static_assert(NL * RPI == 16, "a wave stages one 16-key group");
-  const int st_r4 = lane / LPR;         // row RPI j + st_r4 of the wave's group
-  const int st_ch = lane % LPR;         // 16-byte chunk of the row
   // Page of my keys in the tile that will be requested next.  A wave's threads stage ONE 16-key group (st_row and
   // st_rowk lie in 16 w .. 16 w + 15), hence one page: the table entry is read through the SCALAR cache.  As a vector
   // load its answer came back behind every tile load in flight (loads return in order) — each request for a tile began
@@ -689,12 +705,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
     if (t + 1 < n_tiles) tile_step(t + 1, Set1{});
   }
 
+  if (ABL == 79 && acc[0][0] != 123.f) return;   // (1039 = 1024 + 15: empty loop, epilogue without its LDS reads)                   // everything but the epilogue
   // epilogue: O[query c][dim 32 db + 8 (r >> 2) + 4 hi + (r & 3)] = acc[db][r] / L
   float lr = l + __shfl_xor(l, 32, 64);
   const float inv = (lr > 0.f) ? 1.0f / lr : 0.f;
-  const int row = q_row0 + c;
-  if (row < q_len) {
-    u16* op = reinterpret_cast<u16*>(p.out) + (int64_t)(q_start + row) * p.o_row_stride + (int64_t)h * D + 4 * hi;
+  // Through LDS (the K / V images are free: every wave has passed the last tile's barrier), so that a store
+  // instruction writes whole rows: straight from the accumulator layout each instruction put 16 bytes into each of 32
+  // rows — sixteen such instructions per wave, ~10 us of the 4 x 704 launch by themselves
+  // (tools/ablate_attn_prefill32.py, "empty loop" 16.3 us against 6.1 without the stores).
+  if (q_row0 < q_len) {
+    // Unpadded rows with an XOR swizzle of the 8-byte slots (MI355X_MICROARCH.md, LDS): a ds_write_b64 is served in four
+    // groups of 16 contiguous lanes on 32 banks — 16 rows at the same column need 16 different slot positions mod 16
+    // (slot ^ row does it; a padded stride of 4 banks met pairwise, PMC 6 % of the LDS cycles) — and the ds_read_b128
+    // of whole rows in its four non-contiguous groups is conflict-free exactly when the rows are 256 bytes apart.
+    constexpr int RSO = 2 * D;
+    char* ob = smem + w * 32 * RSO;      // this wave's 32 rows
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -702,8 +727,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
         u16x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = T::from_float(acc[db][4 * rq + i] * inv);
-        *reinterpret_cast<u16x4*>(op + 32 * db + 8 * rq) = o;
+        *reinterpret_cast<u16x4*>(ob + c * RSO + (((8 * db + 2 * rq + hi) ^ (c & (LPR - 1))) << 3)) = o;
       }
+    u16* obase = reinterpret_cast<u16*>(p.out) + (int64_t)h * D + 8 * st_ch;
+#pragma unroll
+    for (int j = 0; j < 32 / RPI; ++j) {
+      const int rl = RPI * j + st_r4;
+      // slots 2 ch, 2 ch + 1 of row rl sit in chunk ch ^ (rl' >> 1), swapped when rl' is odd (rl' = rl mod D / 8)
+      u16x8 v = *reinterpret_cast<const u16x8*>(ob + rl * RSO + 16 * (st_ch ^ ((rl & (LPR - 1)) >> 1)));
+      if (rl & 1) v = u16x8{v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+      if (q_row0 + rl < q_len) *reinterpret_cast<u16x8*>(obase + (int64_t)(q_start + q_row0 + rl) * p.o_row_stride) = v;
+    }
   }
 }
 
@@ -735,7 +769,7 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   if constexpr (D == 128 && PAGED && std::is_same<T, BF16>::value) {
     switch (g_fwd_ablate) {
 #define HX_ABL(n) case n: hx::launcher(attn_fwd32_kernel<T, D, PAGED, n>, grid, 256, lds, stream)(pp); return check_launch();
-      HX_ABL(1) HX_ABL(2) HX_ABL(4) HX_ABL(8) HX_ABL(3) HX_ABL(5) HX_ABL(6) HX_ABL(7) HX_ABL(9) HX_ABL(15) HX_ABL(16) HX_ABL(32) HX_ABL(48) HX_ABL(128) HX_ABL(144)
+      HX_ABL(1) HX_ABL(2) HX_ABL(4) HX_ABL(8) HX_ABL(3) HX_ABL(5) HX_ABL(6) HX_ABL(7) HX_ABL(9) HX_ABL(15) HX_ABL(16) HX_ABL(32) HX_ABL(48) HX_ABL(128) HX_ABL(144) HX_ABL(256) HX_ABL(79) HX_ABL(512) HX_ABL(1039)
 #undef HX_ABL
       default: break;
     }

@@ -10,6 +10,8 @@ from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
 dev, dt = torch.device("cuda:0"), torch.bfloat16
 B, H, D, bs, n = int(os.environ.get("HX_PREFILL_B", "4")), 32, 128, 16, 704
 _lib.lib().hx_debug_set_option(b"fwd_mfma32", int(os.environ.get("HX_FWD32", "1")))
+if os.environ.get("HX_ABL"):      # EXPERIMENTS builds: tools/ablate_attn_prefill32.py's variants under the profiler
+    assert _lib.lib().hx_debug_set_option(b"fwd_ablate", int(os.environ["HX_ABL"])) == 0
 nb_seq = (n + bs - 1) // bs
 g = torch.Generator(device=dev).manual_seed(0)
 kc = torch.randn((B * nb_seq, bs, H, D), generator=g, device=dev, dtype=torch.float32).to(dt)
