@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ttft", action="store_true")
     p.add_argument("--no-serving", action="store_true", help="skip the continuous-batching engine leg")
+    p.add_argument("--no-serving-64", action="store_true",
+                   help="skip the second engine leg with 2 x --batch requests (decode batches past the 32-row fast path)")
     p.add_argument("--no-disaggregated", action="store_true", help="N>1: skip the E/P/D engine leg")
     p.add_argument("--no-migration", action="store_true")
     p.add_argument("--lib-gemm", action="store_true",
@@ -954,6 +956,12 @@ def main():
     serving = None
     if rank == 0 and world == 1 and vision is not None and not args.no_serving:
         serving = measure_serving(model, vision, pixels, shape, dtype, dev, args.batch, prompt_len - 576, n_generate)
+        if not args.no_serving_64:
+            # twice as many requests at once: decode batches of 33 .. 64 rows leave the 5-launch layer (x for 64 rows does
+            # not fit the registers of the activations-in-registers GEMM) for the LDS-slice GEMMs with separate norm /
+            # silu launches — DESIGN.md section 6d
+            serving["twice_the_batch"] = measure_serving(model, vision, pixels, shape, dtype, dev, 2 * args.batch,
+                                                         prompt_len - 576, n_generate)
     # ---- roofline of the dominant hand-written kernel + whole-step fraction (rank 0)
     out = None
     if rank == 0:
