@@ -351,13 +351,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   constexpr int KS = D / 16;         // QK k-steps
   constexpr int NDB = D / 32;        // 32-dim output blocks
   constexpr int KT = 64;             // keys per tile (two 32-key sub-tiles)
-  constexpr int RSK = 2 * D + 16;
-  constexpr int RSV = 2 * D + 64;
+  // LDS images: UNPADDED rows of 2 D bytes with the 16-byte chunks XOR-swizzled per row — the tiles arrive by LDS-DMA
+  // (global_load_lds_dwordx4: 64 lanes x 16 bytes land contiguously, so a row cannot be padded; which chunk of its row
+  // a lane fetches is free).  Chunk c of row r sits at position c ^ kswz(r) in the K and Q images, c ^ vswz(r) in V:
+  //   K / Q, ds_read_b128 of chunk 2 ks + h of rows c = 0 .. 31 (16-lane groups {0-3,12-15,20-27}, ... on 64 banks,
+  //     MI355X_MICROARCH.md LDS): the 16 rows of a group need 16 different positions (D = 128: row & 15) resp. 8
+  //     different ones per row parity (D = 64, two rows per bank row: (row >> 1) & 7);
+  //   V, ds_read_b64_tr_b16 of rows q = 0 .. 3 x 64 bytes (32-lane groups): the four rows go to four different
+  //     64-byte quarters of the bank row (D = 128: (row & 3) << 2) resp. two different ones per row parity (D = 64).
+  constexpr int RSK = 2 * D, RSV = 2 * D;
   constexpr int LPR = D / 8;
   constexpr int NL = KT * LPR / 256;
   constexpr int KTILE = KT * RSK, VTILE = KT * RSV;
+  constexpr int IMG = KTILE + VTILE;       // one tile: K image, V image; two of them
   constexpr int TQ = 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // K[2][KT][RSK] | V[2][KT][RSV]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K[KT][RSK] | V[KT][RSV]] | priority flag
+  auto kswz = [](int row) { return LPR == 16 ? (row & 15) : ((row >> 1) & 7); };
+  auto vswz = [](int row) { return LPR == 16 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); };
   if (ABL == 256) return;                                        // the launch alone
 
   // Workgroup -> (sequence, query tile, head).  Compact grid (x = tile slots, y = heads) as in the
@@ -430,8 +440,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   if (q_row0_wg >= q_len) return;
   const int q_row0 = q_row0_wg + w * 32;
 
-  char* kbuf = smem;
-  char* vbuf = smem + 2 * KTILE;
   const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
   const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
   const int32_t* bt = PAGED ? p.block_table + ((c_i32*)p.cu_block_lens)[b] : nullptr;
@@ -441,13 +449,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   constexpr int RPI = 64 / LPR;         // rows per instruction
   const int st_r4 = lane / LPR;         // row RPI j + st_r4
   const int st_ch = lane % LPR;         // 16-byte chunk of the row
-  // Q: whole rows into a wave-private LDS block (the second K / V images are idle until tile 1 is stored, after the
-  // barrier below), the B-operand fragments out of it.  Loaded straight into the fragment layout every instruction
-  // took 32 bytes of each of 32 rows: 7 us of the 4 x 704 launch (37.0 -> 30.1 us with constants instead).
+  // Q: whole rows into a wave-private LDS block (the second tile image is idle until tile 1 is requested, after the
+  // barrier below; 4 waves x 32 rows fill it exactly), the B-operand fragments out of it, same swizzle as K.  Loaded
+  // straight into the fragment layout every instruction took 32 bytes of each of 32 rows.
   u16x8 qf[KS];
   {
-    constexpr int RSO = 2 * D + 16;
-    char* qb = (w < 2 ? kbuf + KTILE : vbuf + VTILE) + (w & 1) * 32 * RSO;
+    constexpr int RSO = RSK;
+    char* qb = smem + IMG + w * 32 * RSO;
     const u16* qbase = reinterpret_cast<const u16*>(p.q) + (int64_t)h * D + 8 * st_ch;
     u16x8 qrow[32 / RPI];
 #pragma unroll
@@ -457,9 +465,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
       else qrow[j] = *reinterpret_cast<const u16x8*>(qbase + (int64_t)(q_start + qr) * p.q_row_stride);
     }
 #pragma unroll
-    for (int j = 0; j < 32 / RPI; ++j) *reinterpret_cast<u16x8*>(qb + (RPI * j + st_r4) * RSO + 16 * st_ch) = qrow[j];
+    for (int j = 0; j < 32 / RPI; ++j)
+      *reinterpret_cast<u16x8*>(qb + (RPI * j + st_r4) * RSO + 16 * (st_ch ^ kswz(RPI * j + st_r4))) = qrow[j];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qb + c * RSO + (16 * ks + 8 * hi) * 2);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qb + c * RSO + 16 * ((2 * ks + hi) ^ kswz(c)));
   }
   const int shift = kv_len - q_len;
   const int limit_c = p.causal ? min(kv_len - 1, q_row0 + c + shift) : kv_len - 1;
@@ -467,36 +476,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + TQ - 1, q_len - 1) + shift) : kv_len - 1;
   const int n_tiles = (last_key_wg >= 0) ? last_key_wg / KT + 1 : 0;
 
-  // ---- cooperative tile staging.  Wave w stages the tile's keys 16 w .. 16 w + 15 (a 16-key group never straddles a
-  // page: block_size % 16 == 0), instruction j its rows RPI j .. RPI j + RPI - 1: D / 8 lanes per row, the whole row of
-  // K (and of V) contiguous (D = 128: sixteen lanes, 256 bytes, four rows per instruction).  Every cache line is touched by ONE instruction (round 3 PMC with 64-byte pieces of 16 rows
-  // per instruction: 17 % of the L1's cycles were stalls on a line already in flight), and the LDS stores of sixteen
-  // lanes are one contiguous row piece: no bank conflicts in either image whatever its row stride.
-  static_assert(NL * RPI == 16, "a wave stages one 16-key group");
-  // Page of my keys in the tile that will be requested next.  A wave's threads stage ONE 16-key group (st_row and
-  // st_rowk lie in 16 w .. 16 w + 15), hence one page: the table entry is read through the SCALAR cache.  As a vector
-  // load its answer came back behind every tile load in flight (loads return in order) — each request for a tile began
-  // with a wait for ALL earlier ones, and a second tile in flight bought nothing.
+  // ---- tile staging by LDS-DMA.  Wave w stages the tile's keys 16 w .. 16 w + 15 (a 16-key group never straddles a
+  // page: block_size % 16 == 0), instruction j its rows RPI j .. RPI j + RPI - 1 — D / 8 lanes per row, 1 KiB of the
+  // image per instruction and cache, every cache line touched by one instruction.  Through registers (global load,
+  // ds_write at the end of the tile) the same requests cost 8 of the 37 us of the 4 x 704 launch
+  // (tools/ablate_attn_prefill32.py: "no tile loads"), this way 3.  The loads are inline assembly: told about an LDS-DMA,
+  // hipcc waits for it (vmcnt(0)) in front of every LDS read that follows — the reads of the OTHER image.
+  static_assert(NL * RPI == 16 && RPI * RSK == 1024, "a wave stages one 16-key group, 1 KiB per instruction");
+  // Page of my keys in the tile that will be requested next.  A wave stages ONE 16-key group, hence one page: the
+  // table entry is read through the SCALAR cache, in front of the barrier (a scalar load shares its counter with the
+  // LDS reads and returns out of order — while one is outstanding every LDS read is waited for singly).
   c_i32* bt_s = (c_i32*)bt;
   int page_next = 0;
   auto lookup_page = [&](int t) {
     if (PAGED) page_next = bt_s[__builtin_amdgcn_readfirstlane(page_slot(min(t * KT + 16 * w, kv_len - 1), p.block_size, p.block_shift))];
   };
-  // Two register sets: the tile after next is requested while this tile is computed (with one set the request for
-  // tile t+1 had ONE tile of arithmetic, ~1 us, to come back before the barrier needed it; with everything but the
-  // staging removed the launch still took 29 of its 47 us — tools/ablate_attn_prefill32.py)
-  u16x8 kreg[2][NL], vreg[2][NL];
-#ifndef HX_FWD32_PF
-#define HX_FWD32_PF 1
-#endif
-  constexpr int PF = HX_FWD32_PF;      // tiles a request runs ahead of its use (measured: 1 -> 43.5 us, 2 -> 45.4 us on 4 x 704)
   // Addresses: a wave-uniform part per tile (page and first row of the wave's 16-key group: scalar arithmetic) plus a
-  // per-thread part that changes only where the group runs past the last key (rows are clamped to it).  Per tile and
-  // thread that is two min / multiply / add — the general form (page slot and page row of the thread's own key, with a
-  // runtime branch on the block size being a power of two, for K and V) was ~100 instructions and ~20 branches.
+  // per-thread part that changes only where the group runs past the last key (rows are clamped to it).
   const int last_key = kv_len - 1;
-  auto load_tile = [&](int t, auto set_tag) {
-    constexpr int SET = decltype(set_tag)::value;
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)(smem);
+  auto request_tile = [&](int t, int img) {
     const int g0 = min(t * KT + 16 * w, last_key);      // first key of the wave's group, clamped: uniform
     const int r_max = last_key - g0;                     // rows of the group that exist (>= 0)
     int64_t kb, vb;
@@ -508,25 +507,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
       kb = (int64_t)(k_start + g0) * p.k_row_stride;
       vb = (int64_t)(k_start + g0) * p.v_row_stride;
     }
-    const u16* kp = kbase + kb + 8 * st_ch;
-    const u16* vp = vbase + vb + 8 * st_ch;
+    const uint32_t kd = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(img * IMG + 16 * w * RSK));
+    const uint32_t vd = kd + KTILE;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      const uint32_t r = (uint32_t)min(RPI * j + st_r4, r_max);    // rows past the last key repeat it
-      kreg[SET][j] = *reinterpret_cast<const u16x8*>(kp + r * (uint32_t)p.k_row_stride);
-      vreg[SET][j] = *reinterpret_cast<const u16x8*>(vp + r * (uint32_t)p.v_row_stride);
+      const int R = RPI * j + st_r4;                               // row of the group = row of the tile mod 16
+      const uint32_t r = (uint32_t)min(R, r_max);                  // rows past the last key repeat it
+      const u16* ka = kbase + kb + r * (uint32_t)p.k_row_stride + 8 * (st_ch ^ kswz(R));
+      const u16* va = vbase + vb + r * (uint32_t)p.v_row_stride + 8 * (st_ch ^ vswz(R));
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(ka), "s"(kd + 1024u * j) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(va), "s"(vd + 1024u * j) : "memory", "m0");
     }
   };
-  auto store_tile = [&](int buf, auto set_tag) {
-    constexpr int SET = decltype(set_tag)::value;
-    char* kd = kbuf + buf * KTILE + (16 * w + st_r4) * RSK + 16 * st_ch;
-    char* vd = vbuf + buf * VTILE + (16 * w + st_r4) * RSV + 16 * st_ch;
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      *reinterpret_cast<u16x8*>(kd + RPI * j * RSK) = kreg[SET][j];
-      *reinterpret_cast<u16x8*>(vd + RPI * j * RSV) = vreg[SET][j];
-    }
-  };
+  auto tiles_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
 
@@ -537,17 +530,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   float m = HX_NEG_BIG, l = 0.f;
 
-  // (loads past the last tile repeat it: a branch around a load makes every later wait a wait for ALL loads)
   const int t_last = max(n_tiles - 1, 0);
   if (n_tiles > 0) {
     lookup_page(0);
-    load_tile(0, Set0{});
+    request_tile(0, 0);
     lookup_page(min(1, t_last));
-    store_tile(0, Set0{});
-    if (PF == 2) {
-      load_tile(min(1, t_last), Set1{});
-      lookup_page(min(2, t_last));
-    }
+    tiles_landed();
   }
   // The two workgroups of a CU at DIFFERENT priorities.  At equal priority two waves of a SIMD that happen to be in
   // the same phase slow each other equally and stay in phase — MFMA burst against MFMA burst, softmax against softmax
@@ -559,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   // Only when workgroups queue for the CUs (more than two per CU in the launch): of two workgroups that start together
   // and have nobody waiting for their slot, the favoured one finishes early and the other runs its last tiles alone
   // (one round of 512 equal workgroups, 2048 new tokens of 4096: 128 us without, 135 us with priorities).
-  uint32_t* prio_flag = reinterpret_cast<uint32_t*>(smem + 2 * KTILE + 2 * VTILE);
+  uint32_t* prio_flag = reinterpret_cast<uint32_t*>(smem + 2 * IMG);
   const bool queued = p.wg_priority != 0;
   if (queued && threadIdx.x == 0) *prio_flag = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1;     // HW_ID.wave_id
   __syncthreads();
@@ -568,17 +556,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   // transposed-read lane address inside a 4-row x 32-dim block: lane 4q + pp of each 16-lane group
   // supplies row q, dims 16 half + 4 pp .. + 3 (half = which 16 of the 32 dims this group takes)
   const int tr_q = (lane & 15) >> 2, tr_pp = lane & 3, tr_half = (lane >> 4) & 1;
-  const int tr_off = (4 * hi + tr_q) * RSV + (16 * tr_half + 4 * tr_pp) * 2;
+  const int tr_off = (4 * hi + tr_q) * RSV + (16 * tr_half + 4 * tr_pp) * 2;      // + 64 * (db ^ tr_x): the swizzled quarter
+  const int tr_x = vswz(tr_q) >> 2;
 
   auto tile_step = [&](int t, auto par_tag) {
-    constexpr int PAR = decltype(par_tag)::value;       // t & 1: this tile's LDS image and the register set that is free
+    constexpr int PAR = decltype(par_tag)::value;       // t & 1: this tile's LDS image
     const int cur = (ABL & 8) ? 0 : PAR;
-    if (!(ABL & (8 | 32 | 128))) {
-      load_tile(min(t + PF, t_last), std::integral_constant<int, PF == 2 ? PAR : 1 - PAR>{});   // PF tiles ahead
-    }
+    if (!(ABL & (8 | 32)) && t + 1 < n_tiles) request_tile(t + 1, 1 - PAR);   // lands under this tile's arithmetic
     if (t * KT <= last_key_wave) {
-      const char* kt = kbuf + cur * KTILE;
-      const char* vt = vbuf + cur * VTILE;
+      const char* kt = smem + cur * IMG;
+      const char* vt = kt + KTILE;
       f32x16 s[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -587,17 +574,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
       {
         // all K fragments of sub-tile 0 are requested before its first MFMA, those of sub-tile 1
         // under sub-tile 0's MFMAs: no MFMA waits for a read issued just before it
-        const char* krd = kt + c * RSK + 16 * hi;
+        const char* krd = kt + c * RSK;
+        const int kz = kswz(c);
         u16x8 kfa[KS], kfb[KS];
         if (ABL & 4) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { s[0][r] = 0.01f * (r + lane); s[1][r] = 0.02f * (r + t); }
         } else {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kfa[ks] = *reinterpret_cast<const u16x8*>(krd + 32 * ks);
+        for (int ks = 0; ks < KS; ++ks) kfa[ks] = *reinterpret_cast<const u16x8*>(krd + 16 * ((2 * ks + hi) ^ kz));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          kfb[ks] = *reinterpret_cast<const u16x8*>(krd + 32 * RSK + 32 * ks);
+          kfb[ks] = *reinterpret_cast<const u16x8*>(krd + 32 * RSK + 16 * ((2 * ks + hi) ^ kz));
           s[0] = Mfma32<T>::mma(kfa[ks], qf[ks], s[0]);
         }
 #pragma unroll
@@ -683,8 +671,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
           const char* vrd = vt + (32 * u + 16 * k2) * RSV + tr_off;
 #pragma unroll
           for (int db = 0; db < NDB; ++db) {
-            const u16x4 lo = lds_tr_read(vrd + db * 64);
-            const u16x4 hh = lds_tr_read(vrd + 8 * RSV + db * 64);
+            const u16x4 lo = lds_tr_read(vrd + 64 * (db ^ tr_x));
+            const u16x4 hh = lds_tr_read(vrd + 8 * RSV + 64 * (db ^ tr_x));
             u16x8 vf;
             vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
             vf[4] = hh[0]; vf[5] = hh[1]; vf[6] = hh[2]; vf[7] = hh[3];
@@ -693,10 +681,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
         }
     }
     if (!(ABL & 8)) {
-      // the table entry for the next request HERE, in front of the barrier's wait: a scalar load shares its counter with
-      // the LDS reads and returns out of order — while one is outstanding every LDS read is waited for singly
-      if (!(ABL & (32 | 128))) lookup_page(min(t + PF + 1, t_last));
-      if (!(ABL & 32) && t + 1 < n_tiles) store_tile(cur ^ 1, std::integral_constant<int, 1 - PAR>{});   // tile t+1, requested one tile ago
+      if (!(ABL & 32)) lookup_page(min(t + 2, t_last));       // the table entry for the next request, in front of the barrier's wait
+      tiles_landed();                                        // this wave's part of tile t+1 is in LDS
       if (!(ABL & 16)) __syncthreads();    // tile t+1 visible; everyone is done with tile t's image
     }
   };
@@ -755,7 +741,7 @@ int g_fwd_ablate = 0;   // EXPERIMENTS builds: timing ablations of attn_fwd32_ke
 
 template <typename T, int D, bool PAGED>
 int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
-  const size_t lds = 2 * 64 * ((2 * D + 16) + (2 * D + 64)) + 16;      // K / V images + the workgroup's priority flag
+  const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16;      // two tiles' K / V images + the workgroup's priority flag
   dim3 grid((unsigned)(p.total_q / 128 + batch), p.n_heads, 1);
   AttnParams pp = p;
   pp.wg_priority = (p.total_q / 128) * (int64_t)p.n_heads > 2 * (int64_t)fwd_n_cus() ? 1 : 0;   // more than two workgroups per CU
