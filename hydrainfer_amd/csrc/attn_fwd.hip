@@ -345,7 +345,7 @@ template <> struct Mfma32<BF16> {
 // or one wave per SIMD runs with nothing to hide its latencies behind (measured: 0.8 waves per SIMD
 // on average and 80 us for 4 x 704 tokens with the default bound)
 // ABL (EXPERIMENTS builds, fwd_ablate option; timing only, wrong results): 1 no softmax arithmetic, 2 no P V product,
-// 4 no Q K product, 8 no tile staging and no barrier after the first tile, 16 no barrier, 32 no tile loads / LDS stores, 128 no tile loads (LDS stores of stale registers kept)
+// 4 no Q K product, 8 no tile staging and no barrier after the first tile, 16 no barrier, 32 no tile requests
 template <typename T, int D, bool PAGED, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) {
   constexpr int KS = D / 16;         // QK k-steps
@@ -755,7 +755,7 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   if constexpr (D == 128 && PAGED && std::is_same<T, BF16>::value) {
     switch (g_fwd_ablate) {
 #define HX_ABL(n) case n: hx::launcher(attn_fwd32_kernel<T, D, PAGED, n>, grid, 256, lds, stream)(pp); return check_launch();
-      HX_ABL(1) HX_ABL(2) HX_ABL(4) HX_ABL(8) HX_ABL(3) HX_ABL(5) HX_ABL(6) HX_ABL(7) HX_ABL(9) HX_ABL(15) HX_ABL(16) HX_ABL(32) HX_ABL(48) HX_ABL(128) HX_ABL(144) HX_ABL(256) HX_ABL(79) HX_ABL(512) HX_ABL(1039)
+      HX_ABL(1) HX_ABL(2) HX_ABL(4) HX_ABL(8) HX_ABL(3) HX_ABL(5) HX_ABL(6) HX_ABL(7) HX_ABL(9) HX_ABL(15) HX_ABL(16) HX_ABL(32) HX_ABL(48) HX_ABL(256) HX_ABL(79) HX_ABL(512) HX_ABL(1039)
 #undef HX_ABL
       default: break;
     }

@@ -42,7 +42,7 @@ def timeit(reps=5, n=10):
 l = _lib.lib()
 names = {0: "full kernel", 1: "no softmax arithmetic", 2: "no P V", 4: "no Q K", 8: "no staging, no barrier", 3: "no softmax, no P V",
          5: "no softmax, no Q K", 6: "no Q K, no P V (softmax + staging)", 7: "staging + barrier only", 9: "no softmax, no staging",
-         15: "empty loop", 16: "no barrier (staging kept)", 32: "barrier kept, no tile loads / LDS stores", 48: "neither (= 8)", 128: "no tile loads, LDS stores + barrier kept", 144: "no tile loads, no barrier, LDS stores kept", 256: "the launch alone (workgroups return at once)",
+         15: "empty loop", 16: "no barrier (staging kept)", 32: "barrier kept, no tile requests", 48: "neither (= 8)", 256: "the launch alone (workgroups return at once)",
          79: "empty loop, no epilogue stores", 512: "full kernel, Q fragments not loaded (constants)"}
 for k, nm in names.items():
     assert l.hx_debug_set_option(b"fwd_ablate", k) == 0
