@@ -399,6 +399,43 @@ def test_prefill_row_block_variants_vs_oracle(rows, keys):
 
 
 @pytest.mark.gpu
+def test_prefill_32x32_kernel_fuzz_vs_general_kernel_and_oracle():
+    """The 32x32x16 prefill kernel (K / V tiles by LDS-DMA into XOR-swizzled images, Q and O through LDS as whole rows,
+    lazy running maximum, workgroup priorities) on random ragged paged shapes — query runs from 1 to a few hundred rows
+    with cached prefixes, GQA, both head sizes, every block size, causal and not, fp16 / bf16 — against the 16x16x32
+    kernel on the same inputs (fwd_mfma32 = 0) and, for a third of the cases, the oracle."""
+    import random
+    from hydrainfer_amd import _lib
+    from oracle import ops
+    lib = _lib.lib()
+    rnd = random.Random(20260)
+    try:
+        for case in range(27):
+            dt = (torch.float16, torch.bfloat16)[case % 2]
+            atol, rtol = ATTN_TOL[dt]
+            D = (128, 64)[(case // 2) % 2]
+            H, HK = rnd.choice(((4, 4), (8, 2), (6, 3), (5, 1)))
+            bs = rnd.choice((16, 32, 64))
+            B = rnd.randint(1, 6)
+            q_lens = [rnd.choice((1, rnd.randint(2, 63), rnd.randint(65, 330), 128, 129)) for _ in range(B)]
+            q_lens[rnd.randrange(B)] = rnd.randint(65, 400)          # at least one run that selects the 32x32 kernel
+            kv_lens = [ql + rnd.choice((0, 0, rnd.randint(1, 200), 16 * rnd.randint(1, 9))) for ql in q_lens]
+            causal = case % 5 != 4
+            q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(B, H, HK, D, kv_lens, q_lens, dt, block_size=bs, seed=100 + case)
+            what = f"case {case}: {dt} D={D} H={H}/{HK} block {bs} q={q_lens} kv={kv_lens} causal={causal}"
+            lib.hx_debug_set_option(b"fwd_mfma32", 1)
+            out32 = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens), causal=causal)
+            lib.hx_debug_set_option(b"fwd_mfma32", 0)
+            out16 = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens), causal=causal)
+            assert torch.isfinite(out32.float()).all(), what
+            assert_close_t(out32, out16.cpu(), 2 * atol, rtol, what=what + " (vs the 16x16x32 kernel)")
+            if case % 3 == 0 and causal:
+                assert_close_t(out32, ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b), atol, rtol, what=what + " (vs the oracle)")
+    finally:
+        lib.hx_debug_set_option(b"fwd_mfma32", 1)
+
+
+@pytest.mark.gpu
 def test_prefill_long_run_tilings_agree():
     from hydrainfer_amd import _lib
     from oracle import ops
