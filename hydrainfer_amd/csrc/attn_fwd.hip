@@ -515,8 +515,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
       const uint32_t r = (uint32_t)min(R, r_max);                  // rows past the last key repeat it
       const u16* ka = kbase + kb + r * (uint32_t)p.k_row_stride + 8 * (st_ch ^ kswz(R));
       const u16* va = vbase + vb + r * (uint32_t)p.v_row_stride + 8 * (st_ch ^ vswz(R));
+      // (m0 — the LDS address of the DMA — is a reserved register: naming it as clobbered is all that can be done, and
+      // nothing else in this kernel uses it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(ka), "s"(kd + 1024u * j) : "memory", "m0");
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(va), "s"(vd + 1024u * j) : "memory", "m0");
+#pragma clang diagnostic pop
     }
   };
   auto tiles_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
