@@ -773,6 +773,53 @@ def decode_leg(ctx, model, runner, ctxs, warmup, prompt_len):
     return elapsed
 
 
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 / fp16, MI355X_MICROARCH.md
+
+
+def time_prefill_attention(shape, dtype, dev, n_seqs=4, n_tokens=704, reps=3, launches=10):
+    """`roofline_prefill_attention`: the MFMA-bound kernel of the path — paged causal prefill attention of n_seqs x
+    n_tokens new tokens (the prefill of 4 of the benchmark's requests) through the C ABI (hx_attn, the 32x32x16
+    kernel), HIP events over a hipGraph of `launches` launches on random pages, mean of `reps` replays."""
+    import math
+    from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
+    H, HK, D, bs = shape.num_attention_heads, shape.num_key_value_heads, shape.head_dim, 16
+    g = torch.Generator(device=dev).manual_seed(11)
+    rnd = lambda *s_: torch.randn(s_, device=dev, generator=g).to(dtype)
+    nb = (n_tokens + bs - 1) // bs
+    kc, vc, q = rnd(n_seqs * nb, bs, HK, D), rnd(n_seqs * nb, bs, HK, D), rnd(n_seqs * n_tokens, H, D)
+    out = torch.empty_like(q)
+    perm = torch.randperm(n_seqs * nb, generator=g, device=dev).to(torch.int32)
+    cu_b = torch.arange(0, (n_seqs + 1) * nb, nb, dtype=torch.int32, device=dev)
+    cu = torch.arange(0, (n_seqs + 1) * n_tokens, n_tokens, dtype=torch.int32, device=dev)
+    fn = lambda: mha_varlen_fwd(out, q, kc, vc, cu, cu, perm, cu_b, None, n_tokens, n_tokens, 1 / math.sqrt(D), 0, -1, 0, 0)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(launches):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); graph.replay(); e1.record()
+        torch.cuda.synchronize(dev)
+        ts.append(e0.elapsed_time(e1) / launches * 1e3)
+    us = sum(ts) / len(ts)
+    flops = 4 * H * D * n_seqs * (n_tokens * (n_tokens + 1) // 2)       # Q.K and P.V over the causal triangle
+    tf = flops / us / 1e6
+    return {"bound": "mfma", "kernel": "attn_fwd32_kernel (paged causal prefill attention, v_mfma_f32_32x32x16)",
+            "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+            "traffic": None, "avg_launch_us": round(us, 2), "algorithmic_flops_per_launch": flops,
+            "workload": f"{n_seqs} sequences x {n_tokens} new tokens, H = {H}, D = {D}, block_size {bs}",
+            "timing": f"hipGraph of {launches} launches, mean of {reps} replays, HIP events",
+            "pmc": "profiles/r3_attn_prefill_pmc.json (SQ_VALU_MFMA_BUSY_CYCLES, LDS bank conflicts)"}
+
+
 def roofline_objects(model, runner, ctxs, ms_per_step, args, model_name, with_gemm=True):
     """`roofline` (decode attention kernel), `roofline_gemm`, `whole_step` for one timed leg."""
     B = runner.cfg.batch
@@ -985,6 +1032,7 @@ def main():
                        "parallelism": f"replicas x{n_gpus} (independent requests, no data-path collective)"},
             "roofline": roofline,
             "roofline_gemm": roofline_gemm,
+            "roofline_prefill_attention": None if args.skip_prefill else time_prefill_attention(shape, dtype, dev),
             "whole_step": whole,
             "prefill_batch_ms": None if ttft_ms is None else round(ttft_ms, 2),
             "ttft": ttft, "serving": serving, "migration": None,
