@@ -449,27 +449,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   constexpr int RPI = 64 / LPR;         // rows per instruction
   const int st_r4 = lane / LPR;         // row RPI j + st_r4
   const int st_ch = lane % LPR;         // 16-byte chunk of the row
-  // Q: whole rows into a wave-private LDS block (the second tile image is idle until tile 1 is requested, after the
-  // barrier below; 4 waves x 32 rows fill it exactly), the B-operand fragments out of it, same swizzle as K.  Loaded
-  // straight into the fragment layout every instruction took 32 bytes of each of 32 rows.
-  u16x8 qf[KS];
-  {
-    constexpr int RSO = RSK;
-    char* qb = smem + IMG + w * 32 * RSO;
-    const u16* qbase = reinterpret_cast<const u16*>(p.q) + (int64_t)h * D + 8 * st_ch;
-    u16x8 qrow[32 / RPI];
-#pragma unroll
-    for (int j = 0; j < 32 / RPI; ++j) {
-      const int qr = min(q_row0 + RPI * j + st_r4, q_len - 1);
-      if (ABL == 512) qrow[j] = u16x8{(u16)(0x3c00 + lane), 0x3800, 0x3400, 0x3000, 0x2c00, 0x2800, (u16)(0x2400 + j), 0x2000};
-      else qrow[j] = *reinterpret_cast<const u16x8*>(qbase + (int64_t)(q_start + qr) * p.q_row_stride);
-    }
-#pragma unroll
-    for (int j = 0; j < 32 / RPI; ++j)
-      *reinterpret_cast<u16x8*>(qb + (RPI * j + st_r4) * RSO + 16 * (st_ch ^ kswz(RPI * j + st_r4))) = qrow[j];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qb + c * RSO + 16 * ((2 * ks + hi) ^ kswz(c)));
-  }
   const int shift = kv_len - q_len;
   const int limit_c = p.causal ? min(kv_len - 1, q_row0 + c + shift) : kv_len - 1;
   const int last_key_wave = q_row0 >= q_len ? -1 : p.causal ? min(kv_len - 1, q_row0 + 31 + shift) : kv_len - 1;
@@ -540,8 +519,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
     lookup_page(0);
     request_tile(0, 0);
     lookup_page(min(1, t_last));
-    tiles_landed();
   }
+  // (Q behind the first K / V request: the two round trips overlap instead of following each other)
+  // Q: whole rows into a wave-private LDS block (the second tile image is idle until tile 1 is requested, after the
+  // barrier below; 4 waves x 32 rows fill it exactly), the B-operand fragments out of it, same swizzle as K.  Loaded
+  // straight into the fragment layout every instruction took 32 bytes of each of 32 rows.
+  u16x8 qf[KS];
+  {
+    constexpr int RSO = RSK;
+    char* qb = smem + IMG + w * 32 * RSO;
+    const u16* qbase = reinterpret_cast<const u16*>(p.q) + (int64_t)h * D + 8 * st_ch;
+    u16x8 qrow[32 / RPI];
+#pragma unroll
+    for (int j = 0; j < 32 / RPI; ++j) {
+      const int qr = min(q_row0 + RPI * j + st_r4, q_len - 1);
+      if (ABL == 512) qrow[j] = u16x8{(u16)(0x3c00 + lane), 0x3800, 0x3400, 0x3000, 0x2c00, 0x2800, (u16)(0x2400 + j), 0x2000};
+      else qrow[j] = *reinterpret_cast<const u16x8*>(qbase + (int64_t)(q_start + qr) * p.q_row_stride);
+    }
+#pragma unroll
+    for (int j = 0; j < 32 / RPI; ++j)
+      *reinterpret_cast<u16x8*>(qb + (RPI * j + st_r4) * RSO + 16 * (st_ch ^ kswz(RPI * j + st_r4))) = qrow[j];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qb + c * RSO + 16 * ((2 * ks + hi) ^ kswz(c)));
+  }
+  if (n_tiles > 0) tiles_landed();
   // The two workgroups of a CU at DIFFERENT priorities.  At equal priority two waves of a SIMD that happen to be in
   // the same phase slow each other equally and stay in phase — MFMA burst against MFMA burst, softmax against softmax
   // — and a tile costs its MFMA plus its VALU time (4 x 704: 1.8 us per tile and pair of workgroups with the staging
