@@ -59,76 +59,6 @@ def linear_decode_partial(x: Tensor, weight: Tensor, partial: Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------------------------
-# decode chain (csrc/decode_chain.hip): o GEMM .. down GEMM, both norms, silu*mul and the next
-# layer's qkv GEMM of a decode step as one launch
-# ------------------------------------------------------------------------------------------------
-SYNC_WORDS = _lib.HX_CHAIN_SYNC_WORDS
-SYNC_ERR = _lib.HX_CHAIN_SYNC_ERR
-
-
-def chain_supported(M: int, hidden: int, inter: int, q_size: int, dtype: torch.dtype) -> bool:
-    return (dtype in (torch.float16, torch.bfloat16)
-            and _lib.lib().hx_decode_chain_workspace_bytes(M, hidden, inter, q_size) > 0)
-
-
-def chain_workspace_floats(M: int, hidden: int, inter: int, q_size: int) -> int:
-    return _lib.lib().hx_decode_chain_workspace_bytes(M, hidden, inter, q_size) // 4
-
-
-def decode_chain(attn_out: Tensor, h_in: Tensor, w_o: Tensor, w_gate_up: Tensor, w_down: Tensor,
-                 w_qkv_next: Optional[Tensor], inter: int, norm_post: Tensor, norm_next: Tensor, eps: float,
-                 h_mid: Tensor, h_out: Tensor, x_post: Tensor, act: Tensor, x_next: Tensor,
-                 qkv_partial: Optional[Tensor], workspace: Tensor, sync: Tensor) -> int:
-    """One launch for  h_mid = h_in + attn_out @ Wo^T;  x_post = rms_norm(h_mid, norm_post);
-    act = silu(gate) * up of x_post @ Wgu^T;  h_out = h_mid + act @ Wdown^T;
-    x_next = rms_norm(h_out, norm_next);  qkv_partial = split-K slabs of x_next @ Wqkv_next^T.
-    The four weights are PACKED (pack_weight) flat tensors: w_o of [hidden, q_size], w_gate_up of
-    [2*inter, hidden], w_down of [hidden, inter], w_qkv_next of [qkv_n, hidden] (or None).
-    `sync` is a zeroed int32 tensor of SYNC_WORDS words (zeroed on this stream before the call).
-    Returns the number of qkv slabs (0 without w_qkv_next)."""
-    ts = [attn_out, h_in, w_o, w_gate_up, w_down, norm_post, norm_next, h_mid, h_out, x_post, act, x_next,
-          workspace, sync]
-    _lib.require_gpu(*ts, w_qkv_next, qkv_partial)
-    M, q_size = attn_out.shape
-    hidden = h_in.shape[1]
-    dt = attn_out.dtype
-    for t in (h_in, w_o, w_gate_up, w_down, norm_post, norm_next, h_mid, h_out, x_post, act, x_next):
-        if t.dtype != dt:
-            raise _lib.HydraHipError("decode_chain: all activations / weights must share one dtype")
-    for t in (h_in, h_mid, h_out, x_post, x_next, act, norm_post, norm_next, w_o, w_gate_up, w_down):
-        if not t.is_contiguous():
-            raise _lib.HydraHipError("decode_chain: buffers must be contiguous")
-    if (w_o.numel() != hidden * q_size or w_gate_up.numel() != 2 * inter * hidden or w_down.numel() != hidden * inter
-            or tuple(act.shape) != (M, inter) or any(tuple(t.shape) != (M, hidden) for t in (h_mid, h_out, x_post, x_next))):
-        raise _lib.HydraHipError("decode_chain: shape mismatch (weights must be pack_weight() of the layer's matrices)")
-    if attn_out.stride(1) != 1:
-        raise _lib.HydraHipError("decode_chain: rows must be contiguous")
-    if workspace.dtype != torch.float32 or sync.dtype != torch.int32 or sync.numel() < SYNC_WORDS:
-        raise _lib.HydraHipError("decode_chain: workspace float32, sync int32[SYNC_WORDS]")
-    a = _lib.hx_chain_args()
-    a.M, a.hidden, a.inter, a.q_size = M, hidden, inter, q_size
-    a.dtype, a.eps = _lib.dtype_code(attn_out), float(eps)
-    a.attn_out, a.attn_out_stride, a.h_in = attn_out.data_ptr(), attn_out.stride(0), h_in.data_ptr()
-    a.w_o, a.w_gate_up, a.w_down = w_o.data_ptr(), w_gate_up.data_ptr(), w_down.data_ptr()
-    if w_qkv_next is not None:
-        if qkv_partial is None or qkv_partial.dtype != torch.float32 or w_qkv_next.dtype != dt \
-                or w_qkv_next.numel() % hidden or not w_qkv_next.is_contiguous():
-            raise _lib.HydraHipError("decode_chain: w_qkv_next (packed [n, hidden]) needs a float32 qkv_partial")
-        a.qkv_n, a.w_qkv_next = w_qkv_next.numel() // hidden, w_qkv_next.data_ptr()
-        a.qkv_partial, a.qkv_partial_bytes = qkv_partial.data_ptr(), qkv_partial.numel() * 4
-    a.norm_post_weight, a.norm_next_weight = norm_post.data_ptr(), norm_next.data_ptr()
-    a.h_mid, a.h_out, a.x_post, a.act, a.x_next = (h_mid.data_ptr(), h_out.data_ptr(), x_post.data_ptr(),
-                                                   act.data_ptr(), x_next.data_ptr())
-    a.workspace, a.workspace_bytes, a.sync = workspace.data_ptr(), workspace.numel() * 4, sync.data_ptr()
-    rc = _lib.lib().hx_decode_chain(ctypes.byref(a), _lib.current_stream())
-    if rc < 0:
-        _lib.check(rc, "decode_chain")
-    return rc
-
-
-# ------------------------------------------------------------------------------------------------
-# packed weights (csrc/gemm_skinny.hip: gemm_packed_kernel)
-# ------------------------------------------------------------------------------------------------
 def pack_weight(weight: Tensor) -> Tensor:
     """weight [N, K] -> flat [N*K] in MFMA-fragment order (hx_pack_decode_weight)."""
     _lib.require_gpu(weight)

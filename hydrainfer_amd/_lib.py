@@ -61,20 +61,6 @@ class hx_decode_weight(ctypes.Structure):
 HX_DW_LDS_SLICE, HX_DW_XREG, HX_DW_GATE_UP = 0, 1, 1
 
 
-class hx_chain_args(ctypes.Structure):
-    _fields_ = [
-        ("M", c_int32), ("hidden", c_int32), ("inter", c_int32), ("q_size", c_int32),
-        ("qkv_n", c_int32), ("dtype", c_int32), ("eps", c_float), ("reserved", c_int32),
-        ("attn_out", c_void_p), ("attn_out_stride", c_int64), ("h_in", c_void_p),
-        ("w_o", c_void_p), ("w_gate_up", c_void_p), ("w_down", c_void_p), ("w_qkv_next", c_void_p),
-        ("norm_post_weight", c_void_p), ("norm_next_weight", c_void_p),
-        ("h_mid", c_void_p), ("h_out", c_void_p), ("x_post", c_void_p), ("act", c_void_p),
-        ("x_next", c_void_p), ("qkv_partial", c_void_p), ("qkv_partial_bytes", c_int64),
-        ("workspace", c_void_p), ("workspace_bytes", c_int64), ("sync", c_void_p),
-    ]
-
-
-HX_CHAIN_SYNC_WORDS, HX_CHAIN_SYNC_ERR = 18432, 480
 HX_XREG_SYNC_WORDS = 512
 
 _SIGNATURES = {
@@ -142,14 +128,13 @@ _SIGNATURES = {
     "hx_plan_launch": (c_int, [c_void_p, c_void_p]),
     "hx_plan_destroy": (c_int, [c_void_p]),
     "hx_memset_zero": (c_int, [c_void_p, c_int64, c_void_p]),
+    "hx_measure_read_stream": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 # Only in a library built with `make EXPERIMENTS=1` (include/hydra_hip_experimental.h): rejected experiments and
 # microbenchmarks.  Bound when present; the product path never calls them.
 _EXPERIMENTAL_SIGNATURES = {
     "hx_debug_stream_read": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "hx_decode_chain_workspace_bytes": (c_int64, [c_int64] * 4),
-    "hx_decode_chain": (c_int, [POINTER(hx_chain_args), c_void_p]),
     "hx_debug_paged_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int] + [c_int] * 4 + [c_void_p, c_void_p]),
 }
 
@@ -191,9 +176,8 @@ def exported_symbols():
 
 
 def has_experiments() -> bool:
-    """True if libhydra_hip.so was built with `make EXPERIMENTS=1` (decode chain, four-heads decode attention,
-    read-stream probes)."""
-    return hasattr(lib(), "hx_decode_chain")
+    """True if libhydra_hip.so was built with `make EXPERIMENTS=1` (four-heads decode attention, read-stream probes)."""
+    return hasattr(lib(), "hx_debug_stream_read")
 
 
 def check(status: int, what: str) -> None:

@@ -534,7 +534,14 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
   if (nb < 1) nb = 1;
   if (nb > n_units) nb = n_units;
   int G = (n_units + nb - 1) / nb;
-  if (G * per_unit > kMaxG) G = kMaxG / per_unit;
+  if (G * per_unit > kMaxG) {
+    // the kernel derives its share from gridDim.x (ceil((n_units - b) / nb) units) and keeps one LDS tile set per
+    // row group: a share past kMaxG row groups would index LDS beyond the allocation, so the grid grows instead
+    // (more workgroups than CUs; they run in rounds)
+    G = kMaxG / per_unit;
+    nb = (n_units + G - 1) / G;
+  }
+  if (((n_units + nb - 1) / nb) * per_unit > kMaxG) return HX_ERR_SHAPE;   // cannot happen: nb >= n_units / G
   // (one workgroup per CU even when the last round is partial: its short shares go to the first workgroups of the
   // grid, which are the late starters of a NORM launch — see the kernel)
   const size_t lds = (size_t)G * per_unit * 4 * MB * 1024;

@@ -17,7 +17,6 @@ int gemm_set_option(const char* name, int value);
 int fwd_set_option(const char* name, int value);
 int xreg_set_option(const char* name, int value);
 #if HX_EXPERIMENTS   // `make EXPERIMENTS=1`: rejected experiments kept measurable (not in the default library)
-int chain_set_option(const char* name, int value);
 int decode4_set_option(const char* name, int value);
 bool decode4_applies(const AttnParams& p, int batch, int head_dim, int n_cus);
 int launch_attn_decode4(const AttnParams& p, int batch, int dtype, hipStream_t stream);
@@ -52,7 +51,6 @@ extern "C" int hx_debug_set_option(const char* name, int value) {
   if (rc == HX_ERR_UNSUPPORTED) rc = fwd_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = xreg_set_option(name, value);
 #if HX_EXPERIMENTS
-  if (rc == HX_ERR_UNSUPPORTED) rc = chain_set_option(name, value);
   if (rc == HX_ERR_UNSUPPORTED) rc = decode4_set_option(name, value);
 #endif
   return rc;

@@ -96,6 +96,33 @@ __global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, int
 // memset(p, 0, bytes) on the stream as a KERNEL of this library: recordable in a plan (a torch.zeros inside a
 // recorded region would run once, at recording time, and never again) and a plain kernel node under hipGraph
 // capture (a captured hipMemsetAsync node was seen to leave garbage from the second replay on).  4-byte granularity.
+// hx_measure_read_stream: the read rate of this GPU for the access shape of the weight-streaming kernels (1 KiB
+// contiguous per wave instruction, non-temporal, 8 in flight per wave), nothing computed.
+namespace {
+__global__ __launch_bounds__(256) void read_stream_kernel(const char* __restrict__ base, int64_t n_chunks, float* sink) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  hx::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t c = wave; c < n_chunks; c += n_waves) {
+    const char* p0 = base + c * 8192 + lane * 16;
+    hx::f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const hx::f32x4*>(p0 + u * 1024));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
+}
+}  // namespace
+
+extern "C" int hx_measure_read_stream(const void* p, int64_t bytes, float* sink, hx_stream stream) {
+  if (!p || !sink) return HX_ERR_NULL;
+  if (bytes <= 0 || bytes % 8192) return HX_ERR_SHAPE;
+  if (reinterpret_cast<uintptr_t>(p) & 15u) return HX_ERR_STRIDE;
+  hx::launcher(read_stream_kernel, 1024, 256, 0, (hipStream_t)stream)((const char*)p, bytes / 8192, sink);
+  return check_launch();
+}
+
 extern "C" int hx_memset_zero(void* p, int64_t bytes, hx_stream stream) {
   if (!p || bytes < 0) return HX_ERR_NULL;
   if (bytes == 0) return HX_OK;

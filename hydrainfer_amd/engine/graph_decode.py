@@ -70,6 +70,7 @@ class GraphedDecoder:
         self.launch_has_err = {}
         self.events = [torch.cuda.Event(), torch.cuda.Event()]
         self.launches = 0                  # id of the most recent launch (1-based)
+        self.poisoned_until = 0            # launches <= this id were enqueued behind a failed hand-over: fetch raises
         self.launch_rows = {}              # launch id -> number of live rows
         n_layers = self.model.shape.num_hidden_layers
         self.kv_caches = [KVCache.from_token_cache(self.kv.get_layer_cache(l)) for l in range(n_layers)]
@@ -144,10 +145,15 @@ class GraphedDecoder:
                 self._body(B, params)
             self.prev_tokens.copy_(saved)
         torch.cuda.current_stream(self.dev).wait_stream(side)
+        graph = None
         if self.executor == "plan":
             graph = launch_plan.LaunchPlan(self.dev)
-            out, err = graph.capture(lambda: self._body(B, params))
-        else:
+            try:
+                out, err = graph.capture(lambda: self._body(B, params))
+            except launch_plan.PlanNotRecordable:
+                graph = None       # a step with torch ops in it (library GEMMs, a shape off the hx fast path): hipGraph
+                self.executor = "graph"
+        if graph is None:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out, err = self._body(B, params)
@@ -222,11 +228,19 @@ class GraphedDecoder:
         slot = launch_id % 2
         self.events[slot].synchronize()
         n = self.launch_rows.pop(launch_id)
+        if launch_id <= self.poisoned_until:
+            self.launch_has_err.pop(launch_id, None)
+            raise HydraHipError(f"decode launch {launch_id} was enqueued behind a launch whose in-kernel hand-over gave "
+                                "up: its input tokens were invalid, so are its samples")
         if self.launch_has_err.pop(launch_id, False) and int(self.host_err[slot][0]) != 0:
             # a norm-fused launch consumed activations nobody had produced: this step's tokens are garbage.
             # Later steps run with the add+RMSNorm as separate launches (no in-kernel hand-over).
             self.model.fuse_norm = False
+            # launch N+1 may already be running out of the same graph / plan, fed from this launch's garbage tokens:
+            # let it finish before its buffers (the plan's private pool) go, and refuse its tokens as well
+            torch.cuda.synchronize(self.dev)
             self.graphs.clear()
+            self.poisoned_until = self.launches
             raise HydraHipError(f"decode launch {launch_id}: an in-kernel hand-over (norm-fused GEMM launch) gave up "
                                 "waiting for its producer workgroups; the step's tokens are invalid. Later steps run "
                                 "with the add+RMSNorm as separate launches (fuse_norm = False)")

@@ -8,7 +8,7 @@ r3_launch_chain_experiment.md): equal to the hipGraph when both exist in one pro
 process that replays only plans (bench.py, the engine).
 
     plan = LaunchPlan(device)
-    out = plan.capture(step_fn)       # step_fn's hx_* launches are recorded, nothing runs; torch ops are not allowed
+    out = plan.capture(step_fn)       # step_fn's hx_* launches are recorded, nothing runs; torch ops raise PlanNotRecordable
     plan.replay(); plan.replay()      # ... except through launch_plan.host_op(fn), which is replayed in its place
 
 Everything step_fn allocates comes from a private torch memory pool that lives as long as the plan (the recorded
@@ -18,10 +18,37 @@ import threading
 from typing import Callable, List, Optional
 
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 
 from hydrainfer_amd import _lib
 
 _tls = threading.local()
+
+
+class PlanNotRecordable(_lib.HydraHipError):
+    """The step contains work a launch plan cannot record (a torch op that launches a kernel outside host_op)."""
+
+
+# aten operators that only allocate or re-view memory: they launch nothing, so a recording may contain them
+_VIEW_OR_ALLOC = frozenset((
+    "empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided", "view", "_unsafe_view", "reshape",
+    "_reshape_alias", "as_strided", "slice", "select", "narrow", "expand", "t", "transpose", "permute", "unsqueeze",
+    "squeeze", "detach", "alias", "unbind", "split", "split_with_sizes", "chunk", "unfold", "view_as", "lift_fresh",
+    "flatten", "unflatten", "movedim", "swapaxes", "diagonal", "real", "imag", "view_as_real", "view_as_complex",
+    "sym_size", "sym_stride", "sym_numel", "sym_storage_offset", "is_contiguous", "size", "stride", "numel", "dim"))
+
+
+class _RecordingGuard(TorchDispatchMode):
+    """While a plan is recorded nothing executes: an hx_* launch goes into the plan, a torch op handed to host_op is
+    replayed in its place — and any OTHER torch op would run once now and be missing from every replay, silently
+    (round-3 ADVICE: bench.py --lib-gemm replayed a step without its GEMMs).  This mode turns that into an error."""
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func._schema.name.split("::")[-1]
+        if name not in _VIEW_OR_ALLOC:
+            raise PlanNotRecordable(f"torch op aten::{name} inside a launch-plan recording: it would run once now and "
+                                    "be dropped on replay — wrap it in launch_plan.host_op or use the hipGraph executor")
+        return func(*args, **(kwargs or {}))
 
 
 def current() -> Optional["LaunchPlan"]:
@@ -81,7 +108,8 @@ class LaunchPlan:
             with torch.cuda.use_mem_pool(self.pool, device=self.device):
                 self._begin_segment()
                 try:
-                    result = step_fn()
+                    with _RecordingGuard():
+                        result = step_fn()
                 finally:
                     self._end_segment()
         finally:

@@ -84,10 +84,6 @@ class LlamaForCausalLM:
         # reads each KV head once (3x faster at group 4 and more than pays for the two launches)
         self.fuse_decode_attention = (shape.head_dim in (64, 128, 256)
                                       and shape.num_key_value_heads == shape.num_attention_heads)
-        # decode batches of <= 32 rows: everything between two attention launches (o GEMM, both
-        # norms, gate|up GEMM, silu*mul, down GEMM, the next layer's qkv GEMM) is ONE launch
-        # (csrc/decode_chain.hip) — 2 launches per layer instead of 8, bit-identical results
-        self.use_chain = False   # enabled once the chain launch beats the separate launches
         # decode GEMMs stream PACKED copies of the weights (MFMA-fragment order, contiguous 1 KiB
         # reads: csrc/gemm_skinny.hip gemm_packed_kernel); the row-major tensors stay for the
         # prefill GEMMs (library).  288 GB of HBM: the second copy of a 7B / 13B model is 13 / 26 GB.
@@ -109,7 +105,6 @@ class LlamaForCausalLM:
         self.packed_x: Dict[str, Tensor] = {}
         self.dw: Dict[str, "hip_gemm.DecodeWeight"] = {}       # descriptors of the packed copies (xreg layout)
         self.dw_lds: Dict[str, "hip_gemm.DecodeWeight"] = {}   # ... (LDS-slice layout)
-        self.chain_sync: Optional[Tensor] = None   # [L, SYNC_WORDS] int32 of the last chain step (error words)
         # decode-side weight layouts are built ONCE, by prepare_decode (engine build / runner construction), for
         # the largest decode batch the owner will ever run — never in the middle of serving
         self.decode_rows_prepared = 0
@@ -126,7 +121,7 @@ class LlamaForCausalLM:
         (hydrainfer/model/llama.py:24-27,48-50)."""
         max_rows = min(int(max_rows), 64)
         if max_rows > self.decode_rows_prepared and not self.decode_only:
-            self.pack_decode_weights(all_lds_slice=max_rows > 32 or self.use_chain)
+            self.pack_decode_weights(all_lds_slice=max_rows > 32)
             self.decode_rows_prepared = max_rows
         if not keep_row_major and not self.decode_only and self._all_packed():
             for l in range(self.shape.num_hidden_layers):
@@ -149,18 +144,16 @@ class LlamaForCausalLM:
     def release(self) -> None:
         """Drops every weight tensor (bench.py frees the 7B model before its 13B leg)."""
         self.state, self.packed, self.packed_x, self.dw, self.dw_lds = {}, {}, {}, {}, {}
-        self.xreg_sync = self.chain_sync = None
+        self.xreg_sync = None
 
     def handover_failed(self) -> bool:
         """True if an in-kernel hand-over of the last decode step gave up waiting (word 1 of a norm-fused
-        launch's sync area, HX_CHAIN_SYNC_ERR of a chain launch): that step's activations are garbage.
+        launch's sync area): that step's activations are garbage.
         One small D2H sync — callers on the hot path fold the flag into their token copy instead
         (engine/graph_decode.py)."""
         bad = False
         if self.xreg_sync is not None:
             bad = bool(int(self.xreg_sync[:, :, 1].abs().sum()) != 0)
-        if not bad and self.chain_sync is not None:
-            bad = bool(int(self.chain_sync[:, hip_gemm.SYNC_ERR].abs().sum()) != 0)
         return bad
 
     def handover_error_word(self) -> Optional[Tensor]:
@@ -177,7 +170,7 @@ class LlamaForCausalLM:
         interleaved for the fused silu*mul epilogue), planned for 64 rows the LDS-slice layout.  o and layer 0's qkv
         always take the LDS-slice layout (o: at 33 MB the x broadcast of the other kernel would dominate; layer 0's
         qkv: its x comes row-major from the embedding launch); the LDS-slice copies of the other projections are
-        built only when batches of 33..64 rows (or the experimental decode chain) are announced: all_lds_slice."""
+        built only when batches of 33..64 rows are announced: all_lds_slice."""
         if not (self.use_packed and self.use_hip_gemm and self.dtype in (torch.float16, torch.bfloat16)):
             return
         if self.use_xreg and self._xreg_mlp_ok(32):
@@ -394,47 +387,6 @@ class LlamaForCausalLM:
                 add_rms_norm_slabs(x, h, ws, s_dn, nxt, eps)
         return x
 
-    def _decode_hidden_chain(self, h: Tensor, position_ids: Tensor,
-                             model_params: LanguageModelParameters) -> Tensor:
-        """All-decode step, <= 32 rows: per layer ONE attention launch (slab reduce + RoPE + cache
-        append + paged attention) and ONE chain launch (o GEMM .. next layer's qkv GEMM)."""
-        sh, st = self.shape, self.state
-        n = h.shape[0]
-        H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
-        q_size, kv_size, inter, hid = self.q_size, self.kv_size, sh.intermediate_size, sh.hidden_size
-        eps, L = sh.rms_norm_eps, sh.num_hidden_layers
-        qkv_n = q_size + 2 * kv_size
-        dev, dt = h.device, h.dtype
-        ws_qkv = torch.empty(hip_gemm.workspace_floats(n, qkv_n, hid), dtype=torch.float32, device=dev)
-        ws = torch.empty(hip_gemm.chain_workspace_floats(n, hid, inter, q_size), dtype=torch.float32, device=dev)
-        sync = torch.zeros((L, hip_gemm.SYNC_WORDS), dtype=torch.int32, device=dev)
-        self.chain_sync = sync
-        hbuf = [h, torch.empty_like(h), torch.empty_like(h)]   # residual stream: in / mid / out rotate
-        x_post, x_next = torch.empty_like(h), torch.empty_like(h)
-        act = torch.empty((n, inter), dtype=dt, device=dev)
-        pk = self.packed
-        rms_norm(x_next, h, st["l0.norm1"], eps)
-        s_qkv = self._partial(x_next, "l0.wqkv", ws_qkv)
-        i_in = 0
-        for l in range(L):
-            ap = model_params.attention_params[l]
-            kc, vc = ap.kv_cache.get_kv_cache()
-            o = torch.empty((n, H, D), dtype=dt, device=dev)
-            decode_attention_fused(o, o, o[:, :HK], o[:, :HK], kc, vc, position_ids, self.cos_sin,
-                                   ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
-                                   ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws_qkv, s_qkv)
-            last = l + 1 == L
-            s_next = hip_gemm.decode_chain(
-                o.view(n, q_size), hbuf[i_in], pk[f"l{l}.wo"], pk[f"l{l}.wgu"], pk[f"l{l}.wdown"],
-                None if last else pk[f"l{l + 1}.wqkv"], inter, st[f"l{l}.norm2"],
-                st["norm"] if last else st[f"l{l + 1}.norm1"], eps,
-                hbuf[(i_in + 1) % 3], hbuf[(i_in + 2) % 3], x_post, act, x_next,
-                None if last else ws_qkv, ws, sync[l])
-            if not last:
-                s_qkv = s_next
-            i_in = (i_in + 2) % 3
-        return x_next
-
     def forward_hidden(self, input_ids_or_embeds: Tensor, position_ids: Tensor,
                        model_params: LanguageModelParameters) -> Tensor:
         sh, st = self.shape, self.state
@@ -455,12 +407,6 @@ class LlamaForCausalLM:
         if (self.use_hip_gemm and model_params.all_sequences_decode and self.fuse_decode_attention
                 and n <= 64 and h.dtype in (torch.float16, torch.bfloat16)
                 and sh.hidden_size % 256 == 0 and sh.intermediate_size % 256 == 0):
-            if self.use_chain and n <= 32 and f"l{sh.num_hidden_layers - 1}.wdown" not in self.packed:
-                self.decode_rows_prepared = 0
-                self.prepare_decode(max_rows=64)
-            if self.use_chain and n <= 32 and f"l{sh.num_hidden_layers - 1}.wdown" in self.packed and hip_gemm.chain_supported(
-                    n, sh.hidden_size, sh.intermediate_size, self.q_size, h.dtype):
-                return self._decode_hidden_chain(h, position_ids, model_params)
             return self._decode_hidden_hip_gemm(h, position_ids, model_params, x0)
         H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
         q_size, kv_size, inter = self.q_size, self.kv_size, sh.intermediate_size

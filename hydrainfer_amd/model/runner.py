@@ -107,6 +107,7 @@ class DecodeRunner:
                 q_max_seq_len=1, kv_max_seq_len=self.max_len) for kc in self.kv_caches],
             all_sequences_decode=True)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.executor_used = cfg.executor          # "plan" falls back to "graph" when the step is not recordable
         self.tokens: List[Tensor] = []
 
     # ------------------------------------------------------------------ prefill
@@ -228,11 +229,17 @@ class DecodeRunner:
                 self._step_body()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         self.positions.copy_(saved[0]); self.kv_lens.copy_(saved[1]); self.input_ids.copy_(saved[2])
+        self.executor_used = self.cfg.executor
         if self.cfg.executor == "plan":
             plan = launch_plan.LaunchPlan(self.dev)
-            plan.capture(self._step_body)       # records, runs nothing: the decode state is untouched
-            self.graph = plan
-        else:
+            try:
+                plan.capture(self._step_body)       # records, runs nothing: the decode state is untouched
+                self.graph = plan
+            except launch_plan.PlanNotRecordable:
+                # the step is not all-hx (library GEMMs: use_hip_gemm = False, a shape off the fast path, fp32 ...):
+                # a plan would drop those torch ops on replay — the captured hipGraph records them
+                self.executor_used = "graph"
+        if self.graph is None:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self._step_body()

@@ -19,23 +19,29 @@ KV_RTOL = 2.0 ** -6      # of the pool's largest magnitude: two bf16 ulps up the
                          # order, one from RoPE's T arithmetic on it; RoPE's x*c - y*s cancels, so no per-element bound)
 
 
-def _build(batch=32, prompt_len=40, n_generate=12, layers=2, seed=3):
+def _build(batch=32, prompt_len=40, n_generate=12, layers=2, seed=3, width=(4096, 11008, 32), executor="plan"):
     from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
     from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
-    shape = LlamaShape(4096, 11008, layers, 32, 32, 128, 32064)
+    hidden, inter, heads = width
+    shape = LlamaShape(hidden, inter, layers, heads, heads, 128, 32064)
     model = LlamaForCausalLM.random_init(shape, torch.bfloat16, DEV, seed=seed)
-    runner = DecodeRunner(model, RunnerConfig(batch=batch, prompt_len=prompt_len, n_generate=n_generate, use_graph=True),
-                          seed=seed + 1)
+    runner = DecodeRunner(model, RunnerConfig(batch=batch, prompt_len=prompt_len, n_generate=n_generate, use_graph=True,
+                                              executor=executor), seed=seed + 1)
     return shape, model, runner
 
 
-def test_benchmarked_decode_configuration_matches_oracle():
+# both widths bench.py reports (LLaVA-1.5-7B: the headline; LLaVA-1.5-13B: the `llava_13b` leg, BASELINE configs[2]) and
+# both step executors (the launch plan bench.py / DecodeRunner replay by default, the hipGraph the engine replays)
+@pytest.mark.parametrize("executor", ["plan", "graph"])
+@pytest.mark.parametrize("width", [(4096, 11008, 32), (5120, 13824, 40)], ids=["7b-width", "13b-width"])
+def test_benchmarked_decode_configuration_matches_oracle(width, executor):
+    from hydrainfer_amd import launch_plan
     from oracle.model import OracleAttnMeta, OracleLlama
     B, P, steps, bs = 32, 40, 8, 16
-    shape, model, runner = _build(B, P, steps + 4)
+    shape, model, runner = _build(B, P, steps + 4, width=width, executor=executor)
     # the flags bench.py runs with, and the layouts they imply
     assert model.use_hip_gemm and model.use_packed and model.use_xreg and model.xreg_qkv and model.fuse_norm
-    assert model.fuse_decode_attention and not model.use_chain
+    assert model.fuse_decode_attention
     assert "l1.wqkv" in model.packed_x and "l0.wgu" in model.packed_x and "l0.wo" in model.packed
     oracle = OracleLlama(shape, model.to_reference_state_dict(), torch.bfloat16)
     pool0 = runner.pool.cpu().clone()
@@ -57,7 +63,8 @@ def test_benchmarked_decode_configuration_matches_oracle():
         torch.cuda.synchronize()
         hip_logits.append(stash["logits"].float().cpu().clone())
         hip_tokens.append(runner.input_ids.cpu().clone())
-    assert runner.graph is not None                       # the steps were graph replays
+    assert runner.graph is not None and runner.executor_used == executor     # the steps were replays, by the executor asked for
+    assert isinstance(runner.graph, launch_plan.LaunchPlan) == (executor == "plan")
     assert model.xreg_sync is not None and not model.handover_failed()   # 5-launch layers ran, no hand-over gave up
     generated = runner.generated()                        # raises on a failed hand-over
 

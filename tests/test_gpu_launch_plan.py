@@ -19,6 +19,7 @@ def _run(executor, dt, shape, batch, steps, seed=3, prompt=40):
     for _ in range(steps):
         r.step()
     torch.cuda.synchronize()
+    assert r.executor_used == executor, "an all-hx decode step must be recordable (no silent fall-back to the hipGraph)"
     return r, r.generated(), r.pool.clone()
 
 
@@ -52,6 +53,39 @@ def test_plan_small_and_13b_widths():
         a = _run("graph", torch.bfloat16, sh, batch, 12)
         b = _run("plan", torch.bfloat16, sh, batch, 12)
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+def test_step_with_torch_ops_is_refused_by_the_plan_and_falls_back_to_the_graph():
+    """Round-3 ADVICE: a torch op inside a recording ran once and was dropped on replay, silently — `bench.py
+    --lib-gemm` (use_hip_gemm = False: every decoder GEMM is torch.matmul) replayed a step without its GEMMs.  The
+    recording now raises PlanNotRecordable, DecodeRunner falls back to the captured hipGraph and says so; tokens and
+    KV pool equal the eager (launch by launch) run of the same model."""
+    from hydrainfer_amd import launch_plan
+    from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
+    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
+    sh = LlamaShape(1024, 2816, 2, 8, 8, 128, 2048)
+    outs = {}
+    for name, use_graph in (("eager", False), ("plan", True)):
+        model = LlamaForCausalLM.random_init(sh, torch.bfloat16, DEV, seed=3)
+        model.use_hip_gemm = False
+        r = DecodeRunner(model, RunnerConfig(batch=8, prompt_len=40, n_generate=18, use_graph=use_graph, executor="plan"), seed=4)
+        g = torch.Generator().manual_seed(0)
+        r.prefill(torch.randint(5, sh.vocab_size - 1, (8, 40), generator=g).to(DEV))
+        for _ in range(10):
+            r.step()
+        torch.cuda.synchronize()
+        if use_graph:
+            assert r.executor_used == "graph" and isinstance(r.graph, torch.cuda.CUDAGraph)
+        outs[name] = (r.generated(), r.pool.clone())
+    assert torch.equal(outs["eager"][0], outs["plan"][0]) and torch.equal(outs["eager"][1], outs["plan"][1])
+    # and the guard itself: a kernel-launching torch op inside a recording raises, allocations and views do not
+    plan = launch_plan.LaunchPlan(DEV)
+    x = torch.ones(64, device=DEV)
+    with pytest.raises(launch_plan.PlanNotRecordable, match="aten::"):
+        plan.capture(lambda: x.add_(1))
+    assert float(x.sum()) == 64.0 or float(x.sum()) == 128.0        # (the op may or may not have run: it never reaches a replay)
+    plan2 = launch_plan.LaunchPlan(DEV)
+    plan2.capture(lambda: torch.empty(16, device=DEV).view(4, 4)[1:, :2])
 
 
 def test_plan_buffers_survive_other_allocations():

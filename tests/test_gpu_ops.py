@@ -297,6 +297,43 @@ def test_xreg_gemm_matches_fp32_product_and_is_repeatable(dt, M):
     assert not gemm.xreg_supported(8, 4090, 4096, dt)
 
 
+def test_xreg_gemm_share_past_the_lds_tile_budget_grows_the_grid():
+    """A workgroup keeps one LDS tile set per row group of its share and the share is derived from gridDim.x inside
+    the kernel: when ceil(row groups / workgroups) exceeds the 16 tile sets the launcher sizes LDS for, the grid must
+    grow (round-3 ADVICE: it did not, and the kernel indexed LDS past its allocation).  Reached with a very wide N, a
+    wide gate|up with two K splits' worth of CUs, and the xreg_wgs tuning option."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel import gemm
+    lib, dt, M = _lib.lib(), torch.bfloat16, 32
+
+    def check(N, K, gate_up=False):
+        g = torch.Generator().manual_seed(N + K)
+        x = torch.randn((M, K), generator=g).to(dt).to(DEV)
+        w = (torch.randn((N, K), generator=g) * 0.02).to(dt).to(DEV)
+        ref = x.float() @ w.float().t()
+        a = torch.zeros(gemm.xreg_workspace_floats(M, N, K), dtype=torch.float32, device=DEV)
+        s = gemm.linear_decode_partial_xreg(x, gemm.pack_weight_xreg(w), N, a)
+        got = a.view(s, M, N).sum(0)
+        assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6, f"N={N} K={K}"
+        if gate_up:
+            inter = N // 2
+            act = torch.zeros(gemm.fragment_major_elems(M, inter), dtype=dt, device=DEV)
+            gemm.gate_up_silu_xreg(gemm.to_fragment_major(x), gemm.pack_weight_xreg(w, interleave_halves=True), inter, act,
+                                   frag_shape=(M, K))
+            want = torch.nn.functional.silu(ref[:, :inter]) * ref[:, inter:]
+            got = gemm.from_fragment_major(act, M, inter).float()
+            assert ((got - want).abs() <= 1.6e-2 * want.abs() + 1e-3).all(), f"gate|up N={N} K={K}"
+
+    check(131072, 64)             # 8192 row groups over 256 workgroups: 32 per workgroup without the fix
+    check(66560, 64, gate_up=True)   # 2080 gate/up pairs over 256 workgroups: 9 pairs = 18 tile sets without the fix
+    assert lib.hx_debug_set_option(b"xreg_wgs", 16) == 0
+    try:
+        check(12288, 4096)        # 768 row groups over 16 workgroups
+        check(22016, 4096, gate_up=True)
+    finally:
+        lib.hx_debug_set_option(b"xreg_wgs", 0)
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M", [1, 5, 16, 31, 32])
 def test_fragment_major_producers_are_bit_identical(dt, M):
