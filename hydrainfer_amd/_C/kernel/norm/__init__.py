@@ -2,6 +2,8 @@
 (reference stub: hydrainfer/_C/kernel/norm/__init__.pyi:4-9;
 CUDA original: csrc/kernel/norm/rms_norm.cu:43-63).  bf16 is accepted (extension: the
 reference dispatch, csrc/kernel/dispatch.h:12-28, is fp32/fp16 only)."""
+import ctypes
+from dataclasses import dataclass
 from typing import Optional
 
 import torch
@@ -77,6 +79,67 @@ def embed_rms_norm(ids: Tensor, table: Tensor, weight: Tensor, epsilon: float):
     _lib.check(_lib.lib().hx_embed_rms_norm(h.data_ptr(), x.data_ptr(), ids.data_ptr(), 1 if ids.dtype == torch.int64 else 0,
                                             table.data_ptr(), weight.data_ptr(), float(epsilon), rows, hidden, vocab,
                                             _lib.dtype_code(table), _lib.current_stream()), "embed_rms_norm")
+    return h, x
+
+
+@dataclass
+class StepHead:
+    """What a decode step does before its first GEMM besides the embedding gather + first norm, folded into that
+    launch (hx_decode_step_head): the metadata advance of a device-resident decode loop (model/runner.py) and / or the
+    look-ahead feed of the engine's decoder (engine/graph_decode.py)."""
+    # hx_decode_advance arguments (all or none)
+    positions: Optional[Tensor] = None
+    kv_lens: Optional[Tensor] = None
+    cu_seqlens_k: Optional[Tensor] = None
+    new_cache_slots: Optional[Tensor] = None
+    block_table: Optional[Tensor] = None
+    cu_block_lens: Optional[Tensor] = None
+    batch: int = 0
+    block_size: int = 16
+    stride: int = 1
+    # hx_decode_feed_ids arguments (both or neither)
+    feed_src: Optional[Tensor] = None       # int32 [rows]
+    feed_prev: Optional[Tensor] = None      # int64: the previous launch's samples
+
+
+def decode_step_head(ids: Tensor, table: Tensor, weight: Tensor, epsilon: float, zero: Optional[Tensor] = None,
+                     head: Optional[StepHead] = None):
+    """Extension: embed_rms_norm(ids, table, weight) + memset_zero(zero) + the StepHead's advance / feed, ONE launch
+    (3-4 launches of ~4.6 us each in round 3's decode-step timeline).  Returns (h, x) like embed_rms_norm."""
+    _lib.require_gpu(ids, table, weight, zero)
+    if ids.dim() != 1 or ids.dtype not in (torch.int32, torch.int64) or not ids.is_contiguous():
+        raise _lib.HydraHipError("decode_step_head: ids must be contiguous int32 / int64 [rows]")
+    if table.dim() != 2 or not table.is_contiguous() or weight.dtype != table.dtype or weight.numel() != table.shape[1]:
+        raise _lib.HydraHipError("decode_step_head: table [vocab, hidden] contiguous, weight [hidden] of the same dtype")
+    rows, (vocab, hidden) = ids.numel(), table.shape
+    h = torch.empty((rows, hidden), dtype=table.dtype, device=table.device)
+    x = torch.empty_like(h)
+    a = _lib.hx_step_head_args()
+    a.h_out, a.x_out, a.ids, a.table, a.weight = h.data_ptr(), x.data_ptr(), ids.data_ptr(), table.data_ptr(), weight.data_ptr()
+    a.rows, a.hidden, a.vocab, a.epsilon = rows, hidden, vocab, float(epsilon)
+    a.ids_are_int64, a.dtype = (1 if ids.dtype == torch.int64 else 0), _lib.dtype_code(table)
+    if zero is not None:
+        if not zero.is_contiguous() or (zero.numel() * zero.element_size()) % 4:
+            raise _lib.HydraHipError("decode_step_head: the area to zero must be contiguous, a multiple of 4 bytes")
+        a.zero_ptr, a.zero_bytes = zero.data_ptr(), zero.numel() * zero.element_size()
+    if head is not None:
+        if head.batch > 0:
+            adv = (head.positions, head.kv_lens, head.cu_seqlens_k, head.new_cache_slots, head.block_table, head.cu_block_lens)
+            if any(t is None or t.dtype != torch.int32 or not t.is_contiguous() or not t.is_cuda for t in adv):
+                raise _lib.HydraHipError("decode_step_head: advance arguments must be contiguous int32 device tensors")
+            if (head.positions.numel() < head.batch or head.kv_lens.numel() < head.batch or head.new_cache_slots.numel() < head.batch
+                    or head.cu_seqlens_k.numel() < head.batch + 1 or head.cu_block_lens.numel() < head.batch + 1):
+                raise _lib.HydraHipError("decode_step_head: advance arguments shorter than the batch")
+            (a.positions, a.kv_lens, a.cu_seqlens_k, a.new_cache_slots, a.block_table, a.cu_block_lens) = (t.data_ptr() for t in adv)
+            a.batch, a.block_size, a.stride = int(head.batch), int(head.block_size), int(head.stride)
+        if (head.feed_src is None) != (head.feed_prev is None):
+            raise _lib.HydraHipError("decode_step_head: feed_src and feed_prev come together")
+        if head.feed_src is not None:
+            if (head.feed_src.dtype != torch.int32 or head.feed_prev.dtype != torch.int64 or head.feed_src.numel() < rows
+                    or not head.feed_src.is_contiguous() or not head.feed_prev.is_contiguous()):
+                raise _lib.HydraHipError("decode_step_head: feed_src int32 [rows], feed_prev int64, contiguous")
+            a.feed_src, a.feed_prev = head.feed_src.data_ptr(), head.feed_prev.data_ptr()
+    _lib.check(_lib.lib().hx_decode_step_head(ctypes.byref(a), _lib.current_stream()), "decode_step_head")
     return h, x
 
 

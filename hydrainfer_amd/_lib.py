@@ -61,6 +61,17 @@ class hx_decode_weight(ctypes.Structure):
 HX_DW_LDS_SLICE, HX_DW_XREG, HX_DW_GATE_UP = 0, 1, 1
 
 
+class hx_step_head_args(ctypes.Structure):
+    _fields_ = [
+        ("h_out", c_void_p), ("x_out", c_void_p), ("ids", c_void_p), ("feed_src", c_void_p), ("feed_prev", c_void_p),
+        ("fed_out", c_void_p), ("table", c_void_p), ("weight", c_void_p), ("zero_ptr", c_void_p), ("zero_bytes", c_int64),
+        ("positions", c_void_p), ("kv_lens", c_void_p), ("cu_seqlens_k", c_void_p), ("new_cache_slots", c_void_p),
+        ("block_table", c_void_p), ("cu_block_lens", c_void_p),
+        ("rows", c_int64), ("hidden", c_int64), ("vocab", c_int64), ("epsilon", c_float), ("ids_are_int64", c_int32),
+        ("dtype", c_int32), ("batch", c_int32), ("block_size", c_int32), ("stride", c_int32),
+    ]
+
+
 HX_XREG_SYNC_WORDS = 512
 
 _SIGNATURES = {
@@ -128,6 +139,7 @@ _SIGNATURES = {
     "hx_plan_launch": (c_int, [c_void_p, c_void_p]),
     "hx_plan_destroy": (c_int, [c_void_p]),
     "hx_memset_zero": (c_int, [c_void_p, c_int64, c_void_p]),
+    "hx_decode_step_head": (c_int, [POINTER(hx_step_head_args), c_void_p]),
     "hx_measure_read_stream": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
 }
 

@@ -112,32 +112,8 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(
     const int32_t* __restrict__ block_table, const int32_t* __restrict__ cu_block_lens,
     int32_t batch, int32_t block_size, int32_t stride) {
   __shared__ int32_t scan[256];
-  int32_t carry = 0;
-  if (threadIdx.x == 0) cu_seqlens_k[0] = 0;
-  for (int base = 0; base < batch; base += 256) {
-    const int b = base + threadIdx.x;
-    int32_t len = 0;
-    if (b < batch) {
-      const int32_t pos = positions[b] + stride;
-      positions[b] = pos;
-      len = kv_lens[b] + stride;
-      kv_lens[b] = len;
-      const int32_t page = block_table[cu_block_lens[b] + pos / block_size];
-      new_cache_slots[b] = page * block_size + pos % block_size;
-    }
-    scan[threadIdx.x] = len;
-    __syncthreads();
-    // inclusive Hillis-Steele scan over 256 entries
-    for (int off = 1; off < 256; off <<= 1) {
-      int32_t add = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
-      __syncthreads();
-      scan[threadIdx.x] += add;
-      __syncthreads();
-    }
-    if (b < batch) cu_seqlens_k[b + 1] = carry + scan[threadIdx.x];
-    carry += scan[255];
-    __syncthreads();
-  }
+  hx::decode_advance_block(positions, kv_lens, cu_seqlens_k, new_cache_slots, block_table, cu_block_lens, batch,
+                           block_size, stride, scan);
 }
 
 }  // namespace

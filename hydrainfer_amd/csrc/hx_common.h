@@ -154,4 +154,41 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+
+// One decode step's metadata advance for `batch` sequences by ONE 256-thread workgroup (hx_decode_advance, and the
+// advance role of hx_decode_step_head): positions / kv lengths += stride, cu_seqlens_k = their prefix sum, the new
+// token's cache slot through the block table (hydrainfer/layer/causal_attention.py:147-168).  scan: 256 ints of LDS.
+__device__ __forceinline__ void decode_advance_block(int32_t* __restrict__ positions, int32_t* __restrict__ kv_lens,
+                                                     int32_t* __restrict__ cu_seqlens_k, int32_t* __restrict__ new_cache_slots,
+                                                     const int32_t* __restrict__ block_table,
+                                                     const int32_t* __restrict__ cu_block_lens, int32_t batch,
+                                                     int32_t block_size, int32_t stride, int32_t* scan) {
+  int32_t carry = 0;
+  if (threadIdx.x == 0) cu_seqlens_k[0] = 0;
+  for (int base = 0; base < batch; base += 256) {
+    const int b = base + threadIdx.x;
+    int32_t len = 0;
+    if (b < batch) {
+      const int32_t pos = positions[b] + stride;
+      positions[b] = pos;
+      len = kv_lens[b] + stride;
+      kv_lens[b] = len;
+      const int32_t page = block_table[cu_block_lens[b] + pos / block_size];
+      new_cache_slots[b] = page * block_size + pos % block_size;
+    }
+    scan[threadIdx.x] = len;
+    __syncthreads();
+    // inclusive Hillis-Steele scan over 256 entries
+    for (int off = 1; off < 256; off <<= 1) {
+      int32_t add = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
+      __syncthreads();
+      scan[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (b < batch) cu_seqlens_k[b + 1] = carry + scan[threadIdx.x];
+    carry += scan[255];
+    __syncthreads();
+  }
+}
+
 }  // namespace hx

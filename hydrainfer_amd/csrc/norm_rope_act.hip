@@ -151,15 +151,12 @@ int launch_rms(void* out, void* residual, const void* input, const void* weight,
 // x = rms_norm(h) * w in one launch — same arithmetic and reduction as rms_norm_vec_kernel.
 // ---------------------------------------------------------------------------
 template <typename T, int MAXV>
-__global__ __launch_bounds__(256) void embed_rms_norm_kernel(
-    typename T::storage* __restrict__ h_out, typename T::storage* __restrict__ x_out,
-    const void* __restrict__ ids, int ids_i64, const typename T::storage* __restrict__ table,
-    const typename T::storage* __restrict__ weight, float eps, int32_t hidden, int64_t vocab) {
+__device__ __forceinline__ void embed_rms_norm_row(typename T::storage* __restrict__ h_out, typename T::storage* __restrict__ x_out,
+                                                   int64_t row, int64_t id, const typename T::storage* __restrict__ table,
+                                                   const typename T::storage* __restrict__ weight, float eps, int32_t hidden,
+                                                   int64_t vocab, float* red) {
   typedef typename VecOf<T>::type V;
   constexpr int N = VecOf<T>::N;
-  __shared__ float red[4];
-  const int64_t row = blockIdx.x;
-  int64_t id = ids_i64 ? reinterpret_cast<const int64_t*>(ids)[row] : (int64_t)reinterpret_cast<const int32_t*>(ids)[row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);     // the torch op asserts; here out-of-range ids clamp
   const int nvec = hidden / N;
   const V* in_v = reinterpret_cast<const V*>(table + id * hidden);
@@ -194,6 +191,61 @@ __global__ __launch_bounds__(256) void embed_rms_norm_kernel(
       for (int e = 0; e < N; ++e) o[e] = T::from_float(round_to<T>(x[j][e] * inv) * T::to_float(wv[j][e]));
       out_v[i] = o;
     }
+  }
+}
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void embed_rms_norm_kernel(
+    typename T::storage* __restrict__ h_out, typename T::storage* __restrict__ x_out,
+    const void* __restrict__ ids, int ids_i64, const typename T::storage* __restrict__ table,
+    const typename T::storage* __restrict__ weight, float eps, int32_t hidden, int64_t vocab) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int64_t id = ids_i64 ? reinterpret_cast<const int64_t*>(ids)[row] : (int64_t)reinterpret_cast<const int32_t*>(ids)[row];
+  embed_rms_norm_row<T, MAXV>(h_out, x_out, row, id, table, weight, eps, hidden, vocab, red);
+}
+
+// hx_decode_step_head: everything a decode step does before its first GEMM, ONE launch instead of three or four
+// (round 3's timeline: zero_kernel 4.7 us, decode_advance 4.5, embed_rms_norm 4.8 — each a launch of microseconds of
+// nothing).  Workgroup roles by index: [0, rows) embedding gather + first RMSNorm of row b (its id optionally taken
+// from the previous launch's samples: hx_decode_feed_ids), [rows, rows + n_zero) zero 4 KiB each of the hand-over
+// areas, the last one (if batch > 0) the metadata advance.  The roles touch disjoint memory; each is bit-identical to
+// the separate launch it replaces.
+struct StepHeadParams {
+  void* h_out; void* x_out; const void* ids; const int32_t* feed_src; const int64_t* feed_prev; int64_t* fed_out;
+  const void* table; const void* weight; uint32_t* zero_ptr;
+  int32_t* positions; int32_t* kv_lens; int32_t* cu_seqlens_k; int32_t* new_cache_slots;
+  const int32_t* block_table; const int32_t* cu_block_lens;
+  int64_t vocab, zero_words;
+  float eps;
+  int32_t ids_i64, rows, hidden, n_zero, batch, block_size, stride;
+};
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void decode_step_head_kernel(const StepHeadParams p) {
+  __shared__ float red[4];
+  __shared__ int32_t scan[256];
+  const int b = blockIdx.x;
+  if (b < p.rows) {
+    int64_t id = p.ids_i64 ? reinterpret_cast<const int64_t*>(p.ids)[b] : (int64_t)reinterpret_cast<const int32_t*>(p.ids)[b];
+    if (p.feed_src) {
+      const int32_t s = p.feed_src[b];
+      if (s >= 0) id = p.feed_prev[s];
+    }
+    if (p.fed_out && threadIdx.x == 0) p.fed_out[b] = id;
+    embed_rms_norm_row<T, MAXV>(reinterpret_cast<u16*>(p.h_out), reinterpret_cast<u16*>(p.x_out), b, id,
+                                reinterpret_cast<const u16*>(p.table), reinterpret_cast<const u16*>(p.weight), p.eps, p.hidden,
+                                p.vocab, red);
+  } else if (b < p.rows + p.n_zero) {
+    const int64_t w0 = (int64_t)(b - p.rows) * 1024 + threadIdx.x * 4;      // 4 KiB per workgroup, 16 B per thread
+    if (w0 + 4 <= p.zero_words) {
+      *reinterpret_cast<u32x4*>(p.zero_ptr + w0) = u32x4{0u, 0u, 0u, 0u};
+    } else {
+      for (int64_t i = w0; i < p.zero_words; ++i) p.zero_ptr[i] = 0u;
+    }
+  } else {
+    decode_advance_block(p.positions, p.kv_lens, p.cu_seqlens_k, p.new_cache_slots, p.block_table, p.cu_block_lens, p.batch,
+                         p.block_size, p.stride, scan);
   }
 }
 
@@ -847,6 +899,41 @@ extern "C" int hx_embed_rms_norm(void* h_out, void* x_out, const void* ids, int 
                                                                (const u16*)table, (const u16*)weight, epsilon,  \
                                                                (int)hidden, vocab)
   if (dtype == HX_F16) {
+    if (mv <= 1) HX_L(F16, 1); else if (mv <= 2) HX_L(F16, 2); else HX_L(F16, 4);
+  } else {
+    if (mv <= 1) HX_L(BF16, 1); else if (mv <= 2) HX_L(BF16, 2); else HX_L(BF16, 4);
+  }
+#undef HX_L
+  return check_launch();
+}
+
+extern "C" int hx_decode_step_head(const hx_step_head_args* a, hx_stream stream) {
+  if (!a) return HX_ERR_NULL;
+  if (a->rows <= 0 || a->hidden <= 0 || a->vocab <= 0 || a->zero_bytes < 0 || a->batch < 0) return HX_ERR_SHAPE;
+  if (!a->h_out || !a->x_out || !a->ids || !a->table || !a->weight) return HX_ERR_NULL;
+  if (a->dtype != HX_F16 && a->dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (a->hidden % 8 || a->hidden / 8 > 1024) return HX_ERR_SHAPE;
+  if (!aligned16(a->h_out) || !aligned16(a->x_out) || !aligned16(a->table) || !aligned16(a->weight)) return HX_ERR_STRIDE;
+  if ((a->feed_src == nullptr) != (a->feed_prev == nullptr)) return HX_ERR_NULL;
+  if (a->zero_bytes > 0 && (!a->zero_ptr || (a->zero_bytes & 3) || !aligned16(a->zero_ptr))) return a->zero_ptr ? HX_ERR_STRIDE : HX_ERR_NULL;
+  if (a->batch > 0) {
+    if (!a->positions || !a->kv_lens || !a->cu_seqlens_k || !a->new_cache_slots || !a->block_table || !a->cu_block_lens)
+      return HX_ERR_NULL;
+    if (a->block_size <= 0 || a->stride < 1) return HX_ERR_SHAPE;
+  }
+  StepHeadParams p;
+  p.h_out = a->h_out; p.x_out = a->x_out; p.ids = a->ids; p.feed_src = a->feed_src; p.feed_prev = a->feed_prev;
+  p.fed_out = a->fed_out; p.table = a->table; p.weight = a->weight; p.zero_ptr = (uint32_t*)a->zero_ptr;
+  p.positions = a->positions; p.kv_lens = a->kv_lens; p.cu_seqlens_k = a->cu_seqlens_k; p.new_cache_slots = a->new_cache_slots;
+  p.block_table = a->block_table; p.cu_block_lens = a->cu_block_lens;
+  p.vocab = a->vocab; p.zero_words = a->zero_bytes >> 2; p.eps = a->epsilon; p.ids_i64 = a->ids_are_int64 ? 1 : 0;
+  p.rows = (int32_t)a->rows; p.hidden = (int32_t)a->hidden; p.n_zero = (int32_t)((p.zero_words + 1023) / 1024);
+  p.batch = a->batch; p.block_size = a->block_size; p.stride = a->stride;
+  const unsigned grid = (unsigned)(p.rows + p.n_zero + (p.batch > 0 ? 1 : 0));
+  hipStream_t s = (hipStream_t)stream;
+  const int mv = (int)((a->hidden / 8 + 255) / 256);
+#define HX_L(TT, MV) hx::launcher(decode_step_head_kernel<TT, MV>, grid, 256, 0, s)(p)
+  if (a->dtype == HX_F16) {
     if (mv <= 1) HX_L(F16, 1); else if (mv <= 2) HX_L(F16, 2); else HX_L(F16, 4);
   } else {
     if (mv <= 1) HX_L(BF16, 1); else if (mv <= 2) HX_L(BF16, 2); else HX_L(BF16, 4);

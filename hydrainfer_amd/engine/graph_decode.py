@@ -26,6 +26,7 @@ import torch
 
 from hydrainfer_amd import _lib, launch_plan
 from hydrainfer_amd._lib import HydraHipError
+from hydrainfer_amd._C.kernel.norm import StepHead
 from hydrainfer_amd.layer.causal_attention import AttentionParameters
 from hydrainfer_amd.memory.kv_cache import KVCache
 from hydrainfer_amd.model.llama import LanguageModelParameters
@@ -111,9 +112,16 @@ class GraphedDecoder:
         ids, pos = self._views(B)[:2]
         src = self._views(B)[6]
         lib = _lib.lib()
-        fed = torch.empty(B, dtype=torch.int64, device=self.dev)
-        _lib.check(lib.hx_decode_feed_ids(fed.data_ptr(), ids.data_ptr(), src.data_ptr(), self.prev_tokens.data_ptr(), B,
-                                          _lib.current_stream()), "decode_feed_ids")
+        if self.model.step_head_supported(B):
+            # the look-ahead feed rides in the step's first launch (hx_decode_step_head: id = sample of row src[r] of the
+            # previous launch when src[r] >= 0, else the host-written id) — one launch less per step
+            params.step_head = StepHead(feed_src=src, feed_prev=self.prev_tokens)
+            fed = ids
+        else:
+            params.step_head = None
+            fed = torch.empty(B, dtype=torch.int64, device=self.dev)
+            _lib.check(lib.hx_decode_feed_ids(fed.data_ptr(), ids.data_ptr(), src.data_ptr(), self.prev_tokens.data_ptr(), B,
+                                              _lib.current_stream()), "decode_feed_ids")
         self.model.xreg_sync = None
         # the greedy sampler writes straight into prev_tokens: this launch's feed (above) has read it, the next
         # launch's feed and the D2H copy of the tokens read it after this launch, in stream order

@@ -19,8 +19,8 @@ import torch
 from torch import Tensor
 
 from hydrainfer_amd._C.kernel.activation import silu_and_mul, silu_and_mul_slabs
-from hydrainfer_amd._C.kernel.norm import (add_rms_norm, add_rms_norm_slabs, argmax_rows, embed_rms_norm,
-                                             embed_rms_norm_supported, rms_norm)
+from hydrainfer_amd._C.kernel.norm import (StepHead, add_rms_norm, add_rms_norm_slabs, argmax_rows, decode_step_head,
+                                             embed_rms_norm, embed_rms_norm_supported, rms_norm)
 from hydrainfer_amd._C.kernel.position_embedding import rope_set_kv_cache
 from hydrainfer_amd.layer.causal_attention import AttentionParameters
 from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
@@ -55,6 +55,8 @@ class LanguageModelParameters:
     selected_token_ids: Optional[Tensor] = None  # int64 index tensor on the device
     image_row_index: Optional[Tensor] = None     # int64 rows of the batch that are image tokens (host knows them:
                                                  # spares the nonzero() sync of a boolean-mask assignment)
+    step_head: Optional[StepHead] = None         # decode loops: metadata advance / look-ahead feed folded into the step's
+                                                 # first launch (hx_decode_step_head); the model runs it or raises
 
 
 def build_cos_sin(shape: LlamaShape, dtype: torch.dtype, device) -> Tensor:
@@ -198,6 +200,9 @@ class LlamaForCausalLM:
             self.dw_lds[key], self.packed[key] = dw, dw.packed
         return self.packed.get(key)
 
+    def _new_sync(self, device) -> Tensor:
+        return torch.empty((self.shape.num_hidden_layers, 2, hip_gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=device)
+
     def _xreg_mlp_ok(self, n: int) -> bool:
         hid, inter = self.shape.hidden_size, self.shape.intermediate_size
         return (n <= 32 and self.dtype in (torch.float16, torch.bfloat16) and inter % 32 == 0 and hid % 32 == 0
@@ -294,8 +299,22 @@ class LlamaForCausalLM:
     def embed(self, input_ids: Tensor) -> Tensor:
         return torch.nn.functional.embedding(input_ids, self.state["embed"])
 
+    def _decode_plan(self, n: int, dtype) -> dict:
+        """Which launches a decode step of n rows is made of (decided before the step's first launch, because that
+        launch — hx_decode_step_head — also zeroes the hand-over areas of the norm-fused launches)."""
+        sh = self.shape
+        L, hid, inter = sh.num_hidden_layers, sh.hidden_size, sh.intermediate_size
+        qkv_n = self.q_size + 2 * self.kv_size
+        xreg = self.use_xreg and self._xreg_mlp_ok(n) and f"l{L - 1}.wdown" in self.packed_x
+        fused = xreg and hip_gemm.gate_up_silu_supported(n, inter, hid, dtype)
+        nf_gu = bool(xreg and self.fuse_norm and fused and hip_gemm.norm_xreg_supported(n, 2 * inter, hid, dtype, gate_up=True))
+        nf_qkv = bool(xreg and self.fuse_norm and f"l{L - 1}.wqkv" in self.packed_x
+                      and hip_gemm.norm_xreg_supported(n, qkv_n, hid, dtype))
+        return {"xreg": xreg, "fused": fused, "nf_gu": nf_gu, "nf_qkv": nf_qkv}
+
     def _decode_hidden_hip_gemm(self, h: Tensor, position_ids: Tensor,
-                                model_params: LanguageModelParameters, x0: Optional[Tensor] = None) -> Tensor:
+                                model_params: LanguageModelParameters, x0: Optional[Tensor] = None,
+                                sync: Optional[Tensor] = None) -> Tensor:
         """All-decode step with the weight-streaming HIP GEMMs and fused slab consumers: 8
         launches per layer — qkv GEMM, [slab reduce + RoPE + cache append + attention], o GEMM,
         [slab reduce + residual add + RMSNorm], gate|up GEMM, [slab reduce + silu*mul], down GEMM,
@@ -316,22 +335,20 @@ class LlamaForCausalLM:
             # a caller that never announced its batch size (unit tests, ad-hoc scripts): everything a <= 64-row
             # batch can need, once; the engine / runners call prepare_decode at build time
             self.prepare_decode(max_rows=64)
-        xreg = self.use_xreg and self._xreg_mlp_ok(n) and f"l{L - 1}.wdown" in self.packed_x
+        dp = self._decode_plan(n, h.dtype)
+        xreg, fused, nf_gu, nf_qkv = dp["xreg"], dp["fused"], dp["nf_gu"], dp["nf_qkv"]
         qkv_n = q_size + 2 * kv_size
         ws_q = ws          # where the current layer's qkv slabs live
-        nf_gu = nf_qkv = False
         if xreg:
-            fused = hip_gemm.gate_up_silu_supported(n, inter, hid, h.dtype)
             xf = torch.empty(hip_gemm.fragment_major_elems(n, hid), dtype=h.dtype, device=h.device)
             actf = torch.empty(hip_gemm.fragment_major_elems(n, inter), dtype=h.dtype, device=h.device) if fused else None
             # add+norm folded into the launch that consumes its output (hx_norm_*_xreg): 5 launches per layer
-            nf_gu = self.fuse_norm and fused and hip_gemm.norm_xreg_supported(n, 2 * inter, hid, h.dtype, gate_up=True)
-            nf_qkv = (self.fuse_norm and f"l{L - 1}.wqkv" in self.packed_x
-                      and hip_gemm.norm_xreg_supported(n, qkv_n, hid, h.dtype))
             if nf_gu or nf_qkv:
-                # one zeroed hand-over area per fused launch of this step (a memset node when captured / recorded)
-                sync = torch.empty((L, 2, hip_gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=h.device)
-                _lib.memset_zero(sync)
+                # one zeroed hand-over area per fused launch of this step: zeroed by the step's first launch
+                # (hx_decode_step_head) when the caller came through it, by a launch of its own otherwise
+                if sync is None:
+                    sync = self._new_sync(h.device)
+                    _lib.memset_zero(sync)
                 self.xreg_sync = sync
             if nf_qkv:   # the fused launch reads the down slabs (ws) while it writes the qkv slab
                 ws_q = torch.empty(max(hip_gemm.xreg_workspace_floats(n, qkv_n, hid), hip_gemm.workspace_floats(n, qkv_n, hid)),
@@ -387,27 +404,47 @@ class LlamaForCausalLM:
                 add_rms_norm_slabs(x, h, ws, s_dn, nxt, eps)
         return x
 
+    def _decode_fast_path(self, n: int, dtype, model_params: LanguageModelParameters) -> bool:
+        sh = self.shape
+        return bool(self.use_hip_gemm and model_params.all_sequences_decode and self.fuse_decode_attention
+                    and n <= 64 and dtype in (torch.float16, torch.bfloat16)
+                    and sh.hidden_size % 256 == 0 and sh.intermediate_size % 256 == 0)
+
+    def step_head_supported(self, n_rows: int) -> bool:
+        """True if forward() of an all-decode batch of n_rows token ids runs LanguageModelParameters.step_head."""
+        t = self.state["embed"]
+        return bool(n_rows <= 64 and t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.is_contiguous()
+                    and t.shape[1] % 8 == 0 and t.shape[1] <= 8192)
+
     def forward_hidden(self, input_ids_or_embeds: Tensor, position_ids: Tensor,
                        model_params: LanguageModelParameters) -> Tensor:
         sh, st = self.shape, self.state
-        x0 = None
+        x0 = sync = None
+        head = model_params.step_head
         if input_ids_or_embeds.dtype in (torch.int32, torch.int64):
             ids = input_ids_or_embeds
             if (model_params.all_sequences_decode and ids.dim() == 1 and ids.shape[0] <= 64
                     and embed_rms_norm_supported(ids, st["embed"])):
-                # decode step: embedding gather + the first layer's norm, one launch
-                h, x0 = embed_rms_norm(ids, st["embed"], st["l0.norm1"], sh.rms_norm_eps)
+                # decode step: embedding gather + the first layer's norm + the zeroing of the hand-over areas of the
+                # step's norm-fused launches + the caller's metadata advance / look-ahead feed: ONE launch
+                if self._decode_fast_path(ids.shape[0], st["embed"].dtype, model_params):
+                    dp = self._decode_plan(ids.shape[0], st["embed"].dtype)
+                    if dp["nf_gu"] or dp["nf_qkv"]:
+                        sync = self._new_sync(ids.device)
+                h, x0 = decode_step_head(ids, st["embed"], st["l0.norm1"], sh.rms_norm_eps, zero=sync, head=head)
+                head = None
             else:
                 h = self.embed(ids)
         else:
             h = input_ids_or_embeds
+        if head is not None:
+            raise RuntimeError("LanguageModelParameters.step_head needs the decode fast path (<= 64 rows of token ids, "
+                               "fp16 / bf16 embedding table): the caller must run its advance / feed itself")
         if not h.is_contiguous():
             h = h.contiguous()
         n = h.shape[0]
-        if (self.use_hip_gemm and model_params.all_sequences_decode and self.fuse_decode_attention
-                and n <= 64 and h.dtype in (torch.float16, torch.bfloat16)
-                and sh.hidden_size % 256 == 0 and sh.intermediate_size % 256 == 0):
-            return self._decode_hidden_hip_gemm(h, position_ids, model_params, x0)
+        if self._decode_fast_path(n, h.dtype, model_params):
+            return self._decode_hidden_hip_gemm(h, position_ids, model_params, x0, sync)
         H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
         q_size, kv_size, inter = self.q_size, self.kv_size, sh.intermediate_size
         eps = sh.rms_norm_eps

@@ -18,6 +18,7 @@ import torch
 from torch import Tensor
 
 from hydrainfer_amd import _lib, launch_plan
+from hydrainfer_amd._C.kernel.norm import StepHead
 from hydrainfer_amd.layer.causal_attention import AttentionParameters, AttentionParametersBuilder
 from hydrainfer_amd.memory.block_allocator import BlockAllocator
 from hydrainfer_amd.memory.kv_cache import KVCache
@@ -208,7 +209,15 @@ class DecodeRunner:
             self.cfg.batch, self.cfg.block_size, self.cfg.advance_stride, _lib.current_stream()), "decode_advance")
 
     def _step_body(self) -> None:
-        self._advance()
+        # the metadata advance rides in the step's first launch (hx_decode_step_head) when the model can take it
+        if self.model.step_head_supported(self.cfg.batch):
+            self.decode_params.step_head = StepHead(
+                positions=self.positions, kv_lens=self.kv_lens, cu_seqlens_k=self.cu_k, new_cache_slots=self.slots,
+                block_table=self.block_table, cu_block_lens=self.cu_block_lens, batch=self.cfg.batch,
+                block_size=self.cfg.block_size, stride=self.cfg.advance_stride)
+        else:
+            self.decode_params.step_head = None
+            self._advance()
         self.model.sample_out = self.input_ids     # the sampled ids are the next step's input ids: no copy launch
         try:
             nxt = self.model(self.input_ids, self.positions, self.decode_params)

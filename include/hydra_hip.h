@@ -423,6 +423,35 @@ int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_
                       int32_t* new_cache_slots, const int32_t* block_table,
                       const int32_t* cu_block_lens, int32_t batch, int32_t block_size,
                       int32_t stride, hx_stream stream);
+/* hx_decode_step_head: everything a decode step does before its first GEMM as ONE launch — hx_embed_rms_norm for
+ * `rows` rows (each id optionally replaced by the previous launch's sample like hx_decode_feed_ids: feed_src /
+ * feed_prev, both or neither; fed_out, if given, receives the ids used), hx_memset_zero of zero_bytes at zero_ptr
+ * (the hand-over areas of the step's norm-fused launches; 0 = none) and hx_decode_advance for `batch` sequences
+ * (0 = none).  The three parts touch disjoint memory; each is bit-identical to the separate call. */
+typedef struct hx_step_head_args {
+  void* h_out;               /* [rows, hidden] embedding rows */
+  void* x_out;               /* [rows, hidden] rms_norm(h_out) * weight */
+  const void* ids;           /* [rows] int32 or int64 */
+  const int32_t* feed_src;   /* [rows] or NULL */
+  const int64_t* feed_prev;  /* previous launch's samples, or NULL */
+  int64_t* fed_out;          /* [rows] or NULL */
+  const void* table;         /* [vocab, hidden] */
+  const void* weight;        /* [hidden] */
+  void* zero_ptr;            /* 16-byte aligned, or NULL */
+  int64_t zero_bytes;        /* multiple of 4 */
+  int32_t* positions;        /* hx_decode_advance arguments (batch = 0: unused) */
+  int32_t* kv_lens;
+  int32_t* cu_seqlens_k;
+  int32_t* new_cache_slots;
+  const int32_t* block_table;
+  const int32_t* cu_block_lens;
+  int64_t rows, hidden, vocab;
+  float epsilon;
+  int32_t ids_are_int64;
+  int32_t dtype;             /* HX_F16 | HX_BF16 */
+  int32_t batch, block_size, stride;
+} hx_step_head_args;
+int hx_decode_step_head(const hx_step_head_args* args, hx_stream stream);
 int hx_decode_feed_ids(int64_t* out, const int32_t* ids, const int32_t* src, const int64_t* prev,
                        int32_t n, hx_stream stream);
 int hx_collect_errors(uint32_t* out, const uint32_t* areas, int32_t n_areas, int64_t stride_words,

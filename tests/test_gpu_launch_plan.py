@@ -37,9 +37,9 @@ def test_plan_equals_graph(dt, batch):
         if ex == "plan":
             plan = r.graph
             assert isinstance(plan, launch_plan.LaunchPlan)
-            # advance, embed + norm, memset of the hand-over areas, layer 0's qkv, 5 per layer (attention, o, norm +
-            # gate|up, down, norm + next qkv resp. the final norm), argmax; the lm_head GEMM is a host-side step
-            assert plan.n_launches == 5 * sh.num_hidden_layers + 5
+            # step head (advance + embed + norm + zeroing of the hand-over areas), layer 0's qkv, 5 per layer (attention,
+            # o, norm + gate|up, down, norm + next qkv resp. the final norm), argmax; the lm_head GEMM is a host-side step
+            assert plan.n_launches == 5 * sh.num_hidden_layers + 3
             assert sum(1 for it in plan.items if callable(it)) == 1
         del r
     assert torch.equal(outs["graph"][0], outs["plan"][0]), "sampled tokens differ from the hipGraph run"

@@ -553,3 +553,66 @@ def test_single_entry_decode_linear_dispatches_to_the_layout_kernels(dt):
     assert not gemm.DecodeWeight(wgu, max_rows=64, gate_up=True).interleaved
     with pytest.raises(_lib.HydraHipError):
         gemm.DecodeWeight(wgu, max_rows=65)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_decode_step_head_equals_the_launches_it_replaces(dt):
+    """hx_decode_step_head (embedding gather + first RMSNorm, look-ahead feed, zeroing of the hand-over areas, metadata
+    advance: ONE launch) against hx_decode_feed_ids -> hx_embed_rms_norm, hx_memset_zero and hx_decode_advance run one
+    after the other: every output bit for bit, for all combinations of the optional parts, 7B / 13B / small widths,
+    batches past one scan block."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel.norm import StepHead, decode_step_head, embed_rms_norm
+    lib = _lib.lib()
+    i32 = dict(dtype=torch.int32, device=DEV)
+    for (rows, hidden, vocab, batch, bs) in ((32, 4096, 32064, 32, 16), (7, 5120, 32064, 7, 16), (64, 256, 999, 300, 32), (1, 64, 50, 1, 16)):
+        g = torch.Generator().manual_seed(rows + hidden)
+        table = torch.randn((vocab, hidden), generator=g).to(dt).to(DEV)
+        w = torch.randn(hidden, generator=g).to(dt).to(DEV)
+        for ids_dt in (torch.int64, torch.int32):
+            for with_feed in (False, True):
+                for with_zero in (False, True):
+                    for with_adv in (False, True):
+                        ids = torch.randint(0, vocab, (rows,), generator=g).to(ids_dt).to(DEV)
+                        prev = torch.randint(0, vocab, (rows,), generator=g).to(DEV)
+                        src = torch.randint(-1, rows, (rows,), generator=g).to(torch.int32).to(DEV)
+                        # --- the separate launches
+                        if with_feed:
+                            fed = torch.empty(rows, dtype=torch.int64, device=DEV)
+                            ids32 = ids.to(torch.int32)
+                            _lib.check(lib.hx_decode_feed_ids(fed.data_ptr(), ids32.data_ptr(), src.data_ptr(), prev.data_ptr(), rows,
+                                                              _lib.current_stream()), "feed")
+                            h1, x1 = embed_rms_norm(fed, table, w, 1e-5)
+                        else:
+                            h1, x1 = embed_rms_norm(ids, table, w, 1e-5)
+                        blocks_per = 8
+                        pos = torch.randint(0, blocks_per * bs - 3, (batch,), generator=g).to(torch.int32).to(DEV)
+                        kvl = (pos + 1).clone()
+                        tbl = torch.randperm(batch * blocks_per, generator=g).to(torch.int32).to(DEV)
+                        cub = torch.arange(0, (batch + 1) * blocks_per, blocks_per, **i32)
+                        adv1 = [pos.clone(), kvl.clone(), torch.zeros(batch + 1, **i32), torch.zeros(batch, **i32)]
+                        adv2 = [pos.clone(), kvl.clone(), torch.zeros(batch + 1, **i32), torch.zeros(batch, **i32)]
+                        _lib.check(lib.hx_decode_advance(adv1[0].data_ptr(), adv1[1].data_ptr(), adv1[2].data_ptr(), adv1[3].data_ptr(),
+                                                         tbl.data_ptr(), cub.data_ptr(), batch, bs, 2, _lib.current_stream()), "adv")
+                        area = torch.full((4, 2, 512 + 3), 7, **i32)
+                        # --- one launch
+                        head = StepHead()
+                        if with_adv:
+                            head = StepHead(positions=adv2[0], kv_lens=adv2[1], cu_seqlens_k=adv2[2], new_cache_slots=adv2[3],
+                                            block_table=tbl, cu_block_lens=cub, batch=batch, block_size=bs, stride=2)
+                        if with_feed:
+                            head.feed_src, head.feed_prev = src, prev
+                        ids_in = ids.to(torch.int32) if with_feed else ids
+                        h2, x2 = decode_step_head(ids_in, table, w, 1e-5, zero=area if with_zero else None, head=head)
+                        torch.cuda.synchronize()
+                        assert torch.equal(h1, h2) and torch.equal(x1, x2), (rows, hidden, ids_dt, with_feed)
+                        assert int(area.abs().sum()) == (0 if with_zero else 7 * area.numel())
+                        if with_adv:
+                            assert all(torch.equal(a, b) for a, b in zip(adv1, adv2))
+                        else:
+                            assert torch.equal(adv2[0], pos) and int(adv2[2].abs().sum()) == 0
+    # argument checks
+    with pytest.raises(_lib.HydraHipError):
+        decode_step_head(ids.float(), table, w, 1e-5)
+    with pytest.raises(_lib.HydraHipError):
+        decode_step_head(ids, table, w, 1e-5, head=StepHead(feed_src=src))
