@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
     };
     // 1. producers: workgroup r < M computes row r of x FIRST (nothing of its own in flight yet: the row's
     //    loads and the store drain are not queued behind weight loads — prefetching first cost the whole gain)
-    const int flat = blockIdx.y * gridDim.x + blockIdx.x;
+    const int flat = flat_id;
     const int n_wg = gridDim.x * gridDim.y;
     if (flat < p.M && !(p.stagger & 6))   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
       for (int row = flat; row < p.M; row += n_wg) produce(row);   // several rows only when N is tiny

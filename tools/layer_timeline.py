@@ -23,8 +23,8 @@ def main():
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    # a decode step starts at decode_advance_kernel
-    starts = [i for i, r in enumerate(rows) if "decode_advance" in r[2]]
+    # a decode step starts at its step-head launch (decode_advance_kernel before round 4)
+    starts = [i for i, r in enumerate(rows) if "decode_advance" in r[2] or "decode_step_head" in r[2]]
     steps = []
     for a, b in zip(starts, starts[1:]):
         seg = rows[a:b]
