@@ -58,6 +58,10 @@ def main():
                    f"{gaps.get(k, 0) / calls[k] / 1e3:.2f} |")
         tot_b += busy[k]; tot_g += gaps.get(k, 0)
     out.append(f"\nstep: busy {tot_b / 1e3:.1f} us + gaps {tot_g / 1e3:.1f} us = {(tot_b + tot_g) / 1e3:.1f} us\n")
+    big = [(seg[i][0] - seg[i - 1][1], i, short(seg[i][2])) for i in range(1, len(seg)) if seg[i][0] - seg[i - 1][1] > 500]
+    if big:
+        out.append("gaps over 0.5 us in this step (us, kernel index in the step, kernel that waited): "
+                   + "; ".join(f"{g / 1e3:.1f} @{i} {n[:28]}" for g, i, n in big[:60]) + "\n")
     # one middle layer: kernels between the 16th and 17th attention launch
     att = [i for i, r in enumerate(seg) if "attn_decode" in r[2] or "layer_chain" in r[2]]
     if len(att) > 17:
