@@ -56,6 +56,9 @@ def parse():
     p.add_argument("--no-serving-64", action="store_true",
                    help="skip the second engine leg with 2 x --batch requests (decode batches past the 32-row fast path)")
     p.add_argument("--no-disaggregated", action="store_true", help="N>1: skip the E/P/D engine leg")
+    p.add_argument("--rate", type=float, default=6.0,
+                   help="N>1, E/P/D leg: offered load in requests/s PER D RANK of the Poisson trace (BASELINE configs[4]: "
+                        "benchmark/synthetic_dataset.py requests with benchmark/timestamp.py arrivals); 0 = only the burst at t=0")
     p.add_argument("--no-migration", action="store_true")
     p.add_argument("--lib-gemm", action="store_true",
                    help="library GEMMs (hipBLASLt) for decode too, instead of the weight-streaming HIP kernel")
@@ -335,8 +338,16 @@ def measure_serving(model, vision, pixels, shape, dtype, dev, batch, n_text, max
            [0.0, 0.0], dev)
     reqs = synthetic_requests(batch, n_text, max_tokens, itid, pixels, (min(1000, text_hi - 1), text_hi), 1)
     res = replay(cluster, creator, reqs, [0.0] * batch, dev)
+    gd = node.executor.fill_executor.graph_decoder
+    res["engine_executor"] = gd.executor        # what replays the engine's decode steps: "graph" (hipGraph) or "plan"
+    # HBM held by all weight layouts once this leg has announced its largest decode batch: batches of 33 .. 64 rows add
+    # the LDS-slice copies of the projections the <= 32-row layer runs on the activations-in-registers layout
+    res["weight_bytes_resident"] = model.weight_bytes_resident()
     res["what"] = (f"{batch} requests (1 image + {n_text} text tokens, {max_tokens} generated) admitted at t=0 to one "
-                   "collocated EPD engine: continuous batching, chunked prefill (2048-token budget), hipGraph decode")
+                   f"collocated EPD engine: continuous batching, chunked prefill (2048-token budget), decode steps "
+                   f"replayed by the engine's '{gd.executor}' executor (the headline decode loop replays a launch plan: "
+                   "0.5-1 % faster in a GPU-bound loop, 0.65 ms of host time per step that the engine's one thread does "
+                   "not have — engine/graph_decode.py)")
     return res
 
 
@@ -367,14 +378,17 @@ def build_rank_engine(ctx, model, vision, shape, dtype, dev, batch, n_text, max_
     return RankEngine(ctx.rank, roles, node, group)
 
 
-def measure_disaggregated(ctx, engine, shape, dev, pixels, batch, n_text, max_tokens):
+def measure_disaggregated(ctx, engine, shape, dev, pixels, batch, n_text, max_tokens, rate_per_d=6.0):
     """BASELINE configs[3]/[4]: one E / P / D node per GPU, requests enter at the E ranks, image
     blocks are pulled E->P and KV blocks P->D over the IPC-mapped peer pools (hx_migrate_blocks),
-    control messages over gloo.  32 requests per D rank, all admitted at t=0."""
+    control messages over gloo.  Two traces of 32 requests per D rank: a POISSON trace (configs[4]: exponential
+    inter-arrival gaps, numpy RandomState seeded like benchmark/benchmark.py:136-137, benchmark/timestamp.py:9-16)
+    at rate_per_d x (number of D ranks) requests/s — the headline object — and the burst admitted at t=0
+    (`burst_at_t0`: the worst case for TTFT, the best for tokens/s)."""
     import torch.distributed as dist
     from hydrainfer_amd.engine.distributed import replay_distributed, summarize
     from hydrainfer_amd.engine.request_processor import InstructionCreator
-    from hydrainfer_amd.engine.serve import synthetic_requests
+    from hydrainfer_amd.engine.serve import poisson_arrivals, synthetic_requests
     torch.cuda.set_device(dev)
     itid = image_token_id(shape.vocab_size)
     roles = engine.roles
@@ -393,29 +407,42 @@ def measure_disaggregated(ctx, engine, shape, dev, pixels, batch, n_text, max_to
                                  max_position_embeddings=shape.max_position_embeddings)
     hi = min(31999, itid - 1)
     vocab_text = (min(1000, hi - 1), hi)
+    kv_bytes = (576 + n_text) * 2 * shape.num_hidden_layers * shape.num_key_value_heads * shape.head_dim * 2
 
-    def run(n, gen, seed):
+    def run(n, gen, seed, arrivals):
         reqs = synthetic_requests(n, n_text, gen, itid, pixels, vocab_text, seed)
         engine.open_mailbox(f"disagg{seed}")
         box = [time.perf_counter() + 0.2]
         dist.broadcast_object_list(box, src=0, group=engine.group)
-        mine = replay_distributed(engine, creator, reqs, [0.0] * n, box[0], dev, deadline_s=150)
+        mine = replay_distributed(engine, creator, reqs, arrivals, box[0], dev, deadline_s=150)
         allr = [None] * ctx.world_size
         dist.all_gather_object(allr, mine, group=engine.group)
         merged = {}
         for m in allr:
             merged.update(m)
-        return merged, box[0]
+        res = summarize(merged, box[0])
+        if res["pd_pull_p50_ms"]:
+            res["pd_pull_GBps"] = round(kv_bytes / res["pd_pull_p50_ms"] / 1e6, 1)
+        return res
 
-    run(2 * len(roles), 4, 99)                     # warm-up through every hop
-    merged, t0 = run(batch * n_d, max_tokens, 1)
-    res = summarize(merged, t0)
-    kv_bytes = (576 + n_text) * 2 * shape.num_hidden_layers * shape.num_key_value_heads * shape.head_dim * 2
-    if res["pd_pull_p50_ms"]:
-        res["pd_pull_GBps"] = round(kv_bytes / res["pd_pull_p50_ms"] / 1e6, 1)
+    n = batch * n_d
+    run(2 * len(roles), 4, 99, [0.0] * (2 * len(roles)))                     # warm-up through every hop
+    burst = run(n, max_tokens, 1, [0.0] * n)
+    burst["what"] = f"{n} requests admitted at t=0"
+    if rate_per_d > 0:
+        rate = rate_per_d * n_d
+        res = run(n, max_tokens, 2, poisson_arrivals(n, rate, seed=0))
+        res["arrivals"] = (f"Poisson, {rate:g} requests/s offered ({rate_per_d:g} per D rank), numpy RandomState(0) exponential "
+                           "gaps (benchmark/timestamp.py:9-16, seeded as benchmark/benchmark.py:136-137)")
+        res["rate_req_s"] = rate
+        res["burst_at_t0"] = burst
+    else:
+        res = burst
+        res["arrivals"] = "all at t=0"
     res["kv_bytes_per_request"] = kv_bytes
     res["roles"] = roles
-    res["what"] = (f"{batch * n_d} requests (1 image + {n_text} text tokens, {max_tokens} generated) at t=0; "
+    res["n_ranks"] = len(roles)
+    res["what"] = (f"{n} requests (1 image + {n_text} text tokens, {max_tokens} generated); "
                    "one E/P/D engine node per GPU, pulls over IPC-mapped peer pools, control over gloo")
     return res
 
@@ -956,6 +983,7 @@ def main():
     # serving / TTFT legs prefill on this GPU, so the row-major tensors stay for the library prefill GEMMs
     model.prepare_decode(max_rows=args.batch, keep_row_major=True)
     runner = DecodeRunner(model, cfg, seed=rank)
+    resident_headline = model.weight_bytes_resident()      # before the 64-request serving leg adds its layouts
 
     # multi-GPU: exchange IPC handles and map the neighbour's pool NOW — before any hipGraph is
     # captured (mapping a peer allocation after graphs were instantiated wedged in a 2-process
@@ -1040,6 +1068,10 @@ def main():
     if rank == 0:
         mid_ctx = int(round(sum(ctxs) / len(ctxs)))
         roofline, roofline_gemm, whole = roofline_objects(model, runner, ctxs, ms_per_step, args, model_name)
+        whole["weight_bytes_resident"] = resident_headline
+        whole["weight_layouts"] = ("row-major (the library prefill GEMMs of this EPD replica) + one decode layout per projection "
+                                   "(activations-in-registers; LDS-slice for o and layer 0's qkv); a D-role node keeps only the "
+                                   "decode layout; serving 33..64 rows adds LDS-slice copies: serving.twice_the_batch.weight_bytes_resident")
         roofline["measured_read_stream_ceiling_GBps"] = round(read_stream_ceiling_gbs(dev), 1)
         roofline["measured_copy_GBps"] = round(copy_ceiling_gbs(dev), 1)     # torch copy_ (read + write): NOT a ceiling
         configs_i = {"7b": "configs[1]: LLaVA-1.5-7B bf16, collocated prefill+decode on 1 MI355X",
@@ -1092,14 +1124,14 @@ def main():
         def _leg():
             try:
                 box["r"] = measure_disaggregated(ctx, engine, shape, dev, pixels, args.batch, prompt_len - 576,
-                                                 n_generate)
+                                                 n_generate, args.rate)
             except Exception as e:      # never let the optional leg break the benchmark line
                 box["r"] = {"error": repr(e)[:300]}
         th = threading.Thread(target=_leg, daemon=True)
         th.start()
-        th.join(timeout=240)
+        th.join(timeout=420)
         stuck = th.is_alive()
-        disagg = {"error": "timed out after 240 s"} if stuck else box.get("r")
+        disagg = {"error": "timed out after 420 s"} if stuck else box.get("r")
 
     # ---- LLaVA-1.5-13B leg (BASELINE configs[2]) in the same line: N = 1, 7B model, default flags only
     llava_13b = None

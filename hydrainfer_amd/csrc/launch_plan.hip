@@ -103,13 +103,24 @@ __global__ __launch_bounds__(256) void read_stream_kernel(const char* __restrict
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
   hx::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t c = wave; c < n_chunks; c += n_waves) {
+  // two 8 KiB chunks per wave in flight: the next chunk is requested before the current one is consumed
+  hx::f32x4 v[2][8];
+  auto load = [&](hx::f32x4 (&d)[8], int64_t c) {
     const char* p0 = base + c * 8192 + lane * 16;
-    hx::f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const hx::f32x4*>(p0 + u * 1024));
+    for (int u = 0; u < 8; ++u) d[u] = __builtin_nontemporal_load(reinterpret_cast<const hx::f32x4*>(p0 + u * 1024));
+  };
+  int64_t c = wave;
+  if (c < n_chunks) load(v[0], c);
+  for (; c < n_chunks; c += 2 * n_waves) {
+    if (c + n_waves < n_chunks) load(v[1], c + n_waves);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
+    for (int u = 0; u < 8; ++u) acc += v[0][u];
+    if (c + 2 * n_waves < n_chunks) load(v[0], c + 2 * n_waves);
+    if (c + n_waves < n_chunks) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[1][u];
+    }
   }
   if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
 }

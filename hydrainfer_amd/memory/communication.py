@@ -82,6 +82,39 @@ class RCCLBackend(CommunicationBackend):
             raise MigrationTimeout(f"{what} rank {peer}: no progress within {self.timeout_s:.0f} s or transport error "
                                    f"({str(e)[:120]}) — peer dead or never asked to take part in the transfer") from e
 
+    def connect(self, peer: int, my_rank: int, timeout_s: Optional[float] = None) -> None:
+        """Creates the point-to-point communicator with `peer` NOW, under a bound (round-3 ADVICE): RCCL builds it
+        lazily inside the first isend / irecv, which blocks there — before _bounded_wait's polling loop is ever
+        reached — so a peer that never shows up would hang the FIRST transfer for ever.  Both ranks call this at
+        start-up (the lower rank sends one element, the higher one receives it) from a helper thread that is abandoned
+        after the bound.  Known limit that stays: a transfer is awaited on the calling (engine) thread for its whole
+        duration; the engine overlaps pulls with compute only through the IPC backend, which has no sender half."""
+        import threading
+        bound = self.timeout_s if timeout_s is None else timeout_s
+        dev = self.cache.device
+        box = {}
+
+        def _go():
+            try:
+                if dev.type == "cuda":
+                    torch.cuda.set_device(dev)
+                t = torch.zeros(1, dtype=torch.int32, device=dev)
+                if my_rank < peer:
+                    dist.send(t, dst=peer, group=self.group)
+                else:
+                    dist.recv(t, src=peer, group=self.group)
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                box["ok"] = True
+            except Exception as e:       # reported by the caller's thread
+                box["err"] = e
+        th = threading.Thread(target=_go, daemon=True)
+        th.start()
+        th.join(timeout=bound)
+        if th.is_alive() or "err" in box:
+            raise MigrationTimeout(f"connect to rank {peer}: no communicator within {bound:.0f} s "
+                                   f"({str(box.get('err', 'peer never answered'))[:120]})")
+
     def _staging_for(self, n_blocks: int) -> Tensor:
         L, T, _, bs, H, D = self.cache.shape
         numel = L * T * n_blocks * bs * H * D

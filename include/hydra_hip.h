@@ -476,7 +476,7 @@ int hx_plan_destroy(hx_plan* plan);
 int hx_memset_zero(void* p, int64_t bytes, hx_stream stream);
 /* Measurement aid (SURVEY §8d "measured streaming ceiling"; no reference counterpart): reads `bytes` bytes at p
  * once, the way the weight-streaming kernels of this library read — 1 KiB contiguous per wave instruction,
- * non-temporal, 8 instructions in flight per wave, 1024 workgroups — and does nothing with them.  bench.py times it
+ * non-temporal, two 8 KiB chunks in flight per wave, 1024 workgroups — and does nothing with them.  bench.py times it
  * to report the read rate this GPU reaches in this run beside the 8 TB/s vendor peak.  bytes % 8192 == 0, p 16-byte
  * aligned; sink: one float the kernel never writes (keeps the loads alive). */
 int hx_measure_read_stream(const void* p, int64_t bytes, float* sink, hx_stream stream);

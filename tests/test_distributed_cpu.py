@@ -128,6 +128,8 @@ def _pull_worker(rank, world, port, q, sender_dies, rank2host):
         src = VirtualTokenCache(vid=1, n_blocks_of_cache_manager=6, n_cache_tokens=12, block_table=[5, 0, 2], rank=0)
         dst = VirtualTokenCache(vid=7, n_blocks_of_cache_manager=9, n_cache_tokens=12, block_table=[8, 1, 4], rank=1)
         ctx.barrier()
+        if not sender_dies:      # start-up: the pair's communicator is created under a bound, before any transfer
+            mgr.internode_backend.connect(peer=1 - rank, my_rank=rank, timeout_s=20.0)
         if rank == 0 and sender_dies:
             q.put((rank, "died")); q.close(); q.join_thread()      # flush the feeder thread: _exit would drop the item
             os._exit(17)                                         # the sender is gone before its half of the transfer

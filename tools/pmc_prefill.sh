@@ -1,18 +1,22 @@
 # PMC passes + kernel trace over the prefill attention kernel (4 x 704 tokens): `bash tools/pmc_prefill.sh` on the GPU box.
 # Writes gpurun_out/r3/attn_prefill_pmc.json (medians over the 12 launches of tools/prof_attn_prefill32.py).
-set -e
+set -eu
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repo root (gpurun exports it)}
+test -f "$R/tools/prof_attn_prefill32.py" || { echo "no tools/prof_attn_prefill32.py under $R" >&2; exit 2; }
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3
-rm -rf $O/pmc_prefill_*; mkdir -p $O
+mkdir -p "$O"
+rm -rf "$O"/pmc_prefill_*
 i=0
 for pass in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_SALU" \
             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES" \
             "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_BRANCH"; do
   i=$((i+1))
-  rocprofv3 --pmc $pass --output-format csv -d $O/pmc_prefill_$i -o p -- python3 $R/tools/prof_attn_prefill32.py > /dev/null 2>&1 || echo pass $i failed
+  rocprofv3 --pmc $pass --output-format csv -d $O/pmc_prefill_$i -o p -- python3 $R/tools/prof_attn_prefill32.py > $O/pmc_prefill_$i.log 2>&1 \
+    || { echo "PMC pass $i failed:" >&2; tail -5 $O/pmc_prefill_$i.log >&2; exit 1; }
 done
-rocprofv3 --kernel-trace --output-format csv -d $O/pmc_prefill_trace -o p -- python3 $R/tools/prof_attn_prefill32.py > /dev/null 2>&1 || echo trace failed
+rocprofv3 --kernel-trace --output-format csv -d $O/pmc_prefill_trace -o p -- python3 $R/tools/prof_attn_prefill32.py > $O/pmc_prefill_trace.log 2>&1 \
+  || { echo "kernel trace failed:" >&2; tail -5 $O/pmc_prefill_trace.log >&2; exit 1; }
 cd $R
 python3 - <<'PY'
 import csv, glob, collections, statistics, json
