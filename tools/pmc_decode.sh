@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-4 PMC passes (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, as MI355X_MICROARCH.md's HBM section prescribes) over
+# the decode attention kernel and the activations-in-registers GEMMs, as the 7B decode step launches them:
+#   bash tools/pmc_decode.sh        ->  gpurun_out/r4/r4_attn_decode_pmc.json, r4_gemm_xreg_pmc.json
+set -eu
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repo root (gpurun exports it)}
+O=$R/gpurun_out/r4
+mkdir -p "$O"
+cd /tmp; export TMPDIR=/tmp
+for prog in prof_attn_decode prof_gemm_xreg; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_${prog}_$c
+    rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${prog}_$c -o p -- python3 $R/tools/$prog.py > /tmp/pmc_${prog}_$c.log 2>&1 \
+      || { echo "$prog $c failed" >&2; tail -5 /tmp/pmc_${prog}_$c.log >&2; exit 1; }
+  done
+done
+grep algorithmic_bytes_per_launch /tmp/pmc_prof_attn_decode_FETCH_SIZE.log | tail -1 > /tmp/attn_bytes.txt
+python3 $R/tools/prof_gemm_xreg.py summarize /tmp/pmc_prof_gemm_xreg_FETCH_SIZE /tmp/pmc_prof_gemm_xreg_WRITE_SIZE $O/r4_gemm_xreg_pmc.json > /dev/null
+python3 - "$O/r4_attn_decode_pmc.json" <<'PY'
+import csv, glob, json, statistics, sys
+def med(d, counter):
+    v, dur = [], []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "attn_decode_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                v.append(float(r["Counter_Value"])); dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return statistics.median(v), len(v), statistics.median(dur)
+f, n, dur = med("/tmp/pmc_prof_attn_decode_FETCH_SIZE", "FETCH_SIZE")
+w, _, _ = med("/tmp/pmc_prof_attn_decode_WRITE_SIZE", "WRITE_SIZE")
+toks = open("/tmp/attn_bytes.txt").read().split()
+alg, slab = int(toks[1]), int(toks[3])
+fb, wb = f * 1024 * 2, w * 1024
+json.dump({"kernel": "attn_decode_kernel<BF16,128,4,nt,fused>",
+           "shape": "B=32 H=HK=32 D=128 ctx=832 block_size=16 bf16 (LLaVA-1.5-7B decode, mean context of the generation); q/k/v from the ONE fp32 slab of the qkv GEMM + RoPE + cache append + attention",
+           "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 tools/prof_attn_decode.py (separate passes; bash tools/pmc_decode.sh)",
+           "launches": n, "FETCH_SIZE_KiB_median": f, "WRITE_SIZE_KiB_median": w,
+           "correction": "gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced (16 B/lane) streaming read (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",
+           "fetch_bytes_corrected_x2": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
+           "algorithmic_bytes_per_launch": alg, "qkv_slab_bytes_read": slab,
+           "traffic_over_algorithmic": (fb + wb) / alg, "traffic_over_algorithmic_plus_slabs": (fb + wb) / (alg + slab),
+           "median_duration_ns_under_pmc": dur}, open(sys.argv[1], "w"), indent=1)
+print(open(sys.argv[1]).read())
+PY
+python3 -c "
+import json; d=json.load(open('$O/r4_gemm_xreg_pmc.json'))
+for s in d['shapes']: print(s['name'], s['fetch_over_weights'], s['write_over_output'])"
