@@ -88,7 +88,7 @@ def linear_decode_partial_packed(x: Tensor, packed: Tensor, N: int, partial: Ten
 
 
 # ------------------------------------------------------------------------------------------------
-# activations-in-registers kernel (csrc/gemm_xreg.hip): M <= 32, one slab for K <= 4096
+# activations-in-registers kernel (csrc/gemm_xreg.hip): M <= 32 with one slab for K <= 4096; M <= 64 ("wide") with two
 # ------------------------------------------------------------------------------------------------
 def xreg_supported(M: int, N: int, K: int, dtype: torch.dtype) -> bool:
     return dtype in (torch.float16, torch.bfloat16) and _lib.lib().hx_linear_decode_xreg_supported(M, N, K) == 1
@@ -232,6 +232,49 @@ def norm_gate_up_silu_xreg(residual: Tensor, slabs_in: Tensor, n_splits_in: int,
                "norm_gate_up_silu_xreg")
 
 
+# ---- batches of 33 .. 64 rows: the gate|up product over the interleaved packing, silu*mul as its own launch ----------
+def gate_up_xreg_supported(M: int, inter: int, K: int, dtype: torch.dtype, with_norm: bool = False) -> bool:
+    return (dtype in (torch.float16, torch.bfloat16)
+            and _lib.lib().hx_gate_up_xreg_supported(M, inter, K, 1 if with_norm else 0) == 1)
+
+
+def gate_up_xreg_workspace_floats(M: int, inter: int, K: int) -> int:
+    return _lib.lib().hx_gate_up_xreg_workspace_bytes(M, inter, K) // 4
+
+
+def gate_up_xreg(x: Tensor, packed_gate_up: Tensor, inter: int, partial: Tensor, frag_shape=None) -> int:
+    """fp32 slabs [n_splits, M, 2*inter] ([gate | up] column order) of x[M <= 64, K] @ W_gate_up^T with
+    packed_gate_up = pack_weight_xreg(W [2*inter, K], interleave_halves=True) — the packing hx_gate_up_silu_xreg reads,
+    here WITHOUT the fused silu*mul (silu_and_mul_slabs follows).  Returns the number of slabs."""
+    _lib.require_gpu(x, packed_gate_up, partial)
+    M, K, ldx, fm = _x_args(x, frag_shape)
+    if packed_gate_up.numel() != 2 * inter * K or packed_gate_up.dtype != x.dtype or partial.dtype != torch.float32 \
+            or not partial.is_contiguous():
+        raise _lib.HydraHipError("gate_up_xreg: packed weight [2*inter, K] of x's dtype, partial contiguous float32")
+    rc = _lib.lib().hx_gate_up_xreg(partial.data_ptr(), x.data_ptr(), packed_gate_up.data_ptr(), M, inter, K, ldx, fm,
+                                    partial.numel() * 4, _lib.dtype_code(x), _lib.current_stream())
+    if rc < 0:
+        _lib.check(rc, "gate_up_xreg")
+    return rc
+
+
+def norm_gate_up_xreg(residual: Tensor, slabs_in: Tensor, n_splits_in: int, norm_weight: Tensor, epsilon: float,
+                      x_frag: Tensor, packed_gate_up: Tensor, inter: int, partial: Tensor, sync: Tensor) -> int:
+    """add_rms_norm_slabs(fragment-major) + gate_up_xreg as ONE launch (M <= 64).  Returns the number of slabs."""
+    _lib.require_gpu(residual, slabs_in, norm_weight, x_frag, packed_gate_up, partial, sync)
+    M, K = _norm_checks(residual, slabs_in, n_splits_in, norm_weight, x_frag, sync)
+    if packed_gate_up.numel() != 2 * inter * K or packed_gate_up.dtype != residual.dtype or partial.dtype != torch.float32 \
+            or not partial.is_contiguous():
+        raise _lib.HydraHipError("norm_gate_up_xreg: packed [2*inter, K] (interleaved), partial contiguous float32")
+    rc = _lib.lib().hx_norm_gate_up_xreg(partial.data_ptr(), residual.data_ptr(), slabs_in.data_ptr(), int(n_splits_in),
+                                         norm_weight.data_ptr(), float(epsilon), x_frag.data_ptr(), packed_gate_up.data_ptr(),
+                                         M, inter, K, sync.data_ptr(), partial.numel() * 4, _lib.dtype_code(residual),
+                                         _lib.current_stream())
+    if rc < 0:
+        _lib.check(rc, "norm_gate_up_xreg")
+    return rc
+
+
 # ------------------------------------------------------------------------------------------------
 # the single-entry form (include/hydra_hip.h hx_decode_weight / hx_linear_decode_ex): describe the weight once, the
 # library picks the layout for the largest decode batch it has to serve, packs, and dispatches
@@ -240,14 +283,15 @@ class DecodeWeight:
     """A [N, K] linear weight packed for decode batches of <= max_rows rows.  .layout is "xreg" or "lds_slice";
     .interleaved tells whether a gate|up weight was packed for the fused silu*mul epilogue."""
 
-    def __init__(self, weight: Tensor, max_rows: int = 32, gate_up: bool = False):
+    def __init__(self, weight: Tensor, max_rows: int = 32, gate_up: bool = False, lds_slice: bool = False):
         _lib.require_gpu(weight)
         if weight.dim() != 2 or weight.stride(1) != 1 or weight.dtype not in (torch.float16, torch.bfloat16):
             raise _lib.HydraHipError("DecodeWeight: fp16 / bf16 [N, K] with contiguous rows")
         N, K = weight.shape
         self.desc = _lib.hx_decode_weight()
         _lib.check(_lib.lib().hx_decode_weight_plan(ctypes.byref(self.desc), N, K, _lib.dtype_code(weight), int(max_rows),
-                                                    _lib.HX_DW_GATE_UP if gate_up else 0), "decode_weight_plan")
+                                                    (_lib.HX_DW_GATE_UP if gate_up else 0)
+                                                    | (_lib.HX_DW_FORCE_LDS_SLICE if lds_slice else 0)), "decode_weight_plan")
         self.packed = torch.empty(N * K, dtype=weight.dtype, device=weight.device)
         _lib.check(_lib.lib().hx_decode_weight_pack(ctypes.byref(self.desc), self.packed.data_ptr(), weight.data_ptr(),
                                                     weight.stride(0), _lib.current_stream()), "decode_weight_pack")

@@ -59,6 +59,7 @@ class hx_decode_weight(ctypes.Structure):
 
 
 HX_DW_LDS_SLICE, HX_DW_XREG, HX_DW_GATE_UP = 0, 1, 1
+HX_DW_FORCE_LDS_SLICE = 2
 
 
 class hx_step_head_args(ctypes.Structure):
@@ -140,6 +141,11 @@ _SIGNATURES = {
     "hx_plan_destroy": (c_int, [c_void_p]),
     "hx_memset_zero": (c_int, [c_void_p, c_int64, c_void_p]),
     "hx_decode_step_head": (c_int, [POINTER(hx_step_head_args), c_void_p]),
+    "hx_gate_up_xreg_supported": (c_int, [c_int64, c_int64, c_int64, c_int]),
+    "hx_gate_up_xreg_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "hx_gate_up_xreg": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int64, c_int, c_void_p]),
+    "hx_norm_gate_up_xreg": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int64,
+                                     c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "hx_measure_read_stream": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
 }
 

@@ -58,6 +58,8 @@ struct XregParams {
   int32_t nm_splits;
   float nm_eps;
   void* act;            // EPI = 1: silu(gate)*up, fragment-major [inter/32][MB][64 lanes][8]
+  int32_t interleaved;  // EPI = 0 over a gate|up packing (row groups gate, up, gate, ...): slab columns in [gate | up] order
+  int32_t pk_P;         // wide kernel: k-steps per split of the PACKING (the launch's own splits are halves of those)
 };
 
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
@@ -84,7 +86,8 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
 template <typename T, int MAXV, int MB>
 __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, int n_splits, int64_t slab_stride,
                                              u16* __restrict__ residual, const u16* __restrict__ weight, float eps,
-                                             int hidden, int row, void* x_frag, uint32_t* state, float* red) {
+                                             int hidden, int row, void* x_frag, uint32_t* state, float* red,
+                                             int mb_layout = MB) {   // 16-row blocks of the fragment-major x: ceil(M / 16)
   const int tid = threadIdx.x;
   const int nvec = hidden / 8;
   uint32_t claimed = 1;
@@ -167,7 +170,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
           for (int e = 0; e < 8; ++e)
             o[e] = T::from_float(round_to<T>(x[v * MAXV + j][e] * inv) * T::to_float(w[e]));
           // fragment-major piece ((i / 4) * MB + row / 16) * 64 + (i % 4) * 16 + row % 16
-          const uint32_t piece = (uint32_t)((i >> 2) * MB + (row >> 4)) * 64 + (i & 3) * 16 + (row & 15);
+          const uint32_t piece = (uint32_t)((i >> 2) * mb_layout + (row >> 4)) * 64 + (i & 3) * 16 + (row & 15);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu32x4, o), xrs, piece * 16, 0, 16);
         }
       }
@@ -415,7 +418,9 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
       const int i = pr / MB, mb = pr - i * MB;
       const f32x4 s = tile_sum(i, mb);
       const int m = mb * 16 + c;
-      if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + (rg_of(i) << 4) + 4 * g) = s;
+      const int rg = rg_of(i);
+      const int col = p.interleaved ? ((rg & 1) ? (p.N >> 1) : 0) + ((rg >> 1) << 4) : (rg << 4);
+      if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + col + 4 * g) = s;
     }
   } else {
     for (int pr = w; pr < (G >> 1) * MB; pr += 4) {
@@ -432,6 +437,209 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
     }
   }
   stamp(11);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The same kernel for decode batches of 33 .. 64 rows ("wide": MB = 4).  x for 64 rows is twice the registers, so a
+// workgroup spans HALF of a packed K split (KW = half the packing's k-steps per wave: the SAME packed weights serve
+// both batch ranges — no second copy) and writes twice the slabs; to keep 32 KiB per wave in flight a work unit is a
+// PAIR of 16-row groups (two A fragments per k-step share the four x fragments).  The four waves' tiles are summed
+// through LDS after every unit (one barrier per unit, two tile sets used alternately) — a share of up to 11 units
+// would not fit LDS at 16 KiB each.  EPI = 0 only (silu*mul needs the whole K: hx_silu_and_mul_slabs behind it);
+// NORM as in the 32-row kernel, with up to 64 producers.  Same k-step rotation and summation order per split.
+template <typename T, int KW, int NORM>
+__global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MB = 4, NBUF = (KW + 7) / 8, P = 4 * KW;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int split = blockIdx.y, nb = gridDim.x, b = nb - 1 - (int)blockIdx.x;
+  const int total_ks = p.K >> 5;
+  const int n_rg = p.N >> 4, n_un = n_rg >> 1;
+  const int ks0 = split * P;
+  const int nks = min(P, total_ks - ks0);
+  const int kw = max(0, min(KW, nks - w * KW));
+  const int G = (n_un - b + nb - 1) / nb;                  // this workgroup's units (>= 1): b, b + nb, ...
+  const int mbl = (p.M + 15) >> 4;                         // 16-row blocks of the fragment-major x (3 for 33 .. 48 rows): the
+                                                           // fourth MFMA column block then re-reads the third (rows >= M are never stored)
+  const int j0 = (p.stagger & 1) ? (int)(((unsigned)b * 7u + (unsigned)w * 3u) % (unsigned)KW) : 0;
+  const int flat_id = blockIdx.y * gridDim.x + blockIdx.x;
+  auto rot = [&](int t) { const int r = j0 + t; return r >= KW ? r - KW : r; };
+  // where the launch's split sits inside the packing
+  const int sp = ks0 / p.pk_P, off_in = ks0 - sp * p.pk_P;
+  const int nks_p = min(p.pk_P, total_ks - sp * p.pk_P);
+  const u16* wbase = reinterpret_cast<const u16*>(p.w) + 8 * lane + ((int64_t)sp * p.pk_P * n_rg) * 512;
+  const int wave_k0 = off_in + min(w * KW, max(nks - 1, 0));
+  auto frag_ptr = [&](int rg, int t) {
+    const int r = rot(t);
+    return wbase + ((int64_t)rg * nks_p + wave_k0 + (r < kw ? r : 0)) * 512;
+  };
+  u16x8 buf[2][NBUF][8];
+  auto load_buf = [&](int unit, int q) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (8 * q + j < KW)
+          buf[h][q][j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(frag_ptr(2 * unit + h, 8 * q + j)));
+  };
+  auto unit_of = [&](int i) { return b + i * nb; };
+  u16x8 xb[KW][MB];
+  const u16* xp = reinterpret_cast<const u16*>(p.x) + 8 * g;
+  const u16* zp = reinterpret_cast<const u16*>(g_zero_line) + 8 * g;
+  auto load_x_block = [&](int q) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 8 * q + j;
+      if (t < KW) {
+        const int r = rot(t);
+        const bool ok = r < kw;
+        const int ks = min(ks0 + w * KW + r, total_ks - 1);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const int m = min(mb * 16 + c, p.M - 1);
+          const u16* src = ok ? (p.x_packed ? reinterpret_cast<const u16*>(p.x) + ((int64_t)(ks * mbl + min(mb, mbl - 1)) * 64 + lane) * 8
+                                            : xp + (int64_t)m * p.ldx + (int64_t)ks * 32)
+                              : zp;
+          xb[t][mb] = *reinterpret_cast<const u16x8*>(src);
+        }
+      }
+    }
+  };
+  if (NORM) {
+    uint32_t* st = p.sync + kStateWord;
+    float* red = reinterpret_cast<float*>(smem);
+    int* cmd = reinterpret_cast<int*>(smem) + 16;
+    auto produce = [&](int row) {
+      const bool own = norm_row_256<T, (2 * KW + 31) / 32, MB>(p.nm_partial, p.nm_splits, (int64_t)p.M * p.K,
+                                                               reinterpret_cast<u16*>(p.nm_residual),
+                                                               reinterpret_cast<const u16*>(p.nm_weight), p.nm_eps, p.K, row,
+                                                               const_cast<void*>(p.x), st, red, mbl);
+      if (own) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const uint32_t old = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (old + 1 == (uint32_t)p.M) {
+#pragma unroll
+            for (int cpy = 0; cpy < 8; ++cpy)
+              __hip_atomic_store(p.sync + 32 * (1 + cpy), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      return own;
+    };
+    const int n_wg = gridDim.x * gridDim.y;
+    if (flat_id < p.M && !(p.stagger & 6))
+      for (int row = flat_id; row < p.M; row += n_wg) produce(row);
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) load_buf(unit_of(0), q);
+    __builtin_amdgcn_sched_barrier(0);
+    for (;;) {
+      if (threadIdx.x < 64) {
+        const uint32_t* fl = p.sync + 32 * (1 + (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7));
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        int cc = -1;
+        while (!__builtin_amdgcn_readfirstlane(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          __builtin_amdgcn_s_sleep(8);
+          const uint64_t waited = __builtin_amdgcn_s_memrealtime() - t0;
+          if (waited > kRescueTicks && !(p.stagger & 4)) {
+            const uint32_t sv = lane < p.M ? __hip_atomic_load(st + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+            uint64_t free_rows = __ballot(sv == 0u);
+            if (free_rows) {
+              for (int skip = flat_id % __builtin_popcountll(free_rows); skip > 0; --skip) free_rows &= free_rows - 1;
+              cc = __builtin_ctzll(free_rows);
+              break;
+            }
+          }
+          if (waited > ((p.stagger & 4) ? 200000ull : 100000000ull)) {
+            if (threadIdx.x == 0) __hip_atomic_fetch_or(p.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cc = -2;
+            break;
+          }
+        }
+        if (threadIdx.x == 0) *cmd = cc;
+      }
+      __syncthreads();
+      const int cc = *cmd;
+      __syncthreads();
+      if (cc < 0) break;
+      produce(cc);
+    }
+    asm volatile("" ::: "memory");
+    {
+      const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
+#pragma unroll
+      for (int t = 0; t < KW; ++t) {
+        const int r = rot(t);
+        const bool ok = r < kw;
+        const int ks = min(ks0 + w * KW + r, total_ks - 1);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
+              ok ? xrs : zrs, ok ? (uint32_t)((ks * mbl + min(mb, mbl - 1)) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, 16));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) {
+      load_x_block(q);
+      load_buf(unit_of(0), q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  f32x4 acc[2][MB];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[h][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // tile (set, half h, wave, mb): 1 KiB each
+  f32x4* tiles = reinterpret_cast<f32x4*>(smem) + lane;
+  auto unit = [&](int i, auto refill_tag) {
+    constexpr bool REFILL = decltype(refill_tag)::value;
+    const int u_next = unit_of(i + 1);
+#pragma unroll
+    for (int q = 0; q < NBUF; ++q) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (8 * q + j < KW) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[h][mb] = Mfma<T>::mma(buf[h][q][j], xb[8 * q + j][mb], acc[h][mb]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (REFILL) load_buf(u_next, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int set = i & 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        tiles[(((set * 2 + h) * 4 + w) * MB + mb) * 64] = acc[h][mb];
+        acc[h][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    __syncthreads();       // (plain loads in flight survive it; the next unit writes the OTHER tile set)
+    // 8 tiles (h, mb), two per wave: summed over the four waves in order
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int tt = w + 4 * k, h = tt >> 2, mb = tt & 3;
+      f32x4 sum = tiles[(((set * 2 + h) * 4 + 0) * MB + mb) * 64];
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) sum += tiles[(((set * 2 + h) * 4 + ww) * MB + mb) * 64];
+      const int rg = 2 * unit_of(i) + h;
+      const int col = p.interleaved ? ((rg & 1) ? (p.N >> 1) : 0) + ((rg >> 1) << 4) : (rg << 4);
+      const int m = mb * 16 + c;
+      if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + col + 4 * g) = sum;
+    }
+  };
+  for (int i = 0; i < G - 1; ++i) unit(i, std::true_type{});
+  unit(G - 1, std::false_type{});
 }
 
 // output piece i (16 bytes) of the packed tensor <- its source in the row-major weight
@@ -584,9 +792,58 @@ int launch_any(const XregParams& p, int S, int KW, int dtype, hipStream_t stream
   return MB == 1 ? launch_mb<BF16, 1, EPI, NORM>(p, S, KW, stream) : launch_mb<BF16, 2, EPI, NORM>(p, S, KW, stream);
 }
 
+// ---- 33 .. 64 rows: the wide kernel over the SAME packing (its splits are halves of the packing's) ----------
+// (N, K, how the weight was packed) -> the launch's (splits, k-steps per wave, k-steps per packed split); KW = 0: no
+bool wide_plan(int64_t N, int64_t K, bool gate_up_packing, int* S, int* KW, int* pkP, int* S_packed) {
+  if (N <= 0 || K <= 0 || N % 32 || K % 32) return false;
+  int sp, kwp;
+  xreg_plan(N, K, &sp, &kwp, gate_up_packing);
+  if (kwp <= 0 || (kwp & 1)) return false;
+  const int kw = kwp / 2;
+  if (kw != 2 && kw != 4 && kw != 8 && kw != 10 && kw != 11 && kw != 16) return false;   // the built instantiations
+  const int total_ks = (int)(K >> 5);
+  *KW = kw; *pkP = 4 * kwp; *S = (total_ks + 4 * kw - 1) / (4 * kw); *S_packed = sp;
+  return true;
+}
+
+template <typename T, int KW, int NORM>
+int launch_wide_kw(const XregParams& p, int S, hipStream_t stream) {
+  const int n_units = (int)(p.N >> 5);
+  int nb = n_cus() / S;
+  if (nb < 1) nb = 1;
+  if (nb > n_units) nb = n_units;
+  constexpr size_t lds = 2 * 2 * 4 * 4 * 1024;      // two tile sets x two row groups x four waves x MB tiles of 1 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_wide_kernel<T, KW, NORM>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_rc(e);
+    attr_set = true;
+  }
+  hx::launcher(gemm_xreg_wide_kernel<T, KW, NORM>, dim3((unsigned)nb, (unsigned)S), 256, lds, stream)(p);
+  return check_launch();
+}
+
+template <int NORM>
+int launch_wide(const XregParams& p, int S, int KW, int dtype, hipStream_t stream) {
+#define HX_W(KWV)                                                                                   \
+  case KWV: return dtype == HX_F16 ? launch_wide_kw<F16, KWV, NORM>(p, S, stream) : launch_wide_kw<BF16, KWV, NORM>(p, S, stream)
+  switch (KW) {
+    HX_W(2); HX_W(4); HX_W(8); HX_W(16);
+    case 10: if constexpr (NORM == 0) return dtype == HX_F16 ? launch_wide_kw<F16, 10, 0>(p, S, stream) : launch_wide_kw<BF16, 10, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    case 11: if constexpr (NORM == 0) return dtype == HX_F16 ? launch_wide_kw<F16, 11, 0>(p, S, stream) : launch_wide_kw<BF16, 11, 0>(p, S, stream); else return HX_ERR_SHAPE;
+    default: return HX_ERR_SHAPE;
+  }
+#undef HX_W
+}
+
 bool xreg_ok(int64_t M, int64_t N, int64_t K) {
-  if (M < 1 || M > 32 || N <= 0 || K <= 0 || N % 16 || K % 32) return false;
+  if (M < 1 || M > 64 || N <= 0 || K <= 0 || N % 16 || K % 32) return false;
   int S, KW;
+  if (M > 32) {
+    int pkP, sp;
+    return wide_plan(N, K, false, &S, &KW, &pkP, &sp);
+  }
   xreg_plan(N, K, &S, &KW);
   return KW > 0;
 }
@@ -604,6 +861,41 @@ int xreg_set_option(const char* name, int value) {
 }
 }  // namespace hx
 
+namespace {
+int stagger_bits() {
+  return (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0);
+}
+
+// plain product of <= 64 rows over a packing (plain or gate|up-interleaved) with the wide kernel; returns the slab count
+int wide_product(float* partial, const void* x, const void* packed, int64_t M, int64_t N, int64_t K, int64_t ldx,
+                 int x_fragment_major, bool gate_up_packing, int dtype, hipStream_t stream) {
+  int S, KW, pkP, sp;
+  if (!wide_plan(N, K, gate_up_packing, &S, &KW, &pkP, &sp)) return HX_ERR_SHAPE;
+  XregParams p;
+  p.x = x; p.w = packed; p.partial = partial; p.ldx = ldx; p.act = nullptr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = stagger_bits(); p.x_packed = x_fragment_major ? 1 : 0;
+  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
+  p.interleaved = gate_up_packing ? 1 : 0; p.pk_P = pkP;
+  const int rc = launch_wide<0>(p, S, KW, dtype, stream);
+  return rc ? rc : S;
+}
+
+// add + RMSNorm fused in front of it (K in ONE packed split)
+int wide_norm_product(float* partial, void* residual, const float* slabs_in, int32_t n_splits_in, const void* norm_weight,
+                      float epsilon, void* x_frag, const void* packed, int64_t M, int64_t N, int64_t K, void* sync,
+                      bool gate_up_packing, int dtype, hipStream_t stream) {
+  int S, KW, pkP, sp;
+  if (!wide_plan(N, K, gate_up_packing, &S, &KW, &pkP, &sp) || sp != 1 || K % 8 || K / 8 > 1024) return HX_ERR_SHAPE;
+  XregParams p;
+  p.x = x_frag; p.w = packed; p.partial = partial; p.ldx = K; p.act = nullptr;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = stagger_bits(); p.x_packed = 1;
+  p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
+  p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.interleaved = gate_up_packing ? 1 : 0; p.pk_P = pkP;
+  const int rc = launch_wide<1>(p, S, KW, dtype, stream);
+  return rc ? rc : S;
+}
+}  // namespace
+
 extern "C" int hx_linear_decode_xreg_supported(int64_t M, int64_t N, int64_t K) { return xreg_ok(M, N, K) ? 1 : 0; }
 
 extern "C" int hx_linear_decode_xreg_splits(int64_t N, int64_t K) {
@@ -616,7 +908,12 @@ extern "C" int hx_linear_decode_xreg_splits(int64_t N, int64_t K) {
 extern "C" int64_t hx_linear_decode_xreg_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (!xreg_ok(M, N, K)) return 0;
   int S, KW;
-  xreg_plan(N, K, &S, &KW);
+  if (M > 32) {
+    int pkP, sp;
+    wide_plan(N, K, false, &S, &KW, &pkP, &sp);
+  } else {
+    xreg_plan(N, K, &S, &KW);
+  }
   return (int64_t)S * M * N * (int64_t)sizeof(float);
 }
 
@@ -649,18 +946,19 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
   if (!aligned16(x) || !aligned16(packed_weight) || !aligned16(partial)) return HX_ERR_STRIDE;
   if (partial_bytes < hx_linear_decode_xreg_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
+  if (M > 32) return wide_product(partial, x, packed_weight, M, N, K, ldx, x_fragment_major, false, dtype, (hipStream_t)stream);
   int S, KW;
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = x_fragment_major ? 1 : 0;
-  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
+  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f; p.interleaved = 0; p.pk_P = 0;
   const int rc = launch_any<0>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
 }
 
 extern "C" int hx_gate_up_silu_xreg_supported(int64_t M, int64_t inter, int64_t K) {
-  if (!xreg_ok(M, 2 * inter, K) || inter % 32) return 0;
+  if (M > 32 || !xreg_ok(M, 2 * inter, K) || inter % 32) return 0;   // (the fused epilogue needs the whole K in the workgroup)
   int S, KW;
   xreg_plan(2 * inter, K, &S, &KW, true);
   return S == 1 && (KW == 4 || KW == 8 || KW == 16 || KW == 32 || KW == 40) ? 1 : 0;   // the fused epilogue is built for these
@@ -678,7 +976,7 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   XregParams p;
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = x_fragment_major ? 1 : 0;
-  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f;
+  p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f; p.interleaved = 0; p.pk_P = 0;
   return launch_any<1>(p, 1, KW, dtype, (hipStream_t)stream);
 }
 
@@ -688,6 +986,10 @@ static bool norm_kw_ok(int S, int KW) { return S == 1 && (KW == 4 || KW == 8 || 
 extern "C" int hx_norm_xreg_supported(int64_t M, int64_t N, int64_t K, int gate_up) {
   if (gate_up) return hx_gate_up_silu_xreg_supported(M, N / 2, K);   // same condition: one split, a built k-step count
   if (!xreg_ok(M, N, K)) return 0;
+  if (M > 32) {          // wide kernel: K must sit in ONE split of the packing, rows of <= 4096 x 2 elements
+    int S, KW, pkP, sp;
+    return wide_plan(N, K, false, &S, &KW, &pkP, &sp) && sp == 1 && K % 8 == 0 && K / 8 <= 1024 && KW != 10 && KW != 11 ? 1 : 0;
+  }
   int S, KW;
   xreg_plan(N, K, &S, &KW);
   return norm_kw_ok(S, KW) && K % 8 == 0 && K / 8 <= 2048 ? 1 : 0;
@@ -712,13 +1014,15 @@ extern "C" int hx_norm_linear_decode_xreg(float* partial, void* residual, const 
   if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
   if (!aligned16(packed_weight) || !aligned16(partial)) return HX_ERR_STRIDE;
   if (partial_bytes < hx_linear_decode_xreg_workspace_bytes(M, N, K)) return HX_ERR_WORKSPACE;
+  if (M > 32) return wide_norm_product(partial, residual, slabs_in, n_splits_in, norm_weight, epsilon, x_frag, packed_weight, M, N, K,
+                                       sync, false, dtype, (hipStream_t)stream);
   int S, KW;
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x_frag; p.w = packed_weight; p.partial = partial; p.ldx = K; p.act = nullptr;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
-  p.nm_splits = n_splits_in; p.nm_eps = epsilon;
+  p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.interleaved = 0; p.pk_P = 0;
   rc = launch_any<0, 1>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
 }
@@ -739,8 +1043,50 @@ extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float*
   p.x = x_frag; p.w = packed_gate_up; p.partial = nullptr; p.ldx = K; p.act = act;
   p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
-  p.nm_splits = n_splits_in; p.nm_eps = epsilon;
+  p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.interleaved = 0; p.pk_P = 0;
   return launch_any<1, 1>(p, 1, KW, dtype, (hipStream_t)stream);
+}
+
+// ---- the gate|up product WITHOUT the fused silu*mul, over the interleaved packing (batches of 33 .. 64 rows: x for
+// 64 rows needs two K splits per workgroup, silu*mul the whole K) — slabs in [gate | up] column order for
+// hx_silu_and_mul_slabs.  Optionally with the add + RMSNorm in front.
+extern "C" int hx_gate_up_xreg_supported(int64_t M, int64_t inter, int64_t K, int with_norm) {
+  if (M < 1 || M > 64 || inter <= 0 || inter % 32 || K <= 0 || K % 32) return 0;
+  int S, KW, pkP, sp;
+  if (!wide_plan(2 * inter, K, true, &S, &KW, &pkP, &sp)) return 0;
+  if (with_norm && (sp != 1 || K % 8 || K / 8 > 1024 || KW == 10 || KW == 11)) return 0;
+  return 1;
+}
+
+extern "C" int64_t hx_gate_up_xreg_workspace_bytes(int64_t M, int64_t inter, int64_t K) {
+  int S, KW, pkP, sp;
+  if (M < 1 || M > 64 || !wide_plan(2 * inter, K, true, &S, &KW, &pkP, &sp)) return 0;
+  return (int64_t)S * M * 2 * inter * (int64_t)sizeof(float);
+}
+
+extern "C" int hx_gate_up_xreg(float* partial, const void* x, const void* packed_gate_up, int64_t M, int64_t inter, int64_t K,
+                               int64_t ldx, int x_fragment_major, int64_t partial_bytes, int dtype, hx_stream stream) {
+  if (!partial || !x || !packed_gate_up) return HX_ERR_NULL;
+  if (!hx_gate_up_xreg_supported(M, inter, K, 0) || (!x_fragment_major && ldx % 8)) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (!aligned16(x) || !aligned16(packed_gate_up) || !aligned16(partial)) return HX_ERR_STRIDE;
+  if (partial_bytes < hx_gate_up_xreg_workspace_bytes(M, inter, K)) return HX_ERR_WORKSPACE;
+  return wide_product(partial, x, packed_gate_up, M, 2 * inter, K, ldx, x_fragment_major, true, dtype, (hipStream_t)stream);
+}
+
+extern "C" int hx_norm_gate_up_xreg(float* partial, void* residual, const float* slabs_in, int32_t n_splits_in,
+                                    const void* norm_weight, float epsilon, void* x_frag, const void* packed_gate_up,
+                                    int64_t M, int64_t inter, int64_t K, void* sync, int64_t partial_bytes, int dtype,
+                                    hx_stream stream) {
+  if (!partial || !packed_gate_up) return HX_ERR_NULL;
+  int rc = norm_args_ok(residual, slabs_in, n_splits_in, norm_weight, x_frag, sync);
+  if (rc) return rc;
+  if (!hx_gate_up_xreg_supported(M, inter, K, 1)) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (!aligned16(packed_gate_up) || !aligned16(partial)) return HX_ERR_STRIDE;
+  if (partial_bytes < hx_gate_up_xreg_workspace_bytes(M, inter, K)) return HX_ERR_WORKSPACE;
+  return wide_norm_product(partial, residual, slabs_in, n_splits_in, norm_weight, epsilon, x_frag, packed_gate_up, M, 2 * inter, K,
+                           sync, true, dtype, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -752,10 +1098,19 @@ extern "C" int hx_decode_weight_plan(hx_decode_weight* w, int64_t N, int64_t K, 
   if (!w) return HX_ERR_NULL;
   if (N <= 0 || K <= 0 || max_rows <= 0 || max_rows > 64) return HX_ERR_SHAPE;
   if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
-  if (flags & ~HX_DW_GATE_UP) return HX_ERR_UNSUPPORTED;
+  if (flags & ~(HX_DW_GATE_UP | HX_DW_FORCE_LDS_SLICE)) return HX_ERR_UNSUPPORTED;
+  const bool force_lds = (flags & HX_DW_FORCE_LDS_SLICE) != 0;
+  flags &= ~HX_DW_FORCE_LDS_SLICE;
   w->packed = nullptr;
   w->N = N; w->K = K; w->dtype = dtype; w->flags = flags; w->max_rows = max_rows;
-  const bool xreg = max_rows <= 32 && hx_linear_decode_xreg_supported(max_rows, N, K) == 1;
+  // the activations-in-registers layout serves <= 32 rows always, 33 .. 64 rows where the wide kernel can read the same
+  // packing (a gate|up weight keeps its halves interleaved then: the plain product un-interleaves its slab columns)
+  bool xreg = !force_lds && hx_linear_decode_xreg_supported(max_rows < 32 ? max_rows : 32, N, K) == 1;
+  if (xreg && max_rows > 32) {
+    int S, KW, pkP, sp;
+    const bool gu = (flags & HX_DW_GATE_UP) && N % 32 == 0 && hx_gate_up_silu_xreg_supported(32, N / 2, K) == 1;
+    xreg = wide_plan(N, K, gu, &S, &KW, &pkP, &sp);
+  }
   if (!xreg && (N % 16 || K % 256)) return HX_ERR_SHAPE;
   if ((flags & HX_DW_GATE_UP) && (!xreg || N % 32)) w->flags &= ~HX_DW_GATE_UP;   // no fused epilogue on this layout: halves stay in order
   w->layout = xreg ? HX_DW_XREG : HX_DW_LDS_SLICE;
@@ -766,7 +1121,7 @@ extern "C" int hx_decode_weight_pack(hx_decode_weight* w, void* packed, const vo
   if (!w || !packed || !weight) return HX_ERR_NULL;
   int rc;
   if (w->layout == HX_DW_XREG) {
-    const int inter = (w->flags & HX_DW_GATE_UP) && hx_gate_up_silu_xreg_supported(w->max_rows, w->N / 2, w->K) == 1;
+    const int inter = (w->flags & HX_DW_GATE_UP) && hx_gate_up_silu_xreg_supported(w->max_rows < 32 ? w->max_rows : 32, w->N / 2, w->K) == 1;
     if (!inter) w->flags &= ~HX_DW_GATE_UP;
     rc = hx_pack_decode_weight_xreg(packed, weight, w->N, w->K, ldw, inter, w->dtype, stream);
   } else if (w->layout == HX_DW_LDS_SLICE) {
@@ -780,6 +1135,7 @@ extern "C" int hx_decode_weight_pack(hx_decode_weight* w, void* packed, const vo
 
 extern "C" int64_t hx_linear_decode_ex_workspace_bytes(const hx_decode_weight* w, int64_t M) {
   if (!w || M <= 0) return 0;
+  if (w->layout == HX_DW_XREG && (w->flags & HX_DW_GATE_UP)) return hx_gate_up_xreg_workspace_bytes(M, w->N / 2, w->K);
   return w->layout == HX_DW_XREG ? hx_linear_decode_xreg_workspace_bytes(M, w->N, w->K)
                                  : hx_linear_decode_workspace_bytes(M, w->N, w->K);
 }
@@ -789,7 +1145,8 @@ extern "C" int hx_linear_decode_ex(float* partial, int64_t partial_bytes, const 
   if (!w || !w->packed) return HX_ERR_NULL;
   if (M > w->max_rows) return HX_ERR_SHAPE;
   if (w->layout == HX_DW_XREG) {
-    if (w->flags & HX_DW_GATE_UP) return HX_ERR_UNSUPPORTED;   // interleaved halves: hx_gate_up_silu_xreg consumes this packing
+    if (w->flags & HX_DW_GATE_UP)     // interleaved halves: the fused hx_gate_up_silu_xreg, or this plain product (slabs [gate | up])
+      return hx_gate_up_xreg(partial, x, w->packed, M, w->N / 2, w->K, ldx, x_fragment_major, partial_bytes, w->dtype, stream);
     return hx_linear_decode_partial_xreg(partial, x, w->packed, M, w->N, w->K, ldx, x_fragment_major, partial_bytes,
                                          w->dtype, stream);
   }

@@ -123,7 +123,7 @@ class LlamaForCausalLM:
         (hydrainfer/model/llama.py:24-27,48-50)."""
         max_rows = min(int(max_rows), 64)
         if max_rows > self.decode_rows_prepared and not self.decode_only:
-            self.pack_decode_weights(all_lds_slice=max_rows > 32)
+            self.pack_decode_weights(all_lds_slice=max_rows > 32 and not self._wide_ok(max_rows))
             self.decode_rows_prepared = max_rows
         if not keep_row_major and not self.decode_only and self._all_packed():
             for l in range(self.shape.num_hidden_layers):
@@ -195,7 +195,7 @@ class LlamaForCausalLM:
     def _pack_lds_slice(self, key: str) -> Optional[Tensor]:
         w = self.state[key]
         if key not in self.packed and w.shape[0] % 16 == 0 and w.shape[1] % 256 == 0 and w.stride(1) == 1:
-            dw = hip_gemm.DecodeWeight(w, max_rows=64)          # 33..64 rows: always the LDS-slice layout
+            dw = hip_gemm.DecodeWeight(w, max_rows=64, lds_slice=True)     # row-major x in (o, layer 0's qkv) / 13B-like shapes
             assert dw.layout == "lds_slice"
             self.dw_lds[key], self.packed[key] = dw, dw.packed
         return self.packed.get(key)
@@ -205,9 +205,23 @@ class LlamaForCausalLM:
 
     def _xreg_mlp_ok(self, n: int) -> bool:
         hid, inter = self.shape.hidden_size, self.shape.intermediate_size
-        return (n <= 32 and self.dtype in (torch.float16, torch.bfloat16) and inter % 32 == 0 and hid % 32 == 0
+        if n > 32:
+            return self._wide_ok(n)
+        return (self.dtype in (torch.float16, torch.bfloat16) and inter % 32 == 0 and hid % 32 == 0
                 and hip_gemm.xreg_supported(n, 2 * inter, hid, self.dtype) and hip_gemm.xreg_supported(n, hid, inter, self.dtype)
                 and all(self.state[f"l0.{k}"].stride(1) == 1 for k in ("wgu", "wdown")))
+
+    def _wide_ok(self, n: int) -> bool:
+        """Batches of 33 .. 64 rows on the activations-in-registers layout (the wide kernel reads the <= 32-row packing:
+        no second copy): gate|up, down and qkv of this shape must all be supported (LLaVA-1.5-7B: yes; 13B: its
+        k-steps per wave do not halve — those batches stay on the LDS-slice copies)."""
+        hid, inter = self.shape.hidden_size, self.shape.intermediate_size
+        qkv_n = self.q_size + 2 * self.kv_size
+        return (32 < n <= 64 and self.use_xreg and self.xreg_qkv and self.dtype in (torch.float16, torch.bfloat16)
+                and inter % 32 == 0 and hid % 32 == 0 and self._xreg_mlp_ok(32)
+                and hip_gemm.gate_up_xreg_supported(n, inter, hid, self.dtype)
+                and hip_gemm.xreg_supported(n, hid, inter, self.dtype) and hip_gemm.xreg_supported(n, qkv_n, hid, self.dtype)
+                and hip_gemm.xreg_supported(32, qkv_n, hid, self.dtype))
 
     def _partial(self, x: Tensor, key: str, ws: Tensor) -> int:
         """split-K slabs of x @ state[key]^T into ws; packed weights when available."""
@@ -306,11 +320,15 @@ class LlamaForCausalLM:
         L, hid, inter = sh.num_hidden_layers, sh.hidden_size, sh.intermediate_size
         qkv_n = self.q_size + 2 * self.kv_size
         xreg = self.use_xreg and self._xreg_mlp_ok(n) and f"l{L - 1}.wdown" in self.packed_x
-        fused = xreg and hip_gemm.gate_up_silu_supported(n, inter, hid, dtype)
-        nf_gu = bool(xreg and self.fuse_norm and fused and hip_gemm.norm_xreg_supported(n, 2 * inter, hid, dtype, gate_up=True))
+        wide = bool(xreg and n > 32)       # 33 .. 64 rows: two K splits per product, silu*mul as its own launch (6 launches per layer)
+        fused = xreg and not wide and hip_gemm.gate_up_silu_supported(n, inter, hid, dtype)
+        if wide:
+            nf_gu = bool(self.fuse_norm and hip_gemm.gate_up_xreg_supported(n, inter, hid, dtype, with_norm=True))
+        else:
+            nf_gu = bool(xreg and self.fuse_norm and fused and hip_gemm.norm_xreg_supported(n, 2 * inter, hid, dtype, gate_up=True))
         nf_qkv = bool(xreg and self.fuse_norm and f"l{L - 1}.wqkv" in self.packed_x
                       and hip_gemm.norm_xreg_supported(n, qkv_n, hid, dtype))
-        return {"xreg": xreg, "fused": fused, "nf_gu": nf_gu, "nf_qkv": nf_qkv}
+        return {"xreg": xreg, "fused": fused, "nf_gu": nf_gu, "nf_qkv": nf_qkv, "wide": wide}
 
     def _decode_hidden_hip_gemm(self, h: Tensor, position_ids: Tensor,
                                 model_params: LanguageModelParameters, x0: Optional[Tensor] = None,
@@ -326,7 +344,8 @@ class LlamaForCausalLM:
         q_size, kv_size, inter, hid = self.q_size, self.kv_size, sh.intermediate_size, sh.hidden_size
         eps, L = sh.rms_norm_eps, sh.num_hidden_layers
         ws_n = max(hip_gemm.workspace_floats(n, q_size + 2 * kv_size, hid), hip_gemm.workspace_floats(n, hid, q_size),
-                   hip_gemm.workspace_floats(n, 2 * inter, hid), hip_gemm.workspace_floats(n, hid, inter))
+                   hip_gemm.workspace_floats(n, 2 * inter, hid), hip_gemm.workspace_floats(n, hid, inter),
+                   hip_gemm.xreg_workspace_floats(n, hid, inter))
         ws = torch.empty(ws_n, dtype=torch.float32, device=h.device)
         x = torch.empty_like(h)
         if n > self.decode_rows_prepared and not self.decode_only:
@@ -336,7 +355,7 @@ class LlamaForCausalLM:
             # batch can need, once; the engine / runners call prepare_decode at build time
             self.prepare_decode(max_rows=64)
         dp = self._decode_plan(n, h.dtype)
-        xreg, fused, nf_gu, nf_qkv = dp["xreg"], dp["fused"], dp["nf_gu"], dp["nf_qkv"]
+        xreg, fused, nf_gu, nf_qkv, wide = dp["xreg"], dp["fused"], dp["nf_gu"], dp["nf_qkv"], dp["wide"]
         qkv_n = q_size + 2 * kv_size
         ws_q = ws          # where the current layer's qkv slabs live
         if xreg:
@@ -353,6 +372,8 @@ class LlamaForCausalLM:
             if nf_qkv:   # the fused launch reads the down slabs (ws) while it writes the qkv slab
                 ws_q = torch.empty(max(hip_gemm.xreg_workspace_floats(n, qkv_n, hid), hip_gemm.workspace_floats(n, qkv_n, hid)),
                                    dtype=torch.float32, device=h.device)
+            if wide:     # gate|up slabs of the wide product (the norm-fused form reads the o slabs in ws meanwhile)
+                ws_gu = torch.empty(hip_gemm.gate_up_xreg_workspace_floats(n, inter, hid), dtype=torch.float32, device=h.device)
         if x0 is not None:
             x = x0          # the first layer's norm came with the embedding gather
         else:
@@ -363,7 +384,10 @@ class LlamaForCausalLM:
             kc, vc = ap.kv_cache.get_kv_cache()
             if s_qkv is None:
                 if xreg and f"l{l}.wqkv" in self.packed_x:
-                    s_qkv = hip_gemm.linear_decode_ex(xf, self.dw[f"l{l}.wqkv"], ws_q, frag_shape=(n, hid))
+                    if wide:
+                        s_qkv = hip_gemm.linear_decode_partial_xreg(xf, self.packed_x[f"l{l}.wqkv"], qkv_n, ws_q, frag_shape=(n, hid))
+                    else:
+                        s_qkv = hip_gemm.linear_decode_ex(xf, self.dw[f"l{l}.wqkv"], ws_q, frag_shape=(n, hid))
                 else:
                     s_qkv = self._partial(x, f"l{l}.wqkv", ws_q)
             o = torch.empty((n, H, D), dtype=h.dtype, device=h.device)
@@ -376,7 +400,15 @@ class LlamaForCausalLM:
             if xreg:
                 # fragment-major activations from here to the down projection
                 pgu, pdn = self.packed_x[f"l{l}.wgu"], self.packed_x[f"l{l}.wdown"]
-                if nf_gu:
+                if wide:
+                    # 33 .. 64 rows: (norm +) gate|up to two slabs, then silu*mul (fragment-major for the down product)
+                    if nf_gu:
+                        s_gu = hip_gemm.norm_gate_up_xreg(h, ws, s_o, st[f"l{l}.norm2"], eps, xf, pgu, inter, ws_gu, sync[l, 0])
+                    else:
+                        add_rms_norm_slabs(xf, h, ws, s_o, st[f"l{l}.norm2"], eps, fragment_major=True)
+                        s_gu = hip_gemm.gate_up_xreg(xf, pgu, inter, ws_gu, frag_shape=(n, hid))
+                    a_f = silu_and_mul_slabs(ws_gu, s_gu, n, inter, h.dtype, fragment_major=True)
+                elif nf_gu:
                     hip_gemm.norm_gate_up_silu_xreg(h, ws, s_o, st[f"l{l}.norm2"], eps, xf, pgu, inter, actf, sync[l, 0])
                     a_f = actf
                 else:
@@ -387,7 +419,10 @@ class LlamaForCausalLM:
                     else:
                         s_gu = hip_gemm.linear_decode_partial_xreg(xf, pgu, 2 * inter, ws, frag_shape=(n, hid))
                         a_f = silu_and_mul_slabs(ws, s_gu, n, inter, h.dtype, fragment_major=True)
-                s_dn = hip_gemm.linear_decode_ex(a_f, self.dw[f"l{l}.wdown"], ws, frag_shape=(n, inter))
+                if wide:
+                    s_dn = hip_gemm.linear_decode_partial_xreg(a_f, pdn, hid, ws, frag_shape=(n, inter))
+                else:
+                    s_dn = hip_gemm.linear_decode_ex(a_f, self.dw[f"l{l}.wdown"], ws, frag_shape=(n, inter))
             else:
                 add_rms_norm_slabs(x, h, ws, s_o, st[f"l{l}.norm2"], eps)
                 s_gu = self._partial(x, f"l{l}.wgu", ws)

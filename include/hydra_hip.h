@@ -175,6 +175,8 @@ typedef struct hx_decode_weight {
 #define HX_DW_LDS_SLICE 0
 #define HX_DW_XREG 1
 #define HX_DW_GATE_UP 1
+#define HX_DW_FORCE_LDS_SLICE 2   /* plan flag only (not kept in w->flags): the LDS-slice layout whatever the batch range — the
+                                   * consumer hands over ROW-major activations (the o projection behind the attention output) */
 int hx_decode_weight_plan(hx_decode_weight* w, int64_t N, int64_t K, int dtype, int max_rows, int flags);
 int hx_decode_weight_pack(hx_decode_weight* w, void* packed, const void* weight, int64_t ldw, hx_stream stream);
 int64_t hx_linear_decode_ex_workspace_bytes(const hx_decode_weight* w, int64_t M);
@@ -243,8 +245,8 @@ int hx_linear_decode_partial_xreg(float* partial, const void* x, const void* pac
  * (hx_fragment_major_elems(M, K) elements, a scratch the caller may read afterwards) and counts itself
  * in at `sync`; all workgroups prefetch their weights meanwhile, wait for the last row, then load x.
  * sync: HX_XREG_SYNC_WORDS int32 words, ZERO before the launch, one area per launch in flight (word 1
- * is set if a workgroup gave up waiting after 1 s — never expected).  Needs K in one split and
- * M <= 32 (hx_norm_xreg_supported).  slabs_in must not alias the outputs.  Results equal
+ * is set if a workgroup gave up waiting after 1 s — never expected).  Needs K in one split of the packing
+ * (hx_norm_xreg_supported; M <= 32 for the gate|up + silu*mul form, M <= 64 for the plain product).  slabs_in must not alias the outputs.  Results equal
  * hx_add_rms_norm_slabs_ex + hx_linear_decode_partial_xreg resp. hx_gate_up_silu_xreg bit for bit. */
 #define HX_XREG_SYNC_WORDS 512
 int hx_norm_xreg_supported(int64_t M, int64_t N, int64_t K, int gate_up);
@@ -256,6 +258,21 @@ int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float* slabs_in, 
                               const void* norm_weight, float epsilon, void* x_frag,
                               const void* packed_gate_up, int64_t M, int64_t inter, int64_t K, void* sync,
                               int dtype, hx_stream stream);
+/* Batches of 33 .. 64 rows (the reference's linear layers have no batch limit: hydrainfer/model/llama.py:24-27,48-50):
+ * hx_linear_decode_partial_xreg and hx_norm_linear_decode_xreg take M <= 64 — above 32 rows a workgroup spans HALF of a
+ * packed K split (x for 64 rows fills the registers at half the k-steps) over the SAME packing, so the slab count doubles
+ * (2 for K <= 4096) and no second copy of the weights is needed; hx_*_supported / _workspace_bytes answer per M.  The
+ * gate|up product then comes WITHOUT the fused silu*mul (it needs the whole K): hx_gate_up_xreg / hx_norm_gate_up_xreg
+ * multiply by the interleaved gate|up packing and write fp32 slabs [n_splits][M][2*inter] in plain [gate | up] column
+ * order for hx_silu_and_mul_slabs; they return the slab count (any M <= 64). */
+int hx_gate_up_xreg_supported(int64_t M, int64_t inter, int64_t K, int with_norm);
+int64_t hx_gate_up_xreg_workspace_bytes(int64_t M, int64_t inter, int64_t K);
+int hx_gate_up_xreg(float* partial, const void* x, const void* packed_gate_up, int64_t M, int64_t inter, int64_t K,
+                    int64_t ldx, int x_fragment_major, int64_t partial_bytes, int dtype, hx_stream stream);
+int hx_norm_gate_up_xreg(float* partial, void* residual, const float* slabs_in, int32_t n_splits_in,
+                         const void* norm_weight, float epsilon, void* x_frag, const void* packed_gate_up,
+                         int64_t M, int64_t inter, int64_t K, void* sync, int64_t partial_bytes, int dtype,
+                         hx_stream stream);
 int hx_gate_up_silu_xreg_supported(int64_t M, int64_t inter, int64_t K);
 int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed_gate_up, int64_t M,
                          int64_t inter, int64_t K, int64_t ldx, int x_fragment_major, int dtype,

@@ -616,3 +616,109 @@ def test_decode_step_head_equals_the_launches_it_replaces(dt):
         decode_step_head(ids.float(), table, w, 1e-5)
     with pytest.raises(_lib.HydraHipError):
         decode_step_head(ids, table, w, 1e-5, head=StepHead(feed_src=src))
+
+
+# ---- 33 .. 64 rows: the wide form of the activations-in-registers kernel ------------------------------------
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [33, 48, 64])
+def test_xreg_wide_product_matches_fp32_and_is_repeatable(dt, M):
+    """hx_linear_decode_partial_xreg / hx_gate_up_xreg at 33 .. 64 rows (gemm_xreg_wide_kernel: half a packed K split
+    per workgroup over the SAME packing as the <= 32-row kernel, pairs of row groups, per-pair reduction through LDS)
+    against the fp32 product of the same T inputs (rel. 1e-5 of the largest output: only the summation order differs),
+    row-major x and fragment-major x bit-identical, two runs bit-identical, slab counts as planned; the packing is the
+    one the 32-row kernel reads (checked by running both kernels on it)."""
+    from hydrainfer_amd._C.kernel import gemm
+    from hydrainfer_amd._C.kernel.activation import silu_and_mul_slabs
+    for (N, K) in ((12288, 4096), (4096, 11008), (4096, 4096), (64, 256), (3072, 1024), (1024, 2816), (96, 128)):
+        assert gemm.xreg_supported(M, N, K, dt), (N, K)
+        g = torch.Generator().manual_seed(N + K + M)
+        x = torch.randn((M, K), generator=g).to(dt).to(DEV)
+        w = (torch.randn((N, K), generator=g) * 0.02).to(dt).to(DEV)
+        pk = gemm.pack_weight_xreg(w)
+        a = torch.zeros(gemm.xreg_workspace_floats(M, N, K), dtype=torch.float32, device=DEV)
+        b, c = torch.zeros_like(a), torch.zeros_like(a)
+        s = gemm.linear_decode_partial_xreg(x, pk, N, a)
+        assert s == a.numel() // (M * N) and s == {4096: 2, 11008: 8}.get(K, s)      # twice the slabs of the <= 32-row launch
+        assert gemm.linear_decode_partial_xreg(x, pk, N, b) == s
+        assert gemm.linear_decode_partial_xreg(gemm.to_fragment_major(x), pk, N, c, frag_shape=(M, K)) == s
+        assert torch.equal(a, b) and torch.equal(a, c), f"N={N} K={K}"
+        ref = x.float() @ w.float().t()
+        got = a.view(s, M, N).sum(0)
+        assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6, f"N={N} K={K} M={M} {dt}"
+        # the same packing under the 32-row kernel (first 32 rows)
+        a32 = torch.zeros(gemm.xreg_workspace_floats(32, N, K), dtype=torch.float32, device=DEV)
+        s32 = gemm.linear_decode_partial_xreg(x[:32].contiguous(), pk, N, a32)
+        got32 = a32.view(s32, 32, N).sum(0)
+        assert (got32 - ref[:32]).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6
+    # gate|up over the INTERLEAVED packing: slabs in [gate | up] order, then silu*mul == the fp32 formula
+    for (inter, K) in ((11008, 4096), (2816, 1024), (96, 64)):
+        assert gemm.gate_up_xreg_supported(M, inter, K, dt)
+        g = torch.Generator().manual_seed(inter + M)
+        x = torch.randn((M, K), generator=g).to(dt).to(DEV)
+        w = (torch.randn((2 * inter, K), generator=g) * 0.03).to(dt).to(DEV)
+        pg = gemm.pack_weight_xreg(w, interleave_halves=True)
+        ws = torch.zeros(gemm.gate_up_xreg_workspace_floats(M, inter, K), dtype=torch.float32, device=DEV)
+        s = gemm.gate_up_xreg(gemm.to_fragment_major(x), pg, inter, ws, frag_shape=(M, K))
+        gu = x.float() @ w.float().t()
+        got = ws.view(s, M, 2 * inter).sum(0)
+        assert (got - gu).abs().max().item() <= 1e-5 * gu.abs().max().item() + 1e-6, f"gate|up inter={inter} K={K}"
+        act = gemm.from_fragment_major(silu_and_mul_slabs(ws, s, M, inter, dt, fragment_major=True), M, inter)
+        want = silu_and_mul_slabs(ws, s, M, inter, dt)
+        assert torch.equal(act, want)
+        if M <= 32 + 16:       # the same packing through the fused <= 32-row launch gives the same activations up to T round-off
+            a32 = torch.zeros(gemm.fragment_major_elems(32, inter), dtype=dt, device=DEV)
+            gemm.gate_up_silu_xreg(gemm.to_fragment_major(x[:32].contiguous()), pg, inter, a32, frag_shape=(32, K))
+            ulp = 2.0 ** (-10 if dt == torch.float16 else -7)
+            d = (gemm.from_fragment_major(a32, 32, inter).float() - want[:32].float()).abs()
+            assert (d <= 4 * ulp * want[:32].float().abs() + 0.25 * ulp).all()
+    assert not gemm.xreg_supported(65, 4096, 4096, dt)
+    assert not gemm.gate_up_silu_supported(33, 11008, 4096, dt)          # the fused epilogue stays a <= 32-row launch
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_norm_fused_wide_launches_are_bit_identical(dt):
+    """hx_norm_linear_decode_xreg / hx_norm_gate_up_xreg at 33 .. 64 rows (up to 64 producer workgroups) ==
+    hx_add_rms_norm_slabs_ex followed by the wide product: residual, x and the slabs bit for bit; 30 launches on the
+    same buffers with changing inputs, every launch's hand-over area clean; also with the rescue path alone."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel import gemm
+    from hydrainfer_amd._C.kernel.norm import add_rms_norm_slabs
+    lib = _lib.lib()
+    for (M, hid, inter, S_in) in ((64, 4096, 11008, 8), (33, 4096, 11008, 4), (48, 1024, 2816, 2), (64, 256, 512, 1)):
+        g = torch.Generator().manual_seed(hid + M)
+        nw = torch.randn(hid, generator=g).to(dt).to(DEV)
+        wq = (torch.randn((3 * hid, hid), generator=g) * 0.03).to(dt).to(DEV)
+        wgu = (torch.randn((2 * inter, hid), generator=g) * 0.03).to(dt).to(DEV)
+        assert gemm.norm_xreg_supported(M, 3 * hid, hid, dt) and gemm.gate_up_xreg_supported(M, inter, hid, dt, with_norm=True)
+        pq, pg = gemm.pack_weight_xreg(wq), gemm.pack_weight_xreg(wgu, interleave_halves=True)
+        xf, xf2 = (torch.zeros(gemm.fragment_major_elems(M, hid), dtype=dt, device=DEV) for _ in range(2))
+        a = torch.zeros(gemm.xreg_workspace_floats(M, 3 * hid, hid), dtype=torch.float32, device=DEV)
+        b = torch.zeros_like(a)
+        ga = torch.zeros(gemm.gate_up_xreg_workspace_floats(M, inter, hid), dtype=torch.float32, device=DEV)
+        gb = torch.zeros_like(ga)
+        n_it = 30 if hid == 4096 and M == 64 else 3
+        sync = torch.zeros((2 * n_it + 2, gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=DEV)
+        for it in range(n_it):
+            slabs = torch.randn((S_in, M, hid), generator=g).to(DEV)
+            h = torch.randn((M, hid), generator=g).to(dt).to(DEV)
+            h1, h2, h3, h4 = h.clone(), h.clone(), h.clone(), h.clone()
+            add_rms_norm_slabs(xf, h1, slabs, S_in, nw, 1e-5, fragment_major=True)
+            s = gemm.linear_decode_partial_xreg(xf, pq, 3 * hid, a, frag_shape=(M, hid))
+            s2 = gemm.norm_linear_decode_xreg(h2, slabs, S_in, nw, 1e-5, xf2, pq, 3 * hid, b, sync[2 * it])
+            assert s == s2 and torch.equal(h1, h2) and torch.equal(a, b), f"qkv it={it} M={M} hid={hid}"
+            assert torch.equal(gemm.from_fragment_major(xf, M, hid), gemm.from_fragment_major(xf2, M, hid))
+            add_rms_norm_slabs(xf, h3, slabs, S_in, nw, 1e-5, fragment_major=True)
+            sg = gemm.gate_up_xreg(xf, pg, inter, ga, frag_shape=(M, hid))
+            sg2 = gemm.norm_gate_up_xreg(h4, slabs, S_in, nw, 1e-5, xf2, pg, inter, gb, sync[2 * it + 1])
+            assert sg == sg2 and torch.equal(h3, h4) and torch.equal(ga, gb), f"gate|up it={it} M={M} hid={hid}"
+        # every row produced by the rescue path only
+        assert lib.hx_debug_set_option(b"xreg_no_producers", 1) == 0
+        try:
+            h5 = h.clone()
+            gemm.norm_linear_decode_xreg(h5, slabs, S_in, nw, 1e-5, xf2, pq, 3 * hid, b, sync[2 * n_it])
+            torch.cuda.synchronize()
+        finally:
+            lib.hx_debug_set_option(b"xreg_no_producers", 0)
+        assert torch.equal(h5, h1) and torch.equal(a, b)
+        assert int(sync[:, 1].abs().sum()) == 0
+        assert (sync[:2 * n_it + 1, 0] == M).all()
