@@ -823,6 +823,32 @@ def decode_leg(ctx, model, runner, ctxs, warmup, prompt_len):
     return elapsed
 
 
+def leg_64_rows(ctx, model, args, dev, prompt_len, n_generate, steps=20):
+    """`whole_step_64`: the decode step at TWICE the batch (64 rows; the reference's layers have no batch limit,
+    hydrainfer/model/model_forward.py:29-37) on the same model: 33 .. 64 rows run the wide form of the
+    activations-in-registers GEMMs (6 launches per layer).  KV cache: its random fill (no prefill: only the
+    step is timed), contexts spaced over the generation's 705..959 like the headline."""
+    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
+    B = 2 * args.batch
+    if B > 64:
+        return None
+    cfg = RunnerConfig(batch=B, prompt_len=prompt_len, n_generate=n_generate, use_graph=not args.no_graph, executor=args.executor)
+    runner = DecodeRunner(model, cfg, seed=7)
+    runner.input_ids.copy_(torch.randint(1000, 30000, (B,), device=dev))
+    ctxs = timed_contexts(prompt_len, n_generate, steps)
+    elapsed = decode_leg(ctx, model, runner, ctxs, 3, prompt_len)
+    ms = elapsed / len(ctxs) * 1e3
+    step_bytes = sum(runner.step_bytes(c * B) for c in ctxs) / len(ctxs)
+    gbs = step_bytes / (ms * 1e-3) / 1e9
+    dp = model._decode_plan(B, model.dtype)
+    return {"rows": B, "ms_per_step": round(ms, 4), "value": round(B * len(ctxs) / elapsed, 2), "unit": "tokens/s",
+            "algorithmic_bytes": int(step_bytes), "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+            "launches_per_layer": 6 if dp["wide"] and dp["nf_gu"] and dp["nf_qkv"] else 8,
+            "layer": ("attention | o | norm + gate|up (2 slabs) | silu*mul | down | norm + qkv (2 slabs): wide activations-in-registers "
+                      "kernel over the <= 32-row packing" if dp["wide"] else "LDS-slice GEMMs with separate norm / silu launches"),
+            "weight_bytes_resident": model.weight_bytes_resident(), "contexts": ctx_label(ctxs)}
+
+
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 / fp16, MI355X_MICROARCH.md
 
 
@@ -1063,6 +1089,14 @@ def main():
             # silu launches — DESIGN.md section 6d
             serving["twice_the_batch"] = measure_serving(model, vision, pixels, shape, dtype, dev, 2 * args.batch,
                                                          prompt_len - 576, n_generate)
+    whole_64 = None
+    if rank == 0 and world == 1 and args.model == "7b" and not args.no_serving_64:
+        try:
+            whole_64 = leg_64_rows(ctx, model, args, dev, prompt_len, n_generate)
+        except SystemExit:
+            raise
+        except Exception as e:      # an extra leg must never cost the headline
+            whole_64 = {"error": repr(e)[:300]}
     # ---- roofline of the dominant hand-written kernel + whole-step fraction (rank 0)
     out = None
     if rank == 0:
@@ -1096,6 +1130,7 @@ def main():
             "roofline_gemm": roofline_gemm,
             "roofline_prefill_attention": None if args.skip_prefill else time_prefill_attention(shape, dtype, dev),
             "whole_step": whole,
+            "whole_step_64": whole_64,
             "prefill_batch_ms": None if ttft_ms is None else round(ttft_ms, 2),
             "ttft": ttft, "serving": serving, "migration": None,
         }

@@ -102,6 +102,8 @@ class LlamaForCausalLM:
         # the two add+norm launches of a layer run INSIDE the gate|up and qkv launches (the first 32
         # workgroups produce x while all prefetch weights; in-kernel hand-over): 5 launches per layer
         self.fuse_norm = os.environ.get("HX_FUSE_NORM", "1") == "1"
+        # batches of 33 .. 64 rows on the same layout (the wide kernel: 6 launches per layer, no LDS-slice copies)
+        self.use_wide = os.environ.get("HX_WIDE", "1") == "1"
         self.sample_out: Optional[Tensor] = None   # int64 [rows]: forward() writes the sampled ids here (decode loops)
         self.xreg_sync: Optional[Tensor] = None   # [L, 2, XREG_SYNC_WORDS] of the last step (word 1 = wait gave up)
         self.packed_x: Dict[str, Tensor] = {}
@@ -217,7 +219,7 @@ class LlamaForCausalLM:
         k-steps per wave do not halve — those batches stay on the LDS-slice copies)."""
         hid, inter = self.shape.hidden_size, self.shape.intermediate_size
         qkv_n = self.q_size + 2 * self.kv_size
-        return (32 < n <= 64 and self.use_xreg and self.xreg_qkv and self.dtype in (torch.float16, torch.bfloat16)
+        return (32 < n <= 64 and self.use_wide and self.use_xreg and self.xreg_qkv and self.dtype in (torch.float16, torch.bfloat16)
                 and inter % 32 == 0 and hid % 32 == 0 and self._xreg_mlp_ok(32)
                 and hip_gemm.gate_up_xreg_supported(n, inter, hid, self.dtype)
                 and hip_gemm.xreg_supported(n, hid, inter, self.dtype) and hip_gemm.xreg_supported(n, qkv_n, hid, self.dtype)
