@@ -1086,7 +1086,7 @@ def main():
         if not args.no_serving_64:
             # twice as many requests at once: decode batches of 33 .. 64 rows leave the 5-launch layer (x for 64 rows does
             # not fit the registers of the activations-in-registers GEMM) for the LDS-slice GEMMs with separate norm /
-            # silu launches — DESIGN.md section 6d
+            # silu launches (13B) resp. the 6-launch wide layer (7B) — DESIGN.md section 4
             serving["twice_the_batch"] = measure_serving(model, vision, pixels, shape, dtype, dev, 2 * args.batch,
                                                          prompt_len - 576, n_generate)
     whole_64 = None
