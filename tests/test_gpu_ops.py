@@ -450,7 +450,8 @@ def test_norm_fused_in_front_of_xreg_product_is_bit_identical(dt):
         assert int(sync[:, 1].abs().sum()) == 0          # no workgroup gave up waiting
         assert (sync[:, 0] == M).all()                   # every launch counted each of its M rows in exactly once
     assert not gemm.norm_xreg_supported(32, 4096, 11008, dt)   # K = 11008 takes several splits
-    assert not gemm.norm_xreg_supported(33, 4096, 4096, dt)
+    assert gemm.norm_xreg_supported(33, 4096, 4096, dt) and not gemm.norm_xreg_supported(65, 4096, 4096, dt)   # 33 .. 64 rows: the wide form
+    assert not gemm.norm_xreg_supported(33, 22016, 4096, dt, gate_up=True)      # ... which has no fused silu*mul
 
 
 def test_norm_fused_launch_rescues_rows_nobody_produced():
@@ -536,21 +537,30 @@ def test_single_entry_decode_linear_dispatches_to_the_layout_kernels(dt):
         a.zero_()
         gemm.linear_decode_ex(xf, dw, a, frag_shape=(M, K))
         assert torch.equal(a, b)
-        # up to 64 rows: the LDS-slice layout
+        # up to 64 rows: the same layout and packing where the wide kernel can read it (round 4: all three shapes here) ...
         dl = gemm.DecodeWeight(w, max_rows=64)
+        assert dl.layout == "xreg" and torch.equal(dl.packed, dw.packed)
+        # ... and the LDS-slice layout on request (a projection whose input arrives row-major) or where it cannot
+        dl = gemm.DecodeWeight(w, max_rows=64, lds_slice=True)
         assert dl.layout == "lds_slice" and torch.equal(dl.packed, gemm.pack_weight(w))
         a2 = torch.zeros(dl.workspace_floats(M), dtype=torch.float32, device=DEV)
         b2 = torch.zeros_like(a2)
         assert gemm.linear_decode_ex(x, dl, a2) == gemm.linear_decode_partial_packed(x, dl.packed, N, b2) and torch.equal(a2, b2)
         with pytest.raises(_lib.HydraHipError):
             gemm.linear_decode_ex(xf, dl, a2, frag_shape=(M, K))        # fragment-major x only on the XREG layout
-    # a gate|up weight: interleaved for the fused epilogue, and refused by the plain product
+    w13 = (torch.randn((15360, 5120), generator=g) * 0.05).to(dt).to(DEV)      # 13B qkv: 40 k-steps per wave do not halve
+    assert gemm.DecodeWeight(w13, max_rows=64).layout == "lds_slice" and gemm.DecodeWeight(w13, max_rows=32).layout == "xreg"
+    # a gate|up weight: interleaved for the fused epilogue; the plain product over it un-interleaves its slab columns
     wgu = (torch.randn((2 * 11008, 4096), generator=g) * 0.05).to(dt).to(DEV)
     dgu = gemm.DecodeWeight(wgu, max_rows=32, gate_up=True)
     assert dgu.layout == "xreg" and dgu.interleaved and torch.equal(dgu.packed, gemm.pack_weight_xreg(wgu, interleave_halves=True))
-    with pytest.raises(_lib.HydraHipError):
-        gemm.linear_decode_ex(torch.zeros((4, 4096), dtype=dt, device=DEV), dgu, torch.zeros(4 * 22016, dtype=torch.float32, device=DEV))
-    assert not gemm.DecodeWeight(wgu, max_rows=64, gate_up=True).interleaved
+    x4 = torch.randn((4, 4096), generator=g).to(dt).to(DEV)
+    ws4 = torch.zeros(dgu.workspace_floats(4), dtype=torch.float32, device=DEV)
+    s4 = gemm.linear_decode_ex(x4, dgu, ws4)
+    ref4 = x4.float() @ wgu.float().t()
+    assert (ws4.view(s4, 4, 22016).sum(0) - ref4).abs().max().item() <= 1e-5 * ref4.abs().max().item() + 1e-6
+    d64 = gemm.DecodeWeight(wgu, max_rows=64, gate_up=True)
+    assert d64.layout == "xreg" and d64.interleaved and torch.equal(d64.packed, dgu.packed)
     with pytest.raises(_lib.HydraHipError):
         gemm.DecodeWeight(wgu, max_rows=65)
 
@@ -673,6 +683,22 @@ def test_xreg_wide_product_matches_fp32_and_is_repeatable(dt, M):
             assert (d <= 4 * ulp * want[:32].float().abs() + 0.25 * ulp).all()
     assert not gemm.xreg_supported(65, 4096, 4096, dt)
     assert not gemm.gate_up_silu_supported(33, 11008, 4096, dt)          # the fused epilogue stays a <= 32-row launch
+    # the single dispatching entry, planned for 64 rows: the activations-in-registers layout (one packing for 1 .. 64
+    # rows), a gate|up weight keeps its halves interleaved and hx_linear_decode_ex un-interleaves the slab columns;
+    # few rows through the same entry (the wide kernel with one or two 16-row blocks of x)
+    g = torch.Generator().manual_seed(7 + M)
+    w = (torch.randn((2 * 2816, 1024), generator=g) * 0.03).to(dt).to(DEV)
+    for gate_up in (False, True):
+        dw = gemm.DecodeWeight(w, max_rows=64, gate_up=gate_up)
+        assert dw.layout == "xreg" and dw.interleaved == gate_up
+        for rows in (M, 8):
+            x = torch.randn((rows, 1024), generator=g).to(dt).to(DEV)
+            ws = torch.zeros(dw.workspace_floats(rows), dtype=torch.float32, device=DEV)
+            s = gemm.linear_decode_ex(x, dw, ws)
+            ref = x.float() @ w.float().t()
+            got = ws.view(s, rows, 2 * 2816).sum(0)
+            assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6, (gate_up, rows)
+    assert gemm.DecodeWeight(w, max_rows=64, lds_slice=True).layout == "lds_slice"
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
