@@ -1189,13 +1189,15 @@ def main():
         out["disaggregated"] = disagg if engine_error is None else {"error": engine_error}
         out["llava_13b"] = llava_13b
         print(json.dumps(out), flush=True)
-    if stuck:
-        # A HIP call is wedged in the helper thread of an OPTIONAL leg (peer mapping / migration / E-P-D replay): the
-        # headline line above is complete and valid and names the wedged leg in its "error" field.  Collective teardown
-        # would hang behind the wedged thread, so the process leaves without it — with status 0 unless HX_BENCH_STRICT=1
-        # (the scaling curve of a multi-GPU run must not be lost to a leg that is reported as failed in the line itself).
-        print("bench.py: an optional multi-GPU leg is wedged (see the line's migration / disaggregated error)",
-              file=sys.stderr, flush=True)
+    # A HIP call wedged in the helper thread of an OPTIONAL leg (peer mapping / migration / E-P-D replay) on ANY rank: the
+    # headline line above is complete and valid and names the wedged leg in its "error" field; collective teardown would
+    # hang behind the wedged thread, so EVERY rank leaves without it (agreed through the TCPStore: a rank that exited
+    # alone would leave the others in the final barrier) — with status 0 unless HX_BENCH_STRICT=1: the scaling curve of
+    # a multi-GPU run must not be lost to a leg that the line itself reports as failed.
+    if ctx.any_rank_flagged(bool(stuck), "bench_wedged"):
+        if stuck:
+            print(f"bench.py: rank {rank}: an optional multi-GPU leg is wedged (see the line's migration / disaggregated "
+                  "error)", file=sys.stderr, flush=True)
         sys.stdout.flush()
         os._exit(3 if os.environ.get("HX_BENCH_STRICT") == "1" else 0)
     ctx.shutdown()

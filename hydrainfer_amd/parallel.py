@@ -56,6 +56,24 @@ class DistContext:
             dist.barrier()
             dist.destroy_process_group()
 
+    def any_rank_flagged(self, flag: bool, key: str, timeout_s: float = 30.0) -> bool:
+        """True if ANY rank raised `flag` — agreed through the rendezvous TCPStore (CPU only, no collective: usable while a
+        HIP call is wedged in a helper thread of some rank) within timeout_s; a rank that never reports counts as
+        flagged.  Every rank must call it with the same key."""
+        if not self.enabled:
+            return bool(flag)
+        import time
+        from datetime import timedelta
+        store = dist.distributed_c10d._get_default_store()
+        store.set(f"{key}/{self.rank}", "1" if flag else "0")
+        deadline = time.monotonic() + timeout_s
+        names = [f"{key}/{r}" for r in range(self.world_size)]
+        try:
+            store.wait(names, timedelta(seconds=max(1.0, deadline - time.monotonic())))
+        except Exception:
+            return True
+        return any(store.get(n) == b"1" for n in names)
+
 
 def init_from_env(backend: Optional[str] = None) -> DistContext:
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run."""

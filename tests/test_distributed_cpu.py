@@ -31,6 +31,10 @@ def _worker(rank, world, port, q):
         ctx.barrier()
         assert ctx.max_over_ranks(1.0 + rank) == 2.0
         assert ctx.sum_over_ranks(32.0) == 64.0
+        # agreement without a collective (bench.py's exit when an optional leg is wedged on some rank): any rank's flag
+        # is seen by all, through the rendezvous store
+        assert ctx.any_rank_flagged(False, "t0") is False
+        assert ctx.any_rank_flagged(rank == 1, "t1") is True
         handles = ctx.all_gather_object({"rank": rank, "handle": [rank] * 72, "table": [3 + rank, 1]})
         assert [h["rank"] for h in handles] == [0, 1]
         peer = parallel.migration_peer(rank, world)
