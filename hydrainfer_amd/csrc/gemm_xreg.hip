@@ -813,12 +813,10 @@ int launch_wide_kw(const XregParams& p, int S, hipStream_t stream) {
   if (nb < 1) nb = 1;
   if (nb > n_units) nb = n_units;
   constexpr size_t lds = 2 * 2 * 4 * 4 * 1024;      // two tile sets x two row groups x four waves x MB tiles of 1 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
+  {   // 64 KiB of dynamic LDS: above the default limit (per device, so not cached in a static)
     hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_wide_kernel<T, KW, NORM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
-    attr_set = true;
   }
   hx::launcher(gemm_xreg_wide_kernel<T, KW, NORM>, dim3((unsigned)nb, (unsigned)S), 256, lds, stream)(p);
   return check_launch();
