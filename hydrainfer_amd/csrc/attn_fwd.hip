@@ -436,8 +436,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   const int q_len = cu_q_s[b + 1] - q_start;
   const int k_start = cu_k_s[b];
   const int kv_len = cu_k_s[b + 1] - k_start;
-  const int q_row0_wg = mblk * TQ;
-  if (q_row0_wg >= q_len) return;
+  // Query tiles are aligned to the END of the sequence: the partial tile (q_len % 128 rows) is the FIRST one — under the
+  // causal mask the tile with the fewest keys — and every other tile is full.  Aligned to the start, the partial tile was
+  // the one with the most keys: 704 rows = 5 x 128 + 64 cost 2 + 4 + 6 + 8 + 10 + 11 = 41 tile steps, the last eleven of
+  // them with half of the waves idle; this way 1 + 3 + 5 + 7 + 9 + 11 = 36.  Rows below 0 do not exist: their loads are
+  // clamped, their results are not stored.
+  const int q_row0_wg = q_len - ((q_len + TQ - 1) / TQ - mblk) * TQ;
+  if (q_len <= 0) return;
   const int q_row0 = q_row0_wg + w * 32;
 
   const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   const int st_ch = lane % LPR;         // 16-byte chunk of the row
   const int shift = kv_len - q_len;
   const int limit_c = p.causal ? min(kv_len - 1, q_row0 + c + shift) : kv_len - 1;
-  const int last_key_wave = q_row0 >= q_len ? -1 : p.causal ? min(kv_len - 1, q_row0 + 31 + shift) : kv_len - 1;
+  const int last_key_wave = q_row0 + 31 < 0 ? -1 : p.causal ? min(kv_len - 1, q_row0 + 31 + shift) : kv_len - 1;
   const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + TQ - 1, q_len - 1) + shift) : kv_len - 1;
   const int n_tiles = (last_key_wg >= 0) ? last_key_wg / KT + 1 : 0;
 
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
     u16x8 qrow[32 / RPI];
 #pragma unroll
     for (int j = 0; j < 32 / RPI; ++j) {
-      const int qr = min(q_row0 + RPI * j + st_r4, q_len - 1);
+      const int qr = max(q_row0 + RPI * j + st_r4, 0);
       if (ABL == 512) qrow[j] = u16x8{(u16)(0x3c00 + lane), 0x3800, 0x3400, 0x3000, 0x2c00, 0x2800, (u16)(0x2400 + j), 0x2000};
       else qrow[j] = *reinterpret_cast<const u16x8*>(qbase + (int64_t)(q_start + qr) * p.q_row_stride);
     }
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   // instruction writes whole rows: straight from the accumulator layout each instruction put 16 bytes into each of 32
   // rows — sixteen such instructions per wave, ~10 us of the 4 x 704 launch by themselves
   // (tools/ablate_attn_prefill32.py, "empty loop" 16.3 us against 6.1 without the stores).
-  if (q_row0 < q_len) {
+  if (q_row0 + 31 >= 0) {
     // Unpadded rows with an XOR swizzle of the 8-byte slots (MI355X_MICROARCH.md, LDS): a ds_write_b64 is served in four
     // groups of 16 contiguous lanes on 32 banks — 16 rows at the same column need 16 different slot positions mod 16
     // (slot ^ row does it; a padded stride of 4 banks met pairwise, PMC 6 % of the LDS cycles) — and the ds_read_b128
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
       // slots 2 ch, 2 ch + 1 of row rl sit in chunk ch ^ (rl' >> 1), swapped when rl' is odd (rl' = rl mod D / 8)
       u16x8 v = *reinterpret_cast<const u16x8*>(ob + rl * RSO + 16 * (st_ch ^ ((rl & (LPR - 1)) >> 1)));
       if (rl & 1) v = u16x8{v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
-      if (q_row0 + rl < q_len) *reinterpret_cast<u16x8*>(obase + (int64_t)(q_start + q_row0 + rl) * p.o_row_stride) = v;
+      if (q_row0 + rl >= 0) *reinterpret_cast<u16x8*>(obase + (int64_t)(q_start + q_row0 + rl) * p.o_row_stride) = v;
     }
   }
 }
