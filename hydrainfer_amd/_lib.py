@@ -154,6 +154,7 @@ _SIGNATURES = {
 _EXPERIMENTAL_SIGNATURES = {
     "hx_debug_stream_read": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hx_debug_paged_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int] + [c_int] * 4 + [c_void_p, c_void_p]),
+    "hx_debug_fwd_stamps": (c_int, [c_void_p]),
 }
 
 _lib = None

@@ -22,6 +22,7 @@
 //     [32 keys][D] (row stride 2D+32 bytes => conflict-free transposed reads).
 //   * P is rounded to T before P.V exactly like the reference kernel
 //     (flash_fwd_kernel.h:878); accumulation is fp32.
+#include <algorithm>
 #include <cstring>
 #include <type_traits>
 #include "attn_common.h"
@@ -738,6 +739,553 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same arithmetic in PERSISTENT workgroups: two per CU, each walking a list of (sequence, query tile, head) items.
+// Why: a 128-row query tile of a 704-token prompt has 1 .. 11 key tiles (6 on average), and with one workgroup per item
+// the time around the tile loop — index decode, Q rows and the first K / V tile from HBM with nothing to compute
+// meanwhile, the O rows through LDS and out — was ~9 us per workgroup against ~11 us in its loop (32 x 704 tokens:
+// 266 us where 82 tile steps per workgroup slot at the 1.87 us of the long launches are 153).  Here the next item's Q
+// rows arrive by LDS-DMA in the image that the last tile of the current item leaves free, its first K / V tile is in
+// flight while the current item's O rows go out, and the item after that is decoded meanwhile.
+// Items are dealt out statically, in snake order over the length-sorted item list (round r: item r G + i to workgroup
+// i, the next round backwards), inside the XCD whose L2 holds that head's K / V.
+// ---------------------------------------------------------------------------------------------
+// A uniform value the compiler may not reason about: what is derived from it (strides times constants, the reciprocal
+// of a divisor) is computed where it is used instead of once at kernel entry and then kept, or spilled, across the
+// persistent loop.
+template <typename V> __device__ __forceinline__ V sfresh(V x) { asm volatile("" : "+s"(x)); return x; }
+
+// STAMPS (EXPERIMENTS builds, hx_debug_fwd_stamps): wave 0 of every workgroup appends (100 MHz time << 8 | event) words
+// to its 512-word list in p.stamps (tools/fwd_timeline.py)
+template <typename T, int D, bool PAGED, bool STAMPS = false>
+__global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p) {
+  constexpr int KS = D / 16;         // QK k-steps
+  constexpr int NDB = D / 32;        // 32-dim output blocks
+  constexpr int KT = 64;             // keys per tile (two 32-key sub-tiles)
+  constexpr int RSK = 2 * D, RSV = 2 * D;
+  constexpr int LPR = D / 8;
+  constexpr int NL = KT * LPR / 256;
+  constexpr int KTILE = KT * RSK, VTILE = KT * RSV;
+  constexpr int IMG = KTILE + VTILE;
+  constexpr int TQ = 128;
+  constexpr int RPI = 64 / LPR;         // rows per staging instruction
+  constexpr int NQI = 32 / RPI;         // staging instructions per 32-row block of Q / O
+  static_assert(NL * RPI == 16 && RPI * RSK == 1024, "a wave stages one 16-key group, 1 KiB per instruction");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K[KT][RSK] | V[KT][RSV]] | priority flag
+  auto kswz = [](int row) { return LPR == 16 ? (row & 15) : ((row >> 1) & 7); };
+  auto vswz = [](int row) { return LPR == 16 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); };
+  typedef __attribute__((address_space(4))) const int32_t c_i32;
+
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, hi = lane >> 5;
+  const int st_r4 = lane / LPR;         // staging map: row RPI j + st_r4 of the wave's block, 16-byte chunk st_ch
+  const int st_ch = lane % LPR;
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)(smem);
+  // The arguments as the code BETWEEN items reads them: from the kernel-argument segment, through a pointer the compiler
+  // cannot see through (sfresh).  Read as `p.field`, everything the item decode, the Q request and the epilogue derive
+  // from the arguments is loop-invariant, is hoisted in front of the persistent loop and then lives in — or is spilled
+  // from — the scalar registers the tile loop needs (346 v_readlane / v_writelane in the first build).
+  typedef __attribute__((address_space(4))) const AttnParams c_params;
+  auto kargs = [&]() __attribute__((always_inline)) { return sfresh((c_params*)__builtin_amdgcn_kernarg_segment_ptr()); };
+
+  int n_stamps = 0;
+  auto stamp = [&](int id) __attribute__((always_inline)) {
+    if constexpr (STAMPS) {
+      if (w == 0 && n_stamps < 512) {
+        const uint64_t v = (__builtin_amdgcn_s_memrealtime() << 8) | (uint64_t)id;
+        if (lane == 0) p.stamps[(size_t)blockIdx.x * 512 + n_stamps] = v;
+        ++n_stamps;
+      }
+    }
+  };
+  stamp(1);
+
+  // ---- the items of this workgroup: a table in LDS, built once.  Thread r decodes the item of round r — the r-th entry
+  // of the snake walk over the item list —, all rounds at the same time.  (Decoded one at a time by every wave, through
+  // the scalar cache, an item cost 3 + batch / 4 dependent round trips: 4 - 5 us in front of the first request at
+  // 4 sequences, 7.6 us at 32, and 2 - 3 us at every seam — in-kernel stamps, tools/fwd_timeline.py.  And everything
+  // uniform that the tile loop does not need must stay out of the scalar registers: see kargs above.)
+  // record: n_tiles (0 = no item in this round, -1 = an item without keys: its rows are zero), h, q_row0_wg, q_start,
+  //         q_len, k_start, kv_len, bt_off, first page of the 16-key group of wave 0 .. 3 in the item's first tile
+  struct Work { int h, q_row0_wg, q_start, q_len, k_start, kv_len, bt_off, n_tiles; };
+  constexpr int REC = 12;
+  const int n_groups = (p.batch + 3) >> 2;
+  int* tb_g = reinterpret_cast<int*>(smem + 2 * IMG + 16);             // slots before group g, g = 0 .. n_groups
+  int* items = tb_g + ((n_groups + 1 + 3) & ~3);                        // [n_rounds][REC], 16-byte aligned
+  const int n_rounds = (p.n_tile_slots * p.n_heads + (int)gridDim.x - 1) / (int)gridDim.x;
+  {
+    for (int g = threadIdx.x; g < n_groups; g += 256) {
+      int n = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        n += (p.cu_q[min(4 * g + i + 1, p.batch)] - p.cu_q[min(4 * g + i, p.batch)] + TQ - 1) / TQ;
+      tb_g[g] = n;
+    }
+    __syncthreads();
+    if (w == 0) {
+      int carry = 0;
+      for (int g0 = 0; g0 < n_groups; g0 += 64) {
+        const int g = g0 + lane;
+        const int mine = g < n_groups ? tb_g[g] : 0;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += o;
+        }
+        if (g < n_groups) tb_g[g] = carry + incl - mine;
+        carry += __shfl(incl, 63, 64);
+      }
+      if (lane == 0) tb_g[n_groups] = carry;
+    }
+    __syncthreads();
+    const int n_slots = p.n_tile_slots, gy = p.n_heads;
+    const int total = n_slots * gy;
+    const int G = gridDim.x, wg = blockIdx.x;
+    const bool remap = p.xcd_remap && total % 8 == 0 && gy % 8 == 0 && G % 8 == 0;
+    for (int r = threadIdx.x; r < n_rounds; r += 256) {
+      int* rec = items + r * REC;
+      rec[0] = 0;
+      int slot, h;
+      if (remap) {
+        const int Gx = G / 8, Tx = total / 8, hp = gy / 8;      // XCD x runs workgroups x, x + 8, ...: hp heads each
+        const int x = wg % 8, j = wg / 8;
+        const int i = (r & 1) ? (r + 1) * Gx - 1 - j : r * Gx + j;
+        if (i >= Tx) continue;
+        h = x * hp + i % hp;
+        slot = i / hp;
+      } else {
+        const int i = (r & 1) ? (r + 1) * G - 1 - wg : r * G + wg;
+        if (i >= total) continue;
+        slot = i % n_slots;
+        h = i / n_slots;
+      }
+      // the slot-th (tile rank, sequence) pair: sequences in groups of 4; inside a group rank 0 (each sequence's
+      // longest tile) of its sequences, then rank 1, ...  (Rank-major over ALL sequences spreads the tiles of one
+      // (sequence, head) so far apart in time that they stop sharing K / V in L2.)
+      if (slot >= tb_g[n_groups]) continue;                    // spare slot (the slot count is an upper bound)
+      int lo = 0, hi_g = n_groups;                             // last group whose first slot is <= slot
+      while (hi_g - lo > 1) {
+        const int mid = (lo + hi_g) >> 1;
+        if (tb_g[mid] <= slot) lo = mid; else hi_g = mid;
+      }
+      slot -= tb_g[lo];
+      int tl[4], max_tiles = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tl[i] = (p.cu_q[min(4 * lo + i + 1, p.batch)] - p.cu_q[min(4 * lo + i, p.batch)] + TQ - 1) / TQ;
+        max_tiles = max(max_tiles, tl[i]);
+      }
+      int mblk = -1, b = 0;
+      for (int rank = 0; rank < max_tiles && mblk < 0; ++rank) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (mblk < 0 && tl[i] > rank) {
+            if (slot == 0) { b = 4 * lo + i; mblk = tl[i] - 1 - rank; }
+            --slot;
+          }
+        }
+      }
+      if (mblk < 0) continue;
+      const int q_start = p.cu_q[b], q_len = p.cu_q[b + 1] - q_start;
+      const int k_start = p.cu_k[b], kv_len = p.cu_k[b + 1] - k_start;
+      if (q_len <= 0) continue;
+      // query tiles aligned to the END of the sequence (see attn_fwd32_kernel)
+      const int q_row0_wg = q_len - ((q_len + TQ - 1) / TQ - mblk) * TQ;
+      const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + TQ - 1, q_len - 1) + kv_len - q_len) : kv_len - 1;
+      const int bt_off = PAGED ? p.cu_block_lens[b] : 0;
+      rec[1] = h; rec[2] = q_row0_wg; rec[3] = q_start; rec[4] = q_len; rec[5] = k_start; rec[6] = kv_len; rec[7] = bt_off;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rec[8 + i] = PAGED && last_key_wg >= 0 ? p.block_table[bt_off + page_slot(min(16 * i, kv_len - 1), p.block_size, p.block_shift)] : 0;
+      rec[0] = last_key_wg < 0 ? -1 : last_key_wg / KT + 1;
+    }
+    __syncthreads();
+  }
+  stamp(4);
+  // the first record at or after round r that is an item; those without keys are finished on the way
+  int ri = 0;
+  auto next_item = [&](int r) __attribute__((always_inline)) -> int {
+    for (; r < n_rounds; ++r) {
+      const int n = __builtin_amdgcn_readfirstlane(items[r * REC]);
+      if (n > 0) break;
+      if (n < 0) {
+        c_params* P = kargs();
+        const int h = items[r * REC + 1], q_row0_wg = items[r * REC + 2], q_start = items[r * REC + 3];
+        for (int i = threadIdx.x; i < TQ * LPR; i += 256) {
+          const int row = q_row0_wg + i / LPR;
+          if (row >= 0)
+            *reinterpret_cast<u16x8*>(reinterpret_cast<u16*>(P->out) + (int64_t)(q_start + row) * P->o_row_stride +
+                                      (int64_t)h * D + 8 * (i % LPR)) = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+    }
+    return r;
+  };
+  auto read_item = [&](int r, Work& wk) __attribute__((always_inline)) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const i32x4 a = *reinterpret_cast<const i32x4*>(items + r * REC), b = *reinterpret_cast<const i32x4*>(items + r * REC + 4);
+    wk.n_tiles = __builtin_amdgcn_readfirstlane(a[0]); wk.h = __builtin_amdgcn_readfirstlane(a[1]);
+    wk.q_row0_wg = __builtin_amdgcn_readfirstlane(a[2]); wk.q_start = __builtin_amdgcn_readfirstlane(a[3]);
+    wk.q_len = __builtin_amdgcn_readfirstlane(b[0]); wk.k_start = __builtin_amdgcn_readfirstlane(b[1]);
+    wk.kv_len = __builtin_amdgcn_readfirstlane(b[2]); wk.bt_off = __builtin_amdgcn_readfirstlane(b[3]);
+  };
+
+  // ---- per-item state: the uniform part lives in `cur`, the per-lane part here
+  Work cur;
+  int q_row0 = 0, limit_c = 0, last_key_wave = 0, last_key = 0, shift = 0, t_last = 0;
+  const u16 *kbase = nullptr, *vbase = nullptr;
+  c_i32* bt_s = nullptr;
+  auto setup = [&](const Work& wk) __attribute__((always_inline)) {
+    c_params* P = kargs();
+    q_row0 = wk.q_row0_wg + w * 32;
+    shift = wk.kv_len - wk.q_len;
+    limit_c = P->causal ? min(wk.kv_len - 1, q_row0 + c + shift) : wk.kv_len - 1;
+    last_key_wave = q_row0 + 31 < 0 ? -1 : P->causal ? min(wk.kv_len - 1, q_row0 + 31 + shift) : wk.kv_len - 1;
+    last_key = wk.kv_len - 1;
+    t_last = wk.n_tiles - 1;
+    const int hk = wk.h / sfresh(P->group);
+    kbase = reinterpret_cast<const u16*>(P->k) + (int64_t)hk * P->k_head_stride;
+    vbase = reinterpret_cast<const u16*>(P->v) + (int64_t)hk * P->v_head_stride;
+    bt_s = PAGED ? (c_i32*)(P->block_table + wk.bt_off) : nullptr;
+  };
+
+  // ---- K / V tile staging by LDS-DMA (see attn_fwd32_kernel).  The address of a request is a wave-uniform base — page,
+  // first row of the wave's 16-key group, the instruction's rows: scalar arithmetic — plus a per-lane offset that never
+  // changes (row inside the instruction, swizzled chunk): the vector ALU is not involved, except in a sequence's last
+  // group, whose rows past the last key are clamped to it.
+  int page_next = 0;
+  auto lookup_page = [&](int t) __attribute__((always_inline)) {
+    if (PAGED) page_next = bt_s[__builtin_amdgcn_readfirstlane(page_slot(min(t * KT + 16 * w, last_key), p.block_size, p.block_shift))];
+  };
+  uint32_t koff[NL], voff;
+#pragma unroll
+  for (int j = 0; j < NL; ++j)
+    koff[j] = (uint32_t)st_r4 * (uint32_t)p.k_row_stride * 2u + 16u * (uint32_t)(st_ch ^ kswz(RPI * j + st_r4));
+  voff = (uint32_t)st_r4 * (uint32_t)p.v_row_stride * 2u + 16u * (uint32_t)(st_ch ^ vswz(st_r4));   // vswz(RPI j + r) = vswz(r)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  auto dma = [&](const void* base, uint32_t off, uint32_t lds) __attribute__((always_inline)) {
+    // (m0 — the LDS address of the DMA — is a reserved register: naming it as clobbered is all that can be done, and
+    // nothing else in this kernel uses it)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(lds) : "memory", "m0");
+  };
+  auto dma_flat = [&](const void* addr, uint32_t lds) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(addr), "s"(lds) : "memory", "m0");
+  };
+#pragma clang diagnostic pop
+  auto request_tile = [&](int t, int img) __attribute__((always_inline)) {
+    const int g0 = min(t * KT + 16 * w, last_key);      // first key of the wave's group, clamped: uniform
+    const int r_max = last_key - g0;                     // rows of the group that exist (>= 0)
+    int64_t kb, vb;
+    const int64_t krs = sfresh(p.k_row_stride), vrs = sfresh(p.v_row_stride);
+    if (PAGED) {
+      const int rowg = page_row(g0, p.block_size, p.block_shift);
+      kb = (int64_t)page_next * p.k_block_stride + (int64_t)rowg * krs;
+      vb = (int64_t)page_next * p.v_block_stride + (int64_t)rowg * vrs;
+    } else {
+      kb = (int64_t)(cur.k_start + g0) * krs;
+      vb = (int64_t)(cur.k_start + g0) * vrs;
+    }
+    const uint32_t kd = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(img * IMG + 16 * w * RSK));
+    const uint32_t vd = kd + KTILE;
+    if (r_max >= 15) {
+      const u16* kp = kbase + kb;
+      const u16* vp = vbase + vb;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        dma(kp, koff[j], kd + 1024u * j);
+        dma(vp, voff, vd + 1024u * j);
+        kp = sfresh(kp + RPI * krs);         // (step by step: no table of j x stride products)
+        vp = sfresh(vp + RPI * vrs);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const int R = RPI * j + st_r4;
+        const uint32_t r = (uint32_t)min(R, r_max);                  // rows past the last key repeat it
+        dma_flat(kbase + kb + r * (uint32_t)p.k_row_stride + 8 * (st_ch ^ kswz(R)), kd + 1024u * j);
+        dma_flat(vbase + vb + r * (uint32_t)p.v_row_stride + 8 * (st_ch ^ vswz(R)), vd + 1024u * j);
+      }
+    }
+  };
+  // the 32 Q rows of this wave for item wk -> rows 32 w .. of image img (K's swizzle), whole rows per instruction
+  auto request_q = [&](const Work& wk, int img) __attribute__((always_inline)) {
+    c_params* P = kargs();
+    const u16* qbase = reinterpret_cast<const u16*>(P->q) + (int64_t)wk.h * D;
+    const uint32_t qd = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(img * IMG + w * 32 * RSK));
+#pragma unroll
+    for (int j = 0; j < NQI; ++j) {
+      const int R = RPI * j + st_r4;
+      const int qr = min(max(wk.q_row0_wg + w * 32 + R, 0), wk.q_len - 1);
+      dma_flat(qbase + (int64_t)(wk.q_start + qr) * P->q_row_stride + 8 * (st_ch ^ kswz(R)), qd + 1024u * j);
+    }
+  };
+  auto tiles_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+
+  u16x8 qf[KS];
+  auto read_q = [&](int img) __attribute__((always_inline)) {
+    const char* qb = smem + img * IMG + w * 32 * RSK;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qb + c * RSK + 16 * ((2 * ks + hi) ^ kswz(c)));
+  };
+
+  f32x16 acc[NDB];
+  float m, l;
+  auto reset_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    m = HX_NEG_BIG;
+    l = 0.f;
+  };
+
+  // ---- first item
+  ri = next_item(0);
+  if (ri >= n_rounds) return;
+  read_item(ri, cur);
+  stamp(5);
+  setup(cur);
+  request_q(cur, 1);
+  page_next = __builtin_amdgcn_readfirstlane(items[ri * REC + 8 + w]);
+  request_tile(0, 0);
+  stamp(6);
+  int rn = next_item(ri + 1);                 // the round of the item after this one (n_rounds: none)
+  lookup_page(min(1, t_last));
+  reset_acc();
+  stamp(2);
+  tiles_landed();
+  stamp(3);
+  read_q(1);
+  // The two workgroups of a CU at DIFFERENT priorities (see attn_fwd32_kernel), flipped at every item so that neither
+  // of the two falls behind for good.
+  uint32_t* prio_flag = reinterpret_cast<uint32_t*>(smem + 2 * IMG);
+  const bool use_prio = p.wg_priority != 0;
+  if (use_prio && threadIdx.x == 0) *prio_flag = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1;     // HW_ID.wave_id
+  __syncthreads();
+  bool favoured = use_prio && *prio_flag;
+  if (favoured) __builtin_amdgcn_s_setprio(3);
+
+  // transposed-read lane address inside a 4-row x 32-dim block (see attn_fwd32_kernel)
+  const int tr_q = (lane & 15) >> 2, tr_pp = lane & 3, tr_half = (lane >> 4) & 1;
+  const int tr_off = (4 * hi + tr_q) * RSV + (16 * tr_half + 4 * tr_pp) * 2;
+  const int tr_x = vswz(tr_q) >> 2;
+
+  auto half_max = [](float x) __attribute__((always_inline)) {      // max with lane ^ 32, without the LDS crossbar
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+  };
+  auto half_sum = [](float x) __attribute__((always_inline)) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+  };
+
+  int t = 0;
+  // one 64-key tile of the current item, in image PAR; returns true when the workgroup has no more work
+  auto tile_step = [&](auto par_tag) __attribute__((always_inline)) -> bool {
+    constexpr int PAR = decltype(par_tag)::value;
+    const bool last = t == t_last;
+    stamp(10);
+    if (!last) {
+      request_tile(t + 1, 1 - PAR);                     // lands under this tile's arithmetic
+    } else if (rn < n_rounds) {
+      Work nx;
+      read_item(rn, nx);
+      request_q(nx, 1 - PAR);                           // the free image takes the next item's Q rows
+    }
+    if (t * KT <= last_key_wave) {
+      const char* kt = smem + PAR * IMG;
+      const char* vt = kt + KTILE;
+      f32x16 s[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+      {
+        const char* krd = kt + c * RSK;
+        const int kz = kswz(c);
+        u16x8 kfa[KS], kfb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kfa[ks] = *reinterpret_cast<const u16x8*>(krd + 16 * ((2 * ks + hi) ^ kz));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          kfb[ks] = *reinterpret_cast<const u16x8*>(krd + 32 * RSK + 16 * ((2 * ks + hi) ^ kz));
+          s[0] = Mfma32<T>::mma(kfa[ks], qf[ks], s[0]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[1] = Mfma32<T>::mma(kfb[ks], qf[ks], s[1]);
+        __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, KS, 0);
+      }
+      const bool interior = t * KT + KT - 1 <= min(last_key, p.causal ? q_row0 + shift : last_key);
+      float mx = HX_NEG_BIG;
+      u16x8 pf[2][2];
+      if (interior) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KT + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key > limit_c) s[u][r] = -INFINITY;
+            mx = fmaxf(mx, s[u][r]);
+          }
+      }
+      mx = half_max(mx);
+      // lazy running maximum (see attn_fwd32_kernel)
+      const float m_cand = fmaxf(m, mx * p.scale_log2);
+      const bool grow = m_cand > m + 8.0f;
+      float m_new = m;
+      if (__builtin_amdgcn_ballot_w64(grow)) {
+        m_new = grow ? m_cand : m;
+        const float alpha = fast_exp2(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        m = m_new;
+      }
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 ps2 = {0.f, 0.f};
+      const f32x2 sc2 = {p.scale_log2, p.scale_log2}, mn2 = {-m_new, -m_new};
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 x = f32x2{s[u][r], s[u][r + 1]} * sc2 + mn2;
+          const f32x2 e = {fast_exp2(x[0]), fast_exp2(x[1])};
+          ps2 += e;
+          pf[u][r >> 3][r & 7] = T::from_float(e[0]);
+          pf[u][r >> 3][(r & 7) + 1] = T::from_float(e[1]);
+        }
+      l += ps2[0] + ps2[1];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const char* vrd = vt + (32 * u + 16 * k2) * RSV + tr_off;
+#pragma unroll
+          for (int db = 0; db < NDB; ++db) {
+            const u16x4 lo = lds_tr_read(vrd + 64 * (db ^ tr_x));
+            const u16x4 hh = lds_tr_read(vrd + 8 * RSV + 64 * (db ^ tr_x));
+            u16x8 vf;
+            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+            vf[4] = hh[0]; vf[5] = hh[1]; vf[6] = hh[2]; vf[7] = hh[3];
+            acc[db] = Mfma32<T>::mma(vf, pf[u][k2], acc[db]);
+          }
+        }
+    }
+    stamp(11);
+    if (!last) {
+      lookup_page(min(t + 2, t_last));     // the table entry for the next request, in front of the barrier's wait
+      tiles_landed();                      // this wave's part of tile t + 1 is in LDS
+      stamp(12);
+      __syncthreads();                     // tile t + 1 visible; everyone is done with tile t's image
+      ++t;
+      return false;
+    }
+    // ---- the seam: the item is complete.  Image 1 - PAR holds the next item's Q rows (this wave's own 32), image PAR
+    // the tile just used.
+    tiles_landed();
+    stamp(20);
+    const bool has_next = rn < n_rounds;
+    if (has_next) read_q(1 - PAR);
+    const int e_q_row0 = q_row0;
+    const int64_t e_row = (int64_t)cur.q_start + q_row0;
+    const int e_h = cur.h;
+    __syncthreads();                       // everybody is done with both images
+    stamp(21);
+    if (has_next) {
+      ri = rn;
+      read_item(ri, cur);
+      setup(cur);
+      page_next = __builtin_amdgcn_readfirstlane(items[ri * REC + 8 + w]);      // looked up when the table was built
+      request_tile(0, 1 - PAR);            // in flight while the finished item's rows go out
+    }
+    // O[query c][dim 32 db + 8 (r >> 2) + 4 hi + (r & 3)] = acc[db][r] / L, through LDS so that a store instruction
+    // writes whole rows (see attn_fwd32_kernel); this wave's 32 rows sit in image PAR
+    {
+      const float lr = half_sum(l);
+      const float inv = (lr > 0.f) ? 1.0f / lr : 0.f;
+      if (e_q_row0 + 31 >= 0) {
+        constexpr int RSO = 2 * D;
+        // (the lane's addresses are derived HERE from a lane id the compiler cannot see through: as loop invariants they
+        // were computed at kernel entry, spilled, and every reload waited for vmcnt(0) — the first tile's requests)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int ec = ln & 31, ehi = ln >> 5, er4 = ln / LPR, ech = ln % LPR;
+        char* ob = smem + PAR * IMG + w * 32 * RSO;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            u16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = T::from_float(acc[db][4 * rq + i] * inv);
+            *reinterpret_cast<u16x4*>(ob + ec * RSO + (((8 * db + 2 * rq + ehi) ^ (ec & (LPR - 1))) << 3)) = o;
+          }
+        c_params* P = kargs();
+        const int64_t ors = P->o_row_stride;
+        u16* orow = reinterpret_cast<u16*>(P->out) + (int64_t)e_h * D + 8 * ech + (e_row + er4) * ors;
+        const char* ord = ob + er4 * RSO;
+        auto o_row = [&](int j) __attribute__((always_inline)) {
+          const int rl = RPI * j + er4;
+          u16x8 v = *reinterpret_cast<const u16x8*>(ord + RPI * j * RSO + 16 * (ech ^ ((rl & (LPR - 1)) >> 1)));
+          if (rl & 1) v = u16x8{v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+          return v;
+        };
+        if (e_q_row0 >= 0) {             // all 32 rows exist: NQI store instructions, no predicate
+#pragma unroll
+          for (int j = 0; j < NQI; ++j) *reinterpret_cast<u16x8*>(orow + (int64_t)(RPI * j) * ors) = o_row(j);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NQI; ++j)
+            if (e_q_row0 + RPI * j + er4 >= 0) *reinterpret_cast<u16x8*>(orow + (int64_t)(RPI * j) * ors) = o_row(j);
+        }
+      }
+    }
+    stamp(22);
+    if (!has_next) return true;
+    reset_acc();
+    t = 0;
+    if (use_prio) {
+      favoured = !favoured;
+      if (favoured) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    }
+    rn = next_item(ri + 1);
+    lookup_page(min(1, t_last));
+    // The first tile's requests are older than the O stores: when all NQI of them were issued (a wave whose 32 rows all
+    // exist), waiting for everything but the NQI youngest operations waits for the tile and not for the stores.
+    stamp(23);
+    if (e_q_row0 >= 0 && !STAMPS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NQI) : "memory");
+    else tiles_landed();
+    stamp(24);
+    __syncthreads();
+    return false;
+  };
+  for (;;) {
+    if (tile_step(Set0{})) break;
+    if (tile_step(Set1{})) break;
+  }
+}
+
 int fwd_n_cus() {
   static int n = [] {
     int dev = 0;
@@ -750,13 +1298,44 @@ int fwd_n_cus() {
 
 int g_fwd_ablate = 0;   // EXPERIMENTS builds: timing ablations of attn_fwd32_kernel (wrong results)
 
+unsigned long long* g_fwd_stamps = nullptr;   // EXPERIMENTS builds: hx_debug_fwd_stamps
+int g_fwd_persistent = 1;   // tuning: 0 = one workgroup per (sequence, query tile, head) item, 2 = persistent for dense launches too
+int g_fwd_priority = -1;    // tuning: -1 = automatic, 0 / 1 = the two workgroups of a CU at equal / different priorities
+
 template <typename T, int D, bool PAGED>
 int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16;      // two tiles' K / V images + the workgroup's priority flag
   dim3 grid((unsigned)(p.total_q / 128 + batch), p.n_heads, 1);
   AttnParams pp = p;
   pp.wg_priority = (p.total_q / 128) * (int64_t)p.n_heads > 2 * (int64_t)fwd_n_cus() ? 1 : 0;   // more than two workgroups per CU
+  if (g_fwd_priority >= 0) pp.wg_priority = g_fwd_priority;
   if (p.total_q == 0) return HX_OK;
+  pp.n_tile_slots = (int32_t)(p.total_q / 128 + batch);
+  const int64_t total = (int64_t)pp.n_tile_slots * p.n_heads;
+  const int64_t g = std::min<int64_t>(total, 2 * (int64_t)fwd_n_cus());
+  // the workgroup's item table: the slot count in front of every group of 4 sequences, 12 words per round
+  const size_t table = 4 * (size_t)((((batch + 3) / 4 + 1 + 3) & ~3) + 12 * ((total + g - 1) / g));
+  // (else one workgroup per item: tables that do not fit; dense launches of equal items — the CLIP tower, 8 x 577:
+  // 25.1 us per item against 27.4 — where the static deal puts the second items of a round on the same CUs)
+  if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED)) && 2 * (lds + table) <= 160 * 1024) {
+    const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16 + table;
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32p_kernel<T, D, PAGED>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_rc(e);
+#if HX_EXPERIMENTS
+    if constexpr (D == 128 && PAGED && std::is_same<T, BF16>::value) {
+      if (g_fwd_stamps) {
+        pp.stamps = g_fwd_stamps;
+        e = hipFuncSetAttribute((const void*)attn_fwd32p_kernel<T, D, PAGED, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_rc(e);
+        hx::launcher(attn_fwd32p_kernel<T, D, PAGED, true>, dim3((unsigned)g, 1, 1), 256, lds, stream)(pp);
+        return check_launch();
+      }
+    }
+#endif
+    hx::launcher(attn_fwd32p_kernel<T, D, PAGED>, dim3((unsigned)g, 1, 1), 256, lds, stream)(pp);
+    return check_launch();
+  }
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32_kernel<T, D, PAGED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -840,8 +1419,12 @@ int fwd_set_option(const char* name, int value) {
   if (!strcmp(name, "fwd_key_units")) { g_fwd_keys = value; return HX_OK; }
   if (!strcmp(name, "fwd_mfma32")) { g_fwd_mfma32 = value ? 1 : 0; return HX_OK; }
   if (!strcmp(name, "fwd_ablate")) { g_fwd_ablate = value; return HX_OK; }
+  if (!strcmp(name, "fwd_persistent")) { g_fwd_persistent = value; return HX_OK; }
+  if (!strcmp(name, "fwd_priority")) { g_fwd_priority = value; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
+
+void fwd_set_stamps(void* buf) { g_fwd_stamps = reinterpret_cast<unsigned long long*>(buf); }
 
 bool fwd_supported(int head_dim) {
   return head_dim == 32 || head_dim == 64 || head_dim == 96 || head_dim == 128 || head_dim == 256;

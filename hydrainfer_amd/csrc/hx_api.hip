@@ -16,6 +16,7 @@ int decode_set_option(const char* name, int value);
 int gemm_set_option(const char* name, int value);
 int fwd_set_option(const char* name, int value);
 int xreg_set_option(const char* name, int value);
+void fwd_set_stamps(void* buf);
 #if HX_EXPERIMENTS   // `make EXPERIMENTS=1`: rejected experiments kept measurable (not in the default library)
 int decode4_set_option(const char* name, int value);
 bool decode4_applies(const AttnParams& p, int batch, int head_dim, int n_cus);
@@ -55,6 +56,11 @@ extern "C" int hx_debug_set_option(const char* name, int value) {
 #endif
   return rc;
 }
+
+#if HX_EXPERIMENTS
+// time stamps of the persistent prefill kernel: 512 words per workgroup (see attn_fwd.hip, STAMPS); null switches them off
+extern "C" int hx_debug_fwd_stamps(void* buf) { fwd_set_stamps(buf); return HX_OK; }
+#endif
 
 extern "C" const char* hx_strerror(int status) {
   switch (status) {
@@ -202,6 +208,8 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.causal = a->causal;
   p.xcd_remap = g_fwd_xcd;
   p.wg_priority = 0;
+  p.n_tile_slots = 0;
+  p.stamps = nullptr;
   p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
   // flash_api.cpp:93-111
   if (a->flags & ~HX_ATTN_LOCAL_WINDOW) return HX_ERR_UNSUPPORTED;

@@ -7,6 +7,7 @@
  *   "decode_hpw4" option      — four heads per decode-attention workgroup (attn_decode4.hip: -4 % standalone,
  *                              +-0 in the decode step)
  *   hx_debug_stream_read / hx_debug_paged_read — access-shape probes
+ *   hx_debug_fwd_stamps       — in-kernel time stamps of the persistent prefill attention kernel (tools/fwd_timeline.py)
  */
 #ifndef HYDRA_HIP_EXPERIMENTAL_H
 #define HYDRA_HIP_EXPERIMENTAL_H
@@ -29,6 +30,10 @@ int hx_debug_stream_read(const void* p, int64_t bytes, int variant, int64_t pitc
 int hx_debug_paged_read(const void* kbase, const void* vbase, const int32_t* table, int n_seq, int n_heads,
                         int tiles, int64_t page_bytes, int row_bytes, int heads_per_wg, int waves, int depth,
                         int n_splits, float* sink, hx_stream stream);
+
+/* measurement aid: while `buf` is non-null, bf16 / head_dim 128 / paged launches of the persistent prefill attention
+ * kernel write (100 MHz time << 8 | event) words, 512 per workgroup, into it (events: attn_fwd.hip, STAMPS) */
+int hx_debug_fwd_stamps(void* buf);
 
 #ifdef __cplusplus
 }

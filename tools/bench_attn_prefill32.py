@@ -47,15 +47,22 @@ cases = {"prefill 4x704": paged(4, 704, 704), "prefill 1x704": paged(1, 704, 704
          "chunk 1x2048 of 2048": paged(1, 2048, 2048), "chunk 3x683 of 704": paged(3, 683, 704),
          "chunk 2048 of 4096": paged(1, 2048, 4096), "clip 1x577 d64": dense(1), "clip 8x577 d64": dense(8)}
 l = _lib.lib()
+# (label, options): the 16x16x32 kernel, the 32x32x16 kernel with one workgroup per item, its persistent form
+variants = [("16x16x32", {"fwd_mfma32": 0}), ("32x32x16 per item", {"fwd_persistent": 0}),
+            ("persistent", {}), ("persistent prio 0", {"fwd_priority": 0}), ("persistent prio 1", {"fwd_priority": 1})]
+if len(sys.argv) > 1:
+    variants = [v for v in variants if v[0] in sys.argv[1].split(",")] or variants
+defaults = {"fwd_mfma32": 1, "fwd_persistent": 1, "fwd_priority": -1}
 for name, (fn, flops, out) in cases.items():
-    res = []
-    outs = []
-    for v in (0, 1):
-        l.hx_debug_set_option(b"fwd_mfma32", v)
+    res, outs = [], []
+    for label, opts in variants:
+        for k, v in {**defaults, **opts}.items():
+            l.hx_debug_set_option(k.encode(), v)
         us = timeit(fn)
         fn(); torch.cuda.synchronize()
         outs.append(out.float().clone())
-        res.append(f"{'32x32x16' if v else '16x16x32'} {us:7.1f} us {flops / us / 1e6:5.0f} TF/s")
-    err = (outs[0] - outs[1]).abs().max().item()
-    print(f"{name:22s} {res[0]} | {res[1]} | max |diff| {err:.4f}", flush=True)
-l.hx_debug_set_option(b"fwd_mfma32", 1)
+        res.append(f"{label} {us:6.1f} us {flops / us / 1e6:4.0f} TF")
+    err = max((o - outs[0]).abs().max().item() for o in outs)
+    print(f"{name:22s} " + " | ".join(res) + f" | max |diff| {err:.4f}", flush=True)
+for k, v in defaults.items():
+    l.hx_debug_set_option(k.encode(), v)
