@@ -38,15 +38,22 @@ l.hx_debug_fwd_stamps(None)
 a = buf.cpu().numpy().reshape(512, 512)
 t0 = min(int(r[0]) >> 8 for r in a if r[0])
 ends, pairs, per_wg = [], {}, []
+clocks = []
 for wg, r in enumerate(a):
-    ev = [(int(x) & 255, ((int(x) >> 8) - t0) / 100.0) for x in r if x]
+    raw = [(int(x) & 255, int(x) >> 8) for x in r if x]
+    cyc = dict((e, x) for e, x in raw if e in (30, 31))
+    ev = [(e, (x - t0) / 100.0) for e, x in raw if e not in (30, 31)]
     if not ev:
         continue
+    if 30 in cyc and 31 in cyc:      # shader-clock cycles per 100 MHz tick between kernel entry and the last store
+        clocks.append((cyc[31] - cyc[30]) / max(1e-9, (ev[-1][1] - ev[0][1])) / 1e3)
     ends.append(ev[-1][1])
     for (e0, x0), (e1, x1) in zip(ev, ev[1:]):
         pairs.setdefault((e0, e1), []).append(x1 - x0)
     per_wg.append((wg, ev))
 print(f"{B} x {n} of {kv}: {len(per_wg)} workgroups, last stamp at {max(ends):.2f} us, median {np.median(ends):.2f}, first {min(ends):.2f}")
+if clocks:
+    print(f"shader clock over the workgroups' lifetimes: median {np.median(clocks):.2f} GHz (min {min(clocks):.2f}, max {max(clocks):.2f})")
 tot = sum(sum(v) for v in pairs.values())
 for k, v in sorted(pairs.items(), key=lambda kv: -sum(kv[1])):
     print(f"  {k[0]:3d} -> {k[1]:3d}: n {len(v):6d}  mean {np.mean(v):6.2f} us  p90 {np.percentile(v, 90):6.2f}  share {100 * sum(v) / tot:5.1f} %")
