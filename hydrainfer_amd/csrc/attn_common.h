@@ -31,13 +31,6 @@ __device__ __forceinline__ u16x4 lds_tr_read(const char* lds_ptr) {
   return __builtin_bit_cast(u16x4, r);
 }
 
-// the same from a 32-bit LDS address
-__device__ __forceinline__ u16x4 lds_tr_read_at(uint32_t lds_addr) {
-  typedef __attribute__((address_space(3))) hx_s16x4_t lds_s4;
-  hx_s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(size_t)lds_addr);
-  return __builtin_bit_cast(u16x4, r);
-}
-
 // Finite "minus infinity" for running maxima: keeps exp2(m_old - m_new) == 1 when a
 // lane group has not seen any unmasked key yet (no NaN from inf - inf).
 #define HX_NEG_BIG (-1.0e30f)

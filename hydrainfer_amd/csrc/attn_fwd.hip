@@ -655,20 +655,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
           for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
         m = m_new;
       }
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      f32x2 ps2 = {0.f, 0.f};
-      const f32x2 sc2 = {p.scale_log2, p.scale_log2}, mn2 = {-m_new, -m_new};
+      // (single-instruction fma / add: a packed f32 instruction beside MFMAs costs more than the two it replaces —
+      // MI355X_MICROARCH.md, per-instruction constants; the file is compiled without the SLP vectorizer for the same reason)
+      float pa = 0.f, pb = 0.f;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2 x = f32x2{s[u][r], s[u][r + 1]} * sc2 + mn2;      // v_pk_fma_f32
-          const f32x2 e = {fast_exp2(x[0]), fast_exp2(x[1])};
-          ps2 += e;                                                      // v_pk_add_f32
-          pf[u][r >> 3][r & 7] = T::from_float(e[0]);
-          pf[u][r >> 3][(r & 7) + 1] = T::from_float(e[1]);
+          const float e0 = fast_exp2(fmaf(s[u][r], p.scale_log2, -m_new));
+          const float e1 = fast_exp2(fmaf(s[u][r + 1], p.scale_log2, -m_new));
+          pa += e0;
+          pb += e1;
+          pf[u][r >> 3][r & 7] = T::from_float(e0);
+          pf[u][r >> 3][(r & 7) + 1] = T::from_float(e1);
         }
-      l += ps2[0] + ps2[1];
+      l += pa + pb;
       }
       if (ABL & 2) {
 #pragma unroll
@@ -751,15 +752,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
 // Items are dealt out statically, in snake order over the length-sorted item list (round r: item r G + i to workgroup
 // i, the next round backwards), inside the XCD whose L2 holds that head's K / V.
 // ---------------------------------------------------------------------------------------------
-// body(integral_constant<int, 0>) ... body(integral_constant<int, N - 1>)
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<N, I + 1>(f);
-  }
-}
-
 // A uniform value the compiler may not reason about: what is derived from it (strides times constants, the reciprocal
 // of a divisor) is computed where it is used instead of once at kernel entry and then kept, or spilled, across the
 // persistent loop.
@@ -835,11 +827,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
   int* items = tb_g + ((n_groups + 1 + 3) & ~3);                        // [n_rounds][REC], 16-byte aligned
   const int n_rounds = (p.n_tile_slots * p.n_heads + (int)gridDim.x - 1) / (int)gridDim.x;
   {
+    // the per-sequence arrays first, into the (still unused) tile images: one round trip to global memory instead of one
+    // per step of the decode (group counts -> the group's offsets -> the sequence's offsets -> its pages: 3.3 us in front
+    // of the first request at 4 x 704 tokens)
+    int* sq = reinterpret_cast<int*>(smem);          // cu_q[0 .. batch]
+    int* sk = sq + p.batch + 1;                      // cu_k[0 .. batch]
+    int* sb = sk + p.batch + 1;                      // cu_block_lens[0 .. batch - 1]
+    for (int i = threadIdx.x; i <= p.batch; i += 256) {
+      sq[i] = p.cu_q[i];
+      sk[i] = p.cu_k[i];
+      if (PAGED && i < p.batch) sb[i] = p.cu_block_lens[i];
+    }
+    __syncthreads();
     for (int g = threadIdx.x; g < n_groups; g += 256) {
       int n = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        n += (p.cu_q[min(4 * g + i + 1, p.batch)] - p.cu_q[min(4 * g + i, p.batch)] + TQ - 1) / TQ;
+        n += (sq[min(4 * g + i + 1, p.batch)] - sq[min(4 * g + i, p.batch)] + TQ - 1) / TQ;
       tb_g[g] = n;
     }
     __syncthreads();
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       int tl[4], max_tiles = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        tl[i] = (p.cu_q[min(4 * lo + i + 1, p.batch)] - p.cu_q[min(4 * lo + i, p.batch)] + TQ - 1) / TQ;
+        tl[i] = (sq[min(4 * lo + i + 1, p.batch)] - sq[min(4 * lo + i, p.batch)] + TQ - 1) / TQ;
         max_tiles = max(max_tiles, tl[i]);
       }
       int mblk = -1, b = 0;
@@ -908,13 +912,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
         }
       }
       if (mblk < 0) continue;
-      const int q_start = p.cu_q[b], q_len = p.cu_q[b + 1] - q_start;
-      const int k_start = p.cu_k[b], kv_len = p.cu_k[b + 1] - k_start;
+      const int q_start = sq[b], q_len = sq[b + 1] - q_start;
+      const int k_start = sk[b], kv_len = sk[b + 1] - k_start;
       if (q_len <= 0) continue;
       // query tiles aligned to the END of the sequence (see attn_fwd32_kernel)
       const int q_row0_wg = q_len - ((q_len + TQ - 1) / TQ - mblk) * TQ;
       const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + TQ - 1, q_len - 1) + kv_len - q_len) : kv_len - 1;
-      const int bt_off = PAGED ? p.cu_block_lens[b] : 0;
+      const int bt_off = PAGED ? sb[b] : 0;
       rec[1] = h; rec[2] = q_row0_wg; rec[3] = q_start; rec[4] = q_len; rec[5] = k_start; rec[6] = kv_len; rec[7] = bt_off;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -954,7 +958,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
 
   // ---- per-item state: the uniform part lives in `cur`, the per-lane part here
   Work cur;
-  int q_row0 = 0, limit_c = 0, last_key = 0, shift = 0, n_tiles = 0, n_w = 0;
+  int q_row0 = 0, limit_c = 0, last_key_wave = 0, last_key = 0, shift = 0, t_last = 0;
   const u16 *kbase = nullptr, *vbase = nullptr;
   c_i32* bt_s = nullptr;
   auto setup = [&](const Work& wk) __attribute__((always_inline)) {
@@ -962,32 +966,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     q_row0 = wk.q_row0_wg + w * 32;
     shift = wk.kv_len - wk.q_len;
     limit_c = P->causal ? min(wk.kv_len - 1, q_row0 + c + shift) : wk.kv_len - 1;
-    const int last_key_wave = q_row0 + 31 < 0 ? -1 : P->causal ? min(wk.kv_len - 1, q_row0 + 31 + shift) : wk.kv_len - 1;
-    n_w = last_key_wave >= 0 ? last_key_wave / KT + 1 : 0;          // tiles this wave takes part in
+    last_key_wave = q_row0 + 31 < 0 ? -1 : P->causal ? min(wk.kv_len - 1, q_row0 + 31 + shift) : wk.kv_len - 1;
     last_key = wk.kv_len - 1;
-    n_tiles = wk.n_tiles;
+    t_last = wk.n_tiles - 1;
     const int hk = wk.h / sfresh(P->group);
     kbase = reinterpret_cast<const u16*>(P->k) + (int64_t)hk * P->k_head_stride;
     vbase = reinterpret_cast<const u16*>(P->v) + (int64_t)hk * P->v_head_stride;
     bt_s = PAGED ? (c_i32*)(P->block_table + wk.bt_off) : nullptr;
   };
 
-  // ---- LDS: K0 | K1 | V0 | V1, one 64-key tile each.  K runs one tile ahead of V (the tile pipeline below): step t reads
-  // K(t + 1) from K[(t + 1) & 1] and V(t) from V[t & 1], and starts with the requests for K(t + 2) and V(t + 1) into the
-  // two buffers that step t - 1 was the last to read.  Q rows and O rows pass through the K pair resp. the V pair
-  // between items (32 rows x 4 waves fill a pair exactly).
-  constexpr uint32_t VBASE = 2 * KTILE;
   // ---- K / V tile staging by LDS-DMA (see attn_fwd32_kernel).  The address of a request is a wave-uniform base — page,
   // first row of the wave's 16-key group, the instruction's rows: scalar arithmetic — plus a per-lane offset that never
   // changes (row inside the instruction, swizzled chunk): the vector ALU is not involved, except in a sequence's last
   // group, whose rows past the last key are clamped to it.
-  auto lookup_page = [&](int t) __attribute__((always_inline)) -> int {
-    if (!PAGED) return 0;
-    return bt_s[__builtin_amdgcn_readfirstlane(page_slot(min(t * KT + 16 * w, last_key), p.block_size, p.block_shift))];
+  int page_next = 0;
+  auto lookup_page = [&](int t) __attribute__((always_inline)) {
+    if (PAGED) page_next = bt_s[__builtin_amdgcn_readfirstlane(page_slot(min(t * KT + 16 * w, last_key), p.block_size, p.block_shift))];
   };
-  // (kswz(RPI j + r) = kswz(r) ^ 4 j for both head sizes: instruction j's chunk offset is instruction 0's ^ 64 j)
-  const uint32_t koff_row = (uint32_t)st_r4 * (uint32_t)p.k_row_stride * 2u, koff_ch = 16u * (uint32_t)(st_ch ^ kswz(st_r4));
-  uint32_t voff;
+  uint32_t koff[NL], voff;
+#pragma unroll
+  for (int j = 0; j < NL; ++j)
+    koff[j] = (uint32_t)st_r4 * (uint32_t)p.k_row_stride * 2u + 16u * (uint32_t)(st_ch ^ kswz(RPI * j + st_r4));
   voff = (uint32_t)st_r4 * (uint32_t)p.v_row_stride * 2u + 16u * (uint32_t)(st_ch ^ vswz(st_r4));   // vswz(RPI j + r) = vswz(r)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -1000,57 +999,60 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(addr), "s"(lds) : "memory", "m0");
   };
 #pragma clang diagnostic pop
-  // this wave's 16-key group of tile t: its K rows (is_v = false) or its V rows into buffer t & 1
-  auto request_half = [&](int t, int page, auto v_tag) __attribute__((always_inline)) {
-    constexpr bool IS_V = decltype(v_tag)::value;
+  auto request_tile = [&](int t, int img) __attribute__((always_inline)) {
     const int g0 = min(t * KT + 16 * w, last_key);      // first key of the wave's group, clamped: uniform
     const int r_max = last_key - g0;                     // rows of the group that exist (>= 0)
-    const int64_t rs = sfresh(IS_V ? p.v_row_stride : p.k_row_stride);
-    int64_t eb;
-    if (PAGED) eb = (int64_t)page * (IS_V ? p.v_block_stride : p.k_block_stride) + (int64_t)page_row(g0, p.block_size, p.block_shift) * rs;
-    else eb = (int64_t)(cur.k_start + g0) * rs;
-    const uint32_t d = __builtin_amdgcn_readfirstlane(lds0 + (IS_V ? VBASE : 0u) + (uint32_t)((t & 1) * KTILE + 16 * w * RSK));
-    const u16* bp = (IS_V ? vbase : kbase) + eb;
+    int64_t kb, vb;
+    const int64_t krs = sfresh(p.k_row_stride), vrs = sfresh(p.v_row_stride);
+    if (PAGED) {
+      const int rowg = page_row(g0, p.block_size, p.block_shift);
+      kb = (int64_t)page_next * p.k_block_stride + (int64_t)rowg * krs;
+      vb = (int64_t)page_next * p.v_block_stride + (int64_t)rowg * vrs;
+    } else {
+      kb = (int64_t)(cur.k_start + g0) * krs;
+      vb = (int64_t)(cur.k_start + g0) * vrs;
+    }
+    const uint32_t kd = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(img * IMG + 16 * w * RSK));
+    const uint32_t vd = kd + KTILE;
     if (r_max >= 15) {
+      const u16* kp = kbase + kb;
+      const u16* vp = vbase + vb;
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        dma(bp, IS_V ? voff : koff_row + (koff_ch ^ (64u * j)), d + 1024u * j);
-        bp = sfresh(bp + RPI * rs);           // (step by step: no table of j x stride products)
+        dma(kp, koff[j], kd + 1024u * j);
+        dma(vp, voff, vd + 1024u * j);
+        kp = sfresh(kp + RPI * krs);         // (step by step: no table of j x stride products)
+        vp = sfresh(vp + RPI * vrs);
       }
     } else {
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int r4 = ln / LPR, ch = ln % LPR;
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        const int R = RPI * j + r4;
+        const int R = RPI * j + st_r4;
         const uint32_t r = (uint32_t)min(R, r_max);                  // rows past the last key repeat it
-        dma_flat(bp + r * (uint32_t)rs + 8 * (ch ^ (IS_V ? vswz(R) : kswz(R))), d + 1024u * j);
+        dma_flat(kbase + kb + r * (uint32_t)p.k_row_stride + 8 * (st_ch ^ kswz(R)), kd + 1024u * j);
+        dma_flat(vbase + vb + r * (uint32_t)p.v_row_stride + 8 * (st_ch ^ vswz(R)), vd + 1024u * j);
       }
     }
   };
-  using IsK = std::false_type;
-  using IsV = std::true_type;
-  // the 32 Q rows of this wave for item wk -> rows 32 w .. of the buffer pair at `base` (K's swizzle), whole rows per instruction
-  auto request_q = [&](const Work& wk, uint32_t base) __attribute__((always_inline)) {
+  // the 32 Q rows of this wave for item wk -> rows 32 w .. of image img (K's swizzle), whole rows per instruction
+  auto request_q = [&](const Work& wk, int img) __attribute__((always_inline)) {
     c_params* P = kargs();
     const u16* qbase = reinterpret_cast<const u16*>(P->q) + (int64_t)wk.h * D;
-    const uint32_t qd = __builtin_amdgcn_readfirstlane(lds0 + base + (uint32_t)(w * 32 * RSK));
-    int ln = lane;                          // (derived here, not kept across the tile loop: see the epilogue)
-    asm volatile("" : "+v"(ln));
-    const int r4 = ln / LPR, ch = ln % LPR;
+    const uint32_t qd = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(img * IMG + w * 32 * RSK));
 #pragma unroll
     for (int j = 0; j < NQI; ++j) {
-      const int R = RPI * j + r4;
+      const int R = RPI * j + st_r4;
       const int qr = min(max(wk.q_row0_wg + w * 32 + R, 0), wk.q_len - 1);
-      dma_flat(qbase + (int64_t)(wk.q_start + qr) * P->q_row_stride + 8 * (ch ^ kswz(R)), qd + 1024u * j);
+      dma_flat(qbase + (int64_t)(wk.q_start + qr) * P->q_row_stride + 8 * (st_ch ^ kswz(R)), qd + 1024u * j);
     }
   };
   auto tiles_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
 
   u16x8 qf[KS];
-  auto read_q = [&](uint32_t base) __attribute__((always_inline)) {
-    const char* qb = smem + base + w * 32 * RSK;
+  auto read_q = [&](int img) __attribute__((always_inline)) {
+    const char* qb = smem + img * IMG + w * 32 * RSK;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u16x8*>(qb + c * RSK + 16 * ((2 * ks + hi) ^ kswz(c)));
   };
@@ -1066,23 +1068,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     l = 0.f;
   };
 
-  // ---- first item: Q through the V pair (free until the first step requests V(0)), K(0) beside it
+  // ---- first item
   ri = next_item(0);
   if (ri >= n_rounds) return;
   read_item(ri, cur);
   stamp(5);
   setup(cur);
-  int pg1 = __builtin_amdgcn_readfirstlane(items[ri * REC + 8 + w]);     // page of this wave's keys in tile t + 1 / t + 2
-  request_q(cur, VBASE);
-  request_half(0, pg1, IsK{});
+  request_q(cur, 1);
+  page_next = __builtin_amdgcn_readfirstlane(items[ri * REC + 8 + w]);
+  request_tile(0, 0);
   stamp(6);
   int rn = next_item(ri + 1);                 // the round of the item after this one (n_rounds: none)
-  int pg2 = lookup_page(1);
+  lookup_page(min(1, t_last));
   reset_acc();
   stamp(2);
   tiles_landed();
   stamp(3);
-  read_q(VBASE);
+  read_q(1);
   // The two workgroups of a CU at DIFFERENT priorities (see attn_fwd32_kernel), flipped at every item so that neither
   // of the two falls behind for good.
   uint32_t* prio_flag = reinterpret_cast<uint32_t*>(smem + 2 * IMG);
@@ -1092,21 +1094,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
   bool favoured = use_prio && *prio_flag;
   if (favoured) __builtin_amdgcn_s_setprio(3);
 
-  // LDS read addresses (byte offsets inside a tile buffer): the K fragment of k-step ks for key row c; the transposed
-  // read of a 4-row x 32-dim block of V (see attn_fwd32_kernel) for output block db
-  // (the fragment of k-step ks sits at kaddr0 ^ 32 ks: (2 ks + hi) ^ kz = 2 ks ^ (hi ^ kz), and neither the row offset nor
-  // the dynamic LDS base — 0: the kernel has no static LDS — reaches into bits 5 .. 7)
-  // (likewise the transposed read of output block db: vaddr0 ^ 64 db — the lane's row and its 8 bytes inside the
-  // 64-byte quarter stay clear of bits 6 and 7)
-  uint32_t kaddr0, vaddr0;
-  {
-    const int kz = kswz(c);
-    kaddr0 = lds0 + (uint32_t)(c * RSK + 16 * (hi ^ kz));
-    const int tr_q = (lane & 15) >> 2, tr_pp = lane & 3, tr_half = (lane >> 4) & 1;
-    const int tr_off = (4 * hi + tr_q) * RSV + (16 * tr_half + 4 * tr_pp) * 2;
-    const int tr_x = vswz(tr_q) >> 2;
-    vaddr0 = lds0 + VBASE + (uint32_t)(tr_off + 64 * tr_x);
-  }
+  // transposed-read lane address inside a 4-row x 32-dim block (see attn_fwd32_kernel)
+  const int tr_q = (lane & 15) >> 2, tr_pp = lane & 3, tr_half = (lane >> 4) & 1;
+  const int tr_off = (4 * hi + tr_q) * RSV + (16 * tr_half + 4 * tr_pp) * 2;
+  const int tr_x = vswz(tr_q) >> 2;
 
   auto half_max = [](float x) __attribute__((always_inline)) {      // max with lane ^ 32, without the LDS crossbar
     const uint32_t u = __builtin_bit_cast(uint32_t, x);
@@ -1119,210 +1110,141 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
   };
 
-  // Softmax of one 32-key sub-tile, cut into 8 units so that it can be dealt out over the MFMA slots of a block:
-  // scores s (lane (c, hi): query c, keys key0 + (r & 3) + 8 (r >> 2) + 4 hi) -> P rounded to T, in the layout of the
-  // P V product's B operand; running maximum m and sum l updated.  No branch: the lazy running maximum (a row keeps its
-  // reference until a score exceeds it by more than 2^8; see attn_fwd32_kernel) leaves `alpha` = 1 for the rows that keep
-  // theirs, and the caller rescales the accumulator — after the P V product of the sub-tile BEFORE this one — only when
-  // `grown` says that some row moved.
-  //   unit 0, 1: mask, maximum of scores 0 .. 7 / 8 .. 15; 1 also: exchange with lane ^ 32, new reference, alpha
-  //   unit 2 .. 5: four scores each: exp2(s * scale - m), sums, conversion;  unit 6: l = l * alpha + sum
-  struct Sm { float mx, m_new, alpha, sa, sb; bool grown; };
-  auto sm_unit = [&](auto unit_tag, f32x16& s, int key0, bool masked, u16x8 (&pf)[2], Sm& st) __attribute__((always_inline)) {
-    constexpr int U = decltype(unit_tag)::value;
-    if constexpr (U == 0 || U == 1) {
-      if (masked) {                   // (uniform: a diagonal tile)
-#pragma unroll
-        for (int r = 8 * U; r < 8 * U + 8; ++r) {
-          const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          s[r] = key > limit_c ? -INFINITY : s[r];
-        }
-      }
-      float mx = U == 0 ? s[0] : st.mx;
-#pragma unroll
-      for (int r = U == 0 ? 1 : 8; r < 8 * U + 8; ++r) mx = fmaxf(mx, s[r]);
-      st.mx = mx;
-    }
-    if constexpr (U == 1) {
-      const float mx = half_max(st.mx);
-      const float m_cand = fmaxf(m, mx * p.scale_log2);
-      const bool grow = m_cand > m + 8.0f;
-      st.m_new = grow ? m_cand : m;
-      st.alpha = fast_exp2(m - st.m_new);
-      st.grown = __builtin_amdgcn_ballot_w64(grow) != 0;
-      m = st.m_new;
-      st.sa = 0.f;
-      st.sb = 0.f;
-    }
-    if constexpr (U >= 2 && U <= 5) {
-#pragma unroll
-      for (int r = 4 * (U - 2); r < 4 * (U - 2) + 4; r += 2) {
-        const float e0 = fast_exp2(fmaf(s[r], p.scale_log2, -st.m_new));
-        const float e1 = fast_exp2(fmaf(s[r + 1], p.scale_log2, -st.m_new));
-        st.sa += e0;
-        st.sb += e1;
-        pf[r >> 3][r & 7] = T::from_float(e0);
-        pf[r >> 3][(r & 7) + 1] = T::from_float(e1);
-      }
-    }
-    if constexpr (U == 6) l = fmaf(l, st.alpha, st.sa + st.sb);
-  };
-  auto rescale = [&](float alpha) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
-  };
-
-  // ---- the tile pipeline of a wave.  Sub-tiles (32 keys) in key order: i = 2 tile + u.  Three stages per sub-tile —
-  // S_i = K_i Q^T (KS MFMAs), P_i = softmax(S_i) (vector ALU), O += V_i^T P_i (KS MFMAs) — and step t runs
-  //     block 1:  S(t+1, 0)   beside   softmax of S(t, 1)   beside   O += V(t, 0) P(t, 0)
-  //     block 2:  S(t+1, 1)   beside   softmax of S(t+1, 0) beside   O += V(t, 1) P(t, 1)
-  // so that in every block 2 KS MFMAs of two independent chains stand beside one sub-tile's ~80 vector instructions of
-  // the SAME wave: the matrix pipe no longer depends on the other workgroup of the CU being in the opposite phase
-  // (which it was in 30 % of the MFMA cycles, profiles/r3_attn_prefill_pmc.json: a tile cost its MFMA time plus its
-  // vector time).  A block is KS slots, each fenced for the compiler's scheduler (sched_barrier): the LDS reads of a
-  // later slot's operands (K fragment 4 slots ahead, V fragments 2 ahead: the streams run through both blocks), 8 / KS
-  // units of the softmax, one MFMA of each chain.  Carried from step to step: S(t+1, 1) in s1 and P(t+1, 0) in pf0.
-  // The first step of an item (t = -1) has no V side, the last (t = n - 1) no K side: instantiations of their own, as is
-  // the masked (diagonal) form.
-  f32x16 s1;
-  u16x8 pf0[2];
-  auto body = [&](int t, auto qk_tag, auto pv_tag, bool mask1, bool mask0) __attribute__((always_inline)) {
-    constexpr bool QK = decltype(qk_tag)::value, PV = decltype(pv_tag)::value;
-    constexpr int KD = 4, VD = 2;                         // prefetch distances (slots)
-    const uint32_t kimg = (uint32_t)((t + 1) & 1) * KTILE, vimg = (uint32_t)(t & 1) * VTILE;
-    u16x8 kf[KD + 1];                                     // ring: slot q's fragment in kf[q % (KD + 1)]
-    u16x4 vlo[VD + 1], vhh[VD + 1];
-    auto k_read = [&](auto q_tag) __attribute__((always_inline)) {
-      constexpr int Q = decltype(q_tag)::value;           // 0 .. 2 KS - 1: sub-tile Q / KS, k-step Q % KS
-      if constexpr (QK && Q < 2 * KS)
-        kf[Q % (KD + 1)] = *reinterpret_cast<const __attribute__((address_space(3))) u16x8*>(
-            (size_t)((kaddr0 ^ (uint32_t)(32 * (Q % KS))) + kimg + (uint32_t)((Q / KS) * 32 * RSK)));
-    };
-    auto v_read = [&](auto j_tag) __attribute__((always_inline)) {
-      constexpr int J = decltype(j_tag)::value;           // 0 .. 2 KS - 1: sub-tile J / KS, (k2, db) = (J % KS / NDB, J % NDB)
-      if constexpr (PV && J < 2 * KS) {
-        const uint32_t va = (vaddr0 ^ (uint32_t)(64 * (J % NDB))) + vimg + (uint32_t)((32 * (J / KS) + 16 * ((J % KS) / NDB)) * RSV);
-        vlo[J % (VD + 1)] = lds_tr_read_at(va);
-        vhh[J % (VD + 1)] = lds_tr_read_at(va + 8 * RSV);
-      }
-    };
-    f32x16 s0;
-    u16x8 pf1[2];
-    Sm st1, st0;
-    static_for<KD>([&](auto q) { k_read(q); });
-    static_for<VD>([&](auto j) { v_read(j); });
-    static_for<2 * KS>([&](auto slot_tag) {
-      constexpr int SL = decltype(slot_tag)::value, BL = SL / KS, I = SL % KS;      // block, slot of the block
-      k_read(std::integral_constant<int, SL + KD>{});
-      v_read(std::integral_constant<int, SL + VD>{});
-      static_for<8 / KS>([&](auto uu) {
-        using Unit = std::integral_constant<int, I * (8 / KS) + decltype(uu)::value>;
-        if constexpr (BL == 0) { if constexpr (PV) sm_unit(Unit{}, s1, t * KT + 32, mask1, pf1, st1); }
-        else { if constexpr (QK) sm_unit(Unit{}, s0, (t + 1) * KT, mask0, pf0, st0); }
-      });
-      if constexpr (QK) {
-        f32x16& sd = BL == 0 ? s0 : s1;
-        if constexpr (I == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sd[r] = 0.f;
-        }
-        sd = Mfma32<T>::mma(kf[SL % (KD + 1)], qf[I], sd);
-      }
-      if constexpr (PV) {
-        const u16x4 lo = vlo[SL % (VD + 1)], hh = vhh[SL % (VD + 1)];
-        u16x8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hh[0]; vf[5] = hh[1]; vf[6] = hh[2]; vf[7] = hh[3];
-        if constexpr (BL == 0) acc[I % NDB] = Mfma32<T>::mma(vf, pf0[I / NDB], acc[I % NDB]);
-        else acc[I % NDB] = Mfma32<T>::mma(vf, pf1[I / NDB], acc[I % NDB]);
-      }
-      if constexpr (I == KS - 1) {
-        // (P is first used behind the branch below: without a use in front of it the compiler sinks the whole softmax
-        // out of the block, to the other side of the branch)
-        if constexpr (BL == 0) { if constexpr (PV) asm volatile("" :: "v"(pf1[0]), "v"(pf1[1]), "v"(l)); }
-        else { if constexpr (QK) asm volatile("" :: "v"(pf0[0]), "v"(pf0[1]), "v"(l)); }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (I == KS - 1) {
-        // everything accumulated so far stood on the reference that the softmax of this block left behind
-        if constexpr (BL == 0) { if constexpr (PV) { if (st1.grown) rescale(st1.alpha); } }
-        else { if constexpr (QK) { if (st0.grown) rescale(st0.alpha); } }
-      }
-    });
-  };
-  using Yes = std::true_type;
-  using No = std::false_type;
-
-  // ---- the workgroup's steps: t = -1 .. n_tiles - 1 for every item.  Every wave takes part in every step's requests
-  // and barrier; what it computes in between is its own: nothing while it has no rows (n_w = 0), else the first step
-  // (K side only), n_w - 1 full steps, its last step (V side only), and nothing again while the other waves finish the
-  // tiles past its rows' diagonal.  (One loop per form: with all forms inside one loop the compiler kept two copies of the
-  // 64 accumulator registers and spilled.)
-  int t = -1;
-  auto step_begin = [&]() __attribute__((always_inline)) {
+  int t = 0;
+  // one 64-key tile of the current item, in image PAR; returns true when the workgroup has no more work
+  auto tile_step = [&](auto par_tag) __attribute__((always_inline)) -> bool {
+    constexpr int PAR = decltype(par_tag)::value;
+    const bool last = t == t_last;
     stamp(10);
-    if (t < n_tiles - 1) {
-      if (t + 2 < n_tiles) request_half(t + 2, pg2, IsK{});
-      request_half(t + 1, pg1, IsV{});
+    if (!last) {
+      request_tile(t + 1, 1 - PAR);                     // lands under this tile's arithmetic
     } else if (rn < n_rounds) {
       Work nx;
       read_item(rn, nx);
-      request_q(nx, 0);                                  // both K buffers are free: the next item's Q rows
+      request_q(nx, 1 - PAR);                           // the free image takes the next item's Q rows
     }
-  };
-  auto step_end = [&]() __attribute__((always_inline)) {       // (the last step of an item ends in the seam instead)
-    stamp(11);
-    if (t < n_tiles - 1) {
-      pg1 = pg2;
-      pg2 = lookup_page(min(t + 3, n_tiles - 1));      // in front of the barrier's wait (see attn_fwd32_kernel)
-      tiles_landed();                                  // this wave's part of K(t + 2), V(t + 1) is in LDS
-      stamp(12);
-      __syncthreads();                                 // visible; everyone is done with the buffers of step t
-    }
-    ++t;
-  };
-  // the first key that some row of this wave does not see: a tile reaching it needs the mask
-  auto first_masked = [&]() __attribute__((always_inline)) { return min(last_key, p.causal ? q_row0 + shift : last_key) + 1; };
-  for (;;) {
-    if (n_w > 0) {
-      const int fm = first_masked();
-      step_begin();
-      body(t, Yes{}, No{}, false, KT > fm);
-      step_end();
-      while (t < n_w - 1) {
-        step_begin();
-        body(t, Yes{}, Yes{}, (t + 1) * KT > fm, (t + 2) * KT > fm);
-        step_end();
+    if (t * KT <= last_key_wave) {
+      const char* kt = smem + PAR * IMG;
+      const char* vt = kt + KTILE;
+      f32x16 s[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+      {
+        const char* krd = kt + c * RSK;
+        const int kz = kswz(c);
+        u16x8 kfa[KS], kfb[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kfa[ks] = *reinterpret_cast<const u16x8*>(krd + 16 * ((2 * ks + hi) ^ kz));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          kfb[ks] = *reinterpret_cast<const u16x8*>(krd + 32 * RSK + 16 * ((2 * ks + hi) ^ kz));
+          s[0] = Mfma32<T>::mma(kfa[ks], qf[ks], s[0]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[1] = Mfma32<T>::mma(kfb[ks], qf[ks], s[1]);
+        __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, KS, 0);
       }
-      step_begin();
-      body(t, No{}, Yes{}, (t + 1) * KT > fm, false);
-      step_end();
+      const bool interior = t * KT + KT - 1 <= min(last_key, p.causal ? q_row0 + shift : last_key);
+      float mx = HX_NEG_BIG;
+      u16x8 pf[2][2];
+      if (interior) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KT + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key > limit_c) s[u][r] = -INFINITY;
+            mx = fmaxf(mx, s[u][r]);
+          }
+      }
+      mx = half_max(mx);
+      // lazy running maximum (see attn_fwd32_kernel)
+      const float m_cand = fmaxf(m, mx * p.scale_log2);
+      const bool grow = m_cand > m + 8.0f;
+      float m_new = m;
+      if (__builtin_amdgcn_ballot_w64(grow)) {
+        m_new = grow ? m_cand : m;
+        const float alpha = fast_exp2(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+        m = m_new;
+      }
+      // (single-instruction fma / add: a packed f32 instruction beside MFMAs costs more than the two it replaces —
+      // MI355X_MICROARCH.md, per-instruction constants; the file is compiled without the SLP vectorizer for the same reason)
+      float pa = 0.f, pb = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float e0 = fast_exp2(fmaf(s[u][r], p.scale_log2, -m_new));
+          const float e1 = fast_exp2(fmaf(s[u][r + 1], p.scale_log2, -m_new));
+          pa += e0;
+          pb += e1;
+          pf[u][r >> 3][r & 7] = T::from_float(e0);
+          pf[u][r >> 3][(r & 7) + 1] = T::from_float(e1);
+        }
+      l += pa + pb;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const char* vrd = vt + (32 * u + 16 * k2) * RSV + tr_off;
+#pragma unroll
+          for (int db = 0; db < NDB; ++db) {
+            const u16x4 lo = lds_tr_read(vrd + 64 * (db ^ tr_x));
+            const u16x4 hh = lds_tr_read(vrd + 8 * RSV + 64 * (db ^ tr_x));
+            u16x8 vf;
+            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+            vf[4] = hh[0]; vf[5] = hh[1]; vf[6] = hh[2]; vf[7] = hh[3];
+            acc[db] = Mfma32<T>::mma(vf, pf[u][k2], acc[db]);
+          }
+        }
     }
-    while (t < n_tiles) {
-      step_begin();
-      step_end();
+    stamp(11);
+    if (!last) {
+      lookup_page(min(t + 2, t_last));     // the table entry for the next request, in front of the barrier's wait
+      tiles_landed();                      // this wave's part of tile t + 1 is in LDS
+      stamp(12);
+      __syncthreads();                     // tile t + 1 visible; everyone is done with tile t's image
+      ++t;
+      return false;
     }
-    // ---- the seam: the item is complete.  The K pair holds the next item's Q rows (this wave's own 32).
+    // ---- the seam: the item is complete.  Image 1 - PAR holds the next item's Q rows (this wave's own 32), image PAR
+    // the tile just used.
     tiles_landed();
     stamp(20);
     const bool has_next = rn < n_rounds;
-    if (has_next) read_q(0);
+    if (has_next) read_q(1 - PAR);
     const int e_q_row0 = q_row0;
     const int64_t e_row = (int64_t)cur.q_start + q_row0;
     const int e_h = cur.h;
-    __syncthreads();                       // everybody is done with all four buffers
+    __syncthreads();                       // everybody is done with both images
     stamp(21);
     if (has_next) {
       ri = rn;
       read_item(ri, cur);
       setup(cur);
-      pg1 = __builtin_amdgcn_readfirstlane(items[ri * REC + 8 + w]);      // looked up when the table was built
-      request_half(0, pg1, IsK{});         // in flight while the finished item's rows go out
+      page_next = __builtin_amdgcn_readfirstlane(items[ri * REC + 8 + w]);      // looked up when the table was built
+      request_tile(0, 1 - PAR);            // in flight while the finished item's rows go out
     }
     // O[query c][dim 32 db + 8 (r >> 2) + 4 hi + (r & 3)] = acc[db][r] / L, through LDS so that a store instruction
-    // writes whole rows (see attn_fwd32_kernel); this wave's 32 rows sit in the V pair
+    // writes whole rows (see attn_fwd32_kernel); this wave's 32 rows sit in image PAR
     {
       const float lr = half_sum(l);
       const float inv = (lr > 0.f) ? 1.0f / lr : 0.f;
@@ -1333,7 +1255,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int ec = ln & 31, ehi = ln >> 5, er4 = ln / LPR, ech = ln % LPR;
-        char* ob = smem + VBASE + w * 32 * RSO;
+        char* ob = smem + PAR * IMG + w * 32 * RSO;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -1364,22 +1286,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       }
     }
     stamp(22);
-    if (!has_next) { stamp_cycles(31); return; }
+    if (!has_next) { stamp_cycles(31); return true; }
     reset_acc();
-    t = -1;
+    t = 0;
     if (use_prio) {
       favoured = !favoured;
       if (favoured) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
     }
     rn = next_item(ri + 1);
-    pg2 = lookup_page(min(1, n_tiles - 1));
-    // K(0)'s requests are older than the O stores: when all NQI of them were issued (a wave whose 32 rows all exist),
-    // waiting for everything but the NQI youngest operations waits for the tile and not for the stores.
+    lookup_page(min(1, t_last));
+    // The first tile's requests are older than the O stores: when all NQI of them were issued (a wave whose 32 rows all
+    // exist), waiting for everything but the NQI youngest operations waits for the tile and not for the stores.
     stamp(23);
     if (e_q_row0 >= 0 && !STAMPS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NQI) : "memory");
     else tiles_landed();
     stamp(24);
     __syncthreads();
+    return false;
+  };
+  for (;;) {
+    if (tile_step(Set0{})) break;
+    if (tile_step(Set1{})) break;
   }
 }
 
@@ -1407,6 +1334,10 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   pp.wg_priority = (p.total_q / 128) * (int64_t)p.n_heads > 2 * (int64_t)fwd_n_cus() ? 1 : 0;   // more than two workgroups per CU
   if (g_fwd_priority >= 0) pp.wg_priority = g_fwd_priority;
   if (p.total_q == 0) return HX_OK;
+  const int per_item_priority = pp.wg_priority;
+  // (persistent workgroups: equal priorities — with the packed f32 arithmetic gone from the softmax, 32 x 704 tokens run
+  // in 223 us without and 235 us with the two priorities, 2048 of 4096 in 112.5 either way)
+  if (g_fwd_priority < 0) pp.wg_priority = 0;
   pp.n_tile_slots = (int32_t)(p.total_q / 128 + batch);
   const int64_t total = (int64_t)pp.n_tile_slots * p.n_heads;
   const int64_t g = std::min<int64_t>(total, 2 * (int64_t)fwd_n_cus());
@@ -1414,7 +1345,8 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   const size_t table = 4 * (size_t)((((batch + 3) / 4 + 1 + 3) & ~3) + 12 * ((total + g - 1) / g));
   // (else one workgroup per item: tables that do not fit; dense launches of equal items — the CLIP tower, 8 x 577:
   // 25.1 us per item against 27.4 — where the static deal puts the second items of a round on the same CUs)
-  if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED)) && 2 * (lds + table) <= 160 * 1024) {
+  if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED)) && 2 * (lds + table) <= 160 * 1024 &&
+      4 * (3 * (size_t)batch + 2) <= 2 * 64 * (2 * D + 2 * D)) {
     const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16 + table;
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32p_kernel<T, D, PAGED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1433,6 +1365,7 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
     hx::launcher(attn_fwd32p_kernel<T, D, PAGED>, dim3((unsigned)g, 1, 1), 256, lds, stream)(pp);
     return check_launch();
   }
+  pp.wg_priority = per_item_priority;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32_kernel<T, D, PAGED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
