@@ -812,6 +812,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     }
   };
   stamp_cycles(30);
+  if constexpr (STAMPS) {      // where the workgroup runs: HW_ID (CU_ID [11:8], SH_ID [12], SE_ID [15:13]) and XCC_ID
+    if (w == 0 && n_stamps < 512) {
+      const uint64_t v = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 40) |
+                         ((uint64_t)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 8) | 32u;
+      if (lane == 0) p.stamps[(size_t)blockIdx.x * 512 + n_stamps] = v;
+      ++n_stamps;
+    }
+  }
 
   // ---- the items of this workgroup: a table in LDS, built once.  Thread r decodes the item of round r — the r-th entry
   // of the snake walk over the item list —, all rounds at the same time.  (Decoded one at a time by every wave, through
@@ -872,15 +880,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       int* rec = items + r * REC;
       rec[0] = 0;
       int slot, h;
+      // Which of the round's items, longest first: the dispatcher gives every CU one workgroup before it gives any CU a
+      // second one (in-kernel HW_ID stamps, tools/fwd_timeline.py: workgroups wg and wg + n_cus share a CU, always), so
+      // the second workgroup of a CU takes the items from the short end — CU c gets the c-th longest and the c-th
+      // shortest of a round.  (In id order the two longest tiles of 2048 new tokens of 4096 met on one CU: 112 tile steps
+      // against 84 on the last CU, where every CU now has 98.)
       if (remap) {
         const int Gx = G / 8, Tx = total / 8, hp = gy / 8;      // XCD x runs workgroups x, x + 8, ...: hp heads each
-        const int x = wg % 8, j = wg / 8;
-        const int i = (r & 1) ? (r + 1) * Gx - 1 - j : r * Gx + j;
+        const int x = wg % 8, j = wg / 8, H = p.n_cus / 8;
+        const int pj = j < H ? j : Gx - 1 - (j - H);
+        const int i = (r & 1) ? (r + 1) * Gx - 1 - pj : r * Gx + pj;
         if (i >= Tx) continue;
         h = x * hp + i % hp;
         slot = i / hp;
       } else {
-        const int i = (r & 1) ? (r + 1) * G - 1 - wg : r * G + wg;
+        const int pw = wg < p.n_cus ? wg : G - 1 - (wg - p.n_cus);
+        const int i = (r & 1) ? (r + 1) * G - 1 - pw : r * G + pw;
         if (i >= total) continue;
         slot = i % n_slots;
         h = i / n_slots;
@@ -1085,13 +1100,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
   tiles_landed();
   stamp(3);
   read_q(1);
-  // The two workgroups of a CU at DIFFERENT priorities (see attn_fwd32_kernel), flipped at every item so that neither
-  // of the two falls behind for good.
-  uint32_t* prio_flag = reinterpret_cast<uint32_t*>(smem + 2 * IMG);
+  // Priority goes to the workgroup of a CU that holds the longer item.  Of the two workgroups of a CU the older one wins
+  // the arbitration for the vector issue slots anyway (stamps, 2048 new tokens of 4096: 1.5 us per tile step for the
+  // first-pass workgroups, 2.0 for their partners); the deal gives the first-pass workgroup of a CU the c-th longest item
+  // of an even round and the second-pass workgroup the c-th shortest, the other way round in odd rounds — so the
+  // launch ends with its longest items, and they are the ones to speed up, at the expense of partners that have time.
+  // wg_priority: 0 = equal priorities, 1 = as described.
   const bool use_prio = p.wg_priority != 0;
-  if (use_prio && threadIdx.x == 0) *prio_flag = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1;     // HW_ID.wave_id
+  const bool first_pass = (int)blockIdx.x < p.n_cus;
+  bool favoured = use_prio && (first_pass != ((ri & 1) != 0));
   __syncthreads();
-  bool favoured = use_prio && *prio_flag;
   if (favoured) __builtin_amdgcn_s_setprio(3);
 
   // transposed-read lane address inside a 4-row x 32-dim block (see attn_fwd32_kernel)
@@ -1290,7 +1308,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     reset_acc();
     t = 0;
     if (use_prio) {
-      favoured = !favoured;
+      favoured = first_pass != ((ri & 1) != 0);
       if (favoured) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
     }
     rn = next_item(ri + 1);
@@ -1335,17 +1353,20 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   if (g_fwd_priority >= 0) pp.wg_priority = g_fwd_priority;
   if (p.total_q == 0) return HX_OK;
   const int per_item_priority = pp.wg_priority;
-  // (persistent workgroups: equal priorities — with the packed f32 arithmetic gone from the softmax, 32 x 704 tokens run
-  // in 223 us without and 235 us with the two priorities, 2048 of 4096 in 112.5 either way)
-  if (g_fwd_priority < 0) pp.wg_priority = 0;
+  // (persistent workgroups: priority to the workgroup of a CU that holds the longer item — 32 x 704 tokens 227 us against
+  // 238 at equal priorities, 2048 of 4096 112.7 against 113.5, three processes each)
+  if (g_fwd_priority < 0) pp.wg_priority = 1;
   pp.n_tile_slots = (int32_t)(p.total_q / 128 + batch);
+  pp.n_cus = fwd_n_cus();
   const int64_t total = (int64_t)pp.n_tile_slots * p.n_heads;
   const int64_t g = std::min<int64_t>(total, 2 * (int64_t)fwd_n_cus());
   // the workgroup's item table: the slot count in front of every group of 4 sequences, 12 words per round
   const size_t table = 4 * (size_t)((((batch + 3) / 4 + 1 + 3) & ~3) + 12 * ((total + g - 1) / g));
   // (else one workgroup per item: tables that do not fit; dense launches of equal items — the CLIP tower, 8 x 577:
   // 25.1 us per item against 27.4 — where the static deal puts the second items of a round on the same CUs)
-  if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED)) && 2 * (lds + table) <= 160 * 1024 &&
+  // (and launches of at most one workgroup per CU: 1 x 704 tokens, 192 items, 20.2 us per item against 21.0 — the table
+  // is built for nothing)
+  if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED && total > fwd_n_cus())) && 2 * (lds + table) <= 160 * 1024 &&
       4 * (3 * (size_t)batch + 2) <= 2 * 64 * (2 * D + 2 * D)) {
     const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16 + table;
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32p_kernel<T, D, PAGED>,
