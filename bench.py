@@ -888,12 +888,12 @@ def time_prefill_attention(shape, dtype, dev, n_seqs=4, n_tokens=704, reps=3, la
     us = sum(ts) / len(ts)
     flops = 4 * H * D * n_seqs * (n_tokens * (n_tokens + 1) // 2)       # Q.K and P.V over the causal triangle
     tf = flops / us / 1e6
-    return {"bound": "mfma", "kernel": "attn_fwd32_kernel (paged causal prefill attention, v_mfma_f32_32x32x16)",
+    return {"bound": "mfma", "kernel": "attn_fwd32p_kernel (paged causal prefill attention, v_mfma_f32_32x32x16, persistent workgroups)",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "traffic": None, "avg_launch_us": round(us, 2), "algorithmic_flops_per_launch": flops,
             "workload": f"{n_seqs} sequences x {n_tokens} new tokens, H = {H}, D = {D}, block_size {bs}",
             "timing": f"hipGraph of {launches} launches, mean of {reps} replays, HIP events",
-            "pmc": "profiles/r3_attn_prefill_pmc.json (SQ_VALU_MFMA_BUSY_CYCLES, LDS bank conflicts)"}
+            "pmc": "profiles/r4_attn_prefill_pmc.json (SQ_VALU_MFMA_BUSY_CYCLES, LDS bank conflicts)"}
 
 
 def roofline_objects(model, runner, ctxs, ms_per_step, args, model_name, with_gemm=True):
