@@ -168,6 +168,16 @@ def test_dense_ragged_causal_and_noncausal():
             ref = ops.varlen_attention(q, k, v, cu, cu, causal=causal)
             atol, rtol = ATTN_TOL[dt]
             assert_close_t(out, ref, atol, rtol, what=f"dense causal={causal} {dt}")
+            # the persistent form of the prefill kernel on the dense layout (the launcher keeps the per-item form there)
+            from hydrainfer_amd import _lib
+            forced = torch.empty_like(out)
+            try:
+                _lib.lib().hx_debug_set_option(b"fwd_persistent", 2)
+                mha_varlen_fwd(forced, q.to(DEV), k.to(DEV), v.to(DEV), cu.to(DEV), cu.to(DEV), None, None,
+                               None, max(lens), max(lens), 1 / math.sqrt(D), 0.0, -1, 0 if causal else -1, 0)
+            finally:
+                _lib.lib().hx_debug_set_option(b"fwd_persistent", 1)
+            assert torch.equal(forced, out), f"dense persistent causal={causal} {dt}"
 
 
 def test_softmax_rescale_branch_is_exercised():
@@ -433,6 +443,45 @@ def test_prefill_32x32_kernel_fuzz_vs_general_kernel_and_oracle():
                 assert_close_t(out32, ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b), atol, rtol, what=what + " (vs the oracle)")
     finally:
         lib.hx_debug_set_option(b"fwd_mfma32", 1)
+
+
+@pytest.mark.gpu
+def test_prefill_persistent_kernel_matches_per_item_kernel_and_oracle():
+    """The persistent form of the 32x32x16 prefill kernel (two workgroups per CU walking an item table built in LDS)
+    does the same arithmetic per row as the per-item form: results are BIT-identical, on launches that exercise what
+    only the persistent form has — several rounds per workgroup, spare slots, sequences without query rows inside a
+    batch, more than 64 groups of 4 sequences (two passes of the slot-count scan), head counts with and without the
+    XCD-aware numbering, both head sizes, cached prefixes, non-causal — and the oracle agrees on a sample of rows.
+    (fwd_persistent = 2 forces the persistent form on launches the launcher would give to the per-item kernel.)"""
+    import random
+    from hydrainfer_amd import _lib
+    from oracle import ops
+    lib = _lib.lib()
+    rnd = random.Random(4242)
+    cases = [  # (B, H, HK, D, causal, longest run)
+        (5, 8, 8, 128, True, 700), (37, 8, 2, 128, True, 300), (70, 5, 1, 64, True, 260), (300, 8, 8, 64, True, 140),
+        (9, 16, 16, 64, False, 577), (3, 32, 32, 128, True, 1500), (40, 8, 4, 128, True, 400), (2, 3, 3, 128, True, 130)]
+    try:
+        for ci, (B, H, HK, D, causal, longest) in enumerate(cases):
+            dt = (torch.bfloat16, torch.float16)[ci % 2]
+            q_lens = [rnd.choice((0, 1, rnd.randint(2, 64), rnd.randint(65, longest), 128, 256)) for _ in range(B)]
+            q_lens[rnd.randrange(B)] = longest
+            kv_lens = [ql + rnd.choice((0, 0, rnd.randint(1, 150), 16 * rnd.randint(1, 6))) if ql else rnd.randint(0, 40)
+                       for ql in q_lens]
+            bs = rnd.choice((16, 32))
+            q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(B, H, HK, D, kv_lens, q_lens, dt, block_size=bs, seed=700 + ci)
+            what = f"case {ci}: B={B} H={H}/{HK} D={D} {dt} causal={causal} block {bs}"
+            lib.hx_debug_set_option(b"fwd_persistent", 2)
+            pers = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens), causal=causal)
+            lib.hx_debug_set_option(b"fwd_persistent", 0)
+            item = _run(q, kc, vc, cu_q, cu_k, bt, cu_b, max(q_lens), max(kv_lens), causal=causal)
+            assert torch.isfinite(pers.float()).all(), what
+            assert torch.equal(pers, item), what + f": {(pers.float() - item.float()).abs().max().item()}"
+            if causal and cu_q[-1] <= 6000:
+                atol, rtol = ATTN_TOL[dt]
+                assert_close_t(pers, ops.paged_attention(q, kc, vc, cu_q, cu_k, bt, cu_b), atol, rtol, what=what + " (vs the oracle)")
+    finally:
+        lib.hx_debug_set_option(b"fwd_persistent", 1)
 
 
 @pytest.mark.gpu
