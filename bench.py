@@ -852,7 +852,7 @@ def leg_64_rows(ctx, model, args, dev, prompt_len, n_generate, steps=20):
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 / fp16, MI355X_MICROARCH.md
 
 
-def time_prefill_attention(shape, dtype, dev, n_seqs=4, n_tokens=704, reps=3, launches=10):
+def time_prefill_attention(shape, dtype, dev, n_seqs=4, n_tokens=704, reps=3, launches=10, kv_tokens=None, brief=False):
     """`roofline_prefill_attention`: the MFMA-bound kernel of the path — paged causal prefill attention of n_seqs x
     n_tokens new tokens (the prefill of 4 of the benchmark's requests) through the C ABI (hx_attn, the 32x32x16
     kernel), HIP events over a hipGraph of `launches` launches on random pages, mean of `reps` replays."""
@@ -861,13 +861,15 @@ def time_prefill_attention(shape, dtype, dev, n_seqs=4, n_tokens=704, reps=3, la
     H, HK, D, bs = shape.num_attention_heads, shape.num_key_value_heads, shape.head_dim, 16
     g = torch.Generator(device=dev).manual_seed(11)
     rnd = lambda *s_: torch.randn(s_, device=dev, generator=g).to(dtype)
-    nb = (n_tokens + bs - 1) // bs
+    kv = kv_tokens or n_tokens          # kv > n_tokens: a chunk of a longer prompt (cached prefix of kv - n_tokens keys)
+    nb = (kv + bs - 1) // bs
     kc, vc, q = rnd(n_seqs * nb, bs, HK, D), rnd(n_seqs * nb, bs, HK, D), rnd(n_seqs * n_tokens, H, D)
     out = torch.empty_like(q)
     perm = torch.randperm(n_seqs * nb, generator=g, device=dev).to(torch.int32)
     cu_b = torch.arange(0, (n_seqs + 1) * nb, nb, dtype=torch.int32, device=dev)
     cu = torch.arange(0, (n_seqs + 1) * n_tokens, n_tokens, dtype=torch.int32, device=dev)
-    fn = lambda: mha_varlen_fwd(out, q, kc, vc, cu, cu, perm, cu_b, None, n_tokens, n_tokens, 1 / math.sqrt(D), 0, -1, 0, 0)
+    cu_k = torch.arange(0, (n_seqs + 1) * kv, kv, dtype=torch.int32, device=dev)
+    fn = lambda: mha_varlen_fwd(out, q, kc, vc, cu, cu_k, perm, cu_b, None, n_tokens, kv, 1 / math.sqrt(D), 0, -1, 0, 0)
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
@@ -886,14 +888,27 @@ def time_prefill_attention(shape, dtype, dev, n_seqs=4, n_tokens=704, reps=3, la
         torch.cuda.synchronize(dev)
         ts.append(e0.elapsed_time(e1) / launches * 1e3)
     us = sum(ts) / len(ts)
-    flops = 4 * H * D * n_seqs * (n_tokens * (n_tokens + 1) // 2)       # Q.K and P.V over the causal triangle
+    flops = 4 * H * D * n_seqs * sum(kv - n_tokens + i + 1 for i in range(n_tokens))       # Q.K and P.V over the causal triangle
     tf = flops / us / 1e6
+    if brief:
+        return {"workload": f"{n_seqs} x {n_tokens} new tokens" + (f" of {kv}" if kv != n_tokens else ""), "avg_launch_us": round(us, 2),
+                "achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}
     return {"bound": "mfma", "kernel": "attn_fwd32p_kernel (paged causal prefill attention, v_mfma_f32_32x32x16, persistent workgroups)",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "traffic": None, "avg_launch_us": round(us, 2), "algorithmic_flops_per_launch": flops,
             "workload": f"{n_seqs} sequences x {n_tokens} new tokens, H = {H}, D = {D}, block_size {bs}",
             "timing": f"hipGraph of {launches} launches, mean of {reps} replays, HIP events",
             "pmc": "profiles/r4_attn_prefill_pmc.json (SQ_VALU_MFMA_BUSY_CYCLES, LDS bank conflicts)"}
+
+
+def prefill_attention_object(shape, dtype, dev):
+    """The 4 x 704 launch (the prefill of 4 of the benchmark's requests) as the object's headline, and the two launches the
+    serving legs actually make beside it: all 32 prompts admitted at once, and a 2048-token chunk of a 4096-token prompt."""
+    obj = time_prefill_attention(shape, dtype, dev)
+    obj["other_workloads"] = [time_prefill_attention(shape, dtype, dev, n_seqs=32, launches=4, brief=True),
+                              time_prefill_attention(shape, dtype, dev, n_seqs=1, n_tokens=2048, kv_tokens=4096, launches=6, brief=True)]
+    obj["in_kernel_shader_clock_GHz"] = "1.85-1.96 (profiles/r4_attn_prefill_pmc.json): the MFMA peak at that clock is 1.9-2.0 PFLOP/s"
+    return obj
 
 
 def roofline_objects(model, runner, ctxs, ms_per_step, args, model_name, with_gemm=True):
@@ -1128,7 +1143,7 @@ def main():
                        "parallelism": f"replicas x{n_gpus} (independent requests, no data-path collective)"},
             "roofline": roofline,
             "roofline_gemm": roofline_gemm,
-            "roofline_prefill_attention": None if args.skip_prefill else time_prefill_attention(shape, dtype, dev),
+            "roofline_prefill_attention": None if args.skip_prefill else prefill_attention_object(shape, dtype, dev),
             "whole_step": whole,
             "whole_step_64": whole_64,
             "prefill_batch_ms": None if ttft_ms is None else round(ttft_ms, 2),
