@@ -45,6 +45,8 @@ names = {0: "full kernel", 1: "no softmax arithmetic", 2: "no P V", 4: "no Q K",
          15: "empty loop", 16: "no barrier (staging kept)", 32: "barrier kept, no tile requests", 48: "neither (= 8)", 256: "the launch alone (workgroups return at once)",
          79: "empty loop, no epilogue stores", 512: "full kernel, Q fragments not loaded (constants)"}
 for k, nm in names.items():
+    assert l.hx_debug_set_option(b"fwd_persistent", 0) == 0      # the ablations live in the per-item form of the kernel
     assert l.hx_debug_set_option(b"fwd_ablate", k) == 0
     print(f"  {k:2d} {nm:40s} {timeit():7.1f} us", flush=True)
 l.hx_debug_set_option(b"fwd_ablate", 0)
+l.hx_debug_set_option(b"fwd_persistent", 1)
