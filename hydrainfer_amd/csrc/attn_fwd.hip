@@ -874,11 +874,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     __syncthreads();
     const int n_slots = p.n_tile_slots, gy = p.n_heads;
     const int total = n_slots * gy;
-    const int G = gridDim.x, wg = blockIdx.x;
+    const int G = gridDim.x;
     const bool remap = p.xcd_remap && total % 8 == 0 && gy % 8 == 0 && G % 8 == 0;
-    for (int r = threadIdx.x; r < n_rounds; r += 256) {
-      int* rec = items + r * REC;
+    // (threads n_rounds .. 2 n_rounds - 1 decode the items of the workgroup this one shares its CU with — only their
+    // lengths are kept, for the priority below)
+    const int partner = (int)blockIdx.x < p.n_cus ? (int)blockIdx.x + p.n_cus : (int)blockIdx.x - p.n_cus;
+    int* p_tiles = sb + p.batch;                     // [n_rounds]: tile steps of the partner's items
+    for (int idx = threadIdx.x; idx < 2 * n_rounds; idx += 256) {
+      const bool mine = idx < n_rounds;
+      const int r = mine ? idx : idx - n_rounds;
+      const int wg = mine ? (int)blockIdx.x : partner;
+      int* rec = mine ? items + r * REC : p_tiles + r;
       rec[0] = 0;
+      if (wg >= G) continue;
       int slot, h;
       // Which of the round's items, longest first: the dispatcher gives every CU one workgroup before it gives any CU a
       // second one (in-kernel HW_ID stamps, tools/fwd_timeline.py: workgroups wg and wg + n_cus share a CU, always), so
@@ -933,6 +941,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       // query tiles aligned to the END of the sequence (see attn_fwd32_kernel)
       const int q_row0_wg = q_len - ((q_len + TQ - 1) / TQ - mblk) * TQ;
       const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + TQ - 1, q_len - 1) + kv_len - q_len) : kv_len - 1;
+      if (!mine) { rec[0] = max(last_key_wg / KT + 1, 0); continue; }
       const int bt_off = PAGED ? sb[b] : 0;
       rec[1] = h; rec[2] = q_row0_wg; rec[3] = q_start; rec[4] = q_len; rec[5] = k_start; rec[6] = kv_len; rec[7] = bt_off;
 #pragma unroll
@@ -941,6 +950,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       rec[0] = last_key_wg < 0 ? -1 : last_key_wg / KT + 1;
     }
     __syncthreads();
+  }
+  // Which of the CU's two workgroups has more to do: tile steps of all its items, a third more per step for the younger
+  // workgroup (the older one wins the arbitration for the vector issue slots: 1.5 against 2.0 us per step), two steps'
+  // worth per item for its seam.  The one that would finish later gets the priority (s_setprio), for the whole launch.
+  int work_mine = 0, work_partner = 0;
+  {
+    const bool young = (int)blockIdx.x >= p.n_cus;
+    int* p_tiles = reinterpret_cast<int*>(smem) + 3 * p.batch + 2;
+    for (int r = 0; r < n_rounds; ++r) {
+      const int a = max(__builtin_amdgcn_readfirstlane(items[r * REC]), 0), b = __builtin_amdgcn_readfirstlane(p_tiles[r]);
+      work_mine += a ? a * (young ? 4 : 3) + 6 : 0;
+      work_partner += b ? b * (young ? 3 : 4) + 6 : 0;
+    }
+    __syncthreads();                   // (p_tiles lives in the tile images: read before the first requests)
   }
   stamp(4);
   // the first record at or after round r that is an item; those without keys are finished on the way
@@ -1100,15 +1123,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
   tiles_landed();
   stamp(3);
   read_q(1);
-  // Priority goes to the workgroup of a CU that holds the longer item.  Of the two workgroups of a CU the older one wins
-  // the arbitration for the vector issue slots anyway (stamps, 2048 new tokens of 4096: 1.5 us per tile step for the
-  // first-pass workgroups, 2.0 for their partners); the deal gives the first-pass workgroup of a CU the c-th longest item
-  // of an even round and the second-pass workgroup the c-th shortest, the other way round in odd rounds — so the
-  // launch ends with its longest items, and they are the ones to speed up, at the expense of partners that have time.
-  // wg_priority: 0 = equal priorities, 1 = as described.
+  // wg_priority: 0 = equal priorities, 1 = the workgroup of the CU with more left to do (above) runs at s_setprio 3
   const bool use_prio = p.wg_priority != 0;
-  const bool first_pass = (int)blockIdx.x < p.n_cus;
-  bool favoured = use_prio && (first_pass != ((ri & 1) != 0));
+  const bool favoured = use_prio && (work_mine > work_partner || (work_mine == work_partner && (int)blockIdx.x >= p.n_cus));
   __syncthreads();
   if (favoured) __builtin_amdgcn_s_setprio(3);
 
@@ -1307,10 +1324,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     if (!has_next) { stamp_cycles(31); return true; }
     reset_acc();
     t = 0;
-    if (use_prio) {
-      favoured = first_pass != ((ri & 1) != 0);
-      if (favoured) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-    }
     rn = next_item(ri + 1);
     lookup_page(min(1, t_last));
     // The first tile's requests are older than the O stores: when all NQI of them were issued (a wave whose 32 rows all
@@ -1367,7 +1380,7 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   // (and launches of at most one workgroup per CU: 1 x 704 tokens, 192 items, 20.2 us per item against 21.0 — the table
   // is built for nothing)
   if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED && total > fwd_n_cus())) && 2 * (lds + table) <= 160 * 1024 &&
-      4 * (3 * (size_t)batch + 2) <= 2 * 64 * (2 * D + 2 * D)) {
+      4 * (3 * (size_t)batch + 2 + (size_t)((total + g - 1) / g)) <= 2 * 64 * (2 * D + 2 * D)) {
     const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16 + table;
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32p_kernel<T, D, PAGED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
