@@ -752,15 +752,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
 // Items are dealt out statically, in snake order over the length-sorted item list (round r: item r G + i to workgroup
 // i, the next round backwards), inside the XCD whose L2 holds that head's K / V.
 // ---------------------------------------------------------------------------------------------
-// body(integral_constant<int, 0>) ... body(integral_constant<int, N - 1>)
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<N, I + 1>(f);
-  }
-}
-
 // A uniform value the compiler may not reason about: what is derived from it (strides times constants, the reciprocal
 // of a divisor) is computed where it is used instead of once at kernel entry and then kept, or spilled, across the
 // persistent loop.
@@ -1350,549 +1341,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
   }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// 64 query rows per wave, ONE workgroup (4 waves, 256 rows) per CU, the whole 512-register file per wave.  Where the
-// kernels above stand (in-kernel stamps, profiles/r4_attn_prefill_pmc.json): two waves per SIMD fill the vector issue
-// port — per 64-key tile a wave issues 32 MFMAs beside ~135 vector instructions of softmax, 48 LDS fragment reads and
-// 8 LDS-DMA pieces.  Here every K and V fragment read from LDS, and every DMA piece, feeds TWO 32-row blocks: per MFMA
-// half the LDS reads and half the staging.  With one wave per SIMD nothing else hides the softmax, so it is dealt out
-// over the MFMA slots of the same wave (the tile pipeline of the round-4 experiment): sub-tiles of 32 keys, step t runs
-//     block 1:  S(t+1, 0)   beside   softmax of S(t, 1)   beside   O += V(t, 0) P(t, 0)
-//     block 2:  S(t+1, 1)   beside   softmax of S(t+1, 0) beside   O += V(t, 1) P(t, 1)
-// for both row blocks; K runs one tile ahead of V in LDS (K0 | K1 | V0 | V1), Q and O have an area of their own (a wave's
-// 64 rows: nobody else touches them).  Persistent workgroups with an item table as in attn_fwd32p_kernel; items are
-// 256-row tiles.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int D, bool PAGED>
-__global__ __launch_bounds__(256) void attn_fwd64_kernel(const AttnParams p) {
-  constexpr int KS = D / 16, NDB = D / 32, KT = 64;
-  constexpr int RSK = 2 * D, RSV = 2 * D, LPR = D / 8, NL = KT * LPR / 256;
-  constexpr int KTILE = KT * RSK, VTILE = KT * RSV;
-  constexpr int TQ = 256, WR = 64;                  // rows per workgroup / per wave
-  constexpr int RPI = 64 / LPR, NQI = WR / RPI;     // rows per staging instruction, instructions per wave's Q / O rows
-  constexpr uint32_t VBASE = 2 * KTILE, QBASE = 2 * KTILE + 2 * VTILE, TBASE = QBASE + 4 * WR * RSK;
-  static_assert(NL * RPI == 16 && RPI * RSK == 1024, "a wave stages one 16-key group, 1 KiB per instruction");
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // K0 | K1 | V0 | V1 | Q / O rows of the 4 waves | item table
-  auto kswz = [](int row) { return LPR == 16 ? (row & 15) : ((row >> 1) & 7); };
-  auto vswz = [](int row) { return LPR == 16 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); };
-  typedef __attribute__((address_space(4))) const int32_t c_i32;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c = lane & 31, hi = lane >> 5;
-  const int st_r4 = lane / LPR, st_ch = lane % LPR;
-  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)(smem);
-  typedef __attribute__((address_space(4))) const AttnParams c_params;
-  auto kargs = [&]() __attribute__((always_inline)) { return sfresh((c_params*)__builtin_amdgcn_kernarg_segment_ptr()); };
-
-  // ---- the items of this workgroup (see attn_fwd32p_kernel): a table in LDS, built once
-  struct Work { int h, q_row0_wg, q_start, q_len, k_start, kv_len, bt_off, n_tiles; };
-  constexpr int REC = 12;
-  const int n_groups = (p.batch + 3) >> 2;
-  int* tb_g = reinterpret_cast<int*>(smem + TBASE);
-  int* items = tb_g + ((n_groups + 1 + 3) & ~3);
-  const int n_rounds = (p.n_tile_slots * p.n_heads + (int)gridDim.x - 1) / (int)gridDim.x;
-  {
-    int* sq = reinterpret_cast<int*>(smem);
-    int* sk = sq + p.batch + 1;
-    int* sb = sk + p.batch + 1;
-    for (int i = threadIdx.x; i <= p.batch; i += 256) {
-      sq[i] = p.cu_q[i];
-      sk[i] = p.cu_k[i];
-      if (PAGED && i < p.batch) sb[i] = p.cu_block_lens[i];
-    }
-    __syncthreads();
-    for (int g = threadIdx.x; g < n_groups; g += 256) {
-      int n = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        n += (sq[min(4 * g + i + 1, p.batch)] - sq[min(4 * g + i, p.batch)] + TQ - 1) / TQ;
-      tb_g[g] = n;
-    }
-    __syncthreads();
-    if (w == 0) {
-      int carry = 0;
-      for (int g0 = 0; g0 < n_groups; g0 += 64) {
-        const int g = g0 + lane;
-        const int mine = g < n_groups ? tb_g[g] : 0;
-        int incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int o = __shfl_up(incl, d, 64);
-          if (lane >= d) incl += o;
-        }
-        if (g < n_groups) tb_g[g] = carry + incl - mine;
-        carry += __shfl(incl, 63, 64);
-      }
-      if (lane == 0) tb_g[n_groups] = carry;
-    }
-    __syncthreads();
-    const int n_slots = p.n_tile_slots, gy = p.n_heads;
-    const int total = n_slots * gy;
-    const int G = gridDim.x, wg = blockIdx.x;
-    const bool remap = p.xcd_remap && total % 8 == 0 && gy % 8 == 0 && G % 8 == 0;
-    for (int r = threadIdx.x; r < n_rounds; r += 256) {
-      int* rec = items + r * REC;
-      rec[0] = 0;
-      int slot, h;
-      if (remap) {
-        const int Gx = G / 8, Tx = total / 8, hp = gy / 8;
-        const int x = wg % 8, j = wg / 8;
-        const int i = (r & 1) ? (r + 1) * Gx - 1 - j : r * Gx + j;
-        if (i >= Tx) continue;
-        h = x * hp + i % hp;
-        slot = i / hp;
-      } else {
-        const int i = (r & 1) ? (r + 1) * G - 1 - wg : r * G + wg;
-        if (i >= total) continue;
-        slot = i % n_slots;
-        h = i / n_slots;
-      }
-      if (slot >= tb_g[n_groups]) continue;
-      int lo = 0, hi_g = n_groups;
-      while (hi_g - lo > 1) {
-        const int mid = (lo + hi_g) >> 1;
-        if (tb_g[mid] <= slot) lo = mid; else hi_g = mid;
-      }
-      slot -= tb_g[lo];
-      int tl[4], max_tiles = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        tl[i] = (sq[min(4 * lo + i + 1, p.batch)] - sq[min(4 * lo + i, p.batch)] + TQ - 1) / TQ;
-        max_tiles = max(max_tiles, tl[i]);
-      }
-      int mblk = -1, b = 0;
-      for (int rank = 0; rank < max_tiles && mblk < 0; ++rank) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (mblk < 0 && tl[i] > rank) {
-            if (slot == 0) { b = 4 * lo + i; mblk = tl[i] - 1 - rank; }
-            --slot;
-          }
-        }
-      }
-      if (mblk < 0) continue;
-      const int q_start = sq[b], q_len = sq[b + 1] - q_start;
-      const int k_start = sk[b], kv_len = sk[b + 1] - k_start;
-      if (q_len <= 0) continue;
-      const int q_row0_wg = q_len - ((q_len + TQ - 1) / TQ - mblk) * TQ;      // tiles aligned to the END of the sequence
-      const int last_key_wg = p.causal ? min(kv_len - 1, min(q_row0_wg + TQ - 1, q_len - 1) + kv_len - q_len) : kv_len - 1;
-      const int bt_off = PAGED ? sb[b] : 0;
-      rec[1] = h; rec[2] = q_row0_wg; rec[3] = q_start; rec[4] = q_len; rec[5] = k_start; rec[6] = kv_len; rec[7] = bt_off;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        rec[8 + i] = PAGED && last_key_wg >= 0 ? p.block_table[bt_off + page_slot(min(16 * i, kv_len - 1), p.block_size, p.block_shift)] : 0;
-      rec[0] = last_key_wg < 0 ? -1 : last_key_wg / KT + 1;
-    }
-    __syncthreads();
-  }
-  int ri = 0;
-  auto next_item = [&](int r) __attribute__((always_inline)) -> int {
-    for (; r < n_rounds; ++r) {
-      const int n = __builtin_amdgcn_readfirstlane(items[r * REC]);
-      if (n > 0) break;
-      if (n < 0) {      // an item without keys: its rows are zero
-        c_params* P = kargs();
-        const int h = items[r * REC + 1], q_row0_wg = items[r * REC + 2], q_start = items[r * REC + 3];
-        for (int i = threadIdx.x; i < TQ * LPR; i += 256) {
-          const int row = q_row0_wg + i / LPR;
-          if (row >= 0)
-            *reinterpret_cast<u16x8*>(reinterpret_cast<u16*>(P->out) + (int64_t)(q_start + row) * P->o_row_stride +
-                                      (int64_t)h * D + 8 * (i % LPR)) = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-      }
-    }
-    return r;
-  };
-  auto read_item = [&](int r, Work& wk) __attribute__((always_inline)) {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const i32x4 a = *reinterpret_cast<const i32x4*>(items + r * REC), b = *reinterpret_cast<const i32x4*>(items + r * REC + 4);
-    wk.n_tiles = __builtin_amdgcn_readfirstlane(a[0]); wk.h = __builtin_amdgcn_readfirstlane(a[1]);
-    wk.q_row0_wg = __builtin_amdgcn_readfirstlane(a[2]); wk.q_start = __builtin_amdgcn_readfirstlane(a[3]);
-    wk.q_len = __builtin_amdgcn_readfirstlane(b[0]); wk.k_start = __builtin_amdgcn_readfirstlane(b[1]);
-    wk.kv_len = __builtin_amdgcn_readfirstlane(b[2]); wk.bt_off = __builtin_amdgcn_readfirstlane(b[3]);
-  };
-
-  // ---- per-item state
-  Work cur;
-  int q_row0 = 0, limit_c[2] = {0, 0}, last_key = 0, shift = 0, n_tiles = 0, n_w = 0;
-  const u16 *kbase = nullptr, *vbase = nullptr;
-  c_i32* bt_s = nullptr;
-  auto setup = [&](const Work& wk) __attribute__((always_inline)) {
-    c_params* P = kargs();
-    q_row0 = wk.q_row0_wg + w * WR;
-    shift = wk.kv_len - wk.q_len;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) limit_c[b] = P->causal ? min(wk.kv_len - 1, q_row0 + 32 * b + c + shift) : wk.kv_len - 1;
-    const int last_key_wave = q_row0 + WR - 1 < 0 ? -1 : P->causal ? min(wk.kv_len - 1, q_row0 + WR - 1 + shift) : wk.kv_len - 1;
-    n_w = last_key_wave >= 0 ? last_key_wave / KT + 1 : 0;
-    last_key = wk.kv_len - 1;
-    n_tiles = wk.n_tiles;
-    const int hk = wk.h / sfresh(P->group);
-    kbase = reinterpret_cast<const u16*>(P->k) + (int64_t)hk * P->k_head_stride;
-    vbase = reinterpret_cast<const u16*>(P->v) + (int64_t)hk * P->v_head_stride;
-    bt_s = PAGED ? (c_i32*)(P->block_table + wk.bt_off) : nullptr;
-  };
-  auto lookup_page = [&](int t) __attribute__((always_inline)) -> int {
-    if (!PAGED) return 0;
-    return bt_s[__builtin_amdgcn_readfirstlane(page_slot(min(t * KT + 16 * w, last_key), p.block_size, p.block_shift))];
-  };
-  const uint32_t koff_row = (uint32_t)st_r4 * (uint32_t)p.k_row_stride * 2u, koff_ch = 16u * (uint32_t)(st_ch ^ kswz(st_r4));
-  const uint32_t voff = (uint32_t)st_r4 * (uint32_t)p.v_row_stride * 2u + 16u * (uint32_t)(st_ch ^ vswz(st_r4));
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-  auto dma = [&](const void* base, uint32_t off, uint32_t lds) __attribute__((always_inline)) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(lds) : "memory", "m0");
-  };
-  auto dma_flat = [&](const void* addr, uint32_t lds) __attribute__((always_inline)) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(addr), "s"(lds) : "memory", "m0");
-  };
-#pragma clang diagnostic pop
-  auto request_half = [&](int t, int page, auto v_tag) __attribute__((always_inline)) {
-    constexpr bool IS_V = decltype(v_tag)::value;
-    const int g0 = min(t * KT + 16 * w, last_key);
-    const int r_max = last_key - g0;
-    const int64_t rs = sfresh(IS_V ? p.v_row_stride : p.k_row_stride);
-    int64_t eb;
-    if (PAGED) eb = (int64_t)page * (IS_V ? p.v_block_stride : p.k_block_stride) + (int64_t)page_row(g0, p.block_size, p.block_shift) * rs;
-    else eb = (int64_t)(cur.k_start + g0) * rs;
-    const uint32_t d = __builtin_amdgcn_readfirstlane(lds0 + (IS_V ? VBASE : 0u) + (uint32_t)((t & 1) * KTILE + 16 * w * RSK));
-    const u16* bp = (IS_V ? vbase : kbase) + eb;
-    if (r_max >= 15) {
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        dma(bp, IS_V ? voff : koff_row + (koff_ch ^ (64u * j)), d + 1024u * j);
-        bp = sfresh(bp + RPI * rs);
-      }
-    } else {
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int r4 = ln / LPR, ch = ln % LPR;
-#pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const int R = RPI * j + r4;
-        const uint32_t r = (uint32_t)min(R, r_max);
-        dma_flat(bp + r * (uint32_t)rs + 8 * (ch ^ (IS_V ? vswz(R) : kswz(R))), d + 1024u * j);
-      }
-    }
-  };
-  using IsK = std::false_type;
-  using IsV = std::true_type;
-  // the 64 Q rows of this wave for item wk -> its block of the Q / O area (K's swizzle per 32-row block)
-  auto request_q = [&](const Work& wk) __attribute__((always_inline)) {
-    c_params* P = kargs();
-    const u16* qbase = reinterpret_cast<const u16*>(P->q) + (int64_t)wk.h * D;
-    const uint32_t qd = __builtin_amdgcn_readfirstlane(lds0 + QBASE + (uint32_t)(w * WR * RSK));
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int r4 = ln / LPR, ch = ln % LPR;
-#pragma unroll
-    for (int j = 0; j < NQI; ++j) {
-      const int R = RPI * j + r4;
-      const int qr = min(max(wk.q_row0_wg + w * WR + R, 0), wk.q_len - 1);
-      dma_flat(qbase + (int64_t)(wk.q_start + qr) * P->q_row_stride + 8 * (ch ^ kswz(R & 31)), qd + 1024u * j);
-    }
-  };
-  auto tiles_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
-  u16x8 qf[2][KS];
-  auto read_q = [&]() __attribute__((always_inline)) {
-    const char* qb = smem + QBASE + w * WR * RSK;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        qf[b][ks] = *reinterpret_cast<const u16x8*>(qb + (32 * b + c) * RSK + 16 * ((2 * ks + hi) ^ kswz(c)));
-  };
-  f32x16 acc[2][NDB];
-  float m[2], l[2];
-  auto reset_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-      for (int i = 0; i < NDB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][i][r] = 0.f;
-      m[b] = HX_NEG_BIG;
-      l[b] = 0.f;
-    }
-  };
-
-  // ---- first item
-  ri = next_item(0);
-  if (ri >= n_rounds) return;
-  read_item(ri, cur);
-  setup(cur);
-  int pg1 = __builtin_amdgcn_readfirstlane(items[ri * REC + 8 + w]);
-  request_q(cur);
-  request_half(0, pg1, IsK{});
-  int rn = next_item(ri + 1);
-  int pg2 = lookup_page(1);
-  reset_acc();
-  tiles_landed();
-  read_q();
-  __syncthreads();
-
-  uint32_t kaddr0, vaddr0;
-  {
-    const int kz = kswz(c);
-    kaddr0 = lds0 + (uint32_t)(c * RSK + 16 * (hi ^ kz));
-    const int tr_q = (lane & 15) >> 2, tr_pp = lane & 3, tr_half = (lane >> 4) & 1;
-    const int tr_off = (4 * hi + tr_q) * RSV + (16 * tr_half + 4 * tr_pp) * 2;
-    const int tr_x = vswz(tr_q) >> 2;
-    vaddr0 = lds0 + VBASE + (uint32_t)(tr_off + 64 * tr_x);
-  }
-  auto half_max = [](float x) __attribute__((always_inline)) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, x);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
-  };
-  auto half_sum = [](float x) __attribute__((always_inline)) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, x);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
-  };
-  auto lds_tr_at = [](uint32_t a) __attribute__((always_inline)) {
-    typedef __attribute__((address_space(3))) hx_s16x4_t lds_s4;
-    return __builtin_bit_cast(u16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(size_t)a));
-  };
-
-  // softmax of one 32-key sub-tile of row block b, in 8 units (see the experiment's description in the history):
-  //   unit 0, 1: mask, maximum of scores 0 .. 7 / 8 .. 15; 1 also: exchange with lane ^ 32, new reference, alpha
-  //   unit 2 .. 5: four scores each: exp2(s * scale - m), sums, conversion;  unit 6: l = l * alpha + sum
-  struct Sm { float mx, m_new, alpha, sa, sb; bool grown; };
-  auto sm_unit = [&](auto unit_tag, int b, f32x16& s, int key0, bool masked, u16x8 (&pf)[2], Sm& st) __attribute__((always_inline)) {
-    constexpr int U = decltype(unit_tag)::value;
-    if constexpr (U == 0 || U == 1) {
-      if (masked) {
-#pragma unroll
-        for (int r = 8 * U; r < 8 * U + 8; ++r) {
-          const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          s[r] = key > limit_c[b] ? -INFINITY : s[r];
-        }
-      }
-      float mx = U == 0 ? s[0] : st.mx;
-#pragma unroll
-      for (int r = U == 0 ? 1 : 8; r < 8 * U + 8; ++r) mx = fmaxf(mx, s[r]);
-      st.mx = mx;
-    }
-    if constexpr (U == 1) {
-      const float mx = half_max(st.mx);
-      const float m_cand = fmaxf(m[b], mx * p.scale_log2);
-      const bool grow = m_cand > m[b] + 8.0f;
-      st.m_new = grow ? m_cand : m[b];
-      st.alpha = fast_exp2(m[b] - st.m_new);
-      st.grown = __builtin_amdgcn_ballot_w64(grow) != 0;
-      m[b] = st.m_new;
-      st.sa = 0.f;
-      st.sb = 0.f;
-    }
-    if constexpr (U >= 2 && U <= 5) {
-#pragma unroll
-      for (int r = 4 * (U - 2); r < 4 * (U - 2) + 4; r += 2) {
-        const float e0 = fast_exp2(fmaf(s[r], p.scale_log2, -st.m_new));
-        const float e1 = fast_exp2(fmaf(s[r + 1], p.scale_log2, -st.m_new));
-        st.sa += e0;
-        st.sb += e1;
-        pf[r >> 3][r & 7] = T::from_float(e0);
-        pf[r >> 3][(r & 7) + 1] = T::from_float(e1);
-      }
-    }
-    if constexpr (U == 6) l[b] = fmaf(l[b], st.alpha, st.sa + st.sb);
-  };
-  auto rescale = [&](int b, float alpha) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NDB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[b][i][r] *= alpha;
-  };
-
-  // carried from step to step: S(t+1, 1) and P(t+1, 0) of both row blocks
-  f32x16 s1[2];
-  u16x8 pf0[2][2];
-  auto body = [&](int t, auto qk_tag, auto pv_tag, bool mask1, bool mask0) __attribute__((always_inline)) {
-    constexpr bool QK = decltype(qk_tag)::value, PV = decltype(pv_tag)::value;
-    constexpr int KD = 3, VD = 2;
-    const uint32_t kimg = (uint32_t)((t + 1) & 1) * KTILE, vimg = (uint32_t)(t & 1) * VTILE;
-    u16x8 kf[KD + 1];
-    u16x4 vlo[VD + 1], vhh[VD + 1];
-    auto k_read = [&](auto q_tag) __attribute__((always_inline)) {
-      constexpr int Q = decltype(q_tag)::value;
-      if constexpr (QK && Q < 2 * KS)
-        kf[Q % (KD + 1)] = *reinterpret_cast<const __attribute__((address_space(3))) u16x8*>(
-            (size_t)((kaddr0 ^ (uint32_t)(32 * (Q % KS))) + kimg + (uint32_t)((Q / KS) * 32 * RSK)));
-    };
-    auto v_read = [&](auto j_tag) __attribute__((always_inline)) {
-      constexpr int J = decltype(j_tag)::value;
-      if constexpr (PV && J < 2 * KS) {
-        const uint32_t va = (vaddr0 ^ (uint32_t)(64 * (J % NDB))) + vimg + (uint32_t)((32 * (J / KS) + 16 * ((J % KS) / NDB)) * RSV);
-        vlo[J % (VD + 1)] = lds_tr_at(va);
-        vhh[J % (VD + 1)] = lds_tr_at(va + 8 * RSV);
-      }
-    };
-    f32x16 s0[2];
-    u16x8 pf1[2][2];
-    Sm st1[2], st0[2];
-    static_for<KD>([&](auto q) { k_read(q); });
-    static_for<VD>([&](auto j) { v_read(j); });
-    static_for<2 * KS>([&](auto slot_tag) {
-      constexpr int SL = decltype(slot_tag)::value, BL = SL / KS, I = SL % KS;
-      k_read(std::integral_constant<int, SL + KD>{});
-      v_read(std::integral_constant<int, SL + VD>{});
-      static_for<2>([&](auto b_tag) {
-        constexpr int B = decltype(b_tag)::value;
-        static_for<8 / KS>([&](auto uu) {
-          using Unit = std::integral_constant<int, I * (8 / KS) + decltype(uu)::value>;
-          if constexpr (BL == 0) { if constexpr (PV) sm_unit(Unit{}, B, s1[B], t * KT + 32, mask1, pf1[B], st1[B]); }
-          else { if constexpr (QK) sm_unit(Unit{}, B, s0[B], (t + 1) * KT, mask0, pf0[B], st0[B]); }
-        });
-      });
-      if constexpr (QK) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          f32x16& sd = BL == 0 ? s0[b] : s1[b];
-          if constexpr (I == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sd[r] = 0.f;
-          }
-          sd = Mfma32<T>::mma(kf[SL % (KD + 1)], qf[b][I], sd);
-        }
-      }
-      if constexpr (PV) {
-        const u16x4 lo = vlo[SL % (VD + 1)], hh = vhh[SL % (VD + 1)];
-        u16x8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hh[0]; vf[5] = hh[1]; vf[6] = hh[2]; vf[7] = hh[3];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if constexpr (BL == 0) acc[b][I % NDB] = Mfma32<T>::mma(vf, pf0[b][I / NDB], acc[b][I % NDB]);
-          else acc[b][I % NDB] = Mfma32<T>::mma(vf, pf1[b][I / NDB], acc[b][I % NDB]);
-        }
-      }
-      if constexpr (I == KS - 1) {
-        // (a use of P in front of the branch below: or the compiler sinks the softmax to the other side of it)
-        if constexpr (BL == 0) { if constexpr (PV) asm volatile("" :: "v"(pf1[0][0]), "v"(pf1[0][1]), "v"(pf1[1][0]), "v"(pf1[1][1]), "v"(l[0]), "v"(l[1])); }
-        else { if constexpr (QK) asm volatile("" :: "v"(pf0[0][0]), "v"(pf0[0][1]), "v"(pf0[1][0]), "v"(pf0[1][1]), "v"(l[0]), "v"(l[1])); }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (I == KS - 1) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if constexpr (BL == 0) { if constexpr (PV) { if (st1[b].grown) rescale(b, st1[b].alpha); } }
-          else { if constexpr (QK) { if (st0[b].grown) rescale(b, st0[b].alpha); } }
-        }
-      }
-    });
-  };
-  using Yes = std::true_type;
-  using No = std::false_type;
-
-  int t = -1;
-  auto step_begin = [&]() __attribute__((always_inline)) {
-    if (t < n_tiles - 1) {
-      if (t + 2 < n_tiles) request_half(t + 2, pg2, IsK{});
-      request_half(t + 1, pg1, IsV{});
-    } else if (rn < n_rounds) {
-      Work nx;
-      read_item(rn, nx);
-      request_q(nx);                                     // (the Q / O area is this wave's own: free since its last O row left)
-    }
-  };
-  auto step_end = [&]() __attribute__((always_inline)) {
-    if (t < n_tiles - 1) {
-      pg1 = pg2;
-      pg2 = lookup_page(min(t + 3, n_tiles - 1));
-      tiles_landed();
-      __syncthreads();
-    }
-    ++t;
-  };
-  auto first_masked = [&]() __attribute__((always_inline)) { return min(last_key, p.causal ? q_row0 + shift : last_key) + 1; };
-  for (;;) {
-    if (n_w > 0) {
-      const int fm = first_masked();
-      step_begin();
-      body(t, Yes{}, No{}, false, KT > fm);
-      step_end();
-      while (t < n_w - 1) {
-        step_begin();
-        body(t, Yes{}, Yes{}, (t + 1) * KT > fm, (t + 2) * KT > fm);
-        step_end();
-      }
-      step_begin();
-      body(t, No{}, Yes{}, (t + 1) * KT > fm, false);
-      step_end();
-    }
-    while (t < n_tiles) {
-      step_begin();
-      step_end();
-    }
-    // ---- the seam
-    tiles_landed();
-    const bool has_next = rn < n_rounds;
-    if (has_next) read_q();
-    const int e_q_row0 = q_row0;
-    const int64_t e_row = (int64_t)cur.q_start + q_row0;
-    const int e_h = cur.h;
-    __syncthreads();                       // everybody is done with the four tile buffers
-    if (has_next) {
-      ri = rn;
-      read_item(ri, cur);
-      setup(cur);
-      pg1 = __builtin_amdgcn_readfirstlane(items[ri * REC + 8 + w]);
-      request_half(0, pg1, IsK{});
-    }
-    // O rows through this wave's block of the Q / O area, whole rows per store (see attn_fwd32_kernel)
-    if (e_q_row0 + WR - 1 >= 0) {
-      constexpr int RSO = 2 * D;
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int ec = ln & 31, ehi = ln >> 5, er4 = ln / LPR, ech = ln % LPR;
-      char* ob = smem + QBASE + w * WR * RSO;
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float lr = half_sum(l[b]);
-        const float inv = (lr > 0.f) ? 1.0f / lr : 0.f;
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            u16x4 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = T::from_float(acc[b][db][4 * rq + i] * inv);
-            *reinterpret_cast<u16x4*>(ob + (32 * b + ec) * RSO + (((8 * db + 2 * rq + ehi) ^ (ec & (LPR - 1))) << 3)) = o;
-          }
-      }
-      c_params* P = kargs();
-      const int64_t ors = P->o_row_stride;
-      u16* orow = reinterpret_cast<u16*>(P->out) + (int64_t)e_h * D + 8 * ech + (e_row + er4) * ors;
-      const char* ord = ob + er4 * RSO;
-      auto o_row = [&](int j) __attribute__((always_inline)) {
-        const int rl = RPI * j + er4;
-        u16x8 v = *reinterpret_cast<const u16x8*>(ord + RPI * j * RSO + 16 * (ech ^ ((rl & (LPR - 1)) >> 1)));
-        if (rl & 1) v = u16x8{v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
-        return v;
-      };
-      if (e_q_row0 >= 0) {
-#pragma unroll
-        for (int j = 0; j < NQI; ++j) *reinterpret_cast<u16x8*>(orow + (int64_t)(RPI * j) * ors) = o_row(j);
-      } else {
-#pragma unroll
-        for (int j = 0; j < NQI; ++j)
-          if (e_q_row0 + RPI * j + er4 >= 0) *reinterpret_cast<u16x8*>(orow + (int64_t)(RPI * j) * ors) = o_row(j);
-      }
-    }
-    if (!has_next) return;
-    reset_acc();
-    t = -1;
-    rn = next_item(ri + 1);
-    pg2 = lookup_page(min(1, n_tiles - 1));
-    if (e_q_row0 >= 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NQI) : "memory");
-    else tiles_landed();
-    __syncthreads();
-  }
-}
-
 int fwd_n_cus() {
   static int n = [] {
     int dev = 0;
@@ -1906,7 +1354,6 @@ int fwd_n_cus() {
 int g_fwd_ablate = 0;   // EXPERIMENTS builds: timing ablations of attn_fwd32_kernel (wrong results)
 
 unsigned long long* g_fwd_stamps = nullptr;   // EXPERIMENTS builds: hx_debug_fwd_stamps
-int g_fwd_rows64 = 0;       // tuning: 1 = the 64-rows-per-wave kernel (one workgroup per CU)
 int g_fwd_persistent = 1;   // tuning: 0 = one workgroup per (sequence, query tile, head) item, 2 = persistent for dense launches too
 int g_fwd_priority = -1;    // tuning: -1 = automatic, 0 / 1 = the two workgroups of a CU at equal / different priorities
 
@@ -1922,23 +1369,6 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   // (persistent workgroups: priority to the workgroup of a CU that holds the longer item — 32 x 704 tokens 227 us against
   // 238 at equal priorities, 2048 of 4096 112.7 against 113.5, three processes each)
   if (g_fwd_priority < 0) pp.wg_priority = 1;
-  if (g_fwd_rows64) {
-    // 64 rows per wave: one workgroup per CU, 256-row items
-    AttnParams p6 = p;
-    p6.n_tile_slots = (int32_t)(p.total_q / 256 + batch);
-    p6.n_cus = fwd_n_cus();
-    p6.wg_priority = 0;
-    const int64_t total6 = (int64_t)p6.n_tile_slots * p.n_heads;
-    const int64_t g6 = std::min<int64_t>(total6, (int64_t)fwd_n_cus());
-    const size_t table6 = 4 * (size_t)((((batch + 3) / 4 + 1 + 3) & ~3) + 12 * ((total6 + g6 - 1) / g6));
-    const size_t lds6 = 4 * 64 * (2 * D) + 4 * 64 * (2 * D) + table6;
-    if (lds6 <= 160 * 1024 && 4 * (3 * (size_t)batch + 2) <= 4 * 64 * (2 * D)) {
-      hipError_t e = hipFuncSetAttribute((const void*)attn_fwd64_kernel<T, D, PAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
-      if (e != hipSuccess) return hip_rc(e);
-      hx::launcher(attn_fwd64_kernel<T, D, PAGED>, dim3((unsigned)g6, 1, 1), 256, lds6, stream)(p6);
-      return check_launch();
-    }
-  }
   pp.n_tile_slots = (int32_t)(p.total_q / 128 + batch);
   pp.n_cus = fwd_n_cus();
   const int64_t total = (int64_t)pp.n_tile_slots * p.n_heads;
@@ -2055,7 +1485,6 @@ int fwd_set_option(const char* name, int value) {
   if (!strcmp(name, "fwd_ablate")) { g_fwd_ablate = value; return HX_OK; }
   if (!strcmp(name, "fwd_persistent")) { g_fwd_persistent = value; return HX_OK; }
   if (!strcmp(name, "fwd_priority")) { g_fwd_priority = value; return HX_OK; }
-  if (!strcmp(name, "fwd_rows64")) { g_fwd_rows64 = value ? 1 : 0; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 
