@@ -67,6 +67,8 @@ struct AttnParams {
   int32_t xcd_remap;        // prefill kernel: renumber workgroups so that one head's query tiles share an XCD
   int32_t wg_priority;      // prefill kernel (32x32 form): the two workgroups of a CU run at different priorities
   unsigned long long* stamps;   // EXPERIMENTS builds: time stamps of the persistent prefill kernel (null otherwise)
+  int32_t max_seqlen_k;     // the caller's bound on a sequence's keys (host side: chooses between the forms of the prefill kernel)
+  int32_t seq_group;        // prefill kernel, persistent form: sequences per deal group, 1 / 2 / 4 (set by its launcher)
   int32_t n_cus;            // prefill kernel, persistent form: CUs of the device (set by its launcher)
   int32_t n_tile_slots;     // prefill kernel, persistent form: upper bound of the (sequence, query tile) pairs (set by its launcher)
   float scale_log2;         // softmax_scale * log2(e)

@@ -830,7 +830,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
   //         q_len, k_start, kv_len, bt_off, first page of the 16-key group of wave 0 .. 3 in the item's first tile
   struct Work { int h, q_row0_wg, q_start, q_len, k_start, kv_len, bt_off, n_tiles; };
   constexpr int REC = 12;
-  const int n_groups = (p.batch + 3) >> 2;
+  // Sequences are dealt in groups of `gs`: inside a group rank 0 (each sequence's longest tile) of its sequences, then
+  // rank 1, ...  gs = 4 for up to 4 sequences (longest tiles first over the whole launch), gs = 1 beyond: the tiles of one
+  // (sequence, head) then sit next to each other in the item order, run in the same round on the same XCD, and their K / V
+  // is fetched once — with groups of 4, 32 x 704 tokens read 1014 MB from beyond L2 for 554 MB of unique Q / K / V
+  // (FETCH_SIZE, tools/pmc_prefill_traffic.sh: an L2 hit rate of 27 % on 1.4 GB requested, 5.3 TB/s).
+  const int gs = p.seq_group;
+  const int n_groups = (p.batch + gs - 1) / gs;
   int* tb_g = reinterpret_cast<int*>(smem + 2 * IMG + 16);             // slots before group g, g = 0 .. n_groups
   int* items = tb_g + ((n_groups + 1 + 3) & ~3);                        // [n_rounds][REC], 16-byte aligned
   const int n_rounds = (p.n_tile_slots * p.n_heads + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -851,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       int n = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        n += (sq[min(4 * g + i + 1, p.batch)] - sq[min(4 * g + i, p.batch)] + TQ - 1) / TQ;
+        if (i < gs) n += (sq[min(gs * g + i + 1, p.batch)] - sq[min(gs * g + i, p.batch)] + TQ - 1) / TQ;
       tb_g[g] = n;
     }
     __syncthreads();
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       int tl[4], max_tiles = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        tl[i] = (sq[min(4 * lo + i + 1, p.batch)] - sq[min(4 * lo + i, p.batch)] + TQ - 1) / TQ;
+        tl[i] = i < gs ? (sq[min(gs * lo + i + 1, p.batch)] - sq[min(gs * lo + i, p.batch)] + TQ - 1) / TQ : 0;
         max_tiles = max(max_tiles, tl[i]);
       }
       int mblk = -1, b = 0;
@@ -929,7 +935,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (mblk < 0 && tl[i] > rank) {
-            if (slot == 0) { b = 4 * lo + i; mblk = tl[i] - 1 - rank; }
+            if (slot == 0) { b = gs * lo + i; mblk = tl[i] - 1 - rank; }
             --slot;
           }
         }
@@ -1354,6 +1360,7 @@ int fwd_n_cus() {
 int g_fwd_ablate = 0;   // EXPERIMENTS builds: timing ablations of attn_fwd32_kernel (wrong results)
 
 unsigned long long* g_fwd_stamps = nullptr;   // EXPERIMENTS builds: hx_debug_fwd_stamps
+int g_fwd_seq_group = 0;    // tuning: 0 = automatic, 1 / 2 / 4 = sequences per deal group of the persistent kernel
 int g_fwd_persistent = 1;   // tuning: 0 = one workgroup per (sequence, query tile, head) item, 2 = persistent for dense launches too
 int g_fwd_priority = -1;    // tuning: -1 = automatic, 0 / 1 = the two workgroups of a CU at equal / different priorities
 
@@ -1374,12 +1381,16 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   const int64_t total = (int64_t)pp.n_tile_slots * p.n_heads;
   const int64_t g = std::min<int64_t>(total, 2 * (int64_t)fwd_n_cus());
   // the workgroup's item table: the slot count in front of every group of 4 sequences, 12 words per round
-  const size_t table = 4 * (size_t)((((batch + 3) / 4 + 1 + 3) & ~3) + 12 * ((total + g - 1) / g));
+  pp.seq_group = g_fwd_seq_group > 0 ? g_fwd_seq_group : (batch <= 4 ? 4 : 1);
+  const size_t table = 4 * (size_t)((((batch + pp.seq_group - 1) / pp.seq_group + 1 + 3) & ~3) + 12 * ((total + g - 1) / g));
   // (else one workgroup per item: tables that do not fit; dense launches of equal items — the CLIP tower, 8 x 577:
   // 25.1 us per item against 27.4 — where the static deal puts the second items of a round on the same CUs)
-  // (and launches of at most one workgroup per CU: 1 x 704 tokens, 192 items, 20.2 us per item against 21.0 — the table
-  // is built for nothing)
-  if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED && total > fwd_n_cus())) && 2 * (lds + table) <= 160 * 1024 &&
+  // (and short launches of short items — up to two rounds of tiles with fewer than 24 key tiles: 4 x 704 tokens 32.5 - 33.2 us
+  // per item over many processes, 31.8 - 37.9 persistent; 1 x 704, 192 items, 20.2 against 21.0: the table is built for
+  // little.  Long items gain from the first round on — 2048 new tokens of 4096, one round: 113.6 us against 123.9 — through
+  // the pairing of long with short items on a CU.)
+  const bool worth_it = total > 4 * (int64_t)fwd_n_cus() || (total > fwd_n_cus() && p.max_seqlen_k >= 24 * 64);
+  if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED && worth_it)) && 2 * (lds + table) <= 160 * 1024 &&
       4 * (3 * (size_t)batch + 2 + (size_t)((total + g - 1) / g)) <= 2 * 64 * (2 * D + 2 * D)) {
     const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16 + table;
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32p_kernel<T, D, PAGED>,
@@ -1485,6 +1496,7 @@ int fwd_set_option(const char* name, int value) {
   if (!strcmp(name, "fwd_ablate")) { g_fwd_ablate = value; return HX_OK; }
   if (!strcmp(name, "fwd_persistent")) { g_fwd_persistent = value; return HX_OK; }
   if (!strcmp(name, "fwd_priority")) { g_fwd_priority = value; return HX_OK; }
+  if (!strcmp(name, "fwd_seq_group")) { g_fwd_seq_group = value == 1 || value == 2 || value == 4 ? value : 0; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 
