@@ -893,7 +893,7 @@ def time_prefill_attention(shape, dtype, dev, n_seqs=4, n_tokens=704, reps=3, la
     if brief:
         return {"workload": f"{n_seqs} x {n_tokens} new tokens" + (f" of {kv}" if kv != n_tokens else ""), "avg_launch_us": round(us, 2),
                 "achieved": round(tf, 1), "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}
-    return {"bound": "mfma", "kernel": "attn_fwd32p_kernel (paged causal prefill attention, v_mfma_f32_32x32x16, persistent workgroups)",
+    return {"bound": "mfma", "kernel": "attn_fwd32_kernel / attn_fwd32p_kernel (paged causal prefill attention, v_mfma_f32_32x32x16; one workgroup per item at 4 x 704, persistent workgroups for the two launches under other_workloads)",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "traffic": None, "avg_launch_us": round(us, 2), "algorithmic_flops_per_launch": flops,
             "workload": f"{n_seqs} sequences x {n_tokens} new tokens, H = {H}, D = {D}, block_size {bs}",
