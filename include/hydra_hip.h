@@ -54,7 +54,11 @@ int hx_last_hip_error(void);
  * K/V loads, "decode_small_lo" / "decode_small_hi" = range of (sequence, head) pair counts served
  * by the 8-wave no-split form, "fwd_row_blocks" = 0(auto)|1|2 query row blocks per wave,
  * "fwd_key_units" = 0(auto)|1|2 32-key units per tile and "fwd_xcd_remap" = 0|1 XCD-aware
- * workgroup numbering in the prefill kernel,
+ * workgroup numbering in the prefill kernel, "fwd_persistent" = 0|1(auto)|2 one workgroup per
+ * (sequence, query tile, head) item | persistent workgroups where the launcher expects a gain |
+ * persistent workgroups wherever their tables fit, "fwd_priority" = -1(auto)|0|1 and
+ * "fwd_seq_group" = 0(auto)|1|2|4 for the persistent form (equal priorities or priority to the
+ * workgroup of a CU with more left to do; sequences per deal group),
  * "gemm_rows_per_wave" / "gemm_waves" / "gemm_slab_nt" for the decode GEMM — results are
  * identical for every setting of these.  "decode_gqa" = 0|1 selects the per-query-head or the
  * grouped-query decode kernel for n_heads > n_kv_heads (both within the stated tolerance; the
