@@ -839,7 +839,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
   const int n_groups = (p.batch + gs - 1) / gs;
   int* tb_g = reinterpret_cast<int*>(smem + 2 * IMG + 16);             // slots before group g, g = 0 .. n_groups
   int* items = tb_g + ((n_groups + 1 + 3) & ~3);                        // [n_rounds][REC], 16-byte aligned
-  const int n_rounds = (p.n_tile_slots * p.n_heads + (int)gridDim.x - 1) / (int)gridDim.x;
+  // Unit mode (many sequences: p.unit_mode): what is dealt is a UNIT — the k-th longest and the k-th shortest query tile
+  // of one (sequence, head), run back to back by one workgroup (two records per round).  Under the causal mask every
+  // unit of a sequence costs about the same (704 tokens: 11 + 1, 9 + 3, 7 + 5 tile steps), so the workgroups that share a
+  // sequence's K / V start their units together in every round, not only in the first, and fetch its tiles once.
+  const bool units = p.unit_mode != 0;
+  const int n_rounds = (units ? 2 : 1) * ((p.n_tile_slots * p.n_heads + (int)gridDim.x - 1) / (int)gridDim.x);
   {
     // the per-sequence arrays first, into the (still unused) tile images: one round trip to global memory instead of one
     // per step of the decode (group counts -> the group's offsets -> the sequence's offsets -> its pages: 3.3 us in front
@@ -858,7 +863,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (i < gs) n += (sq[min(gs * g + i + 1, p.batch)] - sq[min(gs * g + i, p.batch)] + TQ - 1) / TQ;
-      tb_g[g] = n;
+      tb_g[g] = units ? (n + 1) >> 1 : n;            // (unit mode: gs = 1, a sequence of n tiles has (n + 1) / 2 units)
     }
     __syncthreads();
     if (w == 0) {
@@ -887,10 +892,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     const int partner = (int)blockIdx.x < p.n_cus ? (int)blockIdx.x + p.n_cus : (int)blockIdx.x - p.n_cus;
     int* p_tiles = sb + p.batch;                     // [n_rounds]: tile steps of the partner's items
     for (int idx = threadIdx.x; idx < 2 * n_rounds; idx += 256) {
-      const bool mine = idx < n_rounds;
-      const int r = mine ? idx : idx - n_rounds;
+      const bool mine = units || idx < n_rounds;
+      if (units && idx >= n_rounds) { p_tiles[idx - n_rounds] = 0; continue; }
+      const int r = units ? idx >> 1 : mine ? idx : idx - n_rounds;          // round (unit mode: records 2 r, 2 r + 1)
+      const int which = units ? idx & 1 : 0;
       const int wg = mine ? (int)blockIdx.x : partner;
-      int* rec = mine ? items + r * REC : p_tiles + r;
+      int* rec = mine ? items + idx * REC : p_tiles + r;
       rec[0] = 0;
       if (wg >= G) continue;
       int slot, h;
@@ -902,14 +909,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       if (remap) {
         const int Gx = G / 8, Tx = total / 8, hp = gy / 8;      // XCD x runs workgroups x, x + 8, ...: hp heads each
         const int x = wg % 8, j = wg / 8, H = p.n_cus / 8;
-        const int pj = j < H ? j : Gx - 1 - (j - H);
-        const int i = (r & 1) ? (r + 1) * Gx - 1 - pj : r * Gx + pj;
+        const int pj = units || j < H ? j : Gx - 1 - (j - H);
+        const int i = (r & 1) && !units ? (r + 1) * Gx - 1 - pj : r * Gx + pj;
         if (i >= Tx) continue;
         h = x * hp + i % hp;
         slot = i / hp;
       } else {
-        const int pw = wg < p.n_cus ? wg : G - 1 - (wg - p.n_cus);
-        const int i = (r & 1) ? (r + 1) * G - 1 - pw : r * G + pw;
+        const int pw = units || wg < p.n_cus ? wg : G - 1 - (wg - p.n_cus);
+        const int i = (r & 1) && !units ? (r + 1) * G - 1 - pw : r * G + pw;
         if (i >= total) continue;
         slot = i % n_slots;
         h = i / n_slots;
@@ -931,12 +938,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
         max_tiles = max(max_tiles, tl[i]);
       }
       int mblk = -1, b = 0;
-      for (int rank = 0; rank < max_tiles && mblk < 0; ++rank) {
+      if (units) {
+        // unit `slot` of sequence lo: its (slot)-th longest tile first, then its (slot)-th shortest (if another one)
+        b = lo;
+        const int k = which ? slot : tl[0] - 1 - slot;
+        mblk = which && 2 * slot == tl[0] - 1 ? -1 : k;
+      } else {
+        for (int rank = 0; rank < max_tiles && mblk < 0; ++rank) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (mblk < 0 && tl[i] > rank) {
-            if (slot == 0) { b = gs * lo + i; mblk = tl[i] - 1 - rank; }
-            --slot;
+          for (int i = 0; i < 4; ++i) {
+            if (mblk < 0 && tl[i] > rank) {
+              if (slot == 0) { b = gs * lo + i; mblk = tl[i] - 1 - rank; }
+              --slot;
+            }
           }
         }
       }
@@ -964,7 +978,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
   {
     const bool young = (int)blockIdx.x >= p.n_cus;
     int* p_tiles = reinterpret_cast<int*>(smem) + 3 * p.batch + 2;
-    for (int r = 0; r < n_rounds; ++r) {
+    for (int r = 0; r < n_rounds && !units; ++r) {
       const int a = max(__builtin_amdgcn_readfirstlane(items[r * REC]), 0), b = __builtin_amdgcn_readfirstlane(p_tiles[r]);
       work_mine += a ? a * (young ? 4 : 3) + 6 : 0;
       work_partner += b ? b * (young ? 3 : 4) + 6 : 0;
@@ -1360,6 +1374,7 @@ int fwd_n_cus() {
 int g_fwd_ablate = 0;   // EXPERIMENTS builds: timing ablations of attn_fwd32_kernel (wrong results)
 
 unsigned long long* g_fwd_stamps = nullptr;   // EXPERIMENTS builds: hx_debug_fwd_stamps
+int g_fwd_units = -1;       // tuning: -1 = automatic, 0 / 1 = the persistent kernel deals single tiles / units of two
 int g_fwd_seq_group = 0;    // tuning: 0 = automatic, 1 / 2 / 4 = sequences per deal group of the persistent kernel
 int g_fwd_persistent = 1;   // tuning: 0 = one workgroup per (sequence, query tile, head) item, 2 = persistent for dense launches too
 int g_fwd_priority = -1;    // tuning: -1 = automatic, 0 / 1 = the two workgroups of a CU at equal / different priorities
@@ -1382,7 +1397,13 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   const int64_t g = std::min<int64_t>(total, 2 * (int64_t)fwd_n_cus());
   // the workgroup's item table: the slot count in front of every group of 4 sequences, 12 words per round
   pp.seq_group = g_fwd_seq_group > 0 ? g_fwd_seq_group : (batch <= 4 ? 4 : 1);
-  const size_t table = 4 * (size_t)((((batch + pp.seq_group - 1) / pp.seq_group + 1 + 3) & ~3) + 12 * ((total + g - 1) / g));
+  // units (pairs of a sequence's tiles) where there are at least two rounds of them
+  const int64_t unit_slots = p.total_q / 256 + batch, total_units = unit_slots * p.n_heads;
+  pp.unit_mode = g_fwd_units >= 0 ? g_fwd_units : (pp.seq_group == 1 && total_units >= 2 * g ? 1 : 0);
+  if (pp.seq_group != 1) pp.unit_mode = 0;
+  if (pp.unit_mode) pp.n_tile_slots = (int32_t)unit_slots;
+  const int64_t rounds = pp.unit_mode ? 2 * ((total_units + g - 1) / g) : (total + g - 1) / g;
+  const size_t table = 4 * (size_t)((((batch + pp.seq_group - 1) / pp.seq_group + 1 + 3) & ~3) + 12 * rounds);
   // (else one workgroup per item: tables that do not fit; dense launches of equal items — the CLIP tower, 8 x 577:
   // 25.1 us per item against 27.4 — where the static deal puts the second items of a round on the same CUs)
   // (and short launches of short items — up to two rounds of tiles with fewer than 24 key tiles: 4 x 704 tokens 32.5 - 33.2 us
@@ -1391,7 +1412,7 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   // the pairing of long with short items on a CU.)
   const bool worth_it = total > 4 * (int64_t)fwd_n_cus() || (total > fwd_n_cus() && p.max_seqlen_k >= 24 * 64);
   if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED && worth_it)) && 2 * (lds + table) <= 160 * 1024 &&
-      4 * (3 * (size_t)batch + 2 + (size_t)((total + g - 1) / g)) <= 2 * 64 * (2 * D + 2 * D)) {
+      4 * (3 * (size_t)batch + 2 + (size_t)rounds) <= 2 * 64 * (2 * D + 2 * D)) {
     const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16 + table;
     hipError_t e = hipFuncSetAttribute((const void*)attn_fwd32p_kernel<T, D, PAGED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1496,6 +1517,7 @@ int fwd_set_option(const char* name, int value) {
   if (!strcmp(name, "fwd_ablate")) { g_fwd_ablate = value; return HX_OK; }
   if (!strcmp(name, "fwd_persistent")) { g_fwd_persistent = value; return HX_OK; }
   if (!strcmp(name, "fwd_priority")) { g_fwd_priority = value; return HX_OK; }
+  if (!strcmp(name, "fwd_units")) { g_fwd_units = value < 0 ? -1 : value ? 1 : 0; return HX_OK; }
   if (!strcmp(name, "fwd_seq_group")) { g_fwd_seq_group = value == 1 || value == 2 || value == 4 ? value : 0; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }

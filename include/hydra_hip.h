@@ -57,8 +57,9 @@ int hx_last_hip_error(void);
  * workgroup numbering in the prefill kernel, "fwd_persistent" = 0|1(auto)|2 one workgroup per
  * (sequence, query tile, head) item | persistent workgroups where the launcher expects a gain |
  * persistent workgroups wherever their tables fit, "fwd_priority" = -1(auto)|0|1 and
- * "fwd_seq_group" = 0(auto)|1|2|4 for the persistent form (equal priorities or priority to the
- * workgroup of a CU with more left to do; sequences per deal group),
+ * "fwd_seq_group" = 0(auto)|1|2|4, "fwd_units" = -1(auto)|0|1 for the persistent form (equal
+ * priorities or priority to the workgroup of a CU with more left to do; sequences per deal group;
+ * single tiles or units of a sequence's k-th longest and k-th shortest tile),
  * "gemm_rows_per_wave" / "gemm_waves" / "gemm_slab_nt" for the decode GEMM — results are
  * identical for every setting of these.  "decode_gqa" = 0|1 selects the per-query-head or the
  * grouped-query decode kernel for n_heads > n_kv_heads (both within the stated tolerance; the
