@@ -941,8 +941,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       if (units) {
         // unit `slot` of sequence lo: its (slot)-th longest tile first, then its (slot)-th shortest (if another one)
         b = lo;
-        const int k = which ? slot : tl[0] - 1 - slot;
-        mblk = which && 2 * slot == tl[0] - 1 ? -1 : k;
+        const bool short_one = (which != 0) != (p.unit_mode == 2);      // unit_mode 2: the short tile first
+        const int k = short_one ? slot : tl[0] - 1 - slot;
+        mblk = short_one && 2 * slot == tl[0] - 1 ? -1 : k;
       } else {
         for (int rank = 0; rank < max_tiles && mblk < 0; ++rank) {
 #pragma unroll
@@ -1517,7 +1518,7 @@ int fwd_set_option(const char* name, int value) {
   if (!strcmp(name, "fwd_ablate")) { g_fwd_ablate = value; return HX_OK; }
   if (!strcmp(name, "fwd_persistent")) { g_fwd_persistent = value; return HX_OK; }
   if (!strcmp(name, "fwd_priority")) { g_fwd_priority = value; return HX_OK; }
-  if (!strcmp(name, "fwd_units")) { g_fwd_units = value < 0 ? -1 : value ? 1 : 0; return HX_OK; }
+  if (!strcmp(name, "fwd_units")) { g_fwd_units = value < 0 ? -1 : value > 2 ? 1 : value; return HX_OK; }
   if (!strcmp(name, "fwd_seq_group")) { g_fwd_seq_group = value == 1 || value == 2 || value == 4 ? value : 0; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }

@@ -50,7 +50,7 @@ l = _lib.lib()
 # (label, options): the 16x16x32 kernel, the 32x32x16 kernel with one workgroup per item, its persistent form
 variants = [("16x16x32", {"fwd_mfma32": 0}), ("32x32x16 per item", {"fwd_persistent": 0}),
             ("persistent", {}), ("persistent prio 0", {"fwd_priority": 0}), ("persistent prio 1", {"fwd_priority": 1}),
-            ("single tiles", {"fwd_units": 0}), ("units", {"fwd_units": 1}),
+            ("single tiles", {"fwd_units": 0}), ("units", {"fwd_units": 1}), ("units short first", {"fwd_units": 2}),
             ("groups of 4", {"fwd_seq_group": 4}), ("groups of 2", {"fwd_seq_group": 2}), ("groups of 1", {"fwd_seq_group": 1})]
 if len(sys.argv) > 1:
     variants = [v for v in variants if v[0] in sys.argv[1].split(",")] or variants
