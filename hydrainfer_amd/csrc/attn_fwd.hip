@@ -1407,11 +1407,12 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   const size_t table = 4 * (size_t)((((batch + pp.seq_group - 1) / pp.seq_group + 1 + 3) & ~3) + 12 * rounds);
   // (else one workgroup per item: tables that do not fit; dense launches of equal items — the CLIP tower, 8 x 577:
   // 25.1 us per item against 27.4 — where the static deal puts the second items of a round on the same CUs)
-  // (and short launches of short items — up to two rounds of tiles with fewer than 24 key tiles: 4 x 704 tokens 32.5 - 33.2 us
-  // per item over many processes, 31.8 - 37.9 persistent; 1 x 704, 192 items, 20.2 against 21.0: the table is built for
-  // little.  Long items gain from the first round on — 2048 new tokens of 4096, one round: 113.6 us against 123.9 — through
-  // the pairing of long with short items on a CU.)
-  const bool worth_it = total > 4 * (int64_t)fwd_n_cus() || (total > fwd_n_cus() && p.max_seqlen_k >= 24 * 64);
+  // (and launches of at most one round of short items — 1 x 704 tokens, 192 items, 20.2 us per item against 21.0: the
+  // table is built for little.  From the second round on the two forms are within noise of each other on one box and
+  // the persistent one is ahead in a run of launches (bench.py's hipGraph of ten 4 x 704 launches: 32.5 - 32.7 us
+  // against 33.8 - 36.0); long items gain from the first round on — 2048 new tokens of 4096, one round: 113.6 us
+  // against 123.9 — through the pairing of long with short items on a CU.)
+  const bool worth_it = total > 2 * (int64_t)fwd_n_cus() || (total > fwd_n_cus() && p.max_seqlen_k >= 24 * 64);
   if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED && worth_it)) && 2 * (lds + table) <= 160 * 1024 &&
       4 * (3 * (size_t)batch + 2 + (size_t)rounds) <= 2 * 64 * (2 * D + 2 * D)) {
     const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16 + table;
