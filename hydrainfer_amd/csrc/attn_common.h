@@ -68,6 +68,7 @@ struct AttnParams {
   int32_t wg_priority;      // prefill kernel (32x32 form): the two workgroups of a CU run at different priorities
   unsigned long long* stamps;   // EXPERIMENTS builds: time stamps of the persistent prefill kernel (null otherwise)
   int32_t max_seqlen_k;     // the caller's bound on a sequence's keys (host side: chooses between the forms of the prefill kernel)
+  int32_t cu_pairing;       // prefill kernel, persistent form: the second workgroup of a CU takes a round's items from the short end
   int32_t unit_mode;        // prefill kernel, persistent form: deal units (the k-th longest + k-th shortest tile of a sequence)
   int32_t seq_group;        // prefill kernel, persistent form: sequences per deal group, 1 / 2 / 4 (set by its launcher)
   int32_t n_cus;            // prefill kernel, persistent form: CUs of the device (set by its launcher)

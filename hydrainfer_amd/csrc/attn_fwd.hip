@@ -909,13 +909,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
       if (remap) {
         const int Gx = G / 8, Tx = total / 8, hp = gy / 8;      // XCD x runs workgroups x, x + 8, ...: hp heads each
         const int x = wg % 8, j = wg / 8, H = p.n_cus / 8;
-        const int pj = units || j < H ? j : Gx - 1 - (j - H);
+        const int pj = units || !p.cu_pairing || j < H ? j : Gx - 1 - (j - H);
         const int i = (r & 1) && !units ? (r + 1) * Gx - 1 - pj : r * Gx + pj;
         if (i >= Tx) continue;
         h = x * hp + i % hp;
         slot = i / hp;
       } else {
-        const int pw = units || wg < p.n_cus ? wg : G - 1 - (wg - p.n_cus);
+        const int pw = units || !p.cu_pairing || wg < p.n_cus ? wg : G - 1 - (wg - p.n_cus);
         const int i = (r & 1) && !units ? (r + 1) * G - 1 - pw : r * G + pw;
         if (i >= total) continue;
         slot = i % n_slots;
@@ -1375,6 +1375,7 @@ int fwd_n_cus() {
 int g_fwd_ablate = 0;   // EXPERIMENTS builds: timing ablations of attn_fwd32_kernel (wrong results)
 
 unsigned long long* g_fwd_stamps = nullptr;   // EXPERIMENTS builds: hx_debug_fwd_stamps
+int g_fwd_pairing = 1;      // tuning: 0 = the second workgroup of a CU takes its items in list order like the first
 int g_fwd_units = -1;       // tuning: -1 = automatic, 0 / 1 = the persistent kernel deals single tiles / units of two
 int g_fwd_seq_group = 0;    // tuning: 0 = automatic, 1 / 2 / 4 = sequences per deal group of the persistent kernel
 int g_fwd_persistent = 1;   // tuning: 0 = one workgroup per (sequence, query tile, head) item, 2 = persistent for dense launches too
@@ -1398,6 +1399,7 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   const int64_t g = std::min<int64_t>(total, 2 * (int64_t)fwd_n_cus());
   // the workgroup's item table: the slot count in front of every group of 4 sequences, 12 words per round
   pp.seq_group = g_fwd_seq_group > 0 ? g_fwd_seq_group : (batch <= 4 ? 4 : 1);
+  pp.cu_pairing = g_fwd_pairing;
   // units (pairs of a sequence's tiles) where there are at least two rounds of them
   const int64_t unit_slots = p.total_q / 256 + batch, total_units = unit_slots * p.n_heads;
   pp.unit_mode = g_fwd_units >= 0 ? g_fwd_units : (pp.seq_group == 1 && total_units >= 2 * g ? 1 : 0);
@@ -1407,12 +1409,12 @@ int launch_fwd32(const AttnParams& p, int batch, hipStream_t stream) {
   const size_t table = 4 * (size_t)((((batch + pp.seq_group - 1) / pp.seq_group + 1 + 3) & ~3) + 12 * rounds);
   // (else one workgroup per item: tables that do not fit; dense launches of equal items — the CLIP tower, 8 x 577:
   // 25.1 us per item against 27.4 — where the static deal puts the second items of a round on the same CUs)
-  // (and launches of at most one round of short items — 1 x 704 tokens, 192 items, 20.2 us per item against 21.0: the
-  // table is built for little.  From the second round on the two forms are within noise of each other on one box and
-  // the persistent one is ahead in a run of launches (bench.py's hipGraph of ten 4 x 704 launches: 32.5 - 32.7 us
-  // against 33.8 - 36.0); long items gain from the first round on — 2048 new tokens of 4096, one round: 113.6 us
-  // against 123.9 — through the pairing of long with short items on a CU.)
-  const bool worth_it = total > 2 * (int64_t)fwd_n_cus() || (total > fwd_n_cus() && p.max_seqlen_k >= 24 * 64);
+  // (and short launches of short items — up to two rounds of tiles with fewer than 24 key tiles.  Same process, same data,
+  // hipGraph of ten launches: 4 x 704 tokens 33.9 / 31.5 us per item (two page permutations) against 34.0 - 35.0 / 32.7 -
+  // 33.4 persistent in its four settings, 3 x 683 of 704 27.7 / 26.6 against 28.0 - 28.6 / 27.3 - 27.7; 1 x 704, 192
+  // items, 20.2 against 21.0: the table is built for little.  Long items gain from the first round on — 2048 new tokens of
+  // 4096, one round: 113.6 us against 123.9 — through the pairing of long with short items on a CU.)
+  const bool worth_it = total > 4 * (int64_t)fwd_n_cus() || (total > fwd_n_cus() && p.max_seqlen_k >= 24 * 64);
   if ((g_fwd_persistent == 2 || (g_fwd_persistent && PAGED && worth_it)) && 2 * (lds + table) <= 160 * 1024 &&
       4 * (3 * (size_t)batch + 2 + (size_t)rounds) <= 2 * 64 * (2 * D + 2 * D)) {
     const size_t lds = 2 * 64 * (2 * D + 2 * D) + 16 + table;
@@ -1519,6 +1521,7 @@ int fwd_set_option(const char* name, int value) {
   if (!strcmp(name, "fwd_ablate")) { g_fwd_ablate = value; return HX_OK; }
   if (!strcmp(name, "fwd_persistent")) { g_fwd_persistent = value; return HX_OK; }
   if (!strcmp(name, "fwd_priority")) { g_fwd_priority = value; return HX_OK; }
+  if (!strcmp(name, "fwd_pairing")) { g_fwd_pairing = value ? 1 : 0; return HX_OK; }
   if (!strcmp(name, "fwd_units")) { g_fwd_units = value < 0 ? -1 : value > 2 ? 1 : value; return HX_OK; }
   if (!strcmp(name, "fwd_seq_group")) { g_fwd_seq_group = value == 1 || value == 2 || value == 4 ? value : 0; return HX_OK; }
   return HX_ERR_UNSUPPORTED;

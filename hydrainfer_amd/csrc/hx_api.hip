@@ -212,6 +212,7 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.n_cus = 0;
   p.seq_group = 4;
   p.unit_mode = 0;
+  p.cu_pairing = 1;
   p.max_seqlen_k = a->max_seqlen_k;
   p.stamps = nullptr;
   p.scale_log2 = a->softmax_scale * 1.4426950408889634f;

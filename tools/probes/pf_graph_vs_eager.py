@@ -35,7 +35,12 @@ def t_graph(fn, launches, reps=3):
         e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / launches * 1e3)
     return ts
+l = _lib.lib()
 for seed in (0, 11):
-    for name, args in (("32x704", (32, 704, 704)), ("2048of4096", (1, 2048, 4096)), ("4x704", (4, 704, 704))):
+    for name, args in (("4x704", (4, 704, 704)), ("3x683of704", (3, 683, 704))):
         fn = case(*args, seed)
-        print(name, "seed", seed, "eager30 %.1f" % t_eager(fn, 30), "eager4 %.1f" % t_eager(fn, 4), "graph4", ["%.1f" % x for x in t_graph(fn, 4)], "graph30", ["%.1f" % x for x in t_graph(fn, 30)], flush=True)
+        for opts in ({"fwd_persistent": 0}, {"fwd_priority": 0, "fwd_pairing": 0}, {"fwd_priority": 1, "fwd_pairing": 0},
+                     {"fwd_priority": 0, "fwd_pairing": 1}, {"fwd_priority": 1, "fwd_pairing": 1}):
+            for k, val in {"fwd_persistent": 1, "fwd_priority": -1, "fwd_pairing": 1, **opts}.items():
+                l.hx_debug_set_option(k.encode(), val)
+            print(name, "seed", seed, opts, "graph10", ["%.1f" % x for x in t_graph(fn, 10)], "eager30 %.1f" % t_eager(fn, 30), flush=True)
