@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   c_i32* cu_q_s = (c_i32*)p.cu_q;
   c_i32* cu_k_s = (c_i32*)p.cu_k;
   int mblk = -1, h, b = 0;
+  int q_start = 0, q_len = 0, k_start = 0, kv_len = 0, bt_off = 0;      // of sequence b: read with its group's offsets
   {
     const int gx = gridDim.x, gy = gridDim.y;
     const int total = gx * gy;
@@ -404,9 +405,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
     // (the group's five offsets are requested together and kept: with a load inside the rank loop the decode was a
     // chain of up to 24 scalar round trips, ~2 us in front of every workgroup's first request for K / V)
     for (int g0 = 0; g0 < p.batch && mblk < 0; g0 += 4) {
-      int cq[5];
+      // (cu_k and cu_block_lens of the group's sequences ride along: fetched after the sequence was known they were one
+      // more dependent round trip in front of the page lookup and the first K / V request)
+      int cq[5], ck[5], cb[4];
 #pragma unroll
       for (int i = 0; i < 5; ++i) cq[i] = cu_q_s[min(g0 + i, p.batch)];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) ck[i] = cu_k_s[min(g0 + i, p.batch)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cb[i] = PAGED ? ((c_i32*)p.cu_block_lens)[min(g0 + i, p.batch - 1)] : 0;
       int tl[4], max_tiles = 0, group_tiles = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -419,7 +426,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (mblk < 0 && tl[i] > rank) {
-            if (slot == 0) { b = g0 + i; mblk = tl[i] - 1 - rank; }
+            if (slot == 0) {
+              b = g0 + i; mblk = tl[i] - 1 - rank;
+              q_start = cq[i]; q_len = cq[i + 1] - cq[i]; k_start = ck[i]; kv_len = ck[i + 1] - ck[i]; bt_off = cb[i];
+            }
             --slot;
           }
         }
@@ -433,10 +443,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
   const int hk = h / p.group;
   b = __builtin_amdgcn_readfirstlane(b);
 // (priority of this workgroup's waves: see below)
-  const int q_start = cu_q_s[b];
-  const int q_len = cu_q_s[b + 1] - q_start;
-  const int k_start = cu_k_s[b];
-  const int kv_len = cu_k_s[b + 1] - k_start;
   // Query tiles are aligned to the END of the sequence: the partial tile (q_len % 128 rows) is the FIRST one — under the
   // causal mask the tile with the fewest keys — and every other tile is full.  Aligned to the start, the partial tile was
   // the one with the most keys: 704 rows = 5 x 128 + 64 cost 2 + 4 + 6 + 8 + 10 + 11 = 41 tile steps, the last eleven of
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) 
 
   const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
   const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
-  const int32_t* bt = PAGED ? p.block_table + ((c_i32*)p.cu_block_lens)[b] : nullptr;
+  const int32_t* bt = PAGED ? p.block_table + bt_off : nullptr;
 
   // Staging map of a wave (Q here, K / V tiles below, O at the end): instruction j takes rows RPI j .. RPI j + RPI - 1
   // of the wave's block, D / 8 lanes per row — the whole row contiguous.
