@@ -58,8 +58,50 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const char* __restrict
   if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
 }
 
+// variant 5: the contiguous shape by LDS-DMA (global_load_lds_dwordx4: no VGPR write-back), U pieces of 1 KiB in
+//            flight per wave in a ring of U LDS slots, counted vmcnt; nothing reads the LDS
+template <int U, int POLICY>
+__global__ __launch_bounds__(256) void stream_read_lds_kernel(const char* __restrict__ base, int64_t bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + w, n_waves = gridDim.x * 4;
+  const int chunk = U * 1024;
+  const int n_chunks = (int)(bytes / chunk);
+  const uint32_t lds = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)(smem) + (uint32_t)(w * U * 1024);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  for (int c = wave; c < n_chunks; c += n_waves) {
+    const char* p0 = base + (int64_t)c * chunk + lane * 16;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t d = __builtin_amdgcn_readfirstlane(lds + 1024u * u);
+      if (POLICY == 1)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(p0 + 1024 * u), "s"(d) : "memory", "m0");
+      else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(p0 + 1024 * u), "s"(d) : "memory", "m0");
+      // the slot written U pieces ago must have landed before it is overwritten: at most U - 1 older pieces pending
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(U - 1) : "memory");
+    }
+  }
+#pragma clang diagnostic pop
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int U>
 int launch_u(const void* p, int64_t bytes, int variant, int64_t pitch, int policy, int wgs, float* sink, hipStream_t s) {
+  if (variant == 5) {
+    const size_t lds = 4 * U * 1024;
+    if (policy) {
+      hipError_t e = hipFuncSetAttribute((const void*)stream_read_lds_kernel<U, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return hip_rc(e);
+      hx::launcher(stream_read_lds_kernel<U, 1>, wgs, 256, lds, s)((const char*)p, bytes);
+    } else {
+      hipError_t e = hipFuncSetAttribute((const void*)stream_read_lds_kernel<U, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return hip_rc(e);
+      hx::launcher(stream_read_lds_kernel<U, 0>, wgs, 256, lds, s)((const char*)p, bytes);
+    }
+    return check_launch();
+  }
   if (policy) hx::launcher(stream_read_kernel<U, 1>, wgs, 256, 0, s)((const char*)p, bytes, variant, pitch, sink);
   else hx::launcher(stream_read_kernel<U, 0>, wgs, 256, 0, s)((const char*)p, bytes, variant, pitch, sink);
   return check_launch();
@@ -190,7 +232,7 @@ extern "C" int hx_debug_paged_read(const void* kbase, const void* vbase, const i
 extern "C" int hx_debug_stream_read(const void* p, int64_t bytes, int variant, int64_t pitch, int unroll,
                                     int policy, int wgs, float* sink, hx_stream stream) {
   if (!p || !sink || bytes <= 0 || wgs <= 0) return HX_ERR_NULL;
-  if (variant < 0 || variant > 4 || (variant && (pitch <= 0 || pitch % 1024))) return HX_ERR_SHAPE;
+  if (variant < 0 || variant > 5 || (variant && variant < 5 && (pitch <= 0 || pitch % 1024))) return HX_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   switch (unroll) {
     case 4: return launch_u<4>(p, bytes, variant, pitch, policy, wgs, sink, s);

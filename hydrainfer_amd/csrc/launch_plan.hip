@@ -97,30 +97,22 @@ __global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, int
 // recorded region would run once, at recording time, and never again) and a plain kernel node under hipGraph
 // capture (a captured hipMemsetAsync node was seen to leave garbage from the second replay on).  4-byte granularity.
 // hx_measure_read_stream: the read rate of this GPU for the access shape of the weight-streaming kernels (1 KiB
-// contiguous per wave instruction, non-temporal, 8 in flight per wave), nothing computed.
+// contiguous per wave instruction, non-temporal), nothing computed.  Eight loads in flight per wave, consumed before the
+// next eight are requested, 512 workgroups: the best of the shapes of tools/bench_stream.py / tools/probes/stream_lds_dma.py
+// (6.8 - 7.0 TB/s; sixteen in flight from 1024 workgroups, the round's first version of this kernel: 6.3 - 6.5; without
+// the non-temporal hint 5.7 - 6.3; the same stream by LDS-DMA: no different).
 namespace {
 __global__ __launch_bounds__(256) void read_stream_kernel(const char* __restrict__ base, int64_t n_chunks, float* sink) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
   hx::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  // two 8 KiB chunks per wave in flight: the next chunk is requested before the current one is consumed
-  hx::f32x4 v[2][8];
-  auto load = [&](hx::f32x4 (&d)[8], int64_t c) {
+  for (int64_t c = wave; c < n_chunks; c += n_waves) {
     const char* p0 = base + c * 8192 + lane * 16;
+    hx::f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) d[u] = __builtin_nontemporal_load(reinterpret_cast<const hx::f32x4*>(p0 + u * 1024));
-  };
-  int64_t c = wave;
-  if (c < n_chunks) load(v[0], c);
-  for (; c < n_chunks; c += 2 * n_waves) {
-    if (c + n_waves < n_chunks) load(v[1], c + n_waves);
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const hx::f32x4*>(p0 + u * 1024));
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[0][u];
-    if (c + 2 * n_waves < n_chunks) load(v[0], c + 2 * n_waves);
-    if (c + n_waves < n_chunks) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[1][u];
-    }
+    for (int u = 0; u < 8; ++u) acc += v[u];
   }
   if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
 }
@@ -130,7 +122,7 @@ extern "C" int hx_measure_read_stream(const void* p, int64_t bytes, float* sink,
   if (!p || !sink) return HX_ERR_NULL;
   if (bytes <= 0 || bytes % 8192) return HX_ERR_SHAPE;
   if (reinterpret_cast<uintptr_t>(p) & 15u) return HX_ERR_STRIDE;
-  hx::launcher(read_stream_kernel, 1024, 256, 0, (hipStream_t)stream)((const char*)p, bytes / 8192, sink);
+  hx::launcher(read_stream_kernel, 512, 256, 0, (hipStream_t)stream)((const char*)p, bytes / 8192, sink);
   return check_launch();
 }
 
