@@ -112,6 +112,46 @@ def test_sum_out(topk, dtype):
     assert torch.allclose(out.cpu().float(), ref.float(), atol=1e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])
+def test_unpermute_and_sum_out_streaming_forms_equal_the_scalar_forms(dtype):
+    """The 16-byte streaming forms of unpermute / sum_out (valid rows compacted once in map order) against the scalar
+    forms on the same values — selected by handing over a 2-byte-misaligned copy of the permuted rows — bit for bit, at
+    production sizes: 33 tokens x 7168, top 8 of 256 experts, the index map (8 rows) and the mask map (256 rows)."""
+    from hydrainfer_amd._C.kernel.moe import (permute_with_index_map, permute_with_mask_map, sum_out,
+                                              unpermute_with_index_map, unpermute_with_mask_map)
+    n, dim, n_exp, topk = 33, 7168, 256, 8
+    g = torch.Generator().manual_seed(5)
+    tokens = torch.randn((n, dim), generator=g).to(dtype).to(DEV)
+    gating = torch.randn((n, n_exp), generator=g)
+    weights, indices = gating.topk(topk, dim=-1)
+    probs = weights.softmax(dim=-1).to(dtype).to(DEV)
+
+    def misaligned(t):
+        buf = torch.empty(t.numel() + 8, dtype=t.dtype, device=t.device)
+        v = buf[1:1 + t.numel()].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+        return v
+
+    p, rmap = permute_with_index_map(tokens, indices.to(torch.int32).to(DEV))
+    fast = unpermute_with_index_map(p, rmap, probs)
+    slow = unpermute_with_index_map(misaligned(p), rmap, probs)
+    assert torch.equal(fast, slow)
+    assert torch.allclose(fast.float(), tokens.float(), atol=2e-2, rtol=2e-2)      # the probabilities sum to 1
+    routing = torch.zeros((n, n_exp), dtype=torch.bool).scatter(1, indices, True).to(DEV)
+    mprobs = torch.zeros((n, n_exp)).scatter(1, indices, weights.softmax(dim=-1)).to(dtype).to(DEV)
+    pm, mmap = permute_with_mask_map(tokens, routing, topk)
+    fast = unpermute_with_mask_map(pm, mmap, mprobs)
+    slow = unpermute_with_mask_map(misaligned(pm), mmap, mprobs)
+    assert torch.equal(fast, slow)
+    assert torch.allclose(fast.float(), tokens.float(), atol=2e-2, rtol=2e-2)
+    x = p.view(n, topk, dim)          # any [n, topk, dim] values
+    o_fast, o_slow = torch.empty((n, dim), dtype=dtype, device=DEV), torch.empty((n, dim), dtype=dtype, device=DEV)
+    sum_out(x, o_fast)
+    sum_out(misaligned(x), o_slow)
+    assert torch.equal(o_fast, o_slow)
+
+
 def test_hip_moe_ops_against_the_reference_test_oracle_fixtures():
     """tests/golden/g12_moe.npz: inputs and outputs that passed the assertions of the reference's
     own tests/kernel/test_moe.py (its torch references, its tolerances) — the HIP kernels are held
