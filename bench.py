@@ -66,6 +66,8 @@ def parse():
     p.add_argument("--cpu-layers", type=int, default=2)
     p.add_argument("--no-13b", action="store_true", help="skip the short LLaVA-1.5-13B leg (BASELINE configs[2])")
     p.add_argument("--steps-13b", type=int, default=20)
+    p.add_argument("--no-null-step", action="store_true",
+                   help="skip whole_step.null_step (the launch structure's ceiling: the step with math-free stand-in launches)")
     p.add_argument("--dry-run", action="store_true",
                    help="launch plumbing only (ranks, rendezvous, barrier, max-over-ranks timing of empty steps): "
                         "no GPU is touched; the JSON line says dry_run")
@@ -375,7 +377,9 @@ def build_rank_engine(ctx, model, vision, shape, dtype, dev, batch, n_text, max_
                       sched, rank=ctx.rank, max_blocks_per_seq=per_req, world_size=ctx.world_size,
                       release_prefill_weights=False)   # the replica leg of the same process prefills on every rank
     group = None if ctx.backend == "gloo" else dist.new_group(backend="gloo")
-    return RankEngine(ctx.rank, roles, node, group)
+    engine = RankEngine(ctx.rank, roles, node, group)
+    engine.connect_transfer_peers(timeout_s=60)      # send/recv hops only (none with the intra-node IPC pull): bounded
+    return engine
 
 
 def measure_disaggregated(ctx, engine, shape, dev, pixels, batch, n_text, max_tokens, rate_per_d=6.0):
@@ -953,6 +957,103 @@ def roofline_objects(model, runner, ctxs, ms_per_step, args, model_name, with_ge
     return roofline, roofline_gemm, whole
 
 
+def null_step_object(model, runner, ctxs, ms_per_step, reps=5, grid_wgs=256):
+    """`whole_step.null_step` — the ceiling of the step's LAUNCH STRUCTURE on this GPU in this run (round-4 review, item 1a).
+    The decode step replayed as a launch plan in which every launch of a layer is replaced by a math-free stand-in over
+    the SAME bytes with the SAME grid: the paged-read probe over the layer's real KV pages with the real block table
+    (hx_measure_paged_read: (head, sequence) workgroups, the attention kernel's loads, nothing else) and the read-stream
+    probe over the real packed weights of o / gate|up / down / qkv (hx_measure_read_grid, one workgroup per CU like the
+    real launches) — no activations, no arithmetic, no hand-over, no stores; the step's edges (step head, final norm,
+    library lm_head GEMM, argmax) are the REAL kernels on scratch buffers.  One plan per timed context (its tile count),
+    replayed in the timed order, HIP events around each pass, median of `reps` passes.  built / null says how much of what
+    a 5-launch layer can reach the built step reaches; `null_step_best_grid` is the same with 512 workgroups per weight
+    launch (the probe's best shape)."""
+    import statistics
+    from hydrainfer_amd import _lib, launch_plan
+    from hydrainfer_amd._C.kernel.norm import add_rms_norm_slabs, argmax_rows, decode_step_head
+    lib = _lib.lib()
+    sh, dev, dt = model.shape, runner.dev, model.dtype
+    B, bs = runner.cfg.batch, runner.cfg.block_size
+    L, H, HK, D, hid = sh.num_hidden_layers, sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim, sh.hidden_size
+    if HK != H or D * runner.pool.element_size() != 256:
+        return None
+    e = runner.pool.element_size()
+    page_bytes, row_bytes = bs * HK * D * e, HK * D * e
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+
+    def weight(l, n):
+        t = model.packed_x.get(f"l{l}.{n}")
+        return t if t is not None else model.packed[f"l{l}.{n}"]
+
+    def read(t, wgs):
+        nbytes = t.numel() * t.element_size()
+        _lib.check(lib.hx_measure_read_grid(t.data_ptr(), nbytes - nbytes % 8192, wgs, sink.data_ptr(), _lib.current_stream()), "read_grid")
+
+    ids = torch.randint(1000, 30000, (B,), device=dev)
+    slabs = torch.zeros((1, B, hid), dtype=torch.float32, device=dev)
+    w_lm = model.state["lm_head"]
+
+    def record(tiles, wgs):
+        plan = launch_plan.LaunchPlan(dev)
+
+        def body():
+            sync = model._new_sync(dev)
+            h, x0 = decode_step_head(ids, model.state["embed"], model.state["l0.norm1"], sh.rms_norm_eps, zero=sync, head=None)
+            read(weight(0, "wqkv"), wgs)
+            for l in range(L):
+                _lib.check(lib.hx_measure_paged_read(runner.pool[l, 0].data_ptr(), runner.pool[l, 1].data_ptr(),
+                                                     runner.block_table.data_ptr(), runner.blocks_per_seq, B, H, tiles,
+                                                     page_bytes, row_bytes, 256, sink.data_ptr(), _lib.current_stream()), "paged_read")
+                read(weight(l, "wo"), wgs)
+                read(weight(l, "wgu"), wgs)
+                read(weight(l, "wdown"), wgs)
+                if l + 1 < L:
+                    read(weight(l + 1, "wqkv"), wgs)
+            x = torch.empty_like(h)
+            add_rms_norm_slabs(x, h, slabs, 1, model.state["norm"], sh.rms_norm_eps)
+            logits = torch.empty((B, w_lm.shape[0]), dtype=dt, device=dev)
+            launch_plan.host_op(lambda: torch.matmul(x, w_lm.t(), out=logits))
+            argmax_rows(logits, None)
+        plan.capture(body)
+        return plan
+
+    def timed(wgs):
+        plans = {}
+        for c in ctxs:
+            t = (c + bs - 1) // bs
+            if t not in plans:
+                plans[t] = record(t, wgs)
+        order = [plans[(c + bs - 1) // bs] for c in ctxs]
+        for p_ in order[:2]:
+            p_.replay()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for p_ in order:
+                p_.replay()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) / len(ctxs))
+        n = order[0].n_launches
+        del plans, order
+        return statistics.median(ts), n
+
+    null_ms, n_launches = timed(grid_wgs)
+    best_ms, _ = timed(512)
+    step_bytes = sum(runner.step_bytes(c * B) for c in ctxs) / len(ctxs)
+    return {"ms_per_step": round(null_ms, 4), "launches": n_launches + 1,
+            "frac_of_hbm_peak": round(step_bytes / (null_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "built_over_null": round(null_ms / ms_per_step, 4),
+            "null_step_best_grid_ms": round(best_ms, 4),
+            "built_over_null_best_grid": round(best_ms / ms_per_step, 4),
+            "what": "the same plan with every layer launch replaced by a math-free read of the same bytes on the same grid "
+                    "(paged-read probe over the real KV pages + read-stream probe over the real packed weights, "
+                    f"{grid_wgs} workgroups per weight launch), real step edges; built_over_null = null ms / built ms: the share of "
+                    "the 5-launch structure's ceiling the built step reaches on this GPU in this run"}
+
+
 def ctx_label(ctxs):
     if len(ctxs) > 1 and ctxs[1] - ctxs[0] == 1:
         return f"ctx {ctxs[0]}..{ctxs[-1]} (consecutive steps of the generation)"
@@ -981,6 +1082,11 @@ def leg_13b(ctx, args, dtype, dev, rank):
     elapsed = decode_leg(ctx, model, runner, ctxs, args.warmup, prompt_len)
     ms = elapsed / len(ctxs) * 1e3
     roofline, roofline_gemm, whole = roofline_objects(model, runner, ctxs, ms, args, name)
+    if not args.no_null_step:
+        try:
+            whole["null_step"] = null_step_object(model, runner, ctxs, ms)
+        except Exception as e:
+            whole["null_step"] = {"error": repr(e)[:300]}
     return {"workload": f"{name}-shaped random weights, batch {args.batch} decode, paged KV block_size=16, "
                         f"{ctx_label(ctxs)} (BASELINE configs[2]: 13B batch-32 decode HBM-roofline run)",
             "value": round(args.batch * len(ctxs) / elapsed, 2), "unit": "tokens/s", "steps": len(ctxs),
@@ -1118,6 +1224,11 @@ def main():
         mid_ctx = int(round(sum(ctxs) / len(ctxs)))
         roofline, roofline_gemm, whole = roofline_objects(model, runner, ctxs, ms_per_step, args, model_name)
         whole["weight_bytes_resident"] = resident_headline
+        if not args.no_null_step:
+            try:
+                whole["null_step"] = null_step_object(model, runner, ctxs, ms_per_step)
+            except Exception as e:      # a measurement aid must never cost the headline
+                whole["null_step"] = {"error": repr(e)[:300]}
         whole["weight_layouts"] = ("row-major (the library prefill GEMMs of this EPD replica) + one decode layout per projection "
                                    "(activations-in-registers; LDS-slice for o and layer 0's qkv); a D-role node keeps only the "
                                    "decode layout; serving 33..64 rows adds LDS-slice copies: serving.twice_the_batch.weight_bytes_resident")
@@ -1179,9 +1290,11 @@ def main():
                 box["r"] = {"error": repr(e)[:300]}
         th = threading.Thread(target=_leg, daemon=True)
         th.start()
-        th.join(timeout=420)
+        # three replays (warm-up, burst, Poisson) with deadline_s = 150 each + the warm-ups in front of them: a slow but
+        # healthy leg must not be declared wedged (round-4 ADVICE)
+        th.join(timeout=3 * 150 + 120)
         stuck = th.is_alive()
-        disagg = {"error": "timed out after 420 s"} if stuck else box.get("r")
+        disagg = {"error": "timed out after 570 s"} if stuck else box.get("r")
 
     # ---- LLaVA-1.5-13B leg (BASELINE configs[2]) in the same line: N = 1, 7B model, default flags only
     llava_13b = None
@@ -1199,22 +1312,45 @@ def main():
         except Exception as e:      # an extra leg must never cost the headline
             llava_13b = {"error": repr(e)[:300]}
 
+    # ---- every rank's view of the optional legs, folded into the ONE line before rank 0 prints it (round-4 ADVICE: a wedge
+    # on rank k != 0 used to leave a clean line).  Exchanged through the TCPStore — no collective, so it works while a HIP
+    # call is wedged in a helper thread of some rank; a rank that does not report within 120 s counts as wedged.
+    mine = {"stuck": bool(stuck), "failed": []}
+    if ipc_stuck:
+        mine["failed"].append({"leg": "peer mapping", "error": "hipIpcOpenMemHandle did not return within 60 s"})
+    if isinstance(migration, dict) and "error" in migration:
+        mine["failed"].append({"leg": "migration", "error": str(migration["error"])[:200]})
+    if engine_error is not None:
+        mine["failed"].append({"leg": "disaggregated", "error": engine_error[:200]})
+    elif isinstance(disagg, dict) and "error" in disagg:
+        mine["failed"].append({"leg": "disaggregated", "error": str(disagg["error"])[:200]})
+    if isinstance(llava_13b, dict) and "error" in llava_13b:
+        mine["failed"].append({"leg": "llava_13b", "error": str(llava_13b["error"])[:200]})
+    views = ctx.gather_via_store("bench_legs", json.dumps(mine))
+    wedged_ranks = [r for r, v in enumerate(views) if v is None or json.loads(v)["stuck"]]
     if rank == 0:
         out["migration"] = migration
         out["disaggregated"] = disagg if engine_error is None else {"error": engine_error}
         out["llava_13b"] = llava_13b
+        # a reader of this line must treat a non-empty legs_failed / wedged_ranks as RED for those legs: the headline
+        # (value, roofline, whole_step) was measured before any of them ran and stands
+        out["legs_failed"] = [dict(f, rank=r) for r, v in enumerate(views) if v is not None for f in json.loads(v)["failed"]]
+        for extra in ("whole_step_64", "serving"):
+            if isinstance(out.get(extra), dict) and "error" in out[extra]:
+                out["legs_failed"].append({"leg": extra, "error": str(out[extra]["error"])[:200], "rank": 0})
+        out["wedged_ranks"] = wedged_ranks
         print(json.dumps(out), flush=True)
     # A HIP call wedged in the helper thread of an OPTIONAL leg (peer mapping / migration / E-P-D replay) on ANY rank: the
-    # headline line above is complete and valid and names the wedged leg in its "error" field; collective teardown would
-    # hang behind the wedged thread, so EVERY rank leaves without it (agreed through the TCPStore: a rank that exited
-    # alone would leave the others in the final barrier) — with status 0 unless HX_BENCH_STRICT=1: the scaling curve of
-    # a multi-GPU run must not be lost to a leg that the line itself reports as failed.
-    if ctx.any_rank_flagged(bool(stuck), "bench_wedged"):
+    # headline line above is complete and names the wedged ranks and legs; collective teardown would hang behind the
+    # wedged thread, so EVERY rank leaves without it (agreed through the TCPStore above: a rank that exited alone would
+    # leave the others in the final barrier) — with status 3: a hung HIP call is a failure of the run.
+    # HX_BENCH_WEDGE_OK=1 opts in to status 0 (keep a scaling point whose optional leg hung).
+    if wedged_ranks:
         if stuck:
-            print(f"bench.py: rank {rank}: an optional multi-GPU leg is wedged (see the line's migration / disaggregated "
-                  "error)", file=sys.stderr, flush=True)
+            print(f"bench.py: rank {rank}: an optional multi-GPU leg is wedged (see the line's legs_failed / wedged_ranks)",
+                  file=sys.stderr, flush=True)
         sys.stdout.flush()
-        os._exit(3 if os.environ.get("HX_BENCH_STRICT") == "1" else 0)
+        os._exit(0 if os.environ.get("HX_BENCH_WEDGE_OK") == "1" else 3)
     ctx.shutdown()
 
 

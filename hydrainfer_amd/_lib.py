@@ -147,6 +147,8 @@ _SIGNATURES = {
     "hx_norm_gate_up_xreg": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int64,
                                      c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "hx_measure_read_stream": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "hx_measure_read_grid": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "hx_measure_paged_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),
 }
 
 # Only in a library built with `make EXPERIMENTS=1` (include/hydra_hip_experimental.h): rejected experiments and

@@ -126,6 +126,64 @@ extern "C" int hx_measure_read_stream(const void* p, int64_t bytes, float* sink,
   return check_launch();
 }
 
+extern "C" int hx_measure_read_grid(const void* p, int64_t bytes, int n_workgroups, float* sink, hx_stream stream) {
+  if (!p || !sink) return HX_ERR_NULL;
+  if (bytes <= 0 || bytes % 8192 || n_workgroups <= 0 || n_workgroups > 65535) return HX_ERR_SHAPE;
+  if (reinterpret_cast<uintptr_t>(p) & 15u) return HX_ERR_STRIDE;
+  hx::launcher(read_stream_kernel, (unsigned)n_workgroups, 256, 0, (hipStream_t)stream)((const char*)p, bytes / 8192, sink);
+  return check_launch();
+}
+
+// The decode attention kernel's access pattern with the arithmetic removed (the round-4 probe of
+// tools/bench_attn_ceiling.py, moved into the default library for the null layer): grid (head, sequence), 4 waves,
+// wave w owns tiles w, w + 4, ...; one wave instruction = 4 key rows x 256 B; a tile = 4 K + 4 V instructions; register
+// double buffer (tile t + 4 requested before tile t is consumed) like attn_decode_kernel.
+namespace {
+__global__ __launch_bounds__(256) void paged_read_kernel(const char* __restrict__ kbase, const char* __restrict__ vbase,
+                                                         const int32_t* __restrict__ table, int64_t table_stride, int tiles,
+                                                         int64_t page_bytes, int64_t row_bytes, float* sink) {
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t lane_off = (int64_t)(lane >> 4) * row_bytes + (int64_t)h * 256 + (lane & 15) * 16;
+  const int32_t* tb = table + (int64_t)b * table_stride;
+  hx::f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  hx::f32x4 buf[2][8];
+  auto load = [&](hx::f32x4 (&bf)[8], int t) {
+    const int64_t off = (int64_t)tb[t] * page_bytes + lane_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf[i] = __builtin_nontemporal_load(reinterpret_cast<const hx::f32x4*>(kbase + off + (int64_t)i * 4 * row_bytes));
+      bf[4 + i] = __builtin_nontemporal_load(reinterpret_cast<const hx::f32x4*>(vbase + off + (int64_t)i * 4 * row_bytes));
+    }
+  };
+  if (w < tiles) load(buf[0], w);
+  for (int t = w; t < tiles; t += 8) {
+    if (t + 4 < tiles) load(buf[1], t + 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += buf[0][i];
+    if (t + 4 < tiles) {
+      if (t + 8 < tiles) load(buf[0], t + 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += buf[1][i];
+    }
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = acc[0];
+}
+}  // namespace
+
+extern "C" int hx_measure_paged_read(const void* kbase, const void* vbase, const int32_t* table, int64_t table_stride,
+                                     int n_seq, int n_heads, int tiles, int64_t page_bytes, int64_t row_bytes,
+                                     int head_bytes, float* sink, hx_stream stream) {
+  if (!kbase || !vbase || !table || !sink) return HX_ERR_NULL;
+  if (n_seq <= 0 || n_heads <= 0 || tiles <= 0 || table_stride < tiles || head_bytes != 256 || row_bytes < (int64_t)n_heads * 256 ||
+      page_bytes < 16 * row_bytes || n_seq > 65535)
+    return HX_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(kbase) | reinterpret_cast<uintptr_t>(vbase) | (uintptr_t)row_bytes | (uintptr_t)page_bytes) & 15u) return HX_ERR_STRIDE;
+  hx::launcher(paged_read_kernel, dim3((unsigned)n_heads, (unsigned)n_seq), 256, 0, (hipStream_t)stream)(
+      (const char*)kbase, (const char*)vbase, table, table_stride, tiles, page_bytes, row_bytes, sink);
+  return check_launch();
+}
+
 extern "C" int hx_memset_zero(void* p, int64_t bytes, hx_stream stream) {
   if (!p || bytes < 0) return HX_ERR_NULL;
   if (bytes == 0) return HX_OK;

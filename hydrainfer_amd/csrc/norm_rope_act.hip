@@ -272,12 +272,22 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(int64_t* __restrict__
   const bool vec = (ld % 8 == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
   if (vec) {
     const int nvec = n / 8;
-    for (int i = threadIdx.x; i < nvec; i += 1024) {
-      const u16x8 v = *reinterpret_cast<const u16x8*>(p + i * 8);
+    // four independent 16-byte loads per thread in flight (a 32064-wide row is 3.9 per thread): the row is read in one
+    // memory round trip instead of four dependent ones (round 4: 9.0 us per step for a 2 MB read; round 5: see profiles/)
+    for (int i0 = threadIdx.x; i0 < nvec; i0 += 4096) {
+      u16x8 v[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float f = T::to_float(v[e]);
-        if (arg_better(f, i * 8 + e, best, bi)) { best = f; bi = i * 8 + e; }
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u16x8*>(p + (int64_t)min(i0 + 1024 * u, nvec - 1) * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 1024 * u;
+        if (i < nvec) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = T::to_float(v[u][e]);
+            if (arg_better(f, i * 8 + e, best, bi)) { best = f; bi = i * 8 + e; }
+          }
+        }
       }
     }
     for (int i = nvec * 8 + threadIdx.x; i < n; i += 1024) {

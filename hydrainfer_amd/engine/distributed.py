@@ -180,6 +180,19 @@ class RankEngine:
         self.mailbox = LocalMailbox()
         self.reported = self.n_exchanges = self.total_finished = 0
 
+    def connect_transfer_peers(self, timeout_s: Optional[float] = None) -> int:
+        """Call on every rank once at start-up, before the first request: the send/recv communicators of every E -> P
+        (image blocks) and P -> D (KV blocks) hop this rank takes part in are created under a bound
+        (CommunicationBackendManager.connect_peers).  Nothing to do for the IPC pull backend — the intra-node default."""
+        n = 0
+        ep = [(e, p_) for e, te in enumerate(self.roles) if "E" in te for p_, tp in enumerate(self.roles) if "P" in tp]
+        pd = [(p_, d) for p_, tp in enumerate(self.roles) if "P" in tp for d, td in enumerate(self.roles) if "D" in td]
+        for manager, pairs in ((self.node.image_cache_block_manager, ep), (self.node.kv_cache_block_manager, pd)):
+            mm = getattr(manager, "migrate_manager", None)
+            if mm is not None and self.world > 1:
+                n += mm.connect_peers(self.rank, pairs, timeout_s)
+        return n
+
     def open_mailbox(self, epoch: str) -> None:
         """Call on every rank before a run (same epoch everywhere)."""
         if self.world > 1:

@@ -131,6 +131,7 @@ class GraphedDecoder:
             res = self.model(fed, pos, params)
         finally:
             self.model.sample_out = None
+            params.step_head = None      # consumed: a later direct model(...) call with these params must not feed again
         if res.data_ptr() != out.data_ptr():
             launch_plan.host_op(lambda: out.copy_(res))
         # give-up words of the step's in-kernel hand-overs (norm-fused launches) -> one word

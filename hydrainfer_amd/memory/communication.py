@@ -63,6 +63,10 @@ class RCCLBackend(CommunicationBackend):
         # a transfer whose peer never shows up must not hang the rank (the reference's batch_isend_irecv +
         # req.wait(), hydrainfer/memory/communication.py:66-74, waits for ever)
         self.timeout_s = float(os.environ.get("HX_MIGRATE_TIMEOUT_S", "120")) if timeout_s is None else timeout_s
+        # set by a MigrationTimeout: the abandoned send / recv (or the helper thread of connect()) may still sit in the
+        # process group's queue, and anything issued behind it would wait for it — the backend refuses further transfers
+        # instead of queueing them (round-4 ADVICE); the rank fails loudly, a fresh process is the retry
+        self.broken: Optional[str] = None
 
     def _bounded_wait(self, work, what: str, peer: int) -> None:
         """RCCL: poll the work's completion (it is stream-ordered; wait() would only enqueue a stream wait).  gloo
@@ -79,6 +83,7 @@ class RCCLBackend(CommunicationBackend):
                 time.sleep(0.0005)
             work.wait()        # completed: surfaces a transport error, if any, as an exception
         except (RuntimeError, TimeoutError) as e:
+            self.broken = f"{what} rank {peer} timed out"
             raise MigrationTimeout(f"{what} rank {peer}: no progress within {self.timeout_s:.0f} s or transport error "
                                    f"({str(e)[:120]}) — peer dead or never asked to take part in the transfer") from e
 
@@ -112,6 +117,7 @@ class RCCLBackend(CommunicationBackend):
         th.start()
         th.join(timeout=bound)
         if th.is_alive() or "err" in box:
+            self.broken = f"connect to rank {peer} failed"
             raise MigrationTimeout(f"connect to rank {peer}: no communicator within {bound:.0f} s "
                                    f"({str(box.get('err', 'peer never answered'))[:120]})")
 
@@ -125,6 +131,9 @@ class RCCLBackend(CommunicationBackend):
     def migrate_blocks(self, src_virtual_cache, dst_virtual_cache, is_send: bool) -> None:
         table = src_virtual_cache.block_table if is_send else dst_virtual_cache.block_table
         peer = dst_virtual_cache.rank if is_send else src_virtual_cache.rank
+        if self.broken is not None:
+            raise MigrationTimeout(f"send/recv backend unusable after an earlier failure ({self.broken}): an abandoned "
+                                   "operation may still hold the process group")
         if len(table) == 0:
             return
         staging = self._staging_for(len(table))
@@ -191,6 +200,21 @@ class CommunicationBackendManager(CommunicationBackend):
         the receiver's half can complete.  The IPC pull has no sender half."""
         backend = self.intranode_backend if self.in_same_machine(src_rank, dst_rank) else self.internode_backend
         return not isinstance(backend, IPCHandleMemoryBackend)
+
+    def connect_peers(self, my_rank: int, pairs, timeout_s: Optional[float] = None) -> int:
+        """Node start-up (round-4 ADVICE: nothing called RCCLBackend.connect outside the tests): for every (src, dst)
+        rank pair of `pairs` that this rank is part of and whose transfer is a send/recv pair, create the point-to-point
+        communicator NOW under a bound — RCCL would otherwise build it inside the first isend / irecv, where a missing
+        peer hangs the engine thread for ever.  Every rank walks the same sorted pair list, so the blocking
+        handshakes match up.  Returns the number of communicators created; raises MigrationTimeout."""
+        n = 0
+        for src, dst in sorted(set(pairs)):
+            if my_rank not in (src, dst) or src == dst or not self.needs_sender(src, dst):
+                continue
+            backend = self.intranode_backend if self.in_same_machine(src, dst) else self.internode_backend
+            backend.connect(dst if my_rank == src else src, my_rank, timeout_s)
+            n += 1
+        return n
 
     def migrate_blocks(self, src_virtual_cache, dst_virtual_cache, is_send: bool) -> None:
         assert src_virtual_cache.n_cache_tokens == dst_virtual_cache.n_cache_tokens, \

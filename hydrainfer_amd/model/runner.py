@@ -223,6 +223,9 @@ class DecodeRunner:
             nxt = self.model(self.input_ids, self.positions, self.decode_params)
         finally:
             self.model.sample_out = None
+            # consumed by the step's first launch (and recorded in the graph / plan): a later direct model(...) call with
+            # these shared params must not advance positions / kv_lens / slots a second time (round-4 ADVICE)
+            self.decode_params.step_head = None
         if nxt.data_ptr() != self.input_ids.data_ptr():
             launch_plan.host_op(lambda: self.input_ids.copy_(nxt))
 

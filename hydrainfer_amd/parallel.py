@@ -56,7 +56,28 @@ class DistContext:
             dist.barrier()
             dist.destroy_process_group()
 
-    def any_rank_flagged(self, flag: bool, key: str, timeout_s: float = 30.0) -> bool:
+    def gather_via_store(self, key: str, payload: str, timeout_s: float = 120.0) -> List[Optional[str]]:
+        """Every rank's `payload` string, exchanged through the rendezvous TCPStore (CPU only, no collective: usable
+        while a HIP call is wedged in a helper thread of some rank).  A rank that has not reported within timeout_s is
+        None in the result.  Every rank must call it with the same key."""
+        if not self.enabled:
+            return [payload]
+        import time
+        from datetime import timedelta
+        store = dist.distributed_c10d._get_default_store()
+        store.set(f"{key}/{self.rank}", payload)
+        deadline = time.monotonic() + timeout_s
+        out: List[Optional[str]] = []
+        for r in range(self.world_size):
+            name = f"{key}/{r}"
+            try:
+                store.wait([name], timedelta(seconds=max(0.5, deadline - time.monotonic())))
+                out.append(store.get(name).decode())
+            except Exception:
+                out.append(None)
+        return out
+
+    def any_rank_flagged(self, flag: bool, key: str, timeout_s: float = 120.0) -> bool:
         """True if ANY rank raised `flag` — agreed through the rendezvous TCPStore (CPU only, no collective: usable while a
         HIP call is wedged in a helper thread of some rank) within timeout_s; a rank that never reports counts as
         flagged.  Every rank must call it with the same key."""

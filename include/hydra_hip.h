@@ -498,10 +498,26 @@ int hx_plan_destroy(hx_plan* plan);
 int hx_memset_zero(void* p, int64_t bytes, hx_stream stream);
 /* Measurement aid (SURVEY §8d "measured streaming ceiling"; no reference counterpart): reads `bytes` bytes at p
  * once, the way the weight-streaming kernels of this library read — 1 KiB contiguous per wave instruction,
- * non-temporal, two 8 KiB chunks in flight per wave, 1024 workgroups — and does nothing with them.  bench.py times it
- * to report the read rate this GPU reaches in this run beside the 8 TB/s vendor peak.  bytes % 8192 == 0, p 16-byte
- * aligned; sink: one float the kernel never writes (keeps the loads alive). */
+ * non-temporal, ONE 8 KiB chunk (eight 1 KiB loads) in flight per wave, consumed before the next eight are requested,
+ * 512 workgroups of 4 waves — and does nothing with them.  bench.py times it to report the read rate this GPU reaches
+ * in this run beside the 8 TB/s vendor peak.  bytes % 8192 == 0, p 16-byte aligned; sink: one float the kernel never
+ * writes (keeps the loads alive). */
 int hx_measure_read_stream(const void* p, int64_t bytes, float* sink, hx_stream stream);
+/* Measurement aids for the "null layer" (round 5; tools/null_layer.py, bench.py `whole_step.null_step`): the decode
+ * layer's launches with the arithmetic, the activations and the hand-overs removed — what ANY design that runs a layer
+ * as the same number of launches over the same bytes can reach on this GPU.
+ *   hx_measure_read_grid   the kernel of hx_measure_read_stream over `n_workgroups` workgroups (the real grid of the
+ *                          weight-streaming launch it stands in for: 256 = one per CU);
+ *   hx_measure_paged_read  the decode attention kernel's read pattern and grid — (head, sequence) workgroups of 4
+ *                          waves, wave w owns the 16-key tiles w, w + 4, ..., a tile = one page of the paged cache
+ *                          (block_size 16): this head's 256 B (head_bytes) of 16 K rows and 16 V rows at a pitch of
+ *                          row_bytes, pages looked up in `table` (n_seq rows of table_stride int32), two tiles in
+ *                          flight per wave — nothing computed, nothing written.  head_bytes must be 256.
+ * Both record into launch plans like every other launch. */
+int hx_measure_read_grid(const void* p, int64_t bytes, int n_workgroups, float* sink, hx_stream stream);
+int hx_measure_paged_read(const void* kbase, const void* vbase, const int32_t* table, int64_t table_stride, int n_seq,
+                          int n_heads, int tiles, int64_t page_bytes, int64_t row_bytes, int head_bytes, float* sink,
+                          hx_stream stream);
 
 /* ------------------------------------------------------------------------
  * MoE routing / permutation ops (named in north_star; no production caller in the reference).

@@ -35,6 +35,8 @@ def _worker(rank, world, port, q):
         # is seen by all, through the rendezvous store
         assert ctx.any_rank_flagged(False, "t0") is False
         assert ctx.any_rank_flagged(rank == 1, "t1") is True
+        # bench.py's last exchange: every rank's view of its optional legs, as strings through the store
+        assert ctx.gather_via_store("g0", f"view of rank {rank}") == ["view of rank 0", "view of rank 1"]
         handles = ctx.all_gather_object({"rank": rank, "handle": [rank] * 72, "table": [3 + rank, 1]})
         assert [h["rank"] for h in handles] == [0, 1]
         peer = parallel.migration_peer(rank, world)
@@ -58,6 +60,15 @@ def _worker(rank, world, port, q):
         src = VirtualTokenCache(vid=1, n_blocks_of_cache_manager=6, n_cache_tokens=12, block_table=[5, 0, 2], rank=0)
         dst = VirtualTokenCache(vid=7, n_blocks_of_cache_manager=9, n_cache_tokens=12, block_table=[8, 1, 4], rank=1)
         backend.migrate_blocks(src, dst, is_send=(rank == 0))
+        # node start-up: the communicators of the send/recv hops are created under a bound (two hosts -> send/recv backend)
+        from hydrainfer_amd.memory.communication import (CommunicationBackendManager, CommunicationBackendManagerConfig,
+                                                         CommunicationBackendManagerContext)
+        mgr = CommunicationBackendManager(CommunicationBackendManagerConfig(),
+                                          CommunicationBackendManagerContext(None, pool, pool.shape[2], {0: "hostA", 1: "hostB"}))
+        assert mgr.connect_peers(rank, [(0, 1), (0, 1), (1, 1)], timeout_s=60) == 1
+        same = CommunicationBackendManager(CommunicationBackendManagerConfig(),
+                                           CommunicationBackendManagerContext(None, pool, pool.shape[2], {0: "h", 1: "h"}))
+        assert same.connect_peers(rank, [(0, 1)], timeout_s=60) == 0       # the IPC pull has no sender half
         if rank == 1:
             for s, d in zip(src.block_table, dst.block_table):
                 assert torch.equal(pool[:, :, d], src_pool[:, :, s])

@@ -35,3 +35,4 @@ def test_bench_three_ranks_epd_on_one_gpu():
     assert dg["burst_at_t0"]["requests"] == 8 and dg["burst_at_t0"]["output_tokens"] == 8 * 256
     mg = d["migration"]
     assert mg is not None and "error" not in mg, mg
+    assert d["legs_failed"] == [] and d["wedged_ranks"] == [], (d["legs_failed"], d["wedged_ranks"])

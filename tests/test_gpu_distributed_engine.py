@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, roles, port, q):
+def _worker(rank, roles, port, q, per_device=False):
     try:
         import time
         import torch.distributed as dist
@@ -38,7 +38,8 @@ def _worker(rank, roles, port, q):
             import faulthandler
             faulthandler.dump_traceback_later(60, file=open(f"{os.environ['HX_TEST_STACKS']}_{rank}.txt", "w"))
         dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
-        dev, dt = torch.device("cuda:0"), torch.float16
+        # per_device: one process per GPU (BASELINE configs[3]); otherwise every rank stands in on cuda:0
+        dev, dt = torch.device(f"cuda:{rank}" if per_device else "cuda:0"), torch.float16
         torch.cuda.set_device(dev)
         lshape, cshape = LlamaShape(**C.TINY_LLAMA), ClipShape(**C.TINY_CLIP)
         lm = LlavaLanguageModel(LlamaForCausalLM.from_reference_state_dict(lshape, C.tiny_llama_state_dict(dt), dt, dev),
@@ -128,13 +129,11 @@ def _worker(rank, roles, port, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("roles", [["EP", "D"], ["E", "P", "D"]], ids="-".join)
-def test_engine_nodes_in_processes_share_one_gpu(roles):
+def _run(roles, per_device):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, roles, port, q)) for r in range(len(roles))]
+    procs = [ctx.Process(target=_worker, args=(r, roles, port, q, per_device)) for r in range(len(roles))]
     for p in procs:
         p.start()
     try:
@@ -146,3 +145,20 @@ def test_engine_nodes_in_processes_share_one_gpu(roles):
                 p.kill()
     bad = [f"rank {r}: {msg[-1500:]}" for r, msg in results if msg != "ok"]
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("roles", [["EP", "D"], ["E", "P", "D"]], ids="-".join)
+def test_engine_nodes_in_processes_share_one_gpu(roles):
+    _run(roles, per_device=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("roles", [["EP", "D"], ["E", "P", "D"]], ids="-".join)
+def test_engine_nodes_one_process_per_gpu(roles):
+    """BASELINE configs[3] on real devices: rank r owns cuda:r, image blocks E -> P and KV blocks P -> D are pulled over
+    xGMI through the IPC-mapped peer pools (hydrainfer/cluster/epdnode.py:362-447).  Enables itself on a box with enough
+    GPUs; the one-GPU boxes skip it."""
+    if torch.cuda.device_count() < len(roles):
+        pytest.skip(f"needs {len(roles)} GPUs, this box has {torch.cuda.device_count()}")
+    _run(roles, per_device=True)
