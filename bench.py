@@ -1087,10 +1087,21 @@ def leg_13b(ctx, args, dtype, dev, rank):
             whole["null_step"] = null_step_object(model, runner, ctxs, ms)
         except Exception as e:
             whole["null_step"] = {"error": repr(e)[:300]}
+    whole_64 = None
+    if not args.no_serving_64:
+        # configs[4]'s D nodes hold 13B batches of 33 .. 64 rows: round 5 runs them on the wide activations-in-registers
+        # kernel over the SAME packing (k-steps per wave 40 -> 20, 27 -> 14 + 13): 6 launches per layer, no third copy
+        try:
+            whole_64 = leg_64_rows(ctx, model, args, dev, prompt_len, n_generate)
+        except SystemExit:
+            raise
+        except Exception as e:
+            whole_64 = {"error": repr(e)[:300]}
     return {"workload": f"{name}-shaped random weights, batch {args.batch} decode, paged KV block_size=16, "
                         f"{ctx_label(ctxs)} (BASELINE configs[2]: 13B batch-32 decode HBM-roofline run)",
             "value": round(args.batch * len(ctxs) / elapsed, 2), "unit": "tokens/s", "steps": len(ctxs),
-            "ms_per_step": round(ms, 4), "roofline": roofline, "roofline_gemm": roofline_gemm, "whole_step": whole}
+            "ms_per_step": round(ms, 4), "roofline": roofline, "roofline_gemm": roofline_gemm, "whole_step": whole,
+            "whole_step_64": whole_64}
 
 
 def main():

@@ -29,6 +29,7 @@
 //             claims unstarted rows itself: progress needs ONE resident workgroup (hx_norm_*_xreg).
 // Activations between these launches are FRAGMENT-MAJOR (the order the B operands are loaded in;
 // include/hydra_hip.h): row-major x makes every x load touch 16 cache lines for 16 bytes each.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -447,7 +448,12 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
 // through LDS after every unit (one barrier per unit, two tile sets used alternately) — a share of up to 11 units
 // would not fit LDS at 16 KiB each.  EPI = 0 only (silu*mul needs the whole K: hx_silu_and_mul_slabs behind it);
 // NORM as in the 32-row kernel, with up to 64 producers.  Same k-step rotation and summation order per split.
-template <typename T, int KW, int NORM>
+// Round 5: (a) a launch split is HALF of a packing split in the general sense — split s = (packing split s / 2, half
+// s % 2), the first half takes P = 4 KW k-steps, the second one what is left of the packing split (LLaVA-1.5-13B's down
+// projection: 27 k-steps per wave in the packing -> halves of 14 and 13); (b) RG = row groups per work unit: 2 keeps
+// 2 KW KiB per wave in flight; RG = 1 is for KW = 20 (13B's K = 5120: x for 64 rows is 320 registers, a second weight
+// buffer set does not fit beside it).
+template <typename T, int KW, int NORM, int RG = 2>
 __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MB = 4, NBUF = (KW + 7) / 8, P = 4 * KW;
@@ -456,9 +462,12 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p)
   const int g = lane >> 4, c = lane & 15;
   const int split = blockIdx.y, nb = gridDim.x, b = nb - 1 - (int)blockIdx.x;
   const int total_ks = p.K >> 5;
-  const int n_rg = p.N >> 4, n_un = n_rg >> 1;
-  const int ks0 = split * P;
-  const int nks = min(P, total_ks - ks0);
+  const int n_rg = p.N >> 4, n_un = n_rg / RG;
+  // where the launch's split sits inside the packing
+  const int sp = split >> 1, off_in = (split & 1) * P;
+  const int nks_p = min(p.pk_P, total_ks - sp * p.pk_P);
+  const int ks0 = sp * p.pk_P + off_in;
+  const int nks = max(0, min(P, nks_p - off_in));
   const int kw = max(0, min(KW, nks - w * KW));
   const int G = (n_un - b + nb - 1) / nb;                  // this workgroup's units (>= 1): b, b + nb, ...
   const int mbl = (p.M + 15) >> 4;                         // 16-row blocks of the fragment-major x (3 for 33 .. 48 rows): the
@@ -466,23 +475,20 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p)
   const int j0 = (p.stagger & 1) ? (int)(((unsigned)b * 7u + (unsigned)w * 3u) % (unsigned)KW) : 0;
   const int flat_id = blockIdx.y * gridDim.x + blockIdx.x;
   auto rot = [&](int t) { const int r = j0 + t; return r >= KW ? r - KW : r; };
-  // where the launch's split sits inside the packing
-  const int sp = ks0 / p.pk_P, off_in = ks0 - sp * p.pk_P;
-  const int nks_p = min(p.pk_P, total_ks - sp * p.pk_P);
   const u16* wbase = reinterpret_cast<const u16*>(p.w) + 8 * lane + ((int64_t)sp * p.pk_P * n_rg) * 512;
   const int wave_k0 = off_in + min(w * KW, max(nks - 1, 0));
   auto frag_ptr = [&](int rg, int t) {
     const int r = rot(t);
     return wbase + ((int64_t)rg * nks_p + wave_k0 + (r < kw ? r : 0)) * 512;
   };
-  u16x8 buf[2][NBUF][8];
+  u16x8 buf[RG][NBUF][8];
   auto load_buf = [&](int unit, int q) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < RG; ++h)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (8 * q + j < KW)
-          buf[h][q][j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(frag_ptr(2 * unit + h, 8 * q + j)));
+          buf[h][q][j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(frag_ptr(RG * unit + h, 8 * q + j)));
   };
   auto unit_of = [&](int i) { return b + i * nb; };
   u16x8 xb[KW][MB];
@@ -591,12 +597,12 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p)
     }
   }
 
-  f32x4 acc[2][MB];
+  f32x4 acc[RG][MB];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < RG; ++h)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[h][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // tile (set, half h, wave, mb): 1 KiB each
+  // tile (set, row group h of the unit, wave, mb): 1 KiB each
   f32x4* tiles = reinterpret_cast<f32x4*>(smem) + lane;
   auto unit = [&](int i, auto refill_tag) {
     constexpr bool REFILL = decltype(refill_tag)::value;
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p)
       for (int j = 0; j < 8; ++j) {
         if (8 * q + j < KW) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+          for (int h = 0; h < RG; ++h)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[h][mb] = Mfma<T>::mma(buf[h][q][j], xb[8 * q + j][mb], acc[h][mb]);
         }
@@ -618,21 +624,21 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p)
     }
     const int set = i & 1;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < RG; ++h)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        tiles[(((set * 2 + h) * 4 + w) * MB + mb) * 64] = acc[h][mb];
+        tiles[(((set * RG + h) * 4 + w) * MB + mb) * 64] = acc[h][mb];
         acc[h][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     __syncthreads();       // (plain loads in flight survive it; the next unit writes the OTHER tile set)
-    // 8 tiles (h, mb), two per wave: summed over the four waves in order
+    // RG * 4 tiles (h, mb), RG per wave: summed over the four waves in order
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < RG; ++k) {
       const int tt = w + 4 * k, h = tt >> 2, mb = tt & 3;
-      f32x4 sum = tiles[(((set * 2 + h) * 4 + 0) * MB + mb) * 64];
+      f32x4 sum = tiles[(((set * RG + h) * 4 + 0) * MB + mb) * 64];
 #pragma unroll
-      for (int ww = 1; ww < 4; ++ww) sum += tiles[(((set * 2 + h) * 4 + ww) * MB + mb) * 64];
-      const int rg = 2 * unit_of(i) + h;
+      for (int ww = 1; ww < 4; ++ww) sum += tiles[(((set * RG + h) * 4 + ww) * MB + mb) * 64];
+      const int rg = RG * unit_of(i) + h;
       const int col = p.interleaved ? ((rg & 1) ? (p.N >> 1) : 0) + ((rg >> 1) << 4) : (rg << 4);
       const int m = mb * 16 + c;
       if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + col + 4 * g) = sum;
@@ -798,27 +804,37 @@ bool wide_plan(int64_t N, int64_t K, bool gate_up_packing, int* S, int* KW, int*
   if (N <= 0 || K <= 0 || N % 32 || K % 32) return false;
   int sp, kwp;
   xreg_plan(N, K, &sp, &kwp, gate_up_packing);
-  if (kwp <= 0 || (kwp & 1)) return false;
-  const int kw = kwp / 2;
-  if (kw != 2 && kw != 4 && kw != 8 && kw != 10 && kw != 11 && kw != 16) return false;   // the built instantiations
+  if (kwp <= 0) return false;
+  const int kw = (kwp + 1) / 2;      // an odd packing count halves unevenly: 27 -> 14 + 13 (LLaVA-1.5-13B's down projection)
+  if (kw != 2 && kw != 4 && kw != 8 && kw != 10 && kw != 11 && kw != 14 && kw != 16 && kw != 20) return false;   // the built instantiations
   const int total_ks = (int)(K >> 5);
-  *KW = kw; *pkP = 4 * kwp; *S = (total_ks + 4 * kw - 1) / (4 * kw); *S_packed = sp;
+  // launch split s = (packing split s / 2, half s % 2); only the last packing split can be partial, so the splits that
+  // hold k-steps are a prefix of that numbering
+  int n = 0;
+  for (int q = 0; q < sp; ++q) {
+    const int nks_p = std::min(4 * kwp, total_ks - q * 4 * kwp);
+    n += nks_p > 4 * kw ? 2 : 1;
+  }
+  *KW = kw; *pkP = 4 * kwp; *S = n; *S_packed = sp;
   return true;
 }
 
+constexpr int wide_rg(int kw) { return kw == 20 ? 1 : 2; }      // row groups per work unit (the kernel's RG)
+
 template <typename T, int KW, int NORM>
 int launch_wide_kw(const XregParams& p, int S, hipStream_t stream) {
-  const int n_units = (int)(p.N >> 5);
+  constexpr int RG = wide_rg(KW);
+  const int n_units = (int)(p.N >> 4) / RG;
   int nb = n_cus() / S;
   if (nb < 1) nb = 1;
   if (nb > n_units) nb = n_units;
-  constexpr size_t lds = 2 * 2 * 4 * 4 * 1024;      // two tile sets x two row groups x four waves x MB tiles of 1 KiB
-  {   // 64 KiB of dynamic LDS: above the default limit (per device, so not cached in a static)
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_wide_kernel<T, KW, NORM>,
+  constexpr size_t lds = 2 * RG * 4 * 4 * 1024;      // two tile sets x RG row groups x four waves x MB tiles of 1 KiB
+  {   // up to 64 KiB of dynamic LDS: above the default limit (per device, so not cached in a static)
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_wide_kernel<T, KW, NORM, RG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  hx::launcher(gemm_xreg_wide_kernel<T, KW, NORM>, dim3((unsigned)nb, (unsigned)S), 256, lds, stream)(p);
+  hx::launcher(gemm_xreg_wide_kernel<T, KW, NORM, RG>, dim3((unsigned)nb, (unsigned)S), 256, lds, stream)(p);
   return check_launch();
 }
 
@@ -827,7 +843,8 @@ int launch_wide(const XregParams& p, int S, int KW, int dtype, hipStream_t strea
 #define HX_W(KWV)                                                                                   \
   case KWV: return dtype == HX_F16 ? launch_wide_kw<F16, KWV, NORM>(p, S, stream) : launch_wide_kw<BF16, KWV, NORM>(p, S, stream)
   switch (KW) {
-    HX_W(2); HX_W(4); HX_W(8); HX_W(16);
+    HX_W(2); HX_W(4); HX_W(8); HX_W(16); HX_W(20);
+    case 14: if constexpr (NORM == 0) return dtype == HX_F16 ? launch_wide_kw<F16, 14, 0>(p, S, stream) : launch_wide_kw<BF16, 14, 0>(p, S, stream); else return HX_ERR_SHAPE;
     case 10: if constexpr (NORM == 0) return dtype == HX_F16 ? launch_wide_kw<F16, 10, 0>(p, S, stream) : launch_wide_kw<BF16, 10, 0>(p, S, stream); else return HX_ERR_SHAPE;
     case 11: if constexpr (NORM == 0) return dtype == HX_F16 ? launch_wide_kw<F16, 11, 0>(p, S, stream) : launch_wide_kw<BF16, 11, 0>(p, S, stream); else return HX_ERR_SHAPE;
     default: return HX_ERR_SHAPE;
@@ -986,7 +1003,7 @@ extern "C" int hx_norm_xreg_supported(int64_t M, int64_t N, int64_t K, int gate_
   if (!xreg_ok(M, N, K)) return 0;
   if (M > 32) {          // wide kernel: K must sit in ONE split of the packing, rows of <= 4096 x 2 elements
     int S, KW, pkP, sp;
-    return wide_plan(N, K, false, &S, &KW, &pkP, &sp) && sp == 1 && K % 8 == 0 && K / 8 <= 1024 && KW != 10 && KW != 11 ? 1 : 0;
+    return wide_plan(N, K, false, &S, &KW, &pkP, &sp) && sp == 1 && K % 8 == 0 && K / 8 <= 1024 && KW != 10 && KW != 11 && KW != 14 ? 1 : 0;
   }
   int S, KW;
   xreg_plan(N, K, &S, &KW);
@@ -1052,7 +1069,7 @@ extern "C" int hx_gate_up_xreg_supported(int64_t M, int64_t inter, int64_t K, in
   if (M < 1 || M > 64 || inter <= 0 || inter % 32 || K <= 0 || K % 32) return 0;
   int S, KW, pkP, sp;
   if (!wide_plan(2 * inter, K, true, &S, &KW, &pkP, &sp)) return 0;
-  if (with_norm && (sp != 1 || K % 8 || K / 8 > 1024 || KW == 10 || KW == 11)) return 0;
+  if (with_norm && (sp != 1 || K % 8 || K / 8 > 1024 || KW == 10 || KW == 11 || KW == 14)) return 0;
   return 1;
 }
 

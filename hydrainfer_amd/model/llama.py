@@ -215,8 +215,8 @@ class LlamaForCausalLM:
 
     def _wide_ok(self, n: int) -> bool:
         """Batches of 33 .. 64 rows on the activations-in-registers layout (the wide kernel reads the <= 32-row packing:
-        no second copy): gate|up, down and qkv of this shape must all be supported (LLaVA-1.5-7B: yes; 13B: its
-        k-steps per wave do not halve — those batches stay on the LDS-slice copies)."""
+        no second copy): gate|up, down and qkv of this shape must all be supported (LLaVA-1.5-7B, and since round 5
+        LLaVA-1.5-13B: its k-steps per wave, 40 and 27, halve to 20 and 14 + 13; other shapes stay on LDS-slice copies)."""
         hid, inter = self.shape.hidden_size, self.shape.intermediate_size
         qkv_n = self.q_size + 2 * self.kv_size
         return (32 < n <= 64 and self.use_wide and self.use_xreg and self.xreg_qkv and self.dtype in (torch.float16, torch.bfloat16)

@@ -639,7 +639,10 @@ def test_xreg_wide_product_matches_fp32_and_is_repeatable(dt, M):
     one the 32-row kernel reads (checked by running both kernels on it)."""
     from hydrainfer_amd._C.kernel import gemm
     from hydrainfer_amd._C.kernel.activation import silu_and_mul_slabs
-    for (N, K) in ((12288, 4096), (4096, 11008), (4096, 4096), (64, 256), (3072, 1024), (1024, 2816), (96, 128)):
+    # (15360, 5120) / (5120, 13824): LLaVA-1.5-13B's qkv and down (round 5: 20 k-steps per wave with one row group per
+    # unit; 27 k-steps per wave of the packing halved unevenly, 14 + 13)
+    for (N, K) in ((12288, 4096), (4096, 11008), (4096, 4096), (64, 256), (3072, 1024), (1024, 2816), (96, 128),
+                   (15360, 5120), (5120, 13824), (5120, 5120)):
         assert gemm.xreg_supported(M, N, K, dt), (N, K)
         g = torch.Generator().manual_seed(N + K + M)
         x = torch.randn((M, K), generator=g).to(dt).to(DEV)
@@ -648,7 +651,7 @@ def test_xreg_wide_product_matches_fp32_and_is_repeatable(dt, M):
         a = torch.zeros(gemm.xreg_workspace_floats(M, N, K), dtype=torch.float32, device=DEV)
         b, c = torch.zeros_like(a), torch.zeros_like(a)
         s = gemm.linear_decode_partial_xreg(x, pk, N, a)
-        assert s == a.numel() // (M * N) and s == {4096: 2, 11008: 8}.get(K, s)      # twice the slabs of the <= 32-row launch
+        assert s == a.numel() // (M * N) and s == {4096: 2, 11008: 8, 5120: 2, 13824: 8}.get(K, s)      # twice the slabs of the <= 32-row launch
         assert gemm.linear_decode_partial_xreg(x, pk, N, b) == s
         assert gemm.linear_decode_partial_xreg(gemm.to_fragment_major(x), pk, N, c, frag_shape=(M, K)) == s
         assert torch.equal(a, b) and torch.equal(a, c), f"N={N} K={K}"
@@ -661,7 +664,7 @@ def test_xreg_wide_product_matches_fp32_and_is_repeatable(dt, M):
         got32 = a32.view(s32, 32, N).sum(0)
         assert (got32 - ref[:32]).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6
     # gate|up over the INTERLEAVED packing: slabs in [gate | up] order, then silu*mul == the fp32 formula
-    for (inter, K) in ((11008, 4096), (2816, 1024), (96, 64)):
+    for (inter, K) in ((11008, 4096), (2816, 1024), (96, 64), (13824, 5120)):
         assert gemm.gate_up_xreg_supported(M, inter, K, dt)
         g = torch.Generator().manual_seed(inter + M)
         x = torch.randn((M, K), generator=g).to(dt).to(DEV)
@@ -710,7 +713,8 @@ def test_norm_fused_wide_launches_are_bit_identical(dt):
     from hydrainfer_amd._C.kernel import gemm
     from hydrainfer_amd._C.kernel.norm import add_rms_norm_slabs
     lib = _lib.lib()
-    for (M, hid, inter, S_in) in ((64, 4096, 11008, 8), (33, 4096, 11008, 4), (48, 1024, 2816, 2), (64, 256, 512, 1)):
+    for (M, hid, inter, S_in) in ((64, 4096, 11008, 8), (33, 4096, 11008, 4), (48, 1024, 2816, 2), (64, 256, 512, 1),
+                                  (64, 5120, 13824, 8), (33, 5120, 13824, 2)):      # 13B width: 20 k-steps per wave, one row group per unit
         g = torch.Generator().manual_seed(hid + M)
         nw = torch.randn(hid, generator=g).to(dt).to(DEV)
         wq = (torch.randn((3 * hid, hid), generator=g) * 0.03).to(dt).to(DEV)
@@ -722,7 +726,7 @@ def test_norm_fused_wide_launches_are_bit_identical(dt):
         b = torch.zeros_like(a)
         ga = torch.zeros(gemm.gate_up_xreg_workspace_floats(M, inter, hid), dtype=torch.float32, device=DEV)
         gb = torch.zeros_like(ga)
-        n_it = 30 if hid == 4096 and M == 64 else 3
+        n_it = 30 if hid == 4096 and M == 64 else (10 if hid == 5120 and M == 64 else 3)
         sync = torch.zeros((2 * n_it + 2, gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=DEV)
         for it in range(n_it):
             slabs = torch.randn((S_in, M, hid), generator=g).to(DEV)
