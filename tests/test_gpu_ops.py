@@ -651,7 +651,7 @@ def test_xreg_wide_product_matches_fp32_and_is_repeatable(dt, M):
         a = torch.zeros(gemm.xreg_workspace_floats(M, N, K), dtype=torch.float32, device=DEV)
         b, c = torch.zeros_like(a), torch.zeros_like(a)
         s = gemm.linear_decode_partial_xreg(x, pk, N, a)
-        assert s == a.numel() // (M * N) and s == {4096: 2, 11008: 8, 5120: 2, 13824: 8}.get(K, s)      # twice the slabs of the <= 32-row launch
+        assert s == a.numel() // (M * N) and s == {(12288, 4096): 2, (4096, 4096): 2, (4096, 11008): 8, (15360, 5120): 2, (5120, 13824): 8}.get((N, K), s)      # twice the slabs of the <= 32-row launch
         assert gemm.linear_decode_partial_xreg(x, pk, N, b) == s
         assert gemm.linear_decode_partial_xreg(gemm.to_fragment_major(x), pk, N, c, frag_shape=(M, K)) == s
         assert torch.equal(a, b) and torch.equal(a, c), f"N={N} K={K}"
