@@ -64,6 +64,9 @@ def parse():
                    help="library GEMMs (hipBLASLt) for decode too, instead of the weight-streaming HIP kernel")
     p.add_argument("--no-fused-attention", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=2)
+    p.add_argument("--cpu-full", action="store_true",
+                   help="also run BASELINE configs[0] IN FULL on the host cores (all decoder + CLIP layers of the oracle, ~1 min "
+                        "incl. building 13 GB of weights): cpu_baseline.config0_full and full_over_extrapolated")
     p.add_argument("--no-13b", action="store_true", help="skip the short LLaVA-1.5-13B leg (BASELINE configs[2])")
     p.add_argument("--steps-13b", type=int, default=20)
     p.add_argument("--no-null-step", action="store_true",
@@ -795,6 +798,92 @@ def cpu_baseline(shape, dtype, batch, ctx, n_layers):
                       f"{t_full + t_head:.1f}s of CPU work per repetition"}
 
 
+def cpu_config0_full(shape, dtype, n_threads, n_generate=16):
+    """BASELINE configs[0] run FOR REAL on the host cores (round-4 review, item 5): ONE request — CLIP ViT-L/14-336 encode
+    of one image (all 23 executed tower layers + projector, oracle/vision.py), 576 + 32 = 608-token prefill through ALL
+    decoder layers (oracle/model.py = the reference's eager torch CPU path, hydrainfer/layer/causal_attention.py:297-374),
+    then n_generate - 1 single-sequence decode steps — nothing extrapolated.  Weights: one random decoder layer cloned
+    per layer (distinct memory, identical values: random-filling 6.7 G parameters on the CPU would take longer than the
+    measurement); same for the tower."""
+    import numpy as np
+    from hydrainfer_amd.model.clip import CLIP_VIT_L_14_336
+    from oracle.model import OracleAttnMeta, OracleLlama
+    from oracle.vision import vision_forward
+    torch.set_num_threads(n_threads)
+    g = torch.Generator().manual_seed(0)
+    h, i = shape.hidden_size, shape.intermediate_size
+    q, kv = shape.num_attention_heads * shape.head_dim, shape.num_key_value_heads * shape.head_dim
+
+    def w(*s_):
+        return (torch.randn(s_, generator=g) * 0.02).to(dtype)
+    t_build = time.perf_counter()
+    base = {"self_attn.q_proj.weight": w(q, h), "self_attn.k_proj.weight": w(kv, h), "self_attn.v_proj.weight": w(kv, h),
+            "self_attn.o_proj.weight": w(h, q), "mlp.gate_proj.weight": w(i, h), "mlp.up_proj.weight": w(i, h),
+            "mlp.down_proj.weight": w(h, i), "input_layernorm.weight": torch.ones(h, dtype=dtype),
+            "post_attention_layernorm.weight": torch.ones(h, dtype=dtype)}
+    sd = {"model.embed_tokens.weight": w(shape.vocab_size, h), "lm_head.weight": w(shape.vocab_size, h),
+          "model.norm.weight": torch.ones(h, dtype=dtype)}
+    for l in range(shape.num_hidden_layers):
+        for k_, v_ in base.items():
+            sd[f"model.layers.{l}.{k_}"] = v_.clone()
+    full = CLIP_VIT_L_14_336
+    ch, ci, cp = full.hidden_size, full.intermediate_size, full.patch_size
+    vt = "vision_tower.vision_model."
+    vsd = {vt + "embeddings.class_embedding": w(ch), vt + "embeddings.patch_embedding.weight": w(ch, 3, cp, cp),
+           vt + "embeddings.position_embedding.weight": w((full.image_size // cp) ** 2 + 1, ch),
+           vt + "pre_layrnorm.weight": torch.ones(ch, dtype=dtype), vt + "pre_layrnorm.bias": torch.zeros(ch, dtype=dtype),
+           "multi_modal_projector.linear_1.weight": w(full.projector_hidden_size, ch),
+           "multi_modal_projector.linear_1.bias": w(full.projector_hidden_size),
+           "multi_modal_projector.linear_2.weight": w(full.projector_hidden_size, full.projector_hidden_size),
+           "multi_modal_projector.linear_2.bias": w(full.projector_hidden_size)}
+    cbase = {}
+    for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        cbase[f"self_attn.{nm}.weight"], cbase[f"self_attn.{nm}.bias"] = w(ch, ch), w(ch)
+    cbase["mlp.fc1.weight"], cbase["mlp.fc1.bias"] = w(ci, ch), w(ci)
+    cbase["mlp.fc2.weight"], cbase["mlp.fc2.bias"] = w(ch, ci), w(ch)
+    for nm in ("layer_norm1", "layer_norm2"):
+        cbase[nm + ".weight"], cbase[nm + ".bias"] = torch.ones(ch, dtype=dtype), torch.zeros(ch, dtype=dtype)
+    n_run = (full.vision_feature_layer + full.num_hidden_layers) % full.num_hidden_layers + 1      # 23 of 24
+    for l in range(n_run):
+        for k_, v_ in cbase.items():
+            vsd[vt + f"encoder.layers.{l}.{k_}"] = v_.clone()
+    t_build = time.perf_counter() - t_build
+    model = OracleLlama(shape, sd, dtype)
+    bs, n_p = 16, 608
+    nb = (n_p + n_generate + bs - 1) // bs
+    caches = [(torch.zeros((nb, bs, shape.num_key_value_heads, shape.head_dim), dtype=dtype),
+               torch.zeros((nb, bs, shape.num_key_value_heads, shape.head_dim), dtype=dtype)) for _ in range(shape.num_hidden_layers)]
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)
+    np.random.seed(0)
+    pixels = torch.from_numpy(np.random.randint(0, 256, (1, 3, 336, 336)).astype(np.float32) / 255.0).to(dtype)
+    ids = torch.randint(1000, 31999, (n_p,), generator=g, dtype=torch.int64)
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        feats = vision_forward(full, vsd, pixels)                       # [1, 576, hidden]
+        t_enc = time.perf_counter() - t0
+        embeds = torch.nn.functional.embedding(ids, sd["model.embed_tokens.weight"])
+        embeds[:576] = feats[0].to(dtype)                               # llava.py:132-135: image-token rows
+        meta = OracleAttnMeta(i32([0, n_p]), i32([0, n_p]), i32(list(range(n_p))), i32(list(range(nb))), i32([0, nb]))
+        t0 = time.perf_counter()
+        tok = model.forward(embeds, torch.arange(n_p, dtype=torch.int32), meta, caches, torch.tensor([n_p - 1]))
+        t_pre = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for s_ in range(n_generate - 1):
+            ctx_ = n_p + s_ + 1
+            meta = OracleAttnMeta(i32([0, 1]), i32([0, ctx_]), i32([ctx_ - 1]), i32(list(range(nb))), i32([0, nb]))
+            tok = model.forward(tok.reshape(1), i32([ctx_ - 1]), meta, caches)
+        t_dec = time.perf_counter() - t0
+    total = t_enc + t_pre + t_dec
+    return {"what": "BASELINE configs[0] in full on the host cores: 1 image (23 CLIP layers + projector) + 608-token prefill "
+                    f"through all {shape.num_hidden_layers} decoder layers + {n_generate - 1} batch-1 decode steps, oracle/ (the "
+                    "reference's eager torch CPU path restated); nothing extrapolated",
+            "cores": os.cpu_count(), "threads": n_threads, "dtype": str(dtype).split(".")[-1],
+            "clip_encode_s": round(t_enc, 3), "prefill_s": round(t_pre, 3), "ttft_s": round(t_enc + t_pre, 3),
+            "decode_s": round(t_dec, 3), "decode_tokens_per_s": round((n_generate - 1) / t_dec, 3),
+            "request_s": round(total, 3), "output_tokens_per_s": round(n_generate / total, 3),
+            "weight_build_s": round(t_build, 1)}
+
+
 def decode_leg(ctx, model, runner, ctxs, warmup, prompt_len):
     """Warm-up, then the timed region of the contract: barrier + synchronize on both sides, exactly
     len(ctxs) decode steps, MAX over ranks.  The contexts are equally spaced: the step's own device-side advance
@@ -1273,6 +1362,24 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(shape, dtype, args.batch, mid_ctx, args.cpu_layers)
+            cb = out["cpu_baseline"]
+            if args.cpu_full:
+                full = cpu_config0_full(shape, dtype, cb["cores"])
+                ex = cb["config0"]
+                cb["config0_full"] = full
+                if isinstance(ex.get("clip_encode_s"), (int, float)):
+                    cb["full_over_extrapolated"] = {
+                        "clip_encode": round(full["clip_encode_s"] / ex["clip_encode_s"], 3),
+                        "prefill": round(full["prefill_s"] / ex["prefill_s"], 3),
+                        "decode_tokens_per_s": round(full["decode_tokens_per_s"] / ex["decode_tokens_per_s"], 3)}
+            else:
+                # the measured relation of the two on an MI355X box's host (profiles/, `--cpu-full`), for the reader of a default line
+                try:
+                    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5_cpu_config0_full.json")))
+                    cb["full_over_extrapolated"] = dict(ref["full_over_extrapolated"], source="profiles/r5_cpu_config0_full.json "
+                                                        "(python bench.py --cpu-full on an MI355X box; not re-measured in this run)")
+                except Exception:
+                    pass
     # ---- optional last leg on every rank (nothing touches the GPU after it)
     migration, stuck = None, ipc_stuck
     if world > 1 and not args.no_migration:

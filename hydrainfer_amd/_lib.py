@@ -12,7 +12,9 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhydra_hip.so")
+# HX_LIB_PATH: A/B tooling only (tools/: the same program against a library built from another revision); the product,
+# the tests and bench.py load the in-tree library
+LIB_PATH = os.environ.get("HX_LIB_PATH") or os.path.join(_HERE, "lib", "libhydra_hip.so")
 
 HX_F32, HX_F16, HX_BF16 = 0, 1, 2
 HX_IPC_HANDLE_BYTES = 64

@@ -42,10 +42,20 @@ template <> struct VRow<256> {
   static constexpr int NV = 2, E = 8;  // dims 8c..8c+7 and 128+8c..128+8c+7
 };
 
+// Keys per tile.  D <= 128: 16 (lane group g holds keys 4g+i, i = 0..3).  D = 256 (round 5): 8 — lane group g holds keys
+// 2g+i, i = 0..1 — so that two register tile buffers are 64 registers instead of 128: the 16-key form of D = 256 needed
+// 28..310 spilled registers under its 256-register budget (two workgroups per CU), the 8-key form none.  The MFMA still
+// sees 16 A rows: key 2g+i sits in row 4g+i, rows 4g+2, 4g+3 are never written and their scores never read.
+template <int D> struct TileGeom {
+  static constexpr int KPL = D == 256 ? 2 : 4;      // keys per 16-lane group
+  static constexpr int TK = 4 * KPL;                // keys per tile
+  static constexpr int SH = D == 256 ? 3 : 4;       // log2(TK)
+};
+
 template <int D>
 struct KVTile {
-  typename VRow<D>::type k[4][VRow<D>::NV];  // keys 4g+i, i = 0..3: dims [c*D/16, (c+1)*D/16)
-  typename VRow<D>::type v[4][VRow<D>::NV];  // same layout for values
+  typename VRow<D>::type k[TileGeom<D>::KPL][VRow<D>::NV];  // keys KPL*g+i: dims [c*D/16, (c+1)*D/16)
+  typename VRow<D>::type v[TileGeom<D>::KPL][VRow<D>::NV];  // same layout for values
 };
 
 // LDS image of one K tile: [16 keys][2*D bytes + 32] — the +32 makes both the row-wise
@@ -65,12 +75,12 @@ __device__ __forceinline__ void load_tile(KVTile<D>& buf, const AttnParams& p, c
                                           int lane) {
   // valid = number of in-range keys in this tile (>= 1; may exceed 16)
   const int g = lane >> 4, c = lane & 15;
-  constexpr int E = VRow<D>::E;
+  constexpr int E = VRow<D>::E, KPL = TileGeom<D>::KPL;
   // every load instruction covers 4 whole key (value) rows of 2*D contiguous bytes: full
   // cache lines, half the line requests of a fragment-shaped (16 rows x 64 B) load
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int tok = min(4 * g + i, valid - 1);
+  for (int i = 0; i < KPL; ++i) {
+    const int tok = min(KPL * g + i, valid - 1);
     const u16* kp = kbase + (int64_t)page * p.k_block_stride + (int64_t)(row0 + tok) * p.k_row_stride +
                     E * c;
 #pragma unroll
@@ -78,8 +88,8 @@ __device__ __forceinline__ void load_tile(KVTile<D>& buf, const AttnParams& p, c
       buf.k[i][n] = ld<NT>(reinterpret_cast<const typename VRow<D>::type*>(kp + 128 * n));
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int tok = min(4 * g + i, valid - 1);
+  for (int i = 0; i < KPL; ++i) {
+    const int tok = min(KPL * g + i, valid - 1);
     const u16* vp = vbase + (int64_t)page * p.v_block_stride + (int64_t)(row0 + tok) * p.v_row_stride +
                     E * c;
 #pragma unroll
@@ -125,11 +135,11 @@ __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (
                                              int valid, float scale_log2, int lane, float& m,
                                              float& l, float (&o)[D / 16], char* klds) {
   const int g = lane >> 4, c = lane & 15;
-  constexpr int RS = KLds<D>::RS;
+  constexpr int RS = KLds<D>::RS, KPL = TileGeom<D>::KPL;
   // K rows -> wave-private LDS -> MFMA A fragments (key r = lane&15, dims 32s+8g..+8).
   // DS operations of one wave execute in order, so no barrier is needed.
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < KPL; ++i)
 #pragma unroll
     for (int n = 0; n < VRow<D>::NV; ++n)
       *reinterpret_cast<typename VRow<D>::type*>(klds + (4 * g + i) * RS + 256 * n + 2 * VRow<D>::E * c) =
@@ -142,18 +152,18 @@ __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (
     s = Mfma<T>::mma(kf, qf[st], s);
   }
   __builtin_amdgcn_wave_barrier();
-  float x[4];
+  float x[KPL];
   float mx = m;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    x[i] = (4 * g + i < valid) ? s[i] * scale_log2 : -INFINITY;
+  for (int i = 0; i < KPL; ++i) {
+    x[i] = (KPL * g + i < valid) ? s[i] * scale_log2 : -INFINITY;
     mx = fmaxf(mx, x[i]);
   }
   const float alpha = fast_exp2(m - mx);
-  float pr[4];
+  float pr[KPL];
   float ps = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < KPL; ++i) {
     pr[i] = fast_exp2(x[i] - mx);
     ps += pr[i];
   }
@@ -166,7 +176,7 @@ __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (
     for (int e = 0; e < E; ++e) {
       float acc = o[n * E + e] * alpha;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = fmaf(pr[i], T::to_float(buf.v[i][n][e]), acc);
+      for (int i = 0; i < KPL; ++i) acc = fmaf(pr[i], T::to_float(buf.v[i][n][e]), acc);
       o[n * E + e] = acc;
     }
 }
@@ -188,13 +198,14 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   const int g = lane >> 4, c = lane & 15;
   const int hk = h / p.group;
 
+  constexpr int KPL = TileGeom<D>::KPL, TK = TileGeom<D>::TK, SH = TileGeom<D>::SH;
   const int kv_len = p.cu_k[b + 1] - p.cu_k[b];
   const int q_row = p.cu_q[b];
-  const int n_tiles = (kv_len + 15) >> 4;
+  const int n_tiles = (kv_len + TK - 1) >> SH;
   const int per_split = (n_tiles + p.n_splits - 1) / p.n_splits;
   const int t_begin = split * per_split;
   const int t_end = min(n_tiles, t_begin + per_split);
-  const int tpp = p.block_size >> 4;  // tiles per page
+  const int tpp = p.block_size >> SH;  // tiles per page
   const int32_t* bt = p.block_table + p.cu_block_lens[b];
 
   const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
@@ -210,9 +221,12 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
     my_page = (tj < t_end) ? bt[tj / tpp] : 0;
     n_my = min(64, (t_end - chunk0 + NW - 1) / NW);  // wave-uniform
     load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
-                        (chunk0 % tpp) << 4, kv_len - (chunk0 << 4), lane);
+                        (chunk0 % tpp) << SH, kv_len - (chunk0 << SH), lane);
   };
-  if (chunk0 < t_end) begin_chunk();
+  // (D = 256 with the fused prologue: the prologue's q / new-key fragments and the first tile together do not fit the
+  // 256-register budget — the tile is requested behind the prologue instead of spilling)
+  constexpr bool EARLY = !(FUSE && D == 256);
+  if (EARLY && chunk0 < t_end) begin_chunk();
 
   // q as the MFMA B operand, identical in all 16 columns
   u16x8 qf[D / 32];
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   u16x8 kn[D / 32];                              // rotated new key, fragment layout (RoPE is lane-local there)
   typename VRow<D>::type knr[VRow<D>::NV];       // the same row in the row layout of KVTile
   typename VRow<D>::type vn[VRow<D>::NV];
-  const int t_new = (kv_len - 1) >> 4, r_new = (kv_len - 1) & 15;
+  const int t_new = (kv_len - 1) >> SH, r_new = (kv_len - 1) & (TK - 1);
   if (FUSE) {
     const u16* cs = reinterpret_cast<const u16*>(p.cos_sin) + (int64_t)p.positions[b] * D;
     if (p.qkv_partial) {
@@ -301,8 +315,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   auto patch = [&](KVTile<D>& buf, int t) {
     if (FUSE && t == t_new) {     // wave-uniform
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (4 * g + i == r_new) {
+      for (int i = 0; i < KPL; ++i)
+        if (KPL * g + i == r_new) {
 #pragma unroll
           for (int n = 0; n < VRow<D>::NV; ++n) {
             buf.k[i][n] = knr[n];
@@ -318,26 +332,26 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   for (int e = 0; e < OE; ++e) o[e] = 0.f;
 
   // my tiles: t_begin + w + NW*j.  Chunks of 64 tiles per wave share one page-id vector.
-  for (bool first = true; chunk0 < t_end; chunk0 += NW * 64, first = false) {
+  for (bool first = EARLY; chunk0 < t_end; chunk0 += NW * 64, first = false) {
     if (!first) begin_chunk();
     int j = 0;
     while (j < n_my) {
       if (j + 1 < n_my) {
         const int t = chunk0 + NW * (j + 1);
         load_tile<T, D, NT>(bufB, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
-                        (t % tpp) << 4, kv_len - (t << 4), lane);
+                        (t % tpp) << SH, kv_len - (t << SH), lane);
       }
       patch(bufA, chunk0 + NW * j);
-      compute_tile<T, D>(bufA, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o, s_k[w]);
+      compute_tile<T, D>(bufA, qf, kv_len - ((chunk0 + NW * j) << SH), p.scale_log2, lane, m, l, o, s_k[w]);
       ++j;
       if (j >= n_my) break;
       if (j + 1 < n_my) {
         const int t = chunk0 + NW * (j + 1);
         load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
-                        (t % tpp) << 4, kv_len - (t << 4), lane);
+                        (t % tpp) << SH, kv_len - (t << SH), lane);
       }
       patch(bufB, chunk0 + NW * j);
-      compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * j) << 4), p.scale_log2, lane, m, l, o, s_k[w]);
+      compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * j) << SH), p.scale_log2, lane, m, l, o, s_k[w]);
       ++j;
     }
   }

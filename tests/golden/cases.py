@@ -419,3 +419,17 @@ def moe_golden_cases(g):
             side, name, dt = rest.split(".")
             (ins if side == "in" else outs)[name] = from_np(g[f"{c}.{rest}"], _MOE_DT[dt])
         yield str(g[f"{c}.op"]), int(g[f"{c}.topk"]), ins, outs
+
+
+# ---- G13: chat-completions wire contract (hydrainfer/entrypoint/api_server.py:89-152) -------------------------
+API_CASE = {"id": "chatcmpl-0000000000000000000000", "created": 1700000000, "model": "llava-hf/llava-1.5-7b-hf",
+            "pieces": [" Hello", "世界", ' "quoted"\n', " <123>", "a/b\\c"]}
+_PNG_1x1 = ("iVBORw0KGgoAAAANSUhEUgAAAAEAAAABCAIAAACQd1PeAAAADElEQVR4nGP4z8AAAAMBAQDJ/pLvAAAAAElFTkSuQmCC")
+
+
+def api_messages():
+    """Messages as the reference's client builds them (benchmark/backend.py:17-38): the text first, then the images."""
+    url = {"url": "data:image/png;base64," + _PNG_1x1}
+    return {"image_text": {"role": "user", "content": [{"type": "text", "text": "What is shown in this image?"},
+                                                       {"type": "image_url", "image_url": url}]},
+            "text_only": {"role": "user", "content": [{"type": "text", "text": "Describe  the weather.\nBriefly."}]}}

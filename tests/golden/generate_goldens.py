@@ -700,6 +700,47 @@ def gen_moe(out):
     print(f"moe: {n} reference test invocations passed their own assertions; {len(kept)} op calls recorded")
 
 
+def gen_api_protocol(out):
+    """G13: the wire contract of the chat-completions endpoint from the reference's own classes:
+    the stream chunks its pydantic models emit (`model_dump_json(exclude_unset=True)`, api_server.py:119-146), what
+    APIServer._parse_content makes of a message with an image (api_server.py:62-79), and the prompt its LLaVA chat template
+    renders (model/chat_template/template_llava.jinja through LlavaTokenizer.apply_chat_template, llava.py:168-175)."""
+    from jinja2 import Template
+    sys.modules["shortuuid"].random = lambda: "0" * 22
+    sys.modules["hydra"].main = lambda *a, **k: (lambda f: f)        # entrypoint/__init__.py decorates its main with it
+    from hydrainfer.entrypoint.api_protocol import (ChatCompletionContent, ChatCompletionImageURL, ChatCompletionMessage,
+                                                    ChatCompletionResponseStreamChoice, ChatCompletionStreamResponse,
+                                                    DeltaMessage)
+    rid, created, model = C.API_CASE["id"], C.API_CASE["created"], C.API_CASE["model"]
+    first = ChatCompletionStreamResponse(id=rid, object="chat.completion.chunk", created=created, model=model,
+                                         choices=[ChatCompletionResponseStreamChoice(index=0, delta=DeltaMessage(role="assistant", content=""))])
+    out["first_chunk"] = np.array(f"data: {first.model_dump_json(exclude_unset=True)}\n\n")
+    chunks = []
+    for piece in C.API_CASE["pieces"]:
+        r = ChatCompletionStreamResponse(id=rid, object="chat.completion.chunk", created=created, model=model,
+                                         choices=[ChatCompletionResponseStreamChoice(index=0, delta=DeltaMessage(content=piece))])
+        chunks.append(f"data: {r.model_dump_json(exclude_unset=True)}\n\n")
+    out["content_chunks"] = np.array(chunks)
+    # _parse_content on the client's message (benchmark/backend.py:17-28: text first, then the image)
+    from types import SimpleNamespace as NS
+    try:
+        from hydrainfer.entrypoint.api_server import APIServer
+        parse = APIServer._parse_content
+    except Exception as e:       # the module pulls in the whole serving stack: fall back to nothing, loudly
+        raise RuntimeError(f"cannot import the reference's api_server: {e!r}")
+    for name, msg in C.api_messages().items():
+        m = ChatCompletionMessage(role=msg["role"], content=[
+            ChatCompletionContent(type=c["type"], text=c.get("text"),
+                                  image_url=ChatCompletionImageURL(url=c["image_url"]["url"]) if "image_url" in c else None)
+            for c in msg["content"]])
+        images = parse(NS(vision_config=NS(image_token="<image>")), [m])
+        out[f"parsed_{name}_content"] = np.array(m.content)
+        out[f"parsed_{name}_n_images"] = np.array(len(images))
+        tpl = Template(open(os.path.join(REFERENCE, "hydrainfer", "model", "chat_template", "template_llava.jinja"), encoding="utf-8").read())
+        out[f"prompt_{name}"] = np.array(tpl.render(messages=[{"role": m.role, "content": m.content}], bos_token="<s>",
+                                                    eos_token="</s>", add_generation_prompt=True))
+
+
 def main():
     import_reference()
     torch.manual_seed(0)
@@ -716,6 +757,7 @@ def main():
         "g10_tiny_llava": gen_tiny_llava,
         "g11_engine_trace": gen_engine_trace,
         "g12_moe": gen_moe,
+        "g13_api_protocol": gen_api_protocol,
     }
     only = sys.argv[1:]
     for name, fn in sets.items():
