@@ -64,7 +64,7 @@ def rcb_to_wire(rcb: RequestControlBlock) -> dict:
             "metadata": None if md is None else dataclasses.astuple(md),
             "kv": _cache_to_wire(rcb.virtual_kv_cache), "image": _cache_to_wire(rcb.virtual_image_cache),
             "output_token_ids": list(rcb.output_token_ids), "scenario": int(rcb.scenario_type or 0),
-            "metric": dataclasses.asdict(rcb.metric)}
+            "metric": dataclasses.asdict(rcb.metric), "stream_rank": rcb.stream_rank}
 
 
 def rcb_from_wire(w: dict) -> RequestControlBlock:
@@ -77,6 +77,7 @@ def rcb_from_wire(w: dict) -> RequestControlBlock:
     rcb.output_token_ids = list(w["output_token_ids"])
     rcb.scenario_type = ScenarioType(w["scenario"])
     rcb.metric = RequestMetric(**w["metric"])
+    rcb.stream_rank = w.get("stream_rank")
     b = InstructionListBuilder()
     fills: List[Fill] = []
     for rec in w["instructions"]:
@@ -123,6 +124,18 @@ class RemoteNode:
     # receiver side, phase 4 (epdnode.py:443-446) — addressed to the sender
     def free_migrate_request(self, rcb: RequestControlBlock) -> None:
         self.engine.outbox.append((self.rank, "free", rcb.request_id))
+
+
+class MailboxTokenProcessor:
+    """OutputTokenProcessor of a request that is being served by another rank's front end: every sampled token goes to
+    that rank's mailbox with the step's other messages (the reference: ZmqOutputTokenProcessor pushing to the API
+    server's PULL socket, hydrainfer/engine/output_token_processor.py:92-140)."""
+
+    def __init__(self, engine: "RankEngine", dst_rank: int, request_id):
+        self.engine, self.dst_rank, self.request_id = engine, dst_rank, request_id
+
+    def append_token_id(self, token_id: int, is_last_token: bool = False) -> None:
+        self.engine.outbox.append((self.dst_rank, "token", (self.request_id, int(token_id), bool(is_last_token))))
 
 
 class StoreMailbox:
@@ -179,6 +192,48 @@ class RankEngine:
         node.connect(p_nodes if nt.enable_encode else [], d_nodes if nt.enable_prefill else [])
         self.mailbox = LocalMailbox()
         self.reported = self.n_exchanges = self.total_finished = 0
+        # serving front end on this rank (entrypoint/api_server.py): request id -> the OutputTokenProcessor that streams it
+        self.token_handlers: Dict[object, object] = {}
+        self.creator = None          # InstructionCreator for requests submitted by another rank's front end
+
+    # ---- serving: a front end on ONE rank, requests entering where the routing rule says, tokens coming back ----------
+    def submit(self, request, processor, creator, request_index: int) -> None:
+        """Front-end side: start `request` on the rank cluster.py:178-184 picks (image requests round-robin over the E
+        ranks, text-only ones over the P ranks); its tokens — sampled on whichever ranks run its prefill and decode —
+        are delivered to `processor` on THIS rank."""
+        self.token_handlers[request.request_id] = processor
+        dst = entry_rank(request_index, self.roles, request.pixel_values is not None)
+        if dst == self.rank:
+            try:
+                self._start(request, creator, self.rank)
+            except Exception:
+                self.token_handlers.pop(request.request_id, None)
+                raise
+        else:
+            self.outbox.append((dst, "submit", (request, self.rank)))
+
+    def _start(self, request, creator, stream_rank: int) -> None:
+        rcb = creator.process(request)
+        rcb.stream_rank = stream_rank
+        self._attach_stream(rcb)
+        self.node.add_request(rcb)
+
+    def _attach_stream(self, rcb: RequestControlBlock) -> None:
+        if rcb.stream_rank is None:
+            return
+        if rcb.stream_rank == self.rank:
+            h = self.token_handlers.get(rcb.request_id)
+            if h is not None:
+                rcb.register_output_token_processor(_LocalStream(self, rcb.request_id))
+        else:
+            rcb.register_output_token_processor(MailboxTokenProcessor(self, rcb.stream_rank, rcb.request_id))
+
+    def _token(self, request_id, token: int, last: bool) -> None:
+        h = self.token_handlers.get(request_id)
+        if h is not None:
+            h.append_token_id(token, last)
+            if last:
+                del self.token_handlers[request_id]
 
     def connect_transfer_peers(self, timeout_s: Optional[float] = None) -> int:
         """Call on every rank once at start-up, before the first request: the send/recv communicators of every E -> P
@@ -205,7 +260,22 @@ class RankEngine:
     def _deliver(self, src_rank: int, kind: str, payload) -> None:
         if kind == "migrate":
             rcb = rcb_from_wire(payload)
+            self._attach_stream(rcb)
             self.node.migrate(self.peers[src_rank], rcb)
+        elif kind == "token":
+            self._token(*payload)
+        elif kind == "submit":
+            request, stream_rank = payload
+            if self.creator is None:
+                raise RuntimeError("a front end submitted a request to this rank, but RankEngine.creator is not set")
+            try:
+                self._start(request, self.creator, stream_rank)
+            except Exception as e:      # e.g. prompt + max_tokens past the rotary table: the stream must end, loudly
+                self.outbox.append((stream_rank, "failed", (request.request_id, repr(e))))
+        elif kind == "failed":
+            h = self.token_handlers.pop(payload[0], None)
+            if h is not None and hasattr(h, "fail"):
+                h.fail(RuntimeError(payload[1]))
         elif kind == "pull":
             which, src, dst = payload
             self.node.pull_virtual_cache(which, _cache_from_wire(src), _cache_from_wire(dst))
@@ -234,6 +304,16 @@ class RankEngine:
     def step(self) -> int:
         self.node.step()
         return self.exchange()
+
+
+class _LocalStream:
+    """Tokens sampled on the front end's own rank."""
+
+    def __init__(self, engine: RankEngine, request_id):
+        self.engine, self.request_id = engine, request_id
+
+    def append_token_id(self, token_id: int, is_last_token: bool = False) -> None:
+        self.engine._token(self.request_id, int(token_id), bool(is_last_token))
 
 
 def entry_rank(request_index: int, roles: List[str], has_image: bool) -> int:

@@ -77,6 +77,9 @@ class RequestControlBlock:
         self.scenario_type: Optional[ScenarioType] = None
         self.metric = RequestMetric()
         self.eos_hit = False      # set when a token read back late (decode look-ahead) was end-of-sequence
+        self.stream_rank: Optional[int] = None    # multi-process serving: the rank whose front end streams this request's
+                                                  # tokens to a client (engine/distributed.py: the reference pushes them
+                                                  # over zmq from every node, hydrainfer/engine/output_token_processor.py:92-140)
 
     def current_instruction(self) -> Instruction:
         return self.instructions.curr

@@ -85,13 +85,16 @@ class EngineFrontend:
                 break
             n += 1
             try:
-                rcb = self.creator.process(request)           # ValueError: prompt + max_tokens past the rotary table
-                rcb.register_output_token_processor(processor)
-                self.cluster.add_request(rcb)
+                self._start(request, processor)
                 self.n_admitted += 1
             except Exception as e:
                 processor.fail(e)
         return n
+
+    def _start(self, request: TokenRequest, processor: StreamOutputTokenProcessor) -> None:
+        rcb = self.creator.process(request)           # ValueError: prompt + max_tokens past the rotary table
+        rcb.register_output_token_processor(processor)
+        self.cluster.add_request(rcb)
 
     def _loop(self) -> None:
         try:
@@ -115,6 +118,44 @@ class EngineFrontend:
                 except queue.Empty:
                     break
             raise
+
+
+class _RankCluster:
+    """engine.distributed.RankEngine seen as the `cluster` an EngineFrontend steps."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def step(self) -> int:
+        self.engine.step()
+        return 0 if (self.engine.node.idle() and not self.engine.outbox) else 1
+
+
+class RankEngineFrontend(EngineFrontend):
+    """The front end of a multi-process deployment (one engine node per GPU, engine/distributed.py; BASELINE configs[3] /
+    [4]): it runs on ONE rank beside that rank's node; a request starts on the rank the reference's routing rule picks
+    (cluster.py:178-184) and its tokens come back through the mailbox from whichever ranks sample them — the zmq PUSH /
+    PULL pair of the reference (api_server.py:49-60, output_token_processor.py:92-140).  The other ranks run
+    `serve_worker`."""
+
+    def __init__(self, engine, creator: InstructionCreator, device=None):
+        super().__init__(_RankCluster(engine), creator, device)
+        self.engine = engine
+        engine.creator = creator
+        self._index = 0
+
+    def _start(self, request: TokenRequest, processor: StreamOutputTokenProcessor) -> None:
+        self.engine.submit(request, processor, self.creator, self._index)
+        self._index += 1
+
+
+def serve_worker(engine, creator: InstructionCreator, should_stop: Callable[[], bool]) -> None:
+    """Step loop of a rank without a front end: takes `submit` / `migrate` / `pull` / `free` messages, posts tokens."""
+    engine.creator = creator
+    while not should_stop():
+        engine.step()
+        if engine.node.idle() and not engine.outbox:
+            time.sleep(0.0005)
 
 
 _REASONS = {200: "OK", 400: "Bad Request", 404: "Not Found", 405: "Method Not Allowed", 413: "Payload Too Large",

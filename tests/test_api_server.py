@@ -184,3 +184,79 @@ def test_stream_processor_hands_tokens_across_threads():
         th.join()
         return out
     assert asyncio.run(go()) == [" <7>", " <9>", None]
+
+
+# ---- one engine node per process (E / P / D), the front end on rank 0: tokens come back through the mailbox ----------
+def _serve_rank(rank, roles, port, q):
+    try:
+        import time
+        import torch.distributed as dist
+        from hydrainfer_amd.engine import InstructionCreator
+        from hydrainfer_amd.entrypoint import RankEngineFrontend, serve_worker
+        from hydrainfer_amd.model.processor import ClipImageProcessor
+        from tests.test_distributed_engine_cpu import BS, IMAGE_TOKEN, N_IMG, _build_engine, expected_tokens
+        dist.init_process_group("gloo", rank=rank, world_size=len(roles), init_method=f"tcp://127.0.0.1:{port}")
+        engine, kv, img = _build_engine(rank, roles, None)
+        creator = InstructionCreator(IMAGE_TOKEN, N_IMG, BS)
+        engine.open_mailbox("serve0")
+        store = dist.distributed_c10d._get_default_store()
+        dist.barrier()
+        if rank != 0:
+            serve_worker(engine, creator, lambda: store.check(["serve_stop"]))
+            q.put((rank, "ok", len(engine.node.finished)))
+            return
+        tok = SyntheticTokenizer(image_token_id=IMAGE_TOKEN)
+        front = RankEngineFrontend(engine, creator)
+        server = ApiServer(front, tok, ClipImageProcessor(size=8), host="127.0.0.1", port=0, image_size=(8, 8))
+        jobs = [("What is shown in this image?", _png(1), 5), ("Describe the weather. Briefly.", None, 3),
+                ("What is shown in this image?", _png(2), 6), ("one two three four five six seven", _png(1), 4),
+                ("text only again", None, 7), ("What is shown in this image?", _png(3), 2)]
+
+        async def go():
+            await server.start()
+            front.start()
+            try:
+                return await asyncio.gather(*[_client_stream(f"http://127.0.0.1:{server.port}/v1", _payload(t, im, n)) for t, im, n in jobs])
+            finally:
+                front.stop()
+                await server.close()
+        got = asyncio.run(go())
+        store.set("serve_stop", "1")
+        assert front.error is None
+        from hydrainfer_amd.entrypoint.api_protocol import parse_chat_completion_request as parse
+        from hydrainfer_amd.engine import SamplingParameters, TokenRequest
+        for (text, n_events, done), (t, im, n) in zip(got, jobs):
+            ids = tok.encode(tok.apply_chat_template("user", parse(_payload(t, im, n)).text))
+            want = expected_tokens(TokenRequest(0, ids, None, (8, 8), 0, SamplingParameters(max_tokens=n)))
+            assert done and n_events == n + 1
+            assert text == "".join(tok.decode(x) for x in want), (t, text)
+        assert not engine.token_handlers
+        q.put((rank, "ok", len(engine.node.finished)))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), 0))
+
+
+@pytest.mark.parametrize("roles", [["EP", "D"], ["E", "P", "D"]], ids="-".join)
+def test_endpoint_in_front_of_a_multi_process_engine(roles):
+    """BASELINE configs[3] shape of deployment on CPU (gloo, stand-in models with closed-form tokens): the HTTP front end
+    on rank 0, image requests entering at E, text-only ones forwarded to the P rank (cluster.py:178-184), the first token
+    sampled on P and the rest on D — every one of them reaches the client's stream, in order."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_serve_rank, args=(r, roles, port, q)) for r in range(len(roles))]
+    for p in procs:
+        p.start()
+    try:
+        results = [q.get(timeout=240) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert sorted(r[:2] for r in results) == [(r, "ok") for r in range(len(roles))], results
+    finished = {r: n for r, _, n in results}
+    assert finished[len(roles) - 1] == 6 and finished[0] == 0          # every request finished on the D rank

@@ -548,8 +548,10 @@ def test_single_entry_decode_linear_dispatches_to_the_layout_kernels(dt):
         assert gemm.linear_decode_ex(x, dl, a2) == gemm.linear_decode_partial_packed(x, dl.packed, N, b2) and torch.equal(a2, b2)
         with pytest.raises(_lib.HydraHipError):
             gemm.linear_decode_ex(xf, dl, a2, frag_shape=(M, K))        # fragment-major x only on the XREG layout
-    w13 = (torch.randn((15360, 5120), generator=g) * 0.05).to(dt).to(DEV)      # 13B qkv: 40 k-steps per wave do not halve
-    assert gemm.DecodeWeight(w13, max_rows=64).layout == "lds_slice" and gemm.DecodeWeight(w13, max_rows=32).layout == "xreg"
+    w13 = (torch.randn((15360, 5120), generator=g) * 0.05).to(dt).to(DEV)      # 13B qkv: 40 k-steps per wave, halved to 20 (round 5)
+    assert gemm.DecodeWeight(w13, max_rows=64).layout == "xreg" and gemm.DecodeWeight(w13, max_rows=32).layout == "xreg"
+    wodd = (torch.randn((1024, 3584), generator=g) * 0.05).to(dt).to(DEV)      # 29 k-steps per wave: no built half (15)
+    assert gemm.DecodeWeight(wodd, max_rows=64).layout == "lds_slice" and gemm.DecodeWeight(wodd, max_rows=32).layout == "xreg"
     # a gate|up weight: interleaved for the fused epilogue; the plain product over it un-interleaves its slab columns
     wgu = (torch.randn((2 * 11008, 4096), generator=g) * 0.05).to(dt).to(DEV)
     dgu = gemm.DecodeWeight(wgu, max_rows=32, gate_up=True)
