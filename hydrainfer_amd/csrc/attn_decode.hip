@@ -184,7 +184,20 @@ __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (
 // launch bound: 4 workgroups of 4 waves (or 2 of 8) per CU => <= 128 VGPRs for D <= 128; the
 // D = 256 instantiation needs more registers and runs at half that occupancy.
 template <typename T, int D, int NW, bool NT, bool FUSE>
-__global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kernel(
+    const void* __restrict__ h_k, const void* __restrict__ h_v, const int32_t* __restrict__ h_cu_k,
+    const int32_t* __restrict__ h_cu_q, const int32_t* __restrict__ h_block_table,
+    const int32_t* __restrict__ h_cu_block_lens, const int32_t h_meta, const int32_t h_block_size,
+    const AttnParams p_in) {
+  // Leading scalars (14 dwords) = what the head of the dependent chain  kernarg -> cu_* -> page ids -> first K / V tile
+  // needs; they arrive in SGPRs WITH the wave (gemm_xreg.hip, KERNARG PRELOADING).  h_meta = group | n_splits << 8 |
+  // (block_shift & 0xff) << 16.  Round 5: the prologue used to be three scalar round trips in a row (the struct, then
+  // cu_k, then cu_block_lens + the rest of the struct) with two runtime integer divisions between them; now ONE batch of
+  // scalar loads through the preloaded pointers, shifts instead of divisions where the page size is a power of two.
+  AttnParams p = p_in;
+  p.k = h_k; p.v = h_v; p.cu_k = h_cu_k; p.cu_q = h_cu_q; p.block_table = h_block_table;
+  p.cu_block_lens = h_cu_block_lens; p.block_size = h_block_size;
+  p.group = h_meta & 0xff; p.n_splits = (h_meta >> 8) & 0xff; p.block_shift = (int)(int8_t)((h_meta >> 16) & 0xff);
   constexpr int OE = D / 16;  // fp32 partial-output elements per lane
   constexpr int NP = NW * 4;  // partial softmax states per workgroup
   __shared__ float s_m[NP], s_l[NP];
@@ -196,17 +209,21 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int hk = h / p.group;
+  // the sequence's metadata: one batch of scalar loads
+  const int32_t ck0 = h_cu_k[b], ck1 = h_cu_k[b + 1], cbl = h_cu_block_lens[b], q_row = h_cu_q[b];
+  const int hk = p.group == 1 ? h : h / p.group;
 
   constexpr int KPL = TileGeom<D>::KPL, TK = TileGeom<D>::TK, SH = TileGeom<D>::SH;
-  const int kv_len = p.cu_k[b + 1] - p.cu_k[b];
-  const int q_row = p.cu_q[b];
+  const int kv_len = ck1 - ck0;
   const int n_tiles = (kv_len + TK - 1) >> SH;
-  const int per_split = (n_tiles + p.n_splits - 1) / p.n_splits;
+  const int per_split = p.n_splits == 1 ? n_tiles : (n_tiles + p.n_splits - 1) / p.n_splits;
   const int t_begin = split * per_split;
   const int t_end = min(n_tiles, t_begin + per_split);
   const int tpp = p.block_size >> SH;  // tiles per page
-  const int32_t* bt = p.block_table + p.cu_block_lens[b];
+  const int tsh = p.block_shift - SH;  // >= 0: a page is 2^tsh tiles (no runtime division on the way to the first load)
+  auto page_of = [&](int t) { return tsh >= 0 ? t >> tsh : t / tpp; };
+  auto row0_of = [&](int t) { return (tsh >= 0 ? t & ((1 << tsh) - 1) : t % tpp) << SH; };
+  const int32_t* bt = h_block_table + cbl;
 
   const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
   const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
@@ -218,10 +235,10 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   int chunk0 = t_begin + w;
   auto begin_chunk = [&]() {
     const int tj = chunk0 + NW * lane;
-    my_page = (tj < t_end) ? bt[tj / tpp] : 0;
+    my_page = (tj < t_end) ? bt[page_of(tj)] : 0;
     n_my = min(64, (t_end - chunk0 + NW - 1) / NW);  // wave-uniform
     load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
-                        (chunk0 % tpp) << SH, kv_len - (chunk0 << SH), lane);
+                        row0_of(chunk0), kv_len - (chunk0 << SH), lane);
   };
   // (D = 256 with the fused prologue: the prologue's q / new-key fragments and the first tile together do not fit the
   // 256-register budget — the tile is requested behind the prologue instead of spilling)
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
       if (j + 1 < n_my) {
         const int t = chunk0 + NW * (j + 1);
         load_tile<T, D, NT>(bufB, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
-                        (t % tpp) << SH, kv_len - (t << SH), lane);
+                        row0_of(t), kv_len - (t << SH), lane);
       }
       patch(bufA, chunk0 + NW * j);
       compute_tile<T, D>(bufA, qf, kv_len - ((chunk0 + NW * j) << SH), p.scale_log2, lane, m, l, o, s_k[w]);
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
       if (j + 1 < n_my) {
         const int t = chunk0 + NW * (j + 1);
         load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
-                        (t % tpp) << SH, kv_len - (t << SH), lane);
+                        row0_of(t), kv_len - (t << SH), lane);
       }
       patch(bufB, chunk0 + NW * j);
       compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * j) << SH), p.scale_log2, lane, m, l, o, s_k[w]);
@@ -420,22 +437,27 @@ int g_decode_small_lo = 160, g_decode_small_hi = 576;
 int g_decode_waves = 4;  // tuning knobs (hx_debug_set_option)
 int g_decode_nt = 1;   // K/V are read once: non-temporal loads measured +4 % (profiles/r1_attn_decode_variants.txt)
 
+inline int32_t decode_meta(const AttnParams& p) {      // attn_decode_kernel's h_meta
+  return (p.group & 0xff) | ((p.n_splits & 0xff) << 8) | ((p.block_shift & 0xff) << 16);
+}
+
 template <typename T, int D>
 int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
+  if (p.group > 255 || p.n_splits > 255) return HX_ERR_SHAPE;
   dim3 grid(p.n_heads, batch, p.n_splits);
   // 160..576 (sequence, head) pairs and no key split: 8 waves per workgroup share the keys
   // (see decode_pick_splits)
   const int64_t pairs = (int64_t)batch * p.n_heads;
   const bool wide = pairs >= g_decode_small_lo && pairs <= g_decode_small_hi && p.n_splits == 1;
   if (p.k_new || p.qkv_partial) {
-    if (wide) hx::launcher(attn_decode_kernel<T, D, 8, true, true>, grid, 512, 0, stream)(p);
-    else hx::launcher(attn_decode_kernel<T, D, 4, true, true>, grid, 256, 0, stream)(p);
+    if (wide) hx::launcher(attn_decode_kernel<T, D, 8, true, true>, grid, 512, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
+    else hx::launcher(attn_decode_kernel<T, D, 4, true, true>, grid, 256, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
   } else if (g_decode_waves == 8 || wide) {
-    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 8, true, false>, grid, 512, 0, stream)(p);
-    else hx::launcher(attn_decode_kernel<T, D, 8, false, false>, grid, 512, 0, stream)(p);
+    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 8, true, false>, grid, 512, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
+    else hx::launcher(attn_decode_kernel<T, D, 8, false, false>, grid, 512, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
   } else {
-    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 4, true, false>, grid, 256, 0, stream)(p);
-    else hx::launcher(attn_decode_kernel<T, D, 4, false, false>, grid, 256, 0, stream)(p);
+    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 4, true, false>, grid, 256, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
+    else hx::launcher(attn_decode_kernel<T, D, 4, false, false>, grid, 256, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
   }
   int rc = check_launch();
   if (rc) return rc;

@@ -171,7 +171,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmParams p
 // neighbouring waves cover neighbouring bytes; what the packed form saves is the per-wave LDS transpose).  Same k order, same
 // accumulation chains: bit-identical to gemm_skinny_kernel.
 template <typename T, int MB, int R, int NW, int DBG = 0>
-__global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const GemmParams p, const int g_nt_store) {
+__global__ __launch_bounds__(NW * 64) void gemm_packed_kernel(const void* __restrict__ h_x, const void* __restrict__ h_w,
+                                                              float* __restrict__ h_partial, const int64_t h_ldx,
+                                                              const int32_t h_M, const int32_t h_N, const int32_t h_K,
+                                                              const int32_t h_ks_per_split, const int g_nt_store,
+                                                              const GemmParams p_in) {
+  // leading scalars = what the first loads need, preloaded into SGPRs with the wave (gemm_xreg.hip, KERNARG PRELOADING)
+  GemmParams p = p_in;
+  p.x = h_x; p.w = h_w; p.partial = h_partial; p.ldx = h_ldx; p.M = h_M; p.N = h_N; p.K = h_K; p.ks_per_split = h_ks_per_split;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kThreads = NW * 64;
   const int lane = threadIdx.x & 63;
@@ -341,11 +348,11 @@ int launch_gemm_cfg(const GemmParams& p, hipStream_t stream) {
       if (e != hipSuccess) return hip_rc(e);
     }
     if (MB == 2 && (g_slab_nt >> 1)) {   // ablation variants (tools/gemm_ablate.py), batch 17..32 only
-      if ((g_slab_nt >> 1) == 1) hx::launcher(gemm_packed_kernel<T, MB, R, NW, 2>, grid, NW * 64, plds, stream)(p, g_slab_nt & 1);
-      else hx::launcher(gemm_packed_kernel<T, MB, R, NW, 14>, grid, NW * 64, plds, stream)(p, g_slab_nt & 1);
+      if ((g_slab_nt >> 1) == 1) hx::launcher(gemm_packed_kernel<T, MB, R, NW, 2>, grid, NW * 64, plds, stream)(p.x, p.w, p.partial, p.ldx, p.M, p.N, p.K, p.ks_per_split, g_slab_nt & 1, p);
+      else hx::launcher(gemm_packed_kernel<T, MB, R, NW, 14>, grid, NW * 64, plds, stream)(p.x, p.w, p.partial, p.ldx, p.M, p.N, p.K, p.ks_per_split, g_slab_nt & 1, p);
       return check_launch();
     }
-    hx::launcher(gemm_packed_kernel<T, MB, R, NW>, grid, NW * 64, plds, stream)(p, g_slab_nt & 1);
+    hx::launcher(gemm_packed_kernel<T, MB, R, NW>, grid, NW * 64, plds, stream)(p.x, p.w, p.partial, p.ldx, p.M, p.N, p.K, p.ks_per_split, g_slab_nt & 1, p);
     return check_launch();
   }
   const size_t lds = (size_t)MB * 16 * kRS + (size_t)NW * 2048;   // x slice + per-wave transpose images

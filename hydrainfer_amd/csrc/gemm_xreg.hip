@@ -63,6 +63,58 @@ struct XregParams {
   int32_t pk_P;         // wide kernel: k-steps per split of the PACKING (the launch's own splits are halves of those)
 };
 
+// KERNARG PRELOADING (round 5; Makefile: -mllvm -amdgpu-kernarg-preload-count=16).  A by-value struct parameter is read
+// from the kernarg segment by s_loads at the kernel's start — a cold ~0.4 us round trip in front of the first address a
+// wave can form, paid at every launch boundary (the math-free null layer got 0.39 us per launch faster with preloaded
+// arguments, profiles/r5_kernarg_preload.md).  gfx950 can deliver the first 14 argument dwords in SGPRs WITH the wave,
+// but only for scalar / pointer parameters: the kernels therefore take what their first loads need as leading
+// scalars and the struct after them; the copy below lets the rest of the code keep reading `p.field`.
+// The activations-in-registers kernels go further: NOTHING in front of their first loads comes from the struct.  Five pointer slots
+// whose meaning depends on NORM (a norm-fused launch needs the producers' pointers first, x / partial / act late; a plain
+// launch the other way round) and four packed integers — 14 dwords:
+//   NORM = 0: p0 = w, p1 = x, p2 = partial, p3 = act            NORM = 1: p0 = w, p1 = nm_partial, p2 = nm_residual,
+//                                                                          p3 = nm_weight, p4 = sync
+//   a = N / 16 | grid.x << 16     b = K / 32 | M << 16 | x_packed << 24 | interleaved << 25
+//   c = stagger | nm_splits << 8 | pk_P << 16 (wide kernel)       ldx (elements, < 2^31; NORM = 1: the bits of nm_eps instead)
+struct XregHot {
+  const void *p0, *p1, *p2, *p3, *p4;
+  int32_t a, b, c, ldx;
+};
+template <int NORM>
+inline bool xreg_hot(const XregParams& p, unsigned nb, XregHot* h) {
+  if ((p.N >> 4) > 0xffff || nb > 0xffff || (p.K >> 5) > 0xffff || p.M > 255 || p.nm_splits > 255 || p.stagger > 255 ||
+      p.pk_P > 0xffff || p.pk_P < 0 || p.ldx > 0x7fffffff || p.ldx < 0)
+    return false;
+  h->p0 = p.w;
+  if (NORM) { h->p1 = p.nm_partial; h->p2 = p.nm_residual; h->p3 = p.nm_weight; h->p4 = p.sync; }
+  else { h->p1 = p.x; h->p2 = p.partial; h->p3 = p.act; h->p4 = nullptr; }
+  h->a = (int32_t)((uint32_t)(p.N >> 4) | (nb << 16));
+  h->b = (int32_t)((uint32_t)(p.K >> 5) | ((uint32_t)p.M << 16) | ((uint32_t)(p.x_packed ? 1 : 0) << 24) | ((uint32_t)(p.interleaved ? 1 : 0) << 25));
+  h->c = (int32_t)((uint32_t)p.stagger | ((uint32_t)p.nm_splits << 8) | ((uint32_t)p.pk_P << 16));
+  h->ldx = NORM ? __builtin_bit_cast(int32_t, p.nm_eps) : (int32_t)p.ldx;      // (a norm-fused launch reads fragment-major x: no ldx)
+  return true;
+}
+
+#define HX_XREG_HOT_SIG                                                                                             \
+  const void* __restrict__ h_p0, const void* __restrict__ h_p1, const void* __restrict__ h_p2,                        \
+      const void* __restrict__ h_p3, const void* __restrict__ h_p4, const int32_t h_a, const int32_t h_b,            \
+      const int32_t h_c, const int32_t h_ldx
+#define HX_XREG_UNPACK_HOT(NORM_)                                                                                   \
+  XregParams p = p_in;                                                                                              \
+  p.w = h_p0;                                                                                                       \
+  if (NORM_) {                                                                                                      \
+    p.nm_partial = reinterpret_cast<const float*>(h_p1); p.nm_residual = const_cast<void*>(h_p2); p.nm_weight = h_p3; \
+    p.sync = reinterpret_cast<uint32_t*>(const_cast<void*>(h_p4));                                                  \
+  } else {                                                                                                          \
+    p.x = h_p1; p.partial = reinterpret_cast<float*>(const_cast<void*>(h_p2)); p.act = const_cast<void*>(h_p3);     \
+  }                                                                                                                 \
+  p.N = (h_a & 0xffff) << 4; p.K = (h_b & 0xffff) << 5; p.M = (h_b >> 16) & 0xff; p.x_packed = (h_b >> 24) & 1;     \
+  p.interleaved = (h_b >> 25) & 1; p.stagger = h_c & 0xff; p.nm_splits = (h_c >> 8) & 0xff;                         \
+  p.pk_P = (int32_t)((uint32_t)h_c >> 16);                                                                          \
+  if (NORM_) p.nm_eps = __builtin_bit_cast(float, h_ldx);                                                           \
+  else p.ldx = h_ldx;                                                                                               \
+  const int h_nb = (int)((uint32_t)h_a >> 16);      /* gridDim.x (from the hidden arguments it would be one more s_load) */
+
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __attribute__((aligned(128))) u16 g_zero_line[64] = {0};
@@ -95,7 +147,6 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
   if (tid == 0) claimed = __hip_atomic_exchange(state + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   u16x8* res_v = reinterpret_cast<u16x8*>(residual + (int64_t)row * hidden);
   const u16x8* w_v = reinterpret_cast<const u16x8*>(weight);
-  const rsrc_t xrs = make_rsrc(x_frag);
   float x[2 * MAXV][8];
   float ss[2] = {0.f, 0.f};
   u16x8 rr[2 * MAXV], ww[2 * MAXV], hh[2 * MAXV];
@@ -158,6 +209,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
   for (int k = 0; k < 8; ++k) total += red[k];
   const float inv = rsqrtf(total / (float)hidden + eps);
   if (own) {
+    const rsrc_t xrs = make_rsrc(x_frag);      // (built here: x's pointer is not among the preloaded arguments)
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
 #pragma unroll
@@ -186,7 +238,8 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
 // takes whole pairs and writes act = silu(gate) * up with the rounding of hx_silu_and_mul_slabs on the
 // one-slab result (sum -> T, silu -> T, product -> T), fragment-major for the down projection.
 template <typename T, int MB, int KW, int EPI = 0, int DBG = 0, int NORM = 0>
-__global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
+__global__ __launch_bounds__(256) void gemm_xreg_kernel(HX_XREG_HOT_SIG, const XregParams p_in) {
+  HX_XREG_UNPACK_HOT(NORM)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NBUF = (KW + 7) / 8;
   constexpr int P = 4 * KW;
@@ -198,7 +251,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   // their own row groups ~3 us after everybody else (tools/xreg_timeline.py: with a full share they were the launch's
   // tail, 32.3 us against ~28 for the others in the 7B gate|up launch).  The same numbering in every form of the
   // kernel: the k-step rotation (stagger) follows it, and with it the summation order of a row group.
-  const int split = blockIdx.y, nb = gridDim.x, b = nb - 1 - (int)blockIdx.x;
+  const int split = blockIdx.y, nb = h_nb, b = nb - 1 - (int)blockIdx.x;
   const int total_ks = p.K >> 5;
   const int n_rg = p.N >> 4;
   const int ks0 = split * P;
@@ -210,9 +263,9 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
   const int j0 = (p.stagger & 1) ? (int)(((unsigned)b * 7u + (unsigned)w * 3u) % (unsigned)KW) : 0;
   // bit 3 of `stagger` (hx_debug_set_option("xreg_timeline", 1); NORM launches only): the first and the last workgroup
   // of the grid write 100 MHz time stamps of their phases into words 384.. of the sync area (tools/xreg_timeline.py)
-  const int flat_id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int flat_id = blockIdx.y * nb + blockIdx.x;
   auto stamp = [&](int k) {
-    if (NORM && (p.stagger & 8) && threadIdx.x == 0 && (flat_id == 0 || flat_id == (int)(gridDim.x * gridDim.y) - 1))
+    if (NORM && (p.stagger & 8) && threadIdx.x == 0 && (flat_id == 0 || flat_id == (int)(nb * (NORM ? 1u : gridDim.y)) - 1))
       reinterpret_cast<unsigned long long*>(p.sync + 384 + (flat_id ? 32 : 0))[k] = __builtin_amdgcn_s_memrealtime();
   };
   stamp(0);
@@ -291,7 +344,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
     // 1. producers: workgroup r < M computes row r of x FIRST (nothing of its own in flight yet: the row's
     //    loads and the store drain are not queued behind weight loads — prefetching first cost the whole gain)
     const int flat = flat_id;
-    const int n_wg = gridDim.x * gridDim.y;
+    const int n_wg = nb;      // (a norm-fused launch has ONE split: gridDim.y == 1)
     if (flat < p.M && !(p.stagger & 6))   // (bit 1 of `stagger`: test hook — nobody produces up front, every row is rescued)
       for (int row = flat; row < p.M; row += n_wg) produce(row);   // several rows only when N is tiny
     stamp(1);
@@ -454,13 +507,14 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(const XregParams p) {
 // 2 KW KiB per wave in flight; RG = 1 is for KW = 20 (13B's K = 5120: x for 64 rows is 320 registers, a second weight
 // buffer set does not fit beside it).
 template <typename T, int KW, int NORM, int RG = 2>
-__global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p) {
+__global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, const XregParams p_in) {
+  HX_XREG_UNPACK_HOT(NORM)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MB = 4, NBUF = (KW + 7) / 8, P = 4 * KW;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int split = blockIdx.y, nb = gridDim.x, b = nb - 1 - (int)blockIdx.x;
+  const int split = blockIdx.y, nb = h_nb, b = nb - 1 - (int)blockIdx.x;
   const int total_ks = p.K >> 5;
   const int n_rg = p.N >> 4, n_un = n_rg / RG;
   // where the launch's split sits inside the packing
@@ -473,7 +527,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p)
   const int mbl = (p.M + 15) >> 4;                         // 16-row blocks of the fragment-major x (3 for 33 .. 48 rows): the
                                                            // fourth MFMA column block then re-reads the third (rows >= M are never stored)
   const int j0 = (p.stagger & 1) ? (int)(((unsigned)b * 7u + (unsigned)w * 3u) % (unsigned)KW) : 0;
-  const int flat_id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int flat_id = blockIdx.y * nb + blockIdx.x;
   auto rot = [&](int t) { const int r = j0 + t; return r >= KW ? r - KW : r; };
   const u16* wbase = reinterpret_cast<const u16*>(p.w) + 8 * lane + ((int64_t)sp * p.pk_P * n_rg) * 512;
   const int wave_k0 = off_in + min(w * KW, max(nks - 1, 0));
@@ -536,7 +590,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(const XregParams p)
       }
       return own;
     };
-    const int n_wg = gridDim.x * gridDim.y;
+    const int n_wg = nb * (int)gridDim.y;
     if (flat_id < p.M && !(p.stagger & 6))
       for (int row = flat_id; row < p.M; row += n_wg) produce(row);
 #pragma unroll
@@ -765,13 +819,18 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
     if (e != hipSuccess) return hip_rc(e);
   }
   const dim3 grid((unsigned)nb, (unsigned)S);
+  XregHot h;
+  if (!xreg_hot<NORM>(p, (unsigned)nb, &h)) return HX_ERR_SHAPE;
+  if (NORM && S != 1) return HX_ERR_SHAPE;
+#define HX_XREG_LAUNCH(...) hx::launcher(gemm_xreg_kernel<__VA_ARGS__>, grid, 256, lds, stream)(h.p0, h.p1, h.p2, h.p3, h.p4, h.a, h.b, h.c, h.ldx, p)
   if constexpr (EPI == 0 && NORM == 0 && MB == 2 && (KW == 32 || KW == 29)) if (g_dbg) {   // ablation variants (tools/bench_gemm_xreg.py OPTS=xreg_dbg=..)
-    if (g_dbg == 1) hx::launcher(gemm_xreg_kernel<T, MB, KW, 0, 1>, grid, 256, lds, stream)(p);
-    else if (g_dbg == 2) hx::launcher(gemm_xreg_kernel<T, MB, KW, 0, 2>, grid, 256, lds, stream)(p);
-    else hx::launcher(gemm_xreg_kernel<T, MB, KW, 0, 3>, grid, 256, lds, stream)(p);
+    if (g_dbg == 1) HX_XREG_LAUNCH(T, MB, KW, 0, 1);
+    else if (g_dbg == 2) HX_XREG_LAUNCH(T, MB, KW, 0, 2);
+    else HX_XREG_LAUNCH(T, MB, KW, 0, 3);
     return check_launch();
   }
-  hx::launcher(gemm_xreg_kernel<T, MB, KW, EPI, 0, NORM>, grid, 256, lds, stream)(p);
+  HX_XREG_LAUNCH(T, MB, KW, EPI, 0, NORM);
+#undef HX_XREG_LAUNCH
   return check_launch();
 }
 
@@ -834,7 +893,10 @@ int launch_wide_kw(const XregParams& p, int S, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
-  hx::launcher(gemm_xreg_wide_kernel<T, KW, NORM, RG>, dim3((unsigned)nb, (unsigned)S), 256, lds, stream)(p);
+  XregHot h;
+  if (!xreg_hot<NORM>(p, (unsigned)nb, &h)) return HX_ERR_SHAPE;
+  hx::launcher(gemm_xreg_wide_kernel<T, KW, NORM, RG>, dim3((unsigned)nb, (unsigned)S), 256, lds, stream)(
+      h.p0, h.p1, h.p2, h.p3, h.p4, h.a, h.b, h.c, h.ldx, p);
   return check_launch();
 }
 

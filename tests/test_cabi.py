@@ -117,13 +117,16 @@ def test_xreg_split_plan_is_stable():
         assert l.hx_linear_decode_xreg_supported(32, n, k) == 1
         assert l.hx_linear_decode_xreg_workspace_bytes(32, n, k) == s * 32 * n * 4
     # 33 .. 64 rows: the wide kernel reads the SAME packing with half the k-steps per wave (twice the slabs) where the
-    # packing's k-steps per wave halve to a built count: all 7B projections, none of the 13B ones (40 and 27 per wave)
-    for (n, k), s in {(12288, 4096): 2, (4096, 11008): 8, (4096, 4096): 2, (64, 2816): 2}.items():
+    # packing's k-steps per wave halve to a built count: all 7B projections and, since round 5, the 13B ones
+    # (40 -> 20 with one row group per unit; 27 -> 14 + 13)
+    for (n, k), s in {(12288, 4096): 2, (4096, 11008): 8, (4096, 4096): 2, (64, 2816): 2,
+                      (15360, 5120): 2, (5120, 13824): 8}.items():
         assert l.hx_linear_decode_xreg_supported(64, n, k) == 1 and l.hx_linear_decode_xreg_supported(33, n, k) == 1
         assert l.hx_linear_decode_xreg_workspace_bytes(64, n, k) == s * 64 * n * 4, (n, k)
     assert l.hx_gate_up_xreg_supported(64, 11008, 4096, 1) == 1 and l.hx_gate_up_xreg_workspace_bytes(64, 11008, 4096) == 2 * 64 * 22016 * 4
-    assert l.hx_linear_decode_xreg_supported(64, 15360, 5120) == 0 and l.hx_linear_decode_xreg_supported(64, 5120, 13824) == 0
-    assert l.hx_gate_up_xreg_supported(64, 13824, 5120, 0) == 0
+    assert l.hx_gate_up_xreg_supported(64, 13824, 5120, 1) == 1 and l.hx_gate_up_xreg_workspace_bytes(64, 13824, 5120) == 2 * 64 * 27648 * 4
+    assert l.hx_norm_xreg_supported(64, 15360, 5120, 0) == 1 and l.hx_norm_xreg_supported(64, 5120, 13824, 0) == 0
+    assert l.hx_linear_decode_xreg_supported(64, 1024, 3584) == 0       # 29 k-steps per wave: no built half
     assert l.hx_linear_decode_xreg_supported(65, 4096, 4096) == 0
     assert l.hx_gate_up_silu_xreg_supported(33, 11008, 4096) == 0      # the fused silu*mul epilogue: <= 32 rows
     assert l.hx_norm_xreg_supported(64, 12288, 4096, 0) == 1 and l.hx_norm_xreg_supported(64, 4096, 11008, 0) == 0

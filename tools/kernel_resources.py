@@ -4,7 +4,7 @@
 import re, subprocess, sys
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-extra = ["-fno-slp-vectorize"] if "attn_fwd" in src else []
+extra = (["-fno-slp-vectorize"] if "attn_fwd" in src else []) + ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c", src, "-o", "/dev/null",
                     "-Rpass-analysis=kernel-resource-usage"] + extra, capture_output=True, text=True)
 cur = {}
