@@ -540,7 +540,7 @@ def measured_traffic(args, model_name, algorithmic_bytes):
     the RATIO measured / algorithmic bytes of this kernel, and the figure reported is that ratio
     times the algorithmic bytes of the contexts timed here — reported only for the workload that
     was profiled.  Returns (bytes, description) or (None, None)."""
-    for name in ("r4_attn_decode_pmc.json", "r2_attn_decode_pmc.json", "r1_attn_decode_pmc.json"):
+    for name in ("r5_attn_decode_pmc.json", "r4_attn_decode_pmc.json", "r2_attn_decode_pmc.json", "r1_attn_decode_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break

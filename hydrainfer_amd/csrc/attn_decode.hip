@@ -111,12 +111,12 @@ __device__ __forceinline__ void rope_pair(float x, float y, float c, float s, fl
 // NeoX rotation of the fragment set f[s] (lane holds dims 32s+8g+j): the partner of dim d is
 // d +- D/2, i.e. fragment s +- NS/2 of the SAME lane.  cs points at cos_sin[pos] ([2][D/2]).
 template <typename T, int D>
-__device__ __forceinline__ void rope_frags(u16x8 (&f)[D / 32], const u16* cs, int g) {
+__device__ __forceinline__ void rope_frags(u16x8 (&f)[D / 32], const u16x8 (&rc)[D / 64], const u16x8 (&rs)[D / 64]) {
   constexpr int NS = D / 32, HS = NS / 2;
 #pragma unroll
   for (int s = 0; s < HS; ++s) {
-    const u16x8 c = *reinterpret_cast<const u16x8*>(cs + 32 * s + 8 * g);
-    const u16x8 sn = *reinterpret_cast<const u16x8*>(cs + D / 2 + 32 * s + 8 * g);
+    const u16x8 c = rc[s];
+    const u16x8 sn = rs[s];
     u16x8 x = f[s], y = f[s + HS];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -262,7 +262,15 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   typename VRow<D>::type vn[VRow<D>::NV];
   const int t_new = (kv_len - 1) >> SH, r_new = (kv_len - 1) & (TK - 1);
   if (FUSE) {
+    // cos / sin of the new token's position: requested FIRST (round 5), so that the position's scalar load and the two
+    // vector loads behind it run under the slab reduction and its barrier instead of after them
     const u16* cs = reinterpret_cast<const u16*>(p.cos_sin) + (int64_t)p.positions[b] * D;
+    u16x8 rc[D / 64], rs[D / 64];
+#pragma unroll
+    for (int s = 0; s < D / 64; ++s) {
+      rc[s] = *reinterpret_cast<const u16x8*>(cs + 32 * s + 8 * g);
+      rs[s] = *reinterpret_cast<const u16x8*>(cs + D / 2 + 32 * s + 8 * g);
+    }
     if (p.qkv_partial) {
       // q, k, v of this token/head straight from the qkv GEMM's split-K slabs: thread d < D adds
       // the splits of column d in order and rounds once to T (the projection's output
@@ -300,8 +308,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
     for (int n = 0; n < VRow<D>::NV; ++n)
       vn[n] = *reinterpret_cast<const typename VRow<D>::type*>(vp + 128 * n);
     }
-    rope_frags<T, D>(qf, cs, g);
-    rope_frags<T, D>(kn, cs, g);
+    rope_frags<T, D>(qf, rc, rs);
+    rope_frags<T, D>(kn, rc, rs);
     // fragment layout -> row layout through one row of this wave's LDS region
     if (c == 0) {
 #pragma unroll

@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-4 PMC passes (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, as MI355X_MICROARCH.md's HBM section prescribes) over
+# PMC passes (round tag: ROUND, default r5) (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, as MI355X_MICROARCH.md's HBM section prescribes) over
 # the decode attention kernel and the activations-in-registers GEMMs, as the 7B decode step launches them:
-#   bash tools/pmc_decode.sh        ->  gpurun_out/r4/r4_attn_decode_pmc.json, r4_gemm_xreg_pmc.json
+#   [ROUND=r5] bash tools/pmc_decode.sh        ->  gpurun_out/$ROUND/${ROUND}_attn_decode_pmc.json, ${ROUND}_gemm_xreg_pmc.json
 set -eu
 R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repo root (gpurun exports it)}
-O=$R/gpurun_out/r4
+ROUND=${ROUND:-r5}
+O=$R/gpurun_out/$ROUND
 mkdir -p "$O"
 cd /tmp; export TMPDIR=/tmp
 for prog in prof_attn_decode prof_gemm_xreg; do
@@ -15,8 +16,8 @@ for prog in prof_attn_decode prof_gemm_xreg; do
   done
 done
 grep algorithmic_bytes_per_launch /tmp/pmc_prof_attn_decode_FETCH_SIZE.log | tail -1 > /tmp/attn_bytes.txt
-python3 $R/tools/prof_gemm_xreg.py summarize /tmp/pmc_prof_gemm_xreg_FETCH_SIZE /tmp/pmc_prof_gemm_xreg_WRITE_SIZE $O/r4_gemm_xreg_pmc.json > /dev/null
-python3 - "$O/r4_attn_decode_pmc.json" <<'PY'
+python3 $R/tools/prof_gemm_xreg.py summarize /tmp/pmc_prof_gemm_xreg_FETCH_SIZE /tmp/pmc_prof_gemm_xreg_WRITE_SIZE $O/${ROUND}_gemm_xreg_pmc.json > /dev/null
+python3 - "$O/${ROUND}_attn_decode_pmc.json" <<'PY'
 import csv, glob, json, statistics, sys
 def med(d, counter):
     v, dur = [], []
@@ -42,5 +43,5 @@ json.dump({"kernel": "attn_decode_kernel<BF16,128,4,nt,fused>",
 print(open(sys.argv[1]).read())
 PY
 python3 -c "
-import json; d=json.load(open('$O/r4_gemm_xreg_pmc.json'))
+import json; d=json.load(open('$O/${ROUND}_gemm_xreg_pmc.json'))
 for s in d['shapes']: print(s['name'], s['fetch_over_weights'], s['write_over_output'])"

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Kernel trace of the bench command cut into decode steps / one middle layer (tools/layer_timeline.py).
-#   tools/prof_step.sh <tag> [extra bench.py args]   ->  gpurun_out/r4/<tag>_timeline.md, <tag>_kernel_stats.csv, <tag>_bench.json
+#   tools/prof_step.sh <tag> [extra bench.py args]   ->  gpurun_out/$ROUND/<tag>_timeline.md (ROUND defaults to r5), <tag>_kernel_stats.csv, <tag>_bench.json
 set -eu
 R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun exports it)}
 TAG=$1; shift
-OUT=$R/gpurun_out/r4
+OUT=$R/gpurun_out/${ROUND:-r5}
 mkdir -p "$OUT"
 D=/tmp/prof_$TAG
 rm -rf "$D"
