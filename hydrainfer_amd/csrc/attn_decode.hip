@@ -98,6 +98,44 @@ __device__ __forceinline__ void load_tile(KVTile<D>& buf, const AttnParams& p, c
   }
 }
 
+// The same tile through BUFFER loads whose resource is the tile's page (round 5): `ok = false` gives the resource zero
+// records, every lane is out of range and the instruction touches no memory — a tile load that is always ISSUED, so the
+// main loop has no branch around its loads and the compiler's vmcnt counts stay exact (with a branch it waits for the
+// tile it has just requested before computing the previous one: tools/decode_timeline.py).
+typedef __amdgpu_buffer_rsrc_t drsrc_t;
+typedef unsigned int du32x4 __attribute__((__vector_size__(16)));
+typedef unsigned int du32x2 __attribute__((__vector_size__(8)));
+template <bool NT>
+__device__ __forceinline__ u16x8 bld(drsrc_t r, uint32_t off, u16x8) {
+  return __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, NT ? 2 : 0));
+}
+template <bool NT>
+__device__ __forceinline__ u16x4 bld(drsrc_t r, uint32_t off, u16x4) {
+  return __builtin_bit_cast(u16x4, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, NT ? 2 : 0));
+}
+template <typename T, int D, bool NT>
+__device__ __forceinline__ void load_tile_b(KVTile<D>& buf, const AttnParams& p, const u16* kbase, const u16* vbase,
+                                            int page, int row0, int valid, int lane, bool ok) {
+  const int g = lane >> 4, c = lane & 15;
+  constexpr int E = VRow<D>::E, KPL = TileGeom<D>::KPL;
+  const uint32_t nrec = ok ? 0x7fffffffu : 0u;
+  const drsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(kbase + (int64_t)page * p.k_block_stride), 0, nrec, 0x00020000);
+  const drsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(vbase + (int64_t)page * p.v_block_stride), 0, nrec, 0x00020000);
+  const int vmax = max(valid, 1) - 1;
+#pragma unroll
+  for (int i = 0; i < KPL; ++i) {
+    const uint32_t off = (uint32_t)((row0 + min(KPL * g + i, vmax)) * (int)p.k_row_stride + E * c) * 2u;
+#pragma unroll
+    for (int n = 0; n < VRow<D>::NV; ++n) buf.k[i][n] = bld<NT>(kr, off + 256u * n, typename VRow<D>::type{});
+  }
+#pragma unroll
+  for (int i = 0; i < KPL; ++i) {
+    const uint32_t off = (uint32_t)((row0 + min(KPL * g + i, vmax)) * (int)p.v_row_stride + E * c) * 2u;
+#pragma unroll
+    for (int n = 0; n < VRow<D>::NV; ++n) buf.v[i][n] = bld<NT>(vr, off + 256u * n, typename VRow<D>::type{});
+  }
+}
+
 // T-arithmetic rotation of one (x, y) pair, identical to norm_rope_act.hip::rotate_pair
 template <typename T>
 __device__ __forceinline__ void rope_pair(float x, float y, float c, float s, float& xo, float& yo) {
@@ -206,6 +244,16 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   __shared__ __attribute__((aligned(16))) u16 s_qkv[FUSE ? 3 : 1][FUSE ? D : 8];
 
   const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
+#if HX_EXPERIMENTS
+  // in-kernel time stamps (100 MHz), 16 per workgroup, wave 0 only: tools/decode_timeline.py
+  auto STAMP = [&](int k) {
+    if (p_in.stamps && threadIdx.x == 0)
+      p_in.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + k] = __builtin_amdgcn_s_memrealtime();
+  };
+#else
+  auto STAMP = [&](int) {};
+#endif
+  STAMP(0);
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
@@ -228,22 +276,33 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   const u16* kbase = reinterpret_cast<const u16*>(p.k) + (int64_t)hk * p.k_head_stride;
   const u16* vbase = reinterpret_cast<const u16*>(p.v) + (int64_t)hk * p.v_head_stride;
 
-  // Start the HBM stream first: page ids of this wave's first chunk and its first K/V tile are
-  // requested before the q / RoPE / slab prologue, which then runs under their latency.
+  // ORDER OF THE FIRST REQUESTS (round 5; in-kernel stamps, tools/decode_timeline.py).  A wave's loads return in the
+  // order they were issued.  Rounds 1-4 requested the first K / V tile BEFORE the fused prologue's own small loads (qkv
+  // slab, cos / sin): 4096 waves x 8 KiB = 33 MB of HBM traffic stood in front of a few L2 hits in every wave, the
+  // prologue ended 11 us (median; up to 44 us) after the kernel's start, and until then every wave had ONE tile in
+  // flight — HBM idled.  Now: page ids first, then the prologue's loads, then the first tile; the prologue's arithmetic
+  // runs under the tile's latency.
   KVTile<D> bufA, bufB;
   int my_page = 0, n_my = 0;
   int chunk0 = t_begin + w;
-  auto begin_chunk = [&]() {
+  auto request_pages = [&]() {
     const int tj = chunk0 + NW * lane;
     my_page = (tj < t_end) ? bt[page_of(tj)] : 0;
     n_my = min(64, (t_end - chunk0 + NW - 1) / NW);  // wave-uniform
-    load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
-                        row0_of(chunk0), kv_len - (chunk0 << SH), lane);
   };
+  // (UNCONDITIONAL in the prologue: a wave without a tile — a sequence shorter than 16 w keys — reads rows of page 0
+  // that nobody uses.  Under a branch the compiler's wait-count model merges the two paths and makes the prologue wait
+  // for the tile it has just requested.)
+  auto request_first_tile = [&]() {
+    load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
+                        row0_of(chunk0), max(1, kv_len - (chunk0 << SH)), lane);
+  };
+  auto begin_chunk = [&]() { request_pages(); request_first_tile(); };
   // (D = 256 with the fused prologue: the prologue's q / new-key fragments and the first tile together do not fit the
   // 256-register budget — the tile is requested behind the prologue instead of spilling)
   constexpr bool EARLY = !(FUSE && D == 256);
-  if (EARLY && chunk0 < t_end) begin_chunk();
+  STAMP(1);      // scalar metadata in
+  if (EARLY) request_pages();
 
   // q as the MFMA B operand, identical in all 16 columns
   u16x8 qf[D / 32];
@@ -252,6 +311,10 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
                     (int64_t)h * D + 8 * g;
 #pragma unroll
     for (int s = 0; s < D / 32; ++s) qf[s] = *reinterpret_cast<const u16x8*>(qp + 32 * s);
+  }
+  if (!FUSE) {
+    if (EARLY) request_first_tile();
+    STAMP(2);
   }
 
   // FUSE: q and the new token's k arrive un-rotated and the cache does not hold the new token
@@ -275,18 +338,27 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
       // q, k, v of this token/head straight from the qkv GEMM's split-K slabs: thread d < D adds
       // the splits of column d in order and rounds once to T (the projection's output
       // rounding); the three rows are shared through LDS so every slab element is read once
-      // per workgroup.
+      // per workgroup.  Every thread issues the loads (threads >= D the addresses of thread d - D: no divergent
+      // branch around them, so the first tile's request below is not fenced off by a full wait).
       const float* row = p.qkv_partial + (int64_t)b * p.qkv_row;
       const int64_t col0[3] = {(int64_t)h * D, (int64_t)p.n_heads * D + (int64_t)hk * D,
                                (int64_t)p.n_heads * D + (int64_t)(p.n_heads / p.group) * D + (int64_t)hk * D};
-      if (threadIdx.x < D) {
+      const int dcol = threadIdx.x & (D - 1);
+      float sacc[3];
+#pragma unroll
+      for (int which = 0; which < 3; ++which) sacc[which] = row[col0[which] + dcol];
+      if (p.qkv_splits > 1) {
 #pragma unroll
         for (int which = 0; which < 3; ++which) {
-          const float* src = row + col0[which] + threadIdx.x;
-          float acc = src[0];
-          for (int s = 1; s < p.qkv_splits; ++s) acc += src[s * p.qkv_slab_stride];
-          s_qkv[which][threadIdx.x] = T::from_float(acc);
+          const float* src = row + col0[which] + dcol;
+          for (int s = 1; s < p.qkv_splits; ++s) sacc[which] += src[s * p.qkv_slab_stride];
         }
+      }
+      if (EARLY) request_first_tile();      // behind the prologue's loads, in front of their use
+      STAMP(2);      // page ids in, first tile requested
+      if (threadIdx.x < D) {
+#pragma unroll
+        for (int which = 0; which < 3; ++which) s_qkv[which][threadIdx.x] = T::from_float(sacc[which]);
       }
       __syncthreads();
 #pragma unroll
@@ -307,6 +379,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
 #pragma unroll
     for (int n = 0; n < VRow<D>::NV; ++n)
       vn[n] = *reinterpret_cast<const typename VRow<D>::type*>(vp + 128 * n);
+    if (EARLY) request_first_tile();
+    STAMP(2);
     }
     rope_frags<T, D>(qf, rc, rs);
     rope_frags<T, D>(kn, rc, rs);
@@ -351,36 +425,40 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
     }
   };
 
+  STAMP(3);      // prologue done (q / new key rotated, appended)
   float m = HX_NEG_BIG, l = 0.f;
   float o[OE];
 #pragma unroll
   for (int e = 0; e < OE; ++e) o[e] = 0.f;
 
-  // my tiles: t_begin + w + NW*j.  Chunks of 64 tiles per wave share one page-id vector.
-  for (bool first = EARLY; chunk0 < t_end; chunk0 += NW * 64, first = false) {
-    if (!first) begin_chunk();
-    int j = 0;
-    while (j < n_my) {
-      if (j + 1 < n_my) {
-        const int t = chunk0 + NW * (j + 1);
-        load_tile<T, D, NT>(bufB, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
-                        row0_of(t), kv_len - (t << SH), lane);
-      }
+  // my tiles: t_begin + w + NW*j.  Chunks of 64 tiles per wave share one page-id vector.  The loop body is branch-free
+  // around its loads: tile j + 1 is ALWAYS requested before tile j is computed (out of range: a buffer load with zero
+  // records), tile j + 2 before tile j + 1 is computed — two tiles per wave in flight, exact wait counts.
+  auto issue = [&](KVTile<D>& buf, int jj) {
+    const int t = chunk0 + NW * jj;
+    load_tile_b<T, D, NT>(buf, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, min(jj, 63)), row0_of(t),
+                          kv_len - (t << SH), lane, jj < n_my);
+  };
+  auto run_chunk = [&](bool stamp) {
+    for (int j = 0; j < n_my; j += 2) {
+      issue(bufB, j + 1);
       patch(bufA, chunk0 + NW * j);
       compute_tile<T, D>(bufA, qf, kv_len - ((chunk0 + NW * j) << SH), p.scale_log2, lane, m, l, o, s_k[w]);
-      ++j;
-      if (j >= n_my) break;
+      if (stamp && j == 0) STAMP(4);      // first tile computed
+      issue(bufA, j + 2);
       if (j + 1 < n_my) {
-        const int t = chunk0 + NW * (j + 1);
-        load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, j + 1),
-                        row0_of(t), kv_len - (t << SH), lane);
+        patch(bufB, chunk0 + NW * (j + 1));
+        compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * (j + 1)) << SH), p.scale_log2, lane, m, l, o, s_k[w]);
       }
-      patch(bufB, chunk0 + NW * j);
-      compute_tile<T, D>(bufB, qf, kv_len - ((chunk0 + NW * j) << SH), p.scale_log2, lane, m, l, o, s_k[w]);
-      ++j;
     }
+  };
+  if (!EARLY) begin_chunk();
+  run_chunk(true);
+  for (chunk0 += NW * 64; chunk0 < t_end; chunk0 += NW * 64) {      // contexts past 64 tiles per wave (4096 keys at NW = 4)
+    begin_chunk();
+    run_chunk(false);
   }
-
+  STAMP(5);      // last tile computed
   // ---- merge the 16 partial states of this workgroup --------------------------------
   constexpr int E = VRow<D>::E, NV = VRow<D>::NV;
   const int slot = w * 4 + g;
@@ -394,6 +472,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
     for (int e = 0; e < E; ++e) s_o[slot][128 * n + E * c + e] = o[n * E + e];
   __syncthreads();
 
+  STAMP(6);      // merge barrier passed
   const int d = threadIdx.x;
   if (d < D) {
     float M = HX_NEG_BIG;
@@ -419,6 +498,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
       }
     }
   }
+  STAMP(7);
 }
 
 // one workgroup of D threads per (head, sequence)

@@ -1534,6 +1534,7 @@ int fwd_set_option(const char* name, int value) {
 }
 
 void fwd_set_stamps(void* buf) { g_fwd_stamps = reinterpret_cast<unsigned long long*>(buf); }
+void* fwd_get_stamps() { return g_fwd_stamps; }
 
 bool fwd_supported(int head_dim) {
   return head_dim == 32 || head_dim == 64 || head_dim == 96 || head_dim == 128 || head_dim == 256;

@@ -17,6 +17,7 @@ int gemm_set_option(const char* name, int value);
 int fwd_set_option(const char* name, int value);
 int xreg_set_option(const char* name, int value);
 void fwd_set_stamps(void* buf);
+void* fwd_get_stamps();
 #if HX_EXPERIMENTS   // `make EXPERIMENTS=1`: rejected experiments kept measurable (not in the default library)
 int decode4_set_option(const char* name, int value);
 bool decode4_applies(const AttnParams& p, int batch, int head_dim, int n_cus);
@@ -215,6 +216,9 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.cu_pairing = 1;
   p.max_seqlen_k = a->max_seqlen_k;
   p.stamps = nullptr;
+#if HX_EXPERIMENTS
+  p.stamps = reinterpret_cast<unsigned long long*>(fwd_get_stamps());   // decode kernel: tools/decode_timeline.py
+#endif
   p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
   // flash_api.cpp:93-111
   if (a->flags & ~HX_ATTN_LOCAL_WINDOW) return HX_ERR_UNSUPPORTED;
