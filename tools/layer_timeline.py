@@ -30,6 +30,8 @@ def main():
         seg = rows[a:b]
         if len(seg) < 50 or len(seg) > 2000:
             continue
+        if any("paged_read_kernel" in r[2] or "read_stream_kernel" in r[2] for r in seg):
+            continue      # a null step of bench.py's whole_step.null_step (math-free stand-in launches): not a decode step
         span = seg[-1][1] - seg[0][0]
         steps.append((span, a, b))
     if not steps:
