@@ -121,6 +121,9 @@ _SIGNATURES = {
     "hx_migrate_blocks": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 5 + [c_void_p]),
     "hx_pack_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 4 + [c_void_p]),
     "hx_unpack_blocks": (c_int, [c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 4 + [c_void_p]),
+    "hx_migrate_blocks_planes": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 6 + [c_void_p]),
+    "hx_pack_blocks_planes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 4 + [c_void_p]),
+    "hx_unpack_blocks_planes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 4 + [c_void_p]),
     "hx_topk_softmax": (c_int, [c_void_p] * 3 + [c_int64] * 3 + [c_void_p]),
     "hx_grouped_topk_sigmoid": (c_int, [c_void_p] * 4 + [c_int64] * 5 + [c_float, c_void_p]),
     "hx_moe_sort_workspace_bytes": (c_int64, [c_int64, c_int64]),

@@ -383,8 +383,10 @@ int launch_gemm_mb(const GemmParams& p, hipStream_t stream) {
   // 33..64 batch rows: the x slice alone is 133 KB of LDS, so one workgroup per CU whatever its
   // size — four waves cannot keep the CU streaming.  8 waves everywhere; cold-weight timing at
   // M = 48 / 64 (tools/bench_gemm_m.py): qkv 51 -> 31 us with two row groups per wave, o 21.5 -> 18.5
+  // (round 5: up to 1024 units — the o projection — 8 waves x 1 row group are 128 workgroups, half the CUs idle; 4-wave
+  //  workgroups fill the chip: 12.1 -> 10.9 us inside the 64-row step)
   if (MB == 4) {
-    nw = 8;
+    nw = units <= 1024 ? 4 : 8;
     if (units <= 4096 && p.n_splits < 8) rpw = units >= 2048 ? 2 : 1;
   }
   // per-shape override for tuning runs: HX_GEMM_CFG="N:K:R:NW;N:K:R:NW;..."

@@ -137,44 +137,70 @@ extern "C" int hx_ipc_close_all(void) {
   return rc;
 }
 
-extern "C" int hx_migrate_blocks(const int32_t* src_table_host, const int32_t* dst_table_host,
-                                 int64_t n_pairs, const void* src_pool, void* dst_pool,
-                                 int64_t n_layers, int64_t n_tokens, int64_t src_n_blocks,
-                                 int64_t dst_n_blocks, int64_t block_bytes, hx_stream stream) {
-  if (n_pairs < 0 || n_layers < 0 || n_tokens < 0) return HX_ERR_SHAPE;
+extern "C" int hx_migrate_blocks_planes(const int32_t* src_table_host, const int32_t* dst_table_host,
+                                        int64_t n_pairs, const void* src_pool, void* dst_pool, int64_t n_planes,
+                                        int64_t src_n_blocks, int64_t dst_n_blocks, int64_t src_plane_bytes,
+                                        int64_t dst_plane_bytes, int64_t block_bytes, hx_stream stream) {
+  if (n_pairs < 0 || n_planes < 0) return HX_ERR_SHAPE;
   if (n_pairs == 0) return HX_OK;
   if (!src_table_host || !dst_table_host || !src_pool || !dst_pool) return HX_ERR_NULL;
+  // a plane holds its pool's blocks back to back; what lies between two planes is the pool's own business
+  if (src_plane_bytes < src_n_blocks * block_bytes || dst_plane_bytes < dst_n_blocks * block_bytes) return HX_ERR_STRIDE;
+  if (src_plane_bytes % 16 != 0 || dst_plane_bytes % 16 != 0) return HX_ERR_STRIDE;
   for (int64_t i = 0; i < n_pairs; ++i) {
     if (src_table_host[i] < 0 || src_table_host[i] >= src_n_blocks) return HX_ERR_SHAPE;
     if (dst_table_host[i] < 0 || dst_table_host[i] >= dst_n_blocks) return HX_ERR_SHAPE;
   }
-  return launch_copy(src_table_host, dst_table_host, n_pairs, src_pool, dst_pool,
-                     n_layers * n_tokens, src_n_blocks * block_bytes, dst_n_blocks * block_bytes,
-                     block_bytes, false, false, (hipStream_t)stream);
+  return launch_copy(src_table_host, dst_table_host, n_pairs, src_pool, dst_pool, n_planes, src_plane_bytes,
+                     dst_plane_bytes, block_bytes, false, false, (hipStream_t)stream);
+}
+
+extern "C" int hx_migrate_blocks(const int32_t* src_table_host, const int32_t* dst_table_host,
+                                 int64_t n_pairs, const void* src_pool, void* dst_pool,
+                                 int64_t n_layers, int64_t n_tokens, int64_t src_n_blocks,
+                                 int64_t dst_n_blocks, int64_t block_bytes, hx_stream stream) {
+  if (n_layers < 0 || n_tokens < 0) return HX_ERR_SHAPE;
+  return hx_migrate_blocks_planes(src_table_host, dst_table_host, n_pairs, src_pool, dst_pool, n_layers * n_tokens,
+                                  src_n_blocks, dst_n_blocks, src_n_blocks * block_bytes, dst_n_blocks * block_bytes,
+                                  block_bytes, stream);
+}
+
+extern "C" int hx_pack_blocks_planes(const int32_t* table_host, int64_t n_pairs, const void* pool, void* staging,
+                                     int64_t n_planes, int64_t n_blocks, int64_t pool_plane_bytes,
+                                     int64_t block_bytes, hx_stream stream) {
+  if (n_pairs < 0 || n_planes < 0) return HX_ERR_SHAPE;
+  if (n_pairs == 0) return HX_OK;
+  if (!table_host || !pool || !staging) return HX_ERR_NULL;
+  if (pool_plane_bytes < n_blocks * block_bytes || pool_plane_bytes % 16 != 0) return HX_ERR_STRIDE;
+  for (int64_t i = 0; i < n_pairs; ++i)
+    if (table_host[i] < 0 || table_host[i] >= n_blocks) return HX_ERR_SHAPE;
+  return launch_copy(table_host, nullptr, n_pairs, pool, staging, n_planes, pool_plane_bytes,
+                     n_pairs * block_bytes, block_bytes, false, true, (hipStream_t)stream);
 }
 
 extern "C" int hx_pack_blocks(const int32_t* table_host, int64_t n_pairs, const void* pool,
                               void* staging, int64_t n_layers, int64_t n_tokens, int64_t n_blocks,
                               int64_t block_bytes, hx_stream stream) {
-  if (n_pairs < 0) return HX_ERR_SHAPE;
+  return hx_pack_blocks_planes(table_host, n_pairs, pool, staging, n_layers * n_tokens, n_blocks,
+                               n_blocks * block_bytes, block_bytes, stream);
+}
+
+extern "C" int hx_unpack_blocks_planes(const int32_t* table_host, int64_t n_pairs, const void* staging, void* pool,
+                                       int64_t n_planes, int64_t n_blocks, int64_t pool_plane_bytes,
+                                       int64_t block_bytes, hx_stream stream) {
+  if (n_pairs < 0 || n_planes < 0) return HX_ERR_SHAPE;
   if (n_pairs == 0) return HX_OK;
-  if (!table_host || !pool || !staging) return HX_ERR_NULL;
+  if (!table_host || !staging || !pool) return HX_ERR_NULL;
+  if (pool_plane_bytes < n_blocks * block_bytes || pool_plane_bytes % 16 != 0) return HX_ERR_STRIDE;
   for (int64_t i = 0; i < n_pairs; ++i)
     if (table_host[i] < 0 || table_host[i] >= n_blocks) return HX_ERR_SHAPE;
-  return launch_copy(table_host, nullptr, n_pairs, pool, staging, n_layers * n_tokens,
-                     n_blocks * block_bytes, n_pairs * block_bytes, block_bytes, false, true,
-                     (hipStream_t)stream);
+  return launch_copy(nullptr, table_host, n_pairs, staging, pool, n_planes, n_pairs * block_bytes,
+                     pool_plane_bytes, block_bytes, true, false, (hipStream_t)stream);
 }
 
 extern "C" int hx_unpack_blocks(const int32_t* table_host, int64_t n_pairs, const void* staging,
                                 void* pool, int64_t n_layers, int64_t n_tokens, int64_t n_blocks,
                                 int64_t block_bytes, hx_stream stream) {
-  if (n_pairs < 0) return HX_ERR_SHAPE;
-  if (n_pairs == 0) return HX_OK;
-  if (!table_host || !staging || !pool) return HX_ERR_NULL;
-  for (int64_t i = 0; i < n_pairs; ++i)
-    if (table_host[i] < 0 || table_host[i] >= n_blocks) return HX_ERR_SHAPE;
-  return launch_copy(nullptr, table_host, n_pairs, staging, pool, n_layers * n_tokens,
-                     n_pairs * block_bytes, n_blocks * block_bytes, block_bytes, true, false,
-                     (hipStream_t)stream);
+  return hx_unpack_blocks_planes(table_host, n_pairs, staging, pool, n_layers * n_tokens, n_blocks,
+                                 n_blocks * block_bytes, block_bytes, stream);
 }

@@ -1,15 +1,17 @@
 """TokenCacheBlockManager — host-side mirror of hydrainfer/memory/token_cache_manger.py:51-179.
 
-HBM layout: one contiguous pool
+HBM layout: one pool
     (n_layers, n_tokens in {1 image, 2 k/v}, n_blocks, block_size, n_heads, head_size)
 so that every per-layer K or V cache is a contiguous [n_blocks, block_size, H, D] slab and
 a (layer, k/v, block) triple is one contiguous block_size*H*D run — the unit the migration
-gather kernel copies."""
+gather kernel copies.  The (layer, k/v) planes lie a few hundred bytes apart (memory/kv_pool.py:
+K and V of one token on different HBM channels); everything else is the reference's format."""
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
 import torch
 
+import hydrainfer_amd.memory.kv_pool as kv_pool
 from hydrainfer_amd._C.data_transfer.block_migration import get_ipc_mem_handle
 from hydrainfer_amd.memory.block_allocator import BlockAllocator, BlockAllocatorMetrics
 from hydrainfer_amd.memory.communication import (CommunicationBackendManager,
@@ -121,13 +123,16 @@ class TokenCacheBlockManager(BlockTableManager):
         self.dtype = _DTYPES[config.dtype]
         itemsize = torch.empty((), dtype=self.dtype).element_size()
         n_blocks = ipc_safe_n_blocks(config.n_blocks, self.n_layers * self.n_tokens * config.block_size *
-                                     self.n_heads * self.head_size * itemsize)
+                                     self.n_heads * self.head_size * itemsize,
+                                     extra_bytes=self.n_layers * self.n_tokens * kv_pool.KV_POOL_SKEW_BYTES)
         self.device = torch.device(config.device)
 
         # reference fills the pool with randn ("garbage but finite", token_cache_manger.py:65)
-        self.cache_tensor = torch.randn(
-            size=(self.n_layers, self.n_tokens, n_blocks, config.block_size, self.n_heads,
-                  self.head_size), dtype=self.dtype, device=self.device)
+        # the same 6-D shape and the same per-layer views, with the (layer, k/v) planes a few hundred bytes apart so
+        # that K and V of one token do not share an HBM channel (memory/kv_pool.py)
+        self.cache_tensor = kv_pool.allocate_kv_pool(
+            (self.n_layers, self.n_tokens, n_blocks, config.block_size, self.n_heads, self.head_size),
+            self.dtype, self.device, fill="randn")
         super().__init__(n_blocks, config.block_size, context.rank, get_ipc_mem_handle(self.cache_tensor))
         self.migrate_stream = torch.cuda.Stream(device=self.device)
         self.migrate_manager = CommunicationBackendManager(
@@ -157,17 +162,18 @@ class TokenCacheBlockManager(BlockTableManager):
 
 
 # --- pure host logic, usable (and tested) without a GPU --------------------------------
-def ipc_safe_n_blocks(n_blocks: int, bytes_per_block: int) -> int:
-    """Smallest block count >= n_blocks whose pool size is not in [7/8 * 2^k, 2^k).
+def ipc_safe_n_blocks(n_blocks: int, bytes_per_block: int, extra_bytes: int = 0) -> int:
+    """Smallest block count >= n_blocks whose pool size (+ extra_bytes: what the allocation holds beside the blocks,
+    memory/kv_pool.py's plane skew) is not in [7/8 * 2^k, 2^k).
     Observed on this MI355X / ROCm 7.2 pool (tools/ipc_probe2.py): hipIpcOpenMemHandle of an
     allocation of 14, 14.65, 15, 15.5, 30 or 31 GiB never returns, while 8.5, 12, 13, 16, 17, 20
     and 24 GiB map in 1 ms.  Pools that other processes map are therefore sized past the window."""
-    size = n_blocks * bytes_per_block
-    if size <= 0:
+    size = n_blocks * bytes_per_block + extra_bytes
+    if n_blocks * bytes_per_block <= 0:
         return n_blocks
     p2 = 1 << (size - 1).bit_length()          # next power of two >= size
     if size < p2 and size * 8 >= p2 * 7:
-        return -(-p2 // bytes_per_block)
+        return -(-(p2 - extra_bytes) // bytes_per_block)
     return n_blocks
 
 

@@ -11,6 +11,7 @@ MI355X-first differences: the per-step Python metadata build 
 + `.tolist()` sync are replaced by device-resident metadata advanced by one tiny kernel
 (hx_decode_advance), and the whole decode step (193 launches for 7B) is captured once into a
 hipGraph and replayed; sampled tokens stay on the device until the end."""
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -22,6 +23,7 @@ from hydrainfer_amd._C.kernel.norm import StepHead
 from hydrainfer_amd.layer.causal_attention import AttentionParameters, AttentionParametersBuilder
 from hydrainfer_amd.memory.block_allocator import BlockAllocator
 from hydrainfer_amd.memory.kv_cache import KVCache
+import hydrainfer_amd.memory.kv_pool as kv_pool
 from hydrainfer_amd.model.llama import LanguageModelParameters, LlamaForCausalLM
 
 
@@ -78,14 +80,13 @@ class DecodeRunner:
         # window in which hipIpcOpenMemHandle was seen to hang (token_cache_manger.ipc_safe_n_blocks)
         from hydrainfer_amd.memory.token_cache_manger import ipc_safe_n_blocks
         n_blocks = ipc_safe_n_blocks(n_blocks, sh.num_hidden_layers * 2 * bs * sh.num_key_value_heads *
-                                     sh.head_dim * torch.empty((), dtype=dt).element_size())
-        # 6-D pool (token_cache_manger.py:65); randn = "garbage but finite"
+                                     sh.head_dim * torch.empty((), dtype=dt).element_size(),
+                                     extra_bytes=sh.num_hidden_layers * 2 * kv_pool.KV_POOL_SKEW_BYTES)
+        # the reference's 6-D pool (token_cache_manger.py:65) with its planes a few hundred bytes apart
+        # (memory/kv_pool.py); randn = "garbage but finite", layer by layer: bounded fp32 temporaries
         g = torch.Generator(device=dev).manual_seed(seed + 1)
-        self.pool = torch.empty((sh.num_hidden_layers, 2, n_blocks, bs, sh.num_key_value_heads,
-                                 sh.head_dim), dtype=dt, device=dev)
-        for l in range(sh.num_hidden_layers):   # layer by layer: bounded fp32 temporaries
-            self.pool[l].copy_(torch.randn(self.pool[l].shape, generator=g, device=dev,
-                                           dtype=torch.float32).to(dt))
+        self.pool = kv_pool.allocate_kv_pool((sh.num_hidden_layers, 2, n_blocks, bs, sh.num_key_value_heads, sh.head_dim),
+                                             dt, dev, fill="randn", generator=g)
         self.kv_caches = [KVCache(self.pool[l, 0], self.pool[l, 1]) for l in range(sh.num_hidden_layers)]
 
         # device-resident decode metadata (capacity layout: each sequence owns a fixed slice of

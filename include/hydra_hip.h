@@ -427,6 +427,27 @@ int hx_unpack_blocks(const int32_t* table_host, int64_t n_pairs, const void* sta
                      int64_t n_layers, int64_t n_tokens, int64_t n_blocks, int64_t block_bytes,
                      hx_stream stream);
 
+/* The same three copies over pools whose (layer, k/v) PLANES are not back to back: plane p of a pool starts
+ * p * plane_bytes past the pool's base and holds n_blocks blocks contiguously (plane_bytes >= n_blocks * block_bytes,
+ * multiple of 16; n_planes = n_layers * n_tokens).  The entries above are these with plane_bytes = n_blocks * block_bytes —
+ * the reference's contiguous 6-D tensor (hydrainfer/memory/token_cache_manger.py:65).
+ * Why a pool would want spare bytes between planes (round 5, tools/probes/attn_placement.py): K and V of one
+ * (block, token, head) are read by the same wave at the same time, and in the contiguous pool they lie n_blocks *
+ * block_bytes apart — a large power-of-two multiple — so both land on the same HBM channel; with the V plane an odd
+ * multiple of 256 bytes further on, decode attention of 64 sequences runs 5 % faster, the 64-row decode step 3 %, the
+ * 13B step 1 % (hydrainfer_amd/memory/kv_pool.py allocates pools that way; the plane stride travels with the pool's
+ * IPC handle). */
+int hx_migrate_blocks_planes(const int32_t* src_table_host, const int32_t* dst_table_host,
+                             int64_t n_pairs, const void* src_pool, void* dst_pool, int64_t n_planes,
+                             int64_t src_n_blocks, int64_t dst_n_blocks, int64_t src_plane_bytes,
+                             int64_t dst_plane_bytes, int64_t block_bytes, hx_stream stream);
+int hx_pack_blocks_planes(const int32_t* table_host, int64_t n_pairs, const void* pool, void* staging,
+                          int64_t n_planes, int64_t n_blocks, int64_t pool_plane_bytes, int64_t block_bytes,
+                          hx_stream stream);
+int hx_unpack_blocks_planes(const int32_t* table_host, int64_t n_pairs, const void* staging, void* pool,
+                            int64_t n_planes, int64_t n_blocks, int64_t pool_plane_bytes, int64_t block_bytes,
+                            hx_stream stream);
+
 /* ------------------------------------------------------------------------
  * Decode-step metadata advance: device-resident equivalent of one
  * AttentionParametersBuilder pass for an all-decode batch

@@ -56,6 +56,63 @@ def test_pack_unpack_roundtrip_many_pairs():
     assert float(pool2[:, :, rest].float().abs().sum()) == 0
 
 
+def _skewed(t, skew):
+    """The same values in a pool whose planes lie `skew` bytes apart (memory/kv_pool.py)."""
+    from hydrainfer_amd.memory import kv_pool
+    p = kv_pool.allocate_kv_pool(tuple(t.shape), t.dtype, DEV, fill="zeros", skew_bytes=skew)
+    p.copy_(t)
+    return p
+
+
+@pytest.mark.parametrize("skews", [(768, 768), (768, 0), (0, 4352), (256, 1280)])
+def test_migration_between_pools_with_planes_apart(skews):
+    """hx_migrate_blocks_planes / hx_pack_blocks_planes / hx_unpack_blocks_planes: pools whose (layer, k/v) planes are
+    not back to back, every mix with the reference's contiguous pool, against oracle.ops.migrate_blocks; the bytes
+    between the planes are never written."""
+    from hydrainfer_amd._C.data_transfer import block_migration as bm
+    from hydrainfer_amd.memory import kv_pool
+    from oracle import ops
+    src, dst = _pools(seed=3)
+    s_tbl, d_tbl = [9, 0, 4, 3], [1, 6, 2, 0]
+    want = dst.clone()
+    ops.migrate_blocks(s_tbl, d_tbl, src, want)
+    sd, dd = _skewed(src, skews[0]), _skewed(dst, skews[1])
+    assert kv_pool.plane_bytes_of(sd) == 10 * 16 * 4 * 64 * 2 + skews[0]
+    bm.migrate_blocks_local(s_tbl, d_tbl, sd, dd)
+    torch.cuda.synchronize()
+    assert torch.equal(dd.cpu(), want)
+    # through the handle (same process: the exported base is reused): the source's plane stride travels in the handle
+    dd2 = _skewed(dst, skews[1])
+    h = bm.get_ipc_mem_handle(sd)
+    assert len(h) == (80 if skews[0] else 72) and bm.handle_plane_bytes(h) == (kv_pool.plane_bytes_of(sd) if skews[0] else 0)
+    bm.migrate_blocks(s_tbl, d_tbl, h, dd2, src.shape[2])
+    torch.cuda.synchronize()
+    assert torch.equal(dd2.cpu(), want)
+    # pack / unpack (the RCCL path's two halves)
+    staging = torch.empty((3, 2, len(s_tbl), 16, 4, 64), dtype=src.dtype, device=DEV)
+    bm.pack_blocks(s_tbl, sd, staging)
+    dd3 = _skewed(dst, skews[1])
+    bm.unpack_blocks(d_tbl, staging, dd3)
+    torch.cuda.synchronize()
+    assert torch.equal(staging.cpu(), src[:, :, s_tbl]) and torch.equal(dd3.cpu(), want)
+    if skews[1]:      # the spare bytes behind every plane of the destination: still the zeros they were allocated with
+        n = 7 * 16 * 4 * 64
+        flat = torch.as_strided(dd3, (6, skews[1] // 2), (n + skews[1] // 2, 1), dd3.storage_offset() + n)
+        assert float(flat.float().abs().sum()) == 0
+
+
+def test_a_pool_that_is_neither_layout_is_refused():
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.data_transfer import block_migration as bm
+    src, dst = _pools()
+    sd = src.to(DEV)
+    bad = dst.to(DEV).transpose(3, 4)          # blocks no longer contiguous
+    with pytest.raises(_lib.HydraHipError):
+        bm.migrate_blocks_local([0], [0], sd, bad)
+    with pytest.raises(_lib.HydraHipError):
+        bm.pack_blocks([0], bad, torch.empty(1 << 20, dtype=torch.float16, device=DEV))
+
+
 def _ipc_child(handle, src_tbl, dst_tbl, src_n_blocks, q):
     try:
         import torch
@@ -134,7 +191,13 @@ def test_token_cache_block_manager_end_to_end():
     p_mgr = TokenCacheBlockManager(TokenCacheBlockManagerConfig(n_blocks=12, **cfg), ctx)
     d_mgr = TokenCacheBlockManager(TokenCacheBlockManagerConfig(n_blocks=9, **cfg),
                                    TokenCacheBlockManagerContext(rank=1, rank2host={0: "h", 1: "h"}))
-    assert p_mgr.cache_tensor.shape == (3, 2, 12, 16, 4, 64) and len(p_mgr.memory_handle) == 72
+    # 64 handle bytes + 8 offset bytes + 8 bytes of plane stride: the manager's pool keeps its (layer, k/v) planes
+    # KV_POOL_SKEW_BYTES apart (memory/kv_pool.py)
+    from hydrainfer_amd.memory import kv_pool
+    from hydrainfer_amd._C.data_transfer.block_migration import handle_plane_bytes
+    assert p_mgr.cache_tensor.shape == (3, 2, 12, 16, 4, 64) and len(p_mgr.memory_handle) == 80
+    assert handle_plane_bytes(p_mgr.memory_handle) == 12 * 16 * 4 * 64 * 2 + kv_pool.KV_POOL_SKEW_BYTES
+    assert not p_mgr.cache_tensor.is_contiguous() and p_mgr.cache_tensor[1, 1].is_contiguous()
     src = p_mgr.allocate_virtual_cache()
     p_mgr.realloc(src, 40)
     assert src.block_table == [2, 1, 0] and p_mgr.v2p(src, [0, 17, 39]) == [32, 17, 7]

@@ -32,11 +32,14 @@ def main():
             continue
         if any("paged_read_kernel" in r[2] or "read_stream_kernel" in r[2] for r in seg):
             continue      # a null step of bench.py's whole_step.null_step (math-free stand-in launches): not a decode step
+        must = os.environ.get("TIMELINE_MUST_CONTAIN")      # e.g. gemm_xreg_wide: the 64-row steps of bench.py's whole_step_64
+        if must and not any(must in r[2] for r in seg):
+            continue
         span = seg[-1][1] - seg[0][0]
         steps.append((span, a, b))
     if not steps:
         print("no decode steps found"); return
-    lens = statistics.mode([b - a for _, a, b in steps])
+    lens = int(os.environ.get("TIMELINE_KERNELS") or statistics.mode([b - a for _, a, b in steps]))   # (196: bench.py's bare 64-row step)
     steps = [s for s in steps if s[2] - s[1] == lens]
     steps.sort()
     span, a, b = steps[len(steps) // 2]
