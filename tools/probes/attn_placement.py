@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Decision served: bench.py's bare 64-row step is 2 % faster when the serving leg ran before it (7.74 against 7.90 ms);
-the kernel trace puts all of it in the decode-attention launches (136.5 against 141.7 us).  Same block tables, same
-kernel: only where the KV pool lies differs.  This probe times the fused decode-attention launch (B rows, ctx 832,
-7B heads) over pools carved at different places — a fresh allocation, byte offsets into a larger buffer, an
-allocation after allocator churn — to see whether placement is something the pool allocation should control.
+"""Decision served: should the KV pool's allocation control where its bytes lie?  bench.py's bare 64-row step was 2 %
+faster when the serving leg had run before it (7.74 against 7.90 ms); the kernel trace put all of it in the
+decode-attention launches (136.5 against 141.7 us).  Same block tables, same kernel: only where the pool lies differed.
+This probe times the fused decode-attention launch (B rows, ctx 832, 7B heads, the runner's block tables) over pools
+carved out of one buffer at different byte offsets, and with spare bytes between the K and V pools of a layer.
+Result (profiles/r5_kv_pool_placement.md): an odd multiple of 256 bytes between K and V is worth 5-6 % of the launch;
+hydrainfer_amd/memory/kv_pool.py allocates pools that way.
 
     python tools/probes/attn_placement.py [B=64] [L=8]
 """
@@ -58,11 +60,6 @@ def time_pool(pool, reps=5):
         ts.append(e0.elapsed_time(e1) * 1e3 / L)
     ts.sort()
     return ts[len(ts) // 2], ts[0], ts[-1]
-
-
-def carve(buf, off):
-    v = buf[off:off + pool_bytes].view(dt).view(L, 2, n_blocks, bs, H, D)
-    return v
 
 
 def report(name, pool):
