@@ -528,6 +528,11 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
                                                            // fourth MFMA column block then re-reads the third (rows >= M are never stored)
   const int j0 = (p.stagger & 1) ? (int)(((unsigned)b * 7u + (unsigned)w * 3u) % (unsigned)KW) : 0;
   const int flat_id = blockIdx.y * nb + blockIdx.x;
+  auto stamp = [&](int k) {      // (xreg_timeline, as in the 32-row kernel: first and last workgroup of a norm-fused launch)
+    if (NORM && (p.stagger & 8) && threadIdx.x == 0 && (flat_id == 0 || flat_id == (int)(nb * gridDim.y) - 1))
+      reinterpret_cast<unsigned long long*>(p.sync + 384 + (flat_id ? 32 : 0))[k] = __builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
   auto rot = [&](int t) { const int r = j0 + t; return r >= KW ? r - KW : r; };
   const u16* wbase = reinterpret_cast<const u16*>(p.w) + 8 * lane + ((int64_t)sp * p.pk_P * n_rg) * 512;
   const int wave_k0 = off_in + min(w * KW, max(nks - 1, 0));
@@ -596,6 +601,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
 #pragma unroll
     for (int q = 0; q < NBUF; ++q) load_buf(unit_of(0), q);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(1);
     for (;;) {
       if (threadIdx.x < 64) {
         const uint32_t* fl = p.sync + 32 * (1 + (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7));
@@ -627,6 +633,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
       if (cc < 0) break;
       produce(cc);
     }
+    stamp(2);
     asm volatile("" ::: "memory");
     {
       const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
@@ -698,8 +705,9 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
       if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + col + 4 * g) = sum;
     }
   };
-  for (int i = 0; i < G - 1; ++i) unit(i, std::true_type{});
+  for (int i = 0; i < G - 1; ++i) { unit(i, std::true_type{}); if (i < 6) stamp(3 + i); }
   unit(G - 1, std::false_type{});
+  stamp(11);
 }
 
 // output piece i (16 bytes) of the packed tensor <- its source in the row-major weight

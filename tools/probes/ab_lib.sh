@@ -1,0 +1,21 @@
+# A/B of two builds of the library over the whole decode step: build/lib_before/libhydra_hip.so (HX_LIB_PATH) against the
+# in-tree one; fresh process per run, interleaved.    bash tools/probes/ab_lib.sh [reps=4] [extra bench flags]
+REPS=${1:-4}; shift || true
+for rep in $(seq $REPS); do
+for which in before after; do
+  if [ $which = before ]; then export HX_LIB_PATH=$PWD/build/lib_before/libhydra_hip.so; else unset HX_LIB_PATH; fi
+  python bench.py --steps 20 --warmup 5 --no-ttft --no-cpu-baseline --no-serving --no-null-step "$@" 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); l=d.get('llava_13b') or {'ms_per_step':0,'whole_step_64':{'ms_per_step':0}}
+print('LIB[$which]', d['ms_per_step'], d['whole_step_64']['ms_per_step'], l['ms_per_step'], l['whole_step_64']['ms_per_step'])"
+done
+done | tee /tmp/ab.txt
+python - <<'PY'
+import collections, statistics
+d = collections.defaultdict(list)
+for l in open('/tmp/ab.txt'):
+    k = l.split(']')[0] + ']'
+    d[k].append([float(x) for x in l.split(']')[1].split()])
+print("medians: 7B 32 rows | 7B 64 rows | 13B 32 rows | 13B 64 rows (ms per step)")
+for k, v in d.items():
+    print(k, " | ".join("%.4f" % statistics.median(c) for c in zip(*v)))
+PY

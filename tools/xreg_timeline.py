@@ -10,10 +10,11 @@ from hydrainfer_amd.model.llama import LLAVA_1_5_13B, LLAVA_1_5_7B, LlamaForCaus
 from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
 dev = torch.device("cuda:0")
 shape = LLAVA_1_5_13B if len(sys.argv) > 1 and sys.argv[1] == "13b" else LLAVA_1_5_7B
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32          # 33 .. 64: the wide kernel's launches (stamps per unit of two row groups)
 assert _lib.lib().hx_debug_set_option(b"xreg_timeline", 1) == 0
 model = LlamaForCausalLM.random_init(shape, torch.bfloat16, dev, seed=0)
-r = DecodeRunner(model, RunnerConfig(batch=32, prompt_len=704, n_generate=256, use_graph=True, executor="plan"), seed=0)
-r.set_state(831, torch.randint(5, 30000, (32,), device=dev))
+r = DecodeRunner(model, RunnerConfig(batch=B, prompt_len=704, n_generate=256, use_graph=True, executor="plan"), seed=0)
+r.set_state(831, torch.randint(5, 30000, (B,), device=dev))
 r.capture()
 for _ in range(5):
     r.set_state(831); r.step(record=False)
