@@ -1250,6 +1250,9 @@ def main():
     ctxs = timed_contexts(prompt_len, n_generate, steps)
     cfg = RunnerConfig(batch=args.batch, prompt_len=prompt_len, n_generate=n_generate,
                        use_graph=not args.no_graph, executor=args.executor)
+    # the GPU's streaming rates, measured FIRST: at the end of a run the heap is fragmented and a fresh 1 GiB buffer reads
+    # 20 % slower than the decode step itself streams (5.3 against 6.6-6.7 TB/s at the start: profiles/r5_kv_pool_placement.md)
+    stream_rates = (round(read_stream_ceiling_gbs(dev), 1), round(copy_ceiling_gbs(dev), 1))
     model = LlamaForCausalLM.random_init(shape, dtype, dev, seed=0)
     model.use_hip_gemm = not args.lib_gemm
     if args.no_fused_attention:
@@ -1360,8 +1363,8 @@ def main():
         whole["weight_layouts"] = ("row-major (the library prefill GEMMs of this EPD replica) + one decode layout per projection "
                                    "(activations-in-registers; LDS-slice for o and layer 0's qkv); a D-role node keeps only the "
                                    "decode layout; serving 33..64 rows adds LDS-slice copies: serving.twice_the_batch.weight_bytes_resident")
-        roofline["measured_read_stream_ceiling_GBps"] = round(read_stream_ceiling_gbs(dev), 1)
-        roofline["measured_copy_GBps"] = round(copy_ceiling_gbs(dev), 1)     # torch copy_ (read + write): NOT a ceiling
+        roofline["measured_read_stream_ceiling_GBps"] = stream_rates[0]      # (measured before the model was built)
+        roofline["measured_copy_GBps"] = stream_rates[1]     # torch copy_ (read + write): NOT a ceiling
         configs_i = {"7b": "configs[1]: LLaVA-1.5-7B bf16, collocated prefill+decode on 1 MI355X",
                      "13b": "configs[2]: LLaVA-1.5-13B, batch 32, decode HBM-roofline run"}.get(args.model, "smoke shape")
         out = {

@@ -56,7 +56,8 @@ def allocate_kv_pool(shape: Tuple[int, int, int, int, int, int], dtype: torch.dt
             if generator is not None:
                 pool[l].copy_(torch.randn(pool[l].shape, generator=generator, device=device, dtype=torch.float32).to(dtype))
             else:
-                pool[l].normal_()
+                for t in range(T):      # plane by plane: each is contiguous (the strided fill of a whole layer is 5 x slower,
+                    pool[l, t].normal_()    # and an engine that starts serving behind it pays that in its first TTFTs)
         if plane > n_blocks * bs * H * D:      # the spare bytes are never read; finite all the same (dumps, checksums)
             flat.as_strided((L * T, plane - n_blocks * bs * H * D), (plane, 1), n_blocks * bs * H * D).zero_()
     elif fill not in ("zeros", "empty"):
