@@ -120,6 +120,9 @@ __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-
 __device__ __attribute__((aligned(128))) u16 g_zero_line[64] = {0};
 
 static_assert(HX_XREG_SYNC_WORDS >= 320 + 32, "sync area: word 0 arrivals, word 1 error, word 32*(1+xcc) the flag line of that XCD");
+constexpr int kXAux = 16;     // cache policy of the x loads behind the hand-over: 16 = sc1 (past the XCD's L2); 0 = plain (L2 hits after
+                              // an XCD's first reader) was measured again in round 5: first row group, kernel end and step unchanged — the
+                              // 256 KiB per CU are bound by the CU's own 64 B/clk, not by where they come from
 constexpr int kStateWord = 320;        // sync area: one ownership word per row (<= 32)
 constexpr uint64_t kRescueTicks = 3000;   // 30 us of the 100 MHz clock (a normal wait is ~3 us)
 constexpr int kMaxG = 16;
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(HX_XREG_HOT_SIG, const X
         for (int mb = 0; mb < MB; ++mb) {
           // padding slots (K rounded up to the wave's k-step count) read the zero line
           xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
-              ok ? xrs : zrs, ok ? (uint32_t)((ks * MB + mb) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, 16));
+              ok ? xrs : zrs, ok ? (uint32_t)((ks * MB + mb) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, kXAux));
         }
       }
     }
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
           xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
-              ok ? xrs : zrs, ok ? (uint32_t)((ks * mbl + min(mb, mbl - 1)) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, 16));
+              ok ? xrs : zrs, ok ? (uint32_t)((ks * mbl + min(mb, mbl - 1)) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, kXAux));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
