@@ -135,6 +135,7 @@ _SIGNATURES = {
     "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_int32, c_void_p]),
     "hx_decode_feed_ids": (c_int, [c_void_p] * 4 + [c_int32, c_void_p]),
     "hx_collect_errors": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
+    "hx_copy_words2": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "hx_decode_weight_plan": (c_int, [POINTER(hx_decode_weight), c_int64, c_int64, c_int, c_int, c_int]),
     "hx_decode_weight_pack": (c_int, [POINTER(hx_decode_weight), c_void_p, c_void_p, c_int64, c_void_p]),
     "hx_linear_decode_ex_workspace_bytes": (c_int64, [POINTER(hx_decode_weight), c_int64]),

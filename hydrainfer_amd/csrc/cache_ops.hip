@@ -184,7 +184,28 @@ __global__ __launch_bounds__(64) void collect_errors_kernel(uint32_t* __restrict
   for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
   if (threadIdx.x == 0) out[0] = v | (extra ? extra[0] : 0u);
 }
+// two small word arrays moved by ONE launch; either side of either pair may be host-mapped (pinned) memory
+__global__ __launch_bounds__(256) void copy_words2_kernel(uint32_t* __restrict__ dst0, const uint32_t* __restrict__ src0, int32_t n0,
+                                                          uint32_t* __restrict__ dst1, const uint32_t* __restrict__ src1, int32_t n1) {
+  const int stride = gridDim.x * 256;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n0; i += stride) dst0[i] = src0[i];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n1; i += stride) dst1[i] = src1[i];
+}
 }  // namespace
+
+extern "C" int hx_copy_words2(void* dst0, const void* src0, int32_t n0_words, void* dst1, const void* src1, int32_t n1_words,
+                              hx_stream stream) {
+  if (n0_words < 0 || n1_words < 0) return HX_ERR_SHAPE;
+  if ((n0_words > 0 && (!dst0 || !src0)) || (n1_words > 0 && (!dst1 || !src1))) return HX_ERR_NULL;
+  if (n0_words + n1_words == 0) return HX_OK;
+  if ((((uintptr_t)dst0 | (uintptr_t)src0 | (uintptr_t)dst1 | (uintptr_t)src1) & 3) != 0) return HX_ERR_STRIDE;
+  const int n = n0_words > n1_words ? n0_words : n1_words;
+  int blocks = (n + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hx::launcher(copy_words2_kernel, (unsigned)blocks, 256, 0, (hipStream_t)stream)(
+      (uint32_t*)dst0, (const uint32_t*)src0, n0_words, (uint32_t*)dst1, (const uint32_t*)src1, n1_words);
+  return hx::check_launch();
+}
 
 extern "C" int hx_decode_feed_ids(int64_t* out, const int32_t* ids, const int32_t* src, const int64_t* prev,
                                   int32_t n, hx_stream stream) {

@@ -42,6 +42,7 @@ class GraphedDecoder:
         # schedules, stages and runs eager prefill steps — at 16 req/s Poisson the plan measured TPOT p50 7.7 ms and
         # TTFT p50 84 ms against 6.5 / 51 for the graph (tools/bench_engine.py, round 3)
         self.executor = executor or os.environ.get("HX_ENGINE_EXECUTOR", "graph")
+        self.kernel_copies = os.environ.get("HX_ENGINE_KERNEL_COPIES", "1") == "1"      # (0: hipMemcpyAsync, for A/B runs)
         self.lm = language_model                       # LlavaLanguageModel
         self.model = language_model.language_model     # LlamaForCausalLM
         self.kv = kv_cache_block_manager
@@ -197,7 +198,13 @@ class GraphedDecoder:
         flat = [b for r in rows for b in r[4]]
         st[o["tables"]:o["tables"] + len(flat)] = flat
         used = o["tables"] + len(flat)
-        self.static[:used].copy_(self.staging[which][:used], non_blocking=True)
+        if self.kernel_copies:
+            # the step's integers go in by a KERNEL that reads the pinned buffer (hx_copy_words2, include/hydra_hip.h): a
+            # memcpy between two graph launches left the stream idle for ~0.1 ms per step
+            _lib.check(_lib.lib().hx_copy_words2(self.static.data_ptr(), self.staging[which].data_ptr(), used, None, None, 0,
+                                                 _lib.current_stream()), "copy_words2")
+        else:
+            self.static[:used].copy_(self.staging[which][:used], non_blocking=True)
         self.copy_done[which].record()
         return max(r[3] for r in rows)
 
@@ -223,9 +230,15 @@ class GraphedDecoder:
         graph.replay()
         self.launches += 1
         slot = self.launches % 2
-        self.host_tokens[slot][:n].copy_(out[:n], non_blocking=True)
-        if err is not None:
-            self.host_err[slot].copy_(err.view(1), non_blocking=True)
+        if self.kernel_copies:      # tokens (int64: 2 words each) and the give-up word leave by one launch, straight into pinned memory
+            _lib.check(_lib.lib().hx_copy_words2(self.host_tokens[slot].data_ptr(), out.data_ptr(), 2 * n,
+                                                 self.host_err[slot].data_ptr() if err is not None else None,
+                                                 err.data_ptr() if err is not None else None, 1 if err is not None else 0,
+                                                 _lib.current_stream()), "copy_words2")
+        else:
+            self.host_tokens[slot][:n].copy_(out[:n], non_blocking=True)
+            if err is not None:
+                self.host_err[slot].copy_(err.view(1), non_blocking=True)
         self.launch_has_err[self.launches] = err is not None
         self.events[slot].record()
         self.launch_rows[self.launches] = n

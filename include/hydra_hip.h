@@ -499,6 +499,15 @@ int hx_decode_feed_ids(int64_t* out, const int32_t* ids, const int32_t* src, con
                        int32_t n, hx_stream stream);
 int hx_collect_errors(uint32_t* out, const uint32_t* areas, int32_t n_areas, int64_t stride_words,
                       int32_t word, const uint32_t* extra, hx_stream stream);
+/* hx_copy_words2: dst0[0 .. n0) = src0[..], dst1[0 .. n1) = src1[..] (32-bit words, 4-byte aligned, n1 may be 0) as ONE
+ * kernel launch.  Any of the four pointers may be host-mapped pinned memory (hipHostMalloc / torch pin_memory): this is how
+ * the engine's decode loop moves a step's few hundred integers in and its sampled tokens out (engine/graph_decode.py) —
+ * a hipMemcpyAsync between two graph launches cost the stream ~40-120 us of idle time per copy on this ROCm (round 5,
+ * rocprofv3 trace of the serving leg: three copyBuffer launches per step with 9 / 0 / 123 us in front of them); a kernel
+ * is just the next packet in the queue.  Results written to pinned memory are visible to the host once an event recorded
+ * behind the launch has completed (the reference's step does a blocking .tolist(), hydrainfer/engine/executor.py). */
+int hx_copy_words2(void* dst0, const void* src0, int32_t n0_words, void* dst1, const void* src1, int32_t n1_words,
+                   hx_stream stream);
 
 /* ------------------------------------------------------------------------
  * Launch plans: record the launches of a fixed sequence of hx_* calls once, replay them with one

@@ -754,3 +754,28 @@ def test_norm_fused_wide_launches_are_bit_identical(dt):
         assert torch.equal(h5, h1) and torch.equal(a, b)
         assert int(sync[:, 1].abs().sum()) == 0
         assert (sync[:2 * n_it + 1, 0] == M).all()
+
+
+def test_copy_words2_moves_words_between_device_and_pinned_memory():
+    """hx_copy_words2 (the engine decode loop's way in and out, engine/graph_decode.py): pinned -> device, device ->
+    pinned, two pairs in one launch, visible to the host behind an event; odd counts, one empty pair, misalignment refused."""
+    from hydrainfer_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    host_in = torch.arange(1000, dtype=torch.int32).pin_memory()
+    d = torch.zeros(1000, dtype=torch.int32, device=dev)
+    _lib.check(lib.hx_copy_words2(d.data_ptr(), host_in.data_ptr(), 777, None, None, 0, _lib.current_stream()), "copy")
+    torch.cuda.synchronize()
+    assert torch.equal(d[:777].cpu(), host_in[:777]) and int(d[777:].abs().sum()) == 0
+    toks = torch.randint(0, 1 << 40, (64,), dtype=torch.int64, device=dev)
+    err = torch.tensor([5], dtype=torch.int32, device=dev)
+    h_tok, h_err = torch.zeros(64, dtype=torch.int64).pin_memory(), torch.zeros(1, dtype=torch.int32).pin_memory()
+    ev = torch.cuda.Event()
+    _lib.check(lib.hx_copy_words2(h_tok.data_ptr(), toks.data_ptr(), 2 * 37, h_err.data_ptr(), err.data_ptr(), 1,
+                                  _lib.current_stream()), "copy")
+    ev.record()
+    ev.synchronize()
+    assert h_tok[:37].tolist() == toks[:37].cpu().tolist() and int(h_tok[37:].abs().sum()) == 0 and int(h_err[0]) == 5
+    assert lib.hx_copy_words2(None, None, 0, None, None, 0, _lib.current_stream()) == 0
+    assert lib.hx_copy_words2(d.data_ptr() + 2, host_in.data_ptr(), 4, None, None, 0, _lib.current_stream()) != 0
+    assert lib.hx_copy_words2(None, host_in.data_ptr(), 4, None, None, 0, _lib.current_stream()) != 0
