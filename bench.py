@@ -964,9 +964,11 @@ def leg_64_rows(ctx, model, args, dev, prompt_len, n_generate, steps=20):
     dp = model._decode_plan(B, model.dtype)
     return {"rows": B, "ms_per_step": round(ms, 4), "value": round(B * len(ctxs) / elapsed, 2), "unit": "tokens/s",
             "algorithmic_bytes": int(step_bytes), "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-            "launches_per_layer": 6 if dp["wide"] and dp["nf_gu"] and dp["nf_qkv"] else 8,
-            "layer": ("attention | o | norm + gate|up (2 slabs) | silu*mul | down | norm + qkv (2 slabs): wide activations-in-registers "
-                      "kernel over the <= 32-row packing" if dp["wide"] else "LDS-slice GEMMs with separate norm / silu launches"),
+            "launches_per_layer": (5 if dp.get("wide_silu") else 6) if dp["wide"] and dp["nf_gu"] and dp["nf_qkv"] else 8,
+            "layer": (("attention | o | norm + gate|up + silu*mul (both K halves in one workgroup, no slabs) | down | norm + qkv "
+                       "(2 slabs): wide activations-in-registers kernel over the <= 32-row packing" if dp.get("wide_silu") else
+                       "attention | o | norm + gate|up (2 slabs) | silu*mul | down | norm + qkv (2 slabs): wide activations-in-registers "
+                       "kernel over the <= 32-row packing") if dp["wide"] else "LDS-slice GEMMs with separate norm / silu launches"),
             "weight_bytes_resident": model.weight_bytes_resident(), "contexts": ctx_label(ctxs)}
 
 

@@ -275,6 +275,26 @@ def norm_gate_up_xreg(residual: Tensor, slabs_in: Tensor, n_splits_in: int, norm
     return rc
 
 
+def gate_up_silu_wide_supported(M: int, inter: int, K: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.float16, torch.bfloat16) and _lib.lib().hx_gate_up_silu_wide_xreg_supported(M, inter, K) == 1
+
+
+def norm_gate_up_silu_wide_xreg(residual: Tensor, slabs_in: Tensor, n_splits_in: int, norm_weight: Tensor, epsilon: float,
+                                x_frag: Tensor, packed_gate_up: Tensor, inter: int, act: Tensor, sync: Tensor) -> None:
+    """norm_gate_up_xreg + silu_and_mul_slabs(fragment_major=True) as ONE launch without slabs for 33 .. 64 rows: act
+    (fragment-major [ceil(M / 16) * 16, inter]) = silu(gate) * up, bit-identical to the two-launch form."""
+    _lib.require_gpu(residual, slabs_in, norm_weight, x_frag, packed_gate_up, sync, act)
+    M, K = _norm_checks(residual, slabs_in, n_splits_in, norm_weight, x_frag, sync)
+    if packed_gate_up.numel() != 2 * inter * K or packed_gate_up.dtype != residual.dtype:
+        raise _lib.HydraHipError("norm_gate_up_silu_wide_xreg: packed [2*inter, K] (interleaved) of the model dtype")
+    if act.dtype != residual.dtype or not act.is_contiguous() or act.numel() < (M + 15) // 16 * 16 * inter:
+        raise _lib.HydraHipError("norm_gate_up_silu_wide_xreg: act holds ceil(M / 16) * 16 * inter elements of the model dtype")
+    _lib.check(_lib.lib().hx_norm_gate_up_silu_wide_xreg(
+        act.data_ptr(), residual.data_ptr(), slabs_in.data_ptr(), int(n_splits_in), norm_weight.data_ptr(), float(epsilon),
+        x_frag.data_ptr(), packed_gate_up.data_ptr(), M, inter, K, sync.data_ptr(), _lib.dtype_code(residual),
+        _lib.current_stream()), "norm_gate_up_silu_wide_xreg")
+
+
 # ------------------------------------------------------------------------------------------------
 # the single-entry form (include/hydra_hip.h hx_decode_weight / hx_linear_decode_ex): describe the weight once, the
 # library picks the layout for the largest decode batch it has to serve, packs, and dispatches

@@ -152,6 +152,9 @@ _SIGNATURES = {
     "hx_gate_up_xreg": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_int64, c_int, c_void_p]),
     "hx_norm_gate_up_xreg": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_void_p, c_int64, c_int64,
                                      c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "hx_gate_up_silu_wide_xreg_supported": (c_int, [c_int64, c_int64, c_int64]),
+    "hx_norm_gate_up_silu_wide_xreg": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_void_p,
+                                               c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     "hx_measure_read_stream": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "hx_measure_read_grid": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "hx_measure_paged_read": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),

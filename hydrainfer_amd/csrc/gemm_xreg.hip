@@ -509,15 +509,21 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(HX_XREG_HOT_SIG, const X
 // projection: 27 k-steps per wave in the packing -> halves of 14 and 13); (b) RG = row groups per work unit: 2 keeps
 // 2 KW KiB per wave in flight; RG = 1 is for KW = 20 (13B's K = 5120: x for 64 rows is 320 registers, a second weight
 // buffer set does not fit beside it).
-template <typename T, int KW, int NORM, int RG = 2>
+// EPI = 1 (round 5; RG = 2, NORM = 1, a gate|up packing whose split is two halves): BOTH K halves in one workgroup, one
+// after the other — x of the first half, all of the workgroup's units (their reduced tiles wait in LDS, 8 KiB per unit), x of
+// the second half, the units again, and act = silu(gate) * up leaves from the epilogue with hx_silu_and_mul_slabs' order of
+// summation and roundings.  No slabs, no silu*mul launch, nothing between workgroups; the weight stream runs on across
+// the seam (the last unit of the first half refills with the first unit of the second).  gridDim.y == 1.
+template <typename T, int KW, int NORM, int RG = 2, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, const XregParams p_in) {
   HX_XREG_UNPACK_HOT(NORM)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MB = 4, NBUF = (KW + 7) / 8, P = 4 * KW;
+  static_assert(!EPI || (RG == 2 && NORM == 1), "the two-pass form: (gate, up) pairs, norm-fused");
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int split = blockIdx.y, nb = h_nb, b = nb - 1 - (int)blockIdx.x;
+  const int split = EPI ? 0 : (int)blockIdx.y, nb = h_nb, b = nb - 1 - (int)blockIdx.x;
   const int total_ks = p.K >> 5;
   const int n_rg = p.N >> 4, n_un = n_rg / RG;
   // where the launch's split sits inside the packing
@@ -539,18 +545,23 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
   auto rot = [&](int t) { const int r = j0 + t; return r >= KW ? r - KW : r; };
   const u16* wbase = reinterpret_cast<const u16*>(p.w) + 8 * lane + ((int64_t)sp * p.pk_P * n_rg) * 512;
   const int wave_k0 = off_in + min(w * KW, max(nks - 1, 0));
-  auto frag_ptr = [&](int rg, int t) {
+  // what depends on the K half: first k-step, this wave's k-step count, its first k-step inside the packing split
+  struct PassK { int ks0, kw, wk0; };
+  const PassK pa{ks0, kw, wave_k0};
+  const int nks_b = max(0, min(P, nks_p - P));                       // (EPI: the second half)
+  const PassK pb{ks0 + P, max(0, min(KW, nks_b - w * KW)), P + min(w * KW, max(nks_b - 1, 0))};
+  auto frag_ptr = [&](int rg, int t, const PassK& ps) {
     const int r = rot(t);
-    return wbase + ((int64_t)rg * nks_p + wave_k0 + (r < kw ? r : 0)) * 512;
+    return wbase + ((int64_t)rg * nks_p + ps.wk0 + (r < ps.kw ? r : 0)) * 512;
   };
   u16x8 buf[RG][NBUF][8];
-  auto load_buf = [&](int unit, int q) {
+  auto load_buf = [&](int unit, int q, const PassK& ps) {
 #pragma unroll
     for (int h = 0; h < RG; ++h)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (8 * q + j < KW)
-          buf[h][q][j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(frag_ptr(RG * unit + h, 8 * q + j)));
+          buf[h][q][j] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(frag_ptr(RG * unit + h, 8 * q + j, ps)));
   };
   auto unit_of = [&](int i) { return b + i * nb; };
   u16x8 xb[KW][MB];
@@ -602,7 +613,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
     if (flat_id < p.M && !(p.stagger & 6))
       for (int row = flat_id; row < p.M; row += n_wg) produce(row);
 #pragma unroll
-    for (int q = 0; q < NBUF; ++q) load_buf(unit_of(0), q);
+    for (int q = 0; q < NBUF; ++q) load_buf(unit_of(0), q, pa);
     __builtin_amdgcn_sched_barrier(0);
     stamp(1);
     for (;;) {
@@ -638,25 +649,29 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
     }
     stamp(2);
     asm volatile("" ::: "memory");
-    {
-      const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
+  }
+  // the produced x of one K half (behind the hand-over: kXAux loads)
+  auto load_x_norm = [&](const PassK& ps) {
+    const rsrc_t xrs = make_rsrc(p.x), zrs = make_rsrc(g_zero_line);
 #pragma unroll
-      for (int t = 0; t < KW; ++t) {
-        const int r = rot(t);
-        const bool ok = r < kw;
-        const int ks = min(ks0 + w * KW + r, total_ks - 1);
+    for (int t = 0; t < KW; ++t) {
+      const int r = rot(t);
+      const bool ok = r < ps.kw;
+      const int ks = min(ps.ks0 + w * KW + r, total_ks - 1);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-          xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
-              ok ? xrs : zrs, ok ? (uint32_t)((ks * mbl + min(mb, mbl - 1)) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, kXAux));
-      }
+      for (int mb = 0; mb < MB; ++mb)
+        xb[t][mb] = __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(
+            ok ? xrs : zrs, ok ? (uint32_t)((ks * mbl + min(mb, mbl - 1)) * 64 + lane) * 16 : (uint32_t)(lane & 7) * 16, 0, kXAux));
     }
+  };
+  if (NORM) {
+    load_x_norm(pa);
     __builtin_amdgcn_sched_barrier(0);
   } else {
 #pragma unroll
     for (int q = 0; q < NBUF; ++q) {
       load_x_block(q);
-      load_buf(unit_of(0), q);
+      load_buf(unit_of(0), q, pa);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -668,9 +683,9 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
     for (int mb = 0; mb < MB; ++mb) acc[h][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
   // tile (set, row group h of the unit, wave, mb): 1 KiB each
   f32x4* tiles = reinterpret_cast<f32x4*>(smem) + lane;
-  auto unit = [&](int i, auto refill_tag) {
+  // one unit's MFMAs; behind every block of eight k-steps its buffers are requested again for (u_next, ps_next)
+  auto mfma_unit = [&](auto refill_tag, int u_next, const PassK& ps_next) {
     constexpr bool REFILL = decltype(refill_tag)::value;
-    const int u_next = unit_of(i + 1);
 #pragma unroll
     for (int q = 0; q < NBUF; ++q) {
 #pragma unroll
@@ -683,10 +698,13 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (REFILL) load_buf(u_next, q);
+      if (REFILL) load_buf(u_next, q, ps_next);
       __builtin_amdgcn_sched_barrier(0);
     }
-    const int set = i & 1;
+  };
+  // the four waves' tiles of a unit summed in wave order: wave w ends up with tile (h, mb) = ((w + 4 k) >> 2, (w + 4 k) & 3)
+  // in sum[k]; tile sets alternate, so one barrier per unit is enough (plain loads in flight survive it)
+  auto reduce_unit = [&](int set, f32x4 (&sum)[RG]) {
 #pragma unroll
     for (int h = 0; h < RG; ++h)
 #pragma unroll
@@ -694,22 +712,70 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
         tiles[(((set * RG + h) * 4 + w) * MB + mb) * 64] = acc[h][mb];
         acc[h][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    __syncthreads();       // (plain loads in flight survive it; the next unit writes the OTHER tile set)
-    // RG * 4 tiles (h, mb), RG per wave: summed over the four waves in order
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < RG; ++k) {
       const int tt = w + 4 * k, h = tt >> 2, mb = tt & 3;
-      f32x4 sum = tiles[(((set * RG + h) * 4 + 0) * MB + mb) * 64];
+      sum[k] = tiles[(((set * RG + h) * 4 + 0) * MB + mb) * 64];
 #pragma unroll
-      for (int ww = 1; ww < 4; ++ww) sum += tiles[(((set * RG + h) * 4 + ww) * MB + mb) * 64];
-      const int rg = RG * unit_of(i) + h;
-      const int col = p.interleaved ? ((rg & 1) ? (p.N >> 1) : 0) + ((rg >> 1) << 4) : (rg << 4);
-      const int m = mb * 16 + c;
-      if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + col + 4 * g) = sum;
+      for (int ww = 1; ww < 4; ++ww) sum[k] += tiles[(((set * RG + h) * 4 + ww) * MB + mb) * 64];
     }
   };
-  for (int i = 0; i < G - 1; ++i) { unit(i, std::true_type{}); if (i < 6) stamp(3 + i); }
-  unit(G - 1, std::false_type{});
+  if constexpr (!EPI) {
+    auto unit = [&](int i, auto refill_tag) {
+      mfma_unit(refill_tag, unit_of(i + 1), pa);
+      f32x4 sum[RG];
+      reduce_unit(i & 1, sum);
+#pragma unroll
+      for (int k = 0; k < RG; ++k) {
+        const int tt = w + 4 * k, h = tt >> 2, mb = tt & 3;
+        const int rg = RG * unit_of(i) + h;
+        const int col = p.interleaved ? ((rg & 1) ? (p.N >> 1) : 0) + ((rg >> 1) << 4) : (rg << 4);
+        const int m = mb * 16 + c;
+        if (m < p.M) *reinterpret_cast<f32x4*>(p.partial + ((int64_t)split * p.M + m) * p.N + col + 4 * g) = sum[k];
+      }
+    };
+    for (int i = 0; i < G - 1; ++i) { unit(i, std::true_type{}); if (i < 6) stamp(3 + i); }
+    unit(G - 1, std::false_type{});
+  } else {
+    // first K half: the units' reduced tiles go to LDS (wave-private pieces: the same wave adds the second half to them)
+    f32x4* part = reinterpret_cast<f32x4*>(smem + 2 * RG * 4 * MB * 1024) + lane;
+    int n_red = 0;
+    for (int i = 0; i < G; ++i) {
+      const bool seam = i + 1 == G;
+      mfma_unit(std::true_type{}, seam ? unit_of(0) : unit_of(i + 1), seam ? pb : pa);
+      f32x4 sum[RG];
+      reduce_unit(n_red++ & 1, sum);
+#pragma unroll
+      for (int k = 0; k < RG; ++k) part[((i * RG + k) * 4 + w) * 64] = sum[k];
+      if (i < 3) stamp(3 + i);
+    }
+    load_x_norm(pb);
+    __builtin_amdgcn_sched_barrier(0);
+    // second K half, then act[m][16 u + 4 g ..+4] = T(T(silu(T(g0 + g1))) * T(u0 + u1)); wave w holds row block w of both
+    // the gate tile (k = 0) and the up tile (k = 1)
+    auto finish = [&](int i, auto refill_tag) {
+      mfma_unit(refill_tag, unit_of(i + 1), pb);
+      f32x4 sum[RG];
+      reduce_unit(n_red++ & 1, sum);
+      f32x4 gt = part[((i * RG + 0) * 4 + w) * 64], up = part[((i * RG + 1) * 4 + w) * 64];
+      gt += sum[0];
+      up += sum[1];
+      const int m = w * 16 + c;
+      if (m < p.M) {
+        u16x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          r[e] = T::from_float(round_to<T>(silu_f32(round_to<T>(gt[e]))) * round_to<T>(up[e]));
+        // piece ((k / 32) * mbl + m / 16) * 64 + ((k % 32) / 8) * 16 + m % 16, element k % 8
+        const int k = (unit_of(i) << 4) + 4 * g;
+        u16* dst = reinterpret_cast<u16*>(p.act) + ((((int64_t)(k >> 5) * mbl + w) * 64 + ((k & 31) >> 3) * 16 + c) << 3) + (k & 7);
+        *reinterpret_cast<u16x4*>(dst) = r;
+      }
+    };
+    for (int i = 0; i < G - 1; ++i) { finish(i, std::true_type{}); if (i < 3) stamp(6 + i); }
+    finish(G - 1, std::false_type{});
+  }
   stamp(11);
 }
 
@@ -891,22 +957,25 @@ bool wide_plan(int64_t N, int64_t K, bool gate_up_packing, int* S, int* KW, int*
 
 constexpr int wide_rg(int kw) { return kw == 20 ? 1 : 2; }      // row groups per work unit (the kernel's RG)
 
-template <typename T, int KW, int NORM>
+template <typename T, int KW, int NORM, int EPI = 0>
 int launch_wide_kw(const XregParams& p, int S, hipStream_t stream) {
   constexpr int RG = wide_rg(KW);
   const int n_units = (int)(p.N >> 4) / RG;
+  if (EPI) S = 1;                                    // both K halves in one workgroup
   int nb = n_cus() / S;
   if (nb < 1) nb = 1;
   if (nb > n_units) nb = n_units;
-  constexpr size_t lds = 2 * RG * 4 * 4 * 1024;      // two tile sets x RG row groups x four waves x MB tiles of 1 KiB
-  {   // up to 64 KiB of dynamic LDS: above the default limit (per device, so not cached in a static)
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_wide_kernel<T, KW, NORM, RG>,
+  size_t lds = 2 * RG * 4 * 4 * 1024;                // two tile sets x RG row groups x four waves x MB tiles of 1 KiB
+  if (EPI) lds += (size_t)((n_units + nb - 1) / nb) * RG * 4 * 1024;      // + a unit's reduced tiles (first K half) per unit of a workgroup
+  if (lds > 150 * 1024) return HX_ERR_SHAPE;
+  {   // up to 64 KiB (EPI: + 8 KiB per unit) of dynamic LDS: above the default limit (per device, so not cached in a static)
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_xreg_wide_kernel<T, KW, NORM, RG, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_rc(e);
   }
   XregHot h;
   if (!xreg_hot<NORM>(p, (unsigned)nb, &h)) return HX_ERR_SHAPE;
-  hx::launcher(gemm_xreg_wide_kernel<T, KW, NORM, RG>, dim3((unsigned)nb, (unsigned)S), 256, lds, stream)(
+  hx::launcher(gemm_xreg_wide_kernel<T, KW, NORM, RG, EPI>, dim3((unsigned)nb, (unsigned)S), 256, lds, stream)(
       h.p0, h.p1, h.p2, h.p3, h.p4, h.a, h.b, h.c, h.ldx, p);
   return check_launch();
 }
@@ -971,14 +1040,18 @@ int wide_product(float* partial, const void* x, const void* packed, int64_t M, i
 // add + RMSNorm fused in front of it (K in ONE packed split)
 int wide_norm_product(float* partial, void* residual, const float* slabs_in, int32_t n_splits_in, const void* norm_weight,
                       float epsilon, void* x_frag, const void* packed, int64_t M, int64_t N, int64_t K, void* sync,
-                      bool gate_up_packing, int dtype, hipStream_t stream) {
+                      bool gate_up_packing, int dtype, hipStream_t stream, void* act = nullptr) {
   int S, KW, pkP, sp;
   if (!wide_plan(N, K, gate_up_packing, &S, &KW, &pkP, &sp) || sp != 1 || K % 8 || K / 8 > 1024) return HX_ERR_SHAPE;
   XregParams p;
-  p.x = x_frag; p.w = packed; p.partial = partial; p.ldx = K; p.act = nullptr;
+  p.x = x_frag; p.w = packed; p.partial = partial; p.ldx = K; p.act = act;
   p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = stagger_bits(); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
   p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.interleaved = gate_up_packing ? 1 : 0; p.pk_P = pkP;
+  if (act) {      // silu * mul in the launch: both K halves in one workgroup (gemm_xreg_wide_kernel, EPI = 1)
+    if (KW != 16 || S != 2 || pkP != 2 * 4 * KW || !gate_up_packing) return HX_ERR_SHAPE;
+    return dtype == HX_F16 ? launch_wide_kw<F16, 16, 1, 1>(p, S, stream) : launch_wide_kw<BF16, 16, 1, 1>(p, S, stream);
+  }
   const int rc = launch_wide<1>(p, S, KW, dtype, stream);
   return rc ? rc : S;
 }
@@ -1160,6 +1233,27 @@ extern "C" int hx_gate_up_xreg(float* partial, const void* x, const void* packed
   if (!aligned16(x) || !aligned16(packed_gate_up) || !aligned16(partial)) return HX_ERR_STRIDE;
   if (partial_bytes < hx_gate_up_xreg_workspace_bytes(M, inter, K)) return HX_ERR_WORKSPACE;
   return wide_product(partial, x, packed_gate_up, M, 2 * inter, K, ldx, x_fragment_major, true, dtype, (hipStream_t)stream);
+}
+
+extern "C" int hx_gate_up_silu_wide_xreg_supported(int64_t M, int64_t inter, int64_t K) {
+  if (M < 33 || M > 64 || !hx_gate_up_xreg_supported(M, inter, K, 1)) return 0;
+  int S, KW, pkP, sp;
+  if (!wide_plan(2 * inter, K, true, &S, &KW, &pkP, &sp)) return 0;
+  return KW == 16 && S == 2 && sp == 1 && pkP == 2 * 4 * KW ? 1 : 0;      // one packing split of two full halves (K = 4096)
+}
+
+extern "C" int hx_norm_gate_up_silu_wide_xreg(void* act, void* residual, const float* slabs_in, int32_t n_splits_in,
+                                              const void* norm_weight, float epsilon, void* x_frag,
+                                              const void* packed_gate_up, int64_t M, int64_t inter, int64_t K, void* sync,
+                                              int dtype, hx_stream stream) {
+  if (!act || !packed_gate_up) return HX_ERR_NULL;
+  int rc = norm_args_ok(residual, slabs_in, n_splits_in, norm_weight, x_frag, sync);
+  if (rc) return rc;
+  if (!hx_gate_up_silu_wide_xreg_supported(M, inter, K)) return HX_ERR_SHAPE;
+  if (dtype != HX_F16 && dtype != HX_BF16) return HX_ERR_DTYPE;
+  if (!aligned16(packed_gate_up) || !aligned16(act)) return HX_ERR_STRIDE;
+  return wide_norm_product(nullptr, residual, slabs_in, n_splits_in, norm_weight, epsilon, x_frag, packed_gate_up, M, 2 * inter, K,
+                           sync, true, dtype, (hipStream_t)stream, act);
 }
 
 extern "C" int hx_norm_gate_up_xreg(float* partial, void* residual, const float* slabs_in, int32_t n_splits_in,

@@ -104,6 +104,8 @@ class LlamaForCausalLM:
         self.fuse_norm = os.environ.get("HX_FUSE_NORM", "1") == "1"
         # batches of 33 .. 64 rows on the same layout (the wide kernel: 6 launches per layer, no LDS-slice copies)
         self.use_wide = os.environ.get("HX_WIDE", "1") == "1"
+        # ... with silu * mul inside the norm + gate|up launch (round 5: both K halves in one workgroup, no slabs)
+        self.use_wide_silu = os.environ.get("HX_WIDE_SILU", "1") == "1"
         self.sample_out: Optional[Tensor] = None   # int64 [rows]: forward() writes the sampled ids here (decode loops)
         self.xreg_sync: Optional[Tensor] = None   # [L, 2, XREG_SYNC_WORDS] of the last step (word 1 = wait gave up)
         self.packed_x: Dict[str, Tensor] = {}
@@ -330,7 +332,8 @@ class LlamaForCausalLM:
             nf_gu = bool(xreg and self.fuse_norm and fused and hip_gemm.norm_xreg_supported(n, 2 * inter, hid, dtype, gate_up=True))
         nf_qkv = bool(xreg and self.fuse_norm and f"l{L - 1}.wqkv" in self.packed_x
                       and hip_gemm.norm_xreg_supported(n, qkv_n, hid, dtype))
-        return {"xreg": xreg, "fused": fused, "nf_gu": nf_gu, "nf_qkv": nf_qkv, "wide": wide}
+        wide_silu = bool(wide and nf_gu and self.use_wide_silu and hip_gemm.gate_up_silu_wide_supported(n, inter, hid, dtype))
+        return {"xreg": xreg, "fused": fused, "nf_gu": nf_gu, "nf_qkv": nf_qkv, "wide": wide, "wide_silu": wide_silu}
 
     def _decode_hidden_hip_gemm(self, h: Tensor, position_ids: Tensor,
                                 model_params: LanguageModelParameters, x0: Optional[Tensor] = None,
@@ -374,8 +377,10 @@ class LlamaForCausalLM:
             if nf_qkv:   # the fused launch reads the down slabs (ws) while it writes the qkv slab
                 ws_q = torch.empty(max(hip_gemm.xreg_workspace_floats(n, qkv_n, hid), hip_gemm.workspace_floats(n, qkv_n, hid)),
                                    dtype=torch.float32, device=h.device)
-            if wide:     # gate|up slabs of the wide product (the norm-fused form reads the o slabs in ws meanwhile)
+            wide_silu = bool(wide and nf_gu and dp["wide_silu"])
+            if wide and not wide_silu:     # gate|up slabs of the wide product (the norm-fused form reads the o slabs in ws meanwhile)
                 ws_gu = torch.empty(hip_gemm.gate_up_xreg_workspace_floats(n, inter, hid), dtype=torch.float32, device=h.device)
+            actf_w = torch.empty(hip_gemm.fragment_major_elems(n, inter), dtype=h.dtype, device=h.device) if wide_silu else None
         if x0 is not None:
             x = x0          # the first layer's norm came with the embedding gather
         else:
@@ -404,12 +409,17 @@ class LlamaForCausalLM:
                 pgu, pdn = self.packed_x[f"l{l}.wgu"], self.packed_x[f"l{l}.wdown"]
                 if wide:
                     # 33 .. 64 rows: (norm +) gate|up to two slabs, then silu*mul (fragment-major for the down product)
-                    if nf_gu:
-                        s_gu = hip_gemm.norm_gate_up_xreg(h, ws, s_o, st[f"l{l}.norm2"], eps, xf, pgu, inter, ws_gu, sync[l, 0])
+                    if wide_silu:
+                        # silu * mul inside the same launch (both K halves in one workgroup): 5 launches per layer, no slabs
+                        hip_gemm.norm_gate_up_silu_wide_xreg(h, ws, s_o, st[f"l{l}.norm2"], eps, xf, pgu, inter, actf_w, sync[l, 0])
+                        a_f = actf_w
                     else:
-                        add_rms_norm_slabs(xf, h, ws, s_o, st[f"l{l}.norm2"], eps, fragment_major=True)
-                        s_gu = hip_gemm.gate_up_xreg(xf, pgu, inter, ws_gu, frag_shape=(n, hid))
-                    a_f = silu_and_mul_slabs(ws_gu, s_gu, n, inter, h.dtype, fragment_major=True)
+                        if nf_gu:
+                            s_gu = hip_gemm.norm_gate_up_xreg(h, ws, s_o, st[f"l{l}.norm2"], eps, xf, pgu, inter, ws_gu, sync[l, 0])
+                        else:
+                            add_rms_norm_slabs(xf, h, ws, s_o, st[f"l{l}.norm2"], eps, fragment_major=True)
+                            s_gu = hip_gemm.gate_up_xreg(xf, pgu, inter, ws_gu, frag_shape=(n, hid))
+                        a_f = silu_and_mul_slabs(ws_gu, s_gu, n, inter, h.dtype, fragment_major=True)
                 elif nf_gu:
                     hip_gemm.norm_gate_up_silu_xreg(h, ws, s_o, st[f"l{l}.norm2"], eps, xf, pgu, inter, actf, sync[l, 0])
                     a_f = actf

@@ -278,6 +278,17 @@ int hx_norm_gate_up_xreg(float* partial, void* residual, const float* slabs_in, 
                          const void* norm_weight, float epsilon, void* x_frag, const void* packed_gate_up,
                          int64_t M, int64_t inter, int64_t K, void* sync, int64_t partial_bytes, int dtype,
                          hx_stream stream);
+/* hx_norm_gate_up_silu_wide_xreg (round 5): the norm-fused gate|up product of 33 .. 64 rows WITH silu * mul — one launch
+ * and no slabs instead of hx_norm_gate_up_xreg + hx_silu_and_mul_slabs.  A workgroup does BOTH K halves of its (gate, up)
+ * row-group pairs one after the other (x of the first half, all its units — their reduced tiles wait in LDS —, x of the
+ * second half, the units again) and writes act (fragment-major, ceil(M / 16) row blocks, as hx_silu_and_mul_slabs_ex with
+ * out_fragment_major) with the same order of summation and the same roundings: bit-identical to the two-launch form.
+ * Supported where the packing's one split is two full halves of 16 k-steps per wave (K = 4096: LLaVA-1.5-7B). */
+int hx_gate_up_silu_wide_xreg_supported(int64_t M, int64_t inter, int64_t K);
+int hx_norm_gate_up_silu_wide_xreg(void* act, void* residual, const float* slabs_in, int32_t n_splits_in,
+                                   const void* norm_weight, float epsilon, void* x_frag,
+                                   const void* packed_gate_up, int64_t M, int64_t inter, int64_t K, void* sync,
+                                   int dtype, hx_stream stream);
 int hx_gate_up_silu_xreg_supported(int64_t M, int64_t inter, int64_t K);
 int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed_gate_up, int64_t M,
                          int64_t inter, int64_t K, int64_t ldx, int x_fragment_major, int dtype,

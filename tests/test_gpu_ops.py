@@ -779,3 +779,54 @@ def test_copy_words2_moves_words_between_device_and_pinned_memory():
     assert lib.hx_copy_words2(None, None, 0, None, None, 0, _lib.current_stream()) == 0
     assert lib.hx_copy_words2(d.data_ptr() + 2, host_in.data_ptr(), 4, None, None, 0, _lib.current_stream()) != 0
     assert lib.hx_copy_words2(None, host_in.data_ptr(), 4, None, None, 0, _lib.current_stream()) != 0
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_wide_gate_up_with_silu_in_the_launch_is_bit_identical(dt):
+    """hx_norm_gate_up_silu_wide_xreg (33 .. 64 rows: a workgroup does both K halves of its (gate, up) pairs and writes
+    silu(gate) * up itself — no slabs) == hx_norm_gate_up_xreg + hx_silu_and_mul_slabs_ex: residual, x and act bit for bit,
+    repeated launches with changing inputs, also with the rescue path alone; rows past M of the last 16-row block are
+    never written."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel import gemm
+    from hydrainfer_amd._C.kernel.activation import silu_and_mul_slabs
+    lib = _lib.lib()
+    hid, inter = 4096, 11008
+    assert gemm.gate_up_silu_wide_supported(64, inter, hid, dt) and gemm.gate_up_silu_wide_supported(33, inter, hid, dt)
+    assert not gemm.gate_up_silu_wide_supported(32, inter, hid, dt)        # <= 32 rows: the one-split kernel's own epilogue
+    assert not gemm.gate_up_silu_wide_supported(64, 13824, 5120, dt)      # 13B: 20 k-steps per wave, one row group per unit
+    assert not gemm.gate_up_silu_wide_supported(64, 2816, 1024, dt)       # K = 1024: halves of 4 k-steps per wave (not built)
+    g = torch.Generator().manual_seed(5)
+    nw = torch.randn(hid, generator=g).to(dt).to(DEV)
+    wgu = (torch.randn((2 * inter, hid), generator=g) * 0.03).to(dt).to(DEV)
+    pg = gemm.pack_weight_xreg(wgu, interleave_halves=True)
+    for M, n_it in ((64, 16), (33, 6), (48, 6)):
+        xf, xf2 = (torch.zeros(gemm.fragment_major_elems(M, hid), dtype=dt, device=DEV) for _ in range(2))
+        ga = torch.zeros(gemm.gate_up_xreg_workspace_floats(M, inter, hid), dtype=torch.float32, device=DEV)
+        sync = torch.zeros((2 * n_it + 2, gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=DEV)
+        act = torch.full((gemm.fragment_major_elems(M, inter),), 7.0, dtype=dt, device=DEV)
+        for it in range(n_it):
+            slabs = torch.randn((4, M, hid), generator=g).to(DEV)
+            h = torch.randn((M, hid), generator=g).to(dt).to(DEV)
+            h1, h2 = h.clone(), h.clone()
+            s = gemm.norm_gate_up_xreg(h1, slabs, 4, nw, 1e-5, xf, pg, inter, ga, sync[2 * it])
+            want = silu_and_mul_slabs(ga, s, M, inter, dt, fragment_major=True)
+            gemm.norm_gate_up_silu_wide_xreg(h2, slabs, 4, nw, 1e-5, xf2, pg, inter, act, sync[2 * it + 1])
+            torch.cuda.synchronize()
+            assert torch.equal(h1, h2), f"residual M={M} it={it}"
+            assert torch.equal(gemm.from_fragment_major(xf, M, hid), gemm.from_fragment_major(xf2, M, hid))
+            assert torch.equal(gemm.from_fragment_major(act, M, inter), gemm.from_fragment_major(want, M, inter)), f"act M={M} it={it}"
+        pad = (M + 15) // 16 * 16
+        if pad > M:      # rows M .. of the last block keep what the buffer held
+            full = act.view(inter // 32, pad // 16, 4, 16, 8)       # [k / 32][row block][(k % 32) / 8][row % 16][k % 8]
+            assert bool((full[:, -1, :, M % 16:, :] == 7.0).all())
+        assert lib.hx_debug_set_option(b"xreg_no_producers", 1) == 0
+        try:
+            h3 = h.clone()
+            act2 = torch.zeros_like(act)
+            gemm.norm_gate_up_silu_wide_xreg(h3, slabs, 4, nw, 1e-5, xf2, pg, inter, act2, sync[2 * n_it])
+            torch.cuda.synchronize()
+        finally:
+            lib.hx_debug_set_option(b"xreg_no_producers", 0)
+        assert torch.equal(h3, h1) and torch.equal(gemm.from_fragment_major(act2, M, inter), gemm.from_fragment_major(want, M, inter))
+        assert int(sync[:, 1].abs().sum()) == 0

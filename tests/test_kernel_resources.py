@@ -47,8 +47,9 @@ def test_register_budgets_of_the_benchmarked_instantiations(table):
     for name in ("gemm_xreg_kernel<BF16, 2, 32, 1, 0, 1>", "gemm_xreg_kernel<BF16, 2, 32, 0, 0, 1>",
                  "gemm_xreg_kernel<BF16, 2, 22, 0, 0, 0>", "gemm_xreg_kernel<BF16, 2, 40, 1, 0, 1>",
                  "gemm_xreg_kernel<BF16, 2, 40, 0, 0, 1>", "gemm_xreg_kernel<BF16, 2, 27, 0, 0, 0>",
-                 "gemm_xreg_wide_kernel<BF16, 16, 1, 2>", "gemm_xreg_wide_kernel<BF16, 11, 0, 2>",
-                 "gemm_xreg_wide_kernel<BF16, 20, 1, 1>", "gemm_xreg_wide_kernel<BF16, 14, 0, 2>"):
+                 "gemm_xreg_wide_kernel<BF16, 16, 1, 2, 0>", "gemm_xreg_wide_kernel<BF16, 16, 1, 2, 1>",
+                 "gemm_xreg_wide_kernel<BF16, 11, 0, 2, 0>", "gemm_xreg_wide_kernel<BF16, 20, 1, 1, 0>",
+                 "gemm_xreg_wide_kernel<BF16, 14, 0, 2, 0>"):
         r = by[name]
         assert r["vgpr_count"] <= 512 and r.get("private_segment_fixed_size", 0) == 0, r
 
