@@ -324,7 +324,7 @@ class LlamaForCausalLM:
         L, hid, inter = sh.num_hidden_layers, sh.hidden_size, sh.intermediate_size
         qkv_n = self.q_size + 2 * self.kv_size
         xreg = self.use_xreg and self._xreg_mlp_ok(n) and f"l{L - 1}.wdown" in self.packed_x
-        wide = bool(xreg and n > 32)       # 33 .. 64 rows: two K splits per product, silu*mul as its own launch (6 launches per layer)
+        wide = bool(xreg and n > 32)       # 33 .. 64 rows: two K splits per product; 6 launches per layer, 5 where wide_silu
         fused = xreg and not wide and hip_gemm.gate_up_silu_supported(n, inter, hid, dtype)
         if wide:
             nf_gu = bool(self.fuse_norm and hip_gemm.gate_up_xreg_supported(n, inter, hid, dtype, with_norm=True))
