@@ -139,7 +139,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
 // OWNERSHIP: a row is computed by whoever first exchanges its state word 0 -> 1 (thread 0; the answer
 // travels with the reduction barrier, so claiming costs no extra round trip); everybody else returns
 // false without having stored anything — the residual is updated exactly once.
-template <typename T, int MAXV, int MB>
+template <typename T, int MAXV, int MB, int KB = 6>      // KB: slab pieces requested per round trip (the wide kernel's down hands over 8)
 __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, int n_splits, int64_t slab_stride,
                                              u16* __restrict__ residual, const u16* __restrict__ weight, float eps,
                                              int hidden, int row, void* x_frag, uint32_t* state, float* red,
@@ -170,7 +170,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
         // slab pieces: all loads of a batch of 6 splits before the first add, adds in split order
         // (norm_rope_act.hip slab_sum8)
         const float* pp = partial + (int64_t)row * hidden + i * 8;
-        constexpr int kB = 6;
+        constexpr int kB = KB;
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
         for (int s0 = 0; s0 < n_splits; s0 += kB) {
           f32x4 pa[kB], pb[kB];
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void gemm_xreg_wide_kernel(HX_XREG_HOT_SIG, co
     float* red = reinterpret_cast<float*>(smem);
     int* cmd = reinterpret_cast<int*>(smem) + 16;
     auto produce = [&](int row) {
-      const bool own = norm_row_256<T, (2 * KW + 31) / 32, MB>(p.nm_partial, p.nm_splits, (int64_t)p.M * p.K,
+      const bool own = norm_row_256<T, (2 * KW + 31) / 32, MB, 8>(p.nm_partial, p.nm_splits, (int64_t)p.M * p.K,
                                                                reinterpret_cast<u16*>(p.nm_residual),
                                                                reinterpret_cast<const u16*>(p.nm_weight), p.nm_eps, p.K, row,
                                                                const_cast<void*>(p.x), st, red, mbl);
