@@ -800,7 +800,7 @@ def test_wide_gate_up_with_silu_in_the_launch_is_bit_identical(dt):
     nw = torch.randn(hid, generator=g).to(dt).to(DEV)
     wgu = (torch.randn((2 * inter, hid), generator=g) * 0.03).to(dt).to(DEV)
     pg = gemm.pack_weight_xreg(wgu, interleave_halves=True)
-    for M, n_it in ((64, 16), (33, 6), (48, 6)):
+    for M, n_it in ((64, 16), (33, 6), (48, 6), (52, 4), (36, 4)):      # (the engine pads decode batches to multiples of 4)
         xf, xf2 = (torch.zeros(gemm.fragment_major_elems(M, hid), dtype=dt, device=DEV) for _ in range(2))
         ga = torch.zeros(gemm.gate_up_xreg_workspace_floats(M, inter, hid), dtype=torch.float32, device=DEV)
         sync = torch.zeros((2 * n_it + 2, gemm.XREG_SYNC_WORDS), dtype=torch.int32, device=DEV)
