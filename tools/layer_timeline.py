@@ -35,6 +35,8 @@ def main():
         must = os.environ.get("TIMELINE_MUST_CONTAIN")      # e.g. gemm_xreg_wide: the 64-row steps of bench.py's whole_step_64
         if must and not any(must in r[2] for r in seg):
             continue
+        if not must and any("gemm_xreg_wide" in r[2] for r in seg):
+            continue      # (a 64-row step has had the 32-row step's launch count since the wide layer went to 5 launches)
         span = seg[-1][1] - seg[0][0]
         steps.append((span, a, b))
     if not steps:
