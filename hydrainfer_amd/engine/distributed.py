@@ -64,7 +64,8 @@ def rcb_to_wire(rcb: RequestControlBlock) -> dict:
             "metadata": None if md is None else dataclasses.astuple(md),
             "kv": _cache_to_wire(rcb.virtual_kv_cache), "image": _cache_to_wire(rcb.virtual_image_cache),
             "output_token_ids": list(rcb.output_token_ids), "scenario": int(rcb.scenario_type or 0),
-            "metric": dataclasses.asdict(rcb.metric), "stream_rank": rcb.stream_rank}
+            "metric": dataclasses.asdict(rcb.metric), "stream_rank": rcb.stream_rank,
+            "path": list(getattr(rcb, "path", []))}
 
 
 def rcb_from_wire(w: dict) -> RequestControlBlock:
@@ -78,6 +79,7 @@ def rcb_from_wire(w: dict) -> RequestControlBlock:
     rcb.scenario_type = ScenarioType(w["scenario"])
     rcb.metric = RequestMetric(**w["metric"])
     rcb.stream_rank = w.get("stream_rank")
+    rcb.path = list(w.get("path", []))       # the ranks that have owned this request, in order
     b = InstructionListBuilder()
     fills: List[Fill] = []
     for rec in w["instructions"]:
@@ -195,14 +197,17 @@ class RankEngine:
         # serving front end on this rank (entrypoint/api_server.py): request id -> the OutputTokenProcessor that streams it
         self.token_handlers: Dict[object, object] = {}
         self.creator = None          # InstructionCreator for requests submitted by another rank's front end
+        self._n_submitted = [0, 0]   # front door: requests so far [text-only, with image] (one round robin per kind)
 
     # ---- serving: a front end on ONE rank, requests entering where the routing rule says, tokens coming back ----------
-    def submit(self, request, processor, creator, request_index: int) -> None:
+    def submit(self, request, processor, creator, request_index: int = 0) -> None:
         """Front-end side: start `request` on the rank cluster.py:178-184 picks (image requests round-robin over the E
-        ranks, text-only ones over the P ranks); its tokens — sampled on whichever ranks run its prefill and decode —
-        are delivered to `processor` on THIS rank."""
+        ranks, text-only ones over the P ranks — two balancers, each with its own cursor); its tokens — sampled on
+        whichever ranks run its prefill and decode — are delivered to `processor` on THIS rank."""
         self.token_handlers[request.request_id] = processor
-        dst = entry_rank(request_index, self.roles, request.pixel_values is not None)
+        has_image = request.pixel_values is not None
+        dst = entry_rank(self._n_submitted[has_image], self.roles, has_image)
+        self._n_submitted[has_image] += 1
         if dst == self.rank:
             try:
                 self._start(request, creator, self.rank)
@@ -215,6 +220,7 @@ class RankEngine:
     def _start(self, request, creator, stream_rank: int) -> None:
         rcb = creator.process(request)
         rcb.stream_rank = stream_rank
+        rcb.path = [self.rank]
         self._attach_stream(rcb)
         self.node.add_request(rcb)
 
@@ -260,6 +266,7 @@ class RankEngine:
     def _deliver(self, src_rank: int, kind: str, payload) -> None:
         if kind == "migrate":
             rcb = rcb_from_wire(payload)
+            rcb.path.append(self.rank)
             self._attach_stream(rcb)
             self.node.migrate(self.peers[src_rank], rcb)
         elif kind == "token":
@@ -316,19 +323,29 @@ class _LocalStream:
         self.engine._token(self.request_id, int(token_id), bool(is_last_token))
 
 
-def entry_rank(request_index: int, roles: List[str], has_image: bool) -> int:
-    """cluster.py:178-184: image requests round-robin over the E nodes, text-only over the P nodes."""
+def entry_rank(kind_ordinal: int, roles: List[str], has_image: bool) -> int:
+    """cluster.py:178-184: image requests round-robin over the E nodes (`ebalancer`), text-only ones over the P nodes
+    (`pbalancer`) — two independent cursors, so `kind_ordinal` counts the requests OF THE SAME KIND seen so far."""
     ranks = [r for r, t in enumerate(roles) if ("E" if has_image else "P") in t]
-    return ranks[request_index % len(ranks)]
+    return ranks[kind_ordinal % len(ranks)]
+
+
+def entry_ranks(requests, roles: List[str]) -> List[int]:
+    """The front door applied to a whole trace in arrival (list) order."""
+    seen, out = [0, 0], []
+    for r in requests:
+        has_image = r.pixel_values is not None
+        out.append(entry_rank(seen[has_image], roles, has_image))
+        seen[has_image] += 1
+    return out
 
 
 def replay_distributed(engine: RankEngine, creator, requests, arrivals: List[float], t0: float,
                        device: Optional[torch.device] = None, deadline_s: float = 600.0) -> dict:
     """Every rank runs this with the same request list; a request enters at the rank
     `entry_rank` names.  Returns this rank's finished requests' metrics."""
-    mine = sorted((i for i, r in enumerate(requests)
-                   if entry_rank(i, engine.roles, r.pixel_values is not None) == engine.rank),
-                  key=lambda i: arrivals[i])
+    door = entry_ranks(requests, engine.roles)
+    mine = sorted((i for i in range(len(requests)) if door[i] == engine.rank), key=lambda i: arrivals[i])
     from hydrainfer_amd.engine.serve import ADMIT_PER_STEP, quiet_gc
     nxt, total = 0, len(requests)
     first_finished = len(engine.node.finished)
@@ -340,6 +357,7 @@ def replay_distributed(engine: RankEngine, creator, requests, arrivals: List[flo
                 admitted += 1
                 i = mine[nxt]
                 rcb = creator.process(requests[i])
+                rcb.path = [engine.rank]
                 engine.node.add_request(rcb)
                 rcb.metric.arrival_time = t0 + arrivals[i]
                 nxt += 1
@@ -357,7 +375,7 @@ def replay_distributed(engine: RankEngine, creator, requests, arrivals: List[flo
         torch.cuda.synchronize(device)
     return {r.request_id: {"arrival": r.metric.arrival_time, "token_times": list(r.metric.token_times),
                            "tokens": list(r.output_token_ids), "ep_transfer": list(r.metric.ep_transfer),
-                           "pd_transfer": list(r.metric.pd_transfer)}
+                           "pd_transfer": list(r.metric.pd_transfer), "path": list(getattr(r, "path", []))}
             for r in engine.node.finished[first_finished:]}
 
 
@@ -370,7 +388,11 @@ def summarize(per_request: Dict[int, dict], t0: float) -> dict:
     hop = lambda key: sorted(r[key][1] - r[key][0] for r in rs if len(r[key]) == 2)
     pct = lambda xs, p: xs[min(len(xs) - 1, int(p * len(xs)))] if xs else None
     ms = lambda v: None if v is None else round(v * 1e3, 3)
-    return {"requests": len(rs), "output_tokens": n_out, "wall_s": round(end - t0, 3),
+    pairs: Dict[str, int] = {}
+    for r in rs:            # hand-overs per (sender rank -> receiver rank) pair: the many-to-many routing at a glance
+        for a, b in zip(r.get("path", []), r.get("path", [])[1:]):
+            pairs[f"{a}->{b}"] = pairs.get(f"{a}->{b}", 0) + 1
+    return {"requests": len(rs), "output_tokens": n_out, "wall_s": round(end - t0, 3), "pulls_per_pair": pairs,
             "output_tok_s": round(n_out / (end - t0), 1),
             "ttft_mean_ms": ms(sum(ttft) / len(ttft)),
             "ttft_p50_ms": ms(pct(ttft, 0.5)), "ttft_p99_ms": ms(pct(ttft, 0.99)),

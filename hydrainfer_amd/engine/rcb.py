@@ -80,6 +80,7 @@ class RequestControlBlock:
         self.stream_rank: Optional[int] = None    # multi-process serving: the rank whose front end streams this request's
                                                   # tokens to a client (engine/distributed.py: the reference pushes them
                                                   # over zmq from every node, hydrainfer/engine/output_token_processor.py:92-140)
+        self.path: List[int] = []                 # multi-process serving: the ranks that have owned this request, in order
 
     def current_instruction(self) -> Instruction:
         return self.instructions.curr

@@ -25,11 +25,11 @@ def _free_port():
     return p
 
 
-def _requests():
+def _requests(n=14):
     from hydrainfer_amd.engine import SamplingParameters, TokenRequest
     g = torch.Generator().manual_seed(31)
     reqs = []
-    for i in range(14):
+    for i in range(n):
         text = torch.randint(1000, 31999, (5 + (i * 7) % 40,), generator=g).tolist()
         has_image = i % 5 != 4
         reqs.append(TokenRequest(i, ([IMAGE_TOKEN] if has_image else []) + text,
@@ -114,7 +114,7 @@ def _worker(rank, roles, port, q, sendrecv=False):
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
         engine, kv, img = _build_engine(rank, roles, None, sendrecv)
-        reqs = _requests()
+        reqs = _requests(14 if world < 8 else 40)
         arrivals = [0.002 * i for i in range(len(reqs))]
         box = [time.perf_counter() + 0.05]
         if world > 1:
@@ -149,6 +149,7 @@ def _worker(rank, roles, port, q, sendrecv=False):
             d_ranks = [r for r, t in enumerate(roles) if "D" in t]
             for r in range(world):           # requests finish on D ranks only
                 assert (len(allr[r][0]) > 0) == (r in d_ranks), f"rank {r} finished {len(allr[r][0])}"
+            _check_routing(roles, reqs, merged, {r: allr[r][0] for r in range(world)})
             if world > 1:
                 assert sum(a[1] for a in allr) > 0          # KV blocks were pulled P -> D
                 if "E" in roles:
@@ -159,6 +160,43 @@ def _worker(rank, roles, port, q, sendrecv=False):
     except Exception:  # pragma: no cover
         import traceback
         q.put((rank, traceback.format_exc()))
+
+
+def _check_routing(roles, reqs, merged, finished_on):
+    """What only a many-to-many topology shows (BASELINE configs[4] = 2E + 2P + 4D): the front door's two round robins
+    (hydrainfer/cluster/cluster.py:178-184), every hop's round robin over ALL its downstream nodes
+    (cluster/epdnode.py:56-75,419-420), every D rank finishing requests pulled from EVERY P pool."""
+    from collections import Counter
+    e = [r for r, t in enumerate(roles) if "E" in t]
+    p_ = [r for r, t in enumerate(roles) if "P" in t]
+    d = [r for r, t in enumerate(roles) if "D" in t]
+    seen = [0, 0]
+    for i, r in enumerate(reqs):
+        has_image = r.pixel_values is not None
+        door = (e if has_image else p_)[seen[has_image] % len(e if has_image else p_)]
+        seen[has_image] += 1
+        path = merged[i]["path"]
+        assert path[0] == door, f"request {i}: entered at rank {path[0]}, the front door says {door}"
+        # E -> P -> D, a node never hands a request to itself, and the last owner is a D rank that finished it
+        want = ["E"] * has_image + ["P", "D"]
+        stages, k = [], 0
+        for rank in path:
+            while k < len(want) and want[k] in roles[rank]:
+                k += 1
+            stages.append(k)
+        assert k == len(want) and all(a != b for a, b in zip(path, path[1:])), (i, path)
+        assert i in finished_on[path[-1]], (i, path)
+    hops = Counter((a, b) for m in merged.values() for a, b in zip(m["path"], m["path"][1:]))
+    for senders, receivers in ((e, p_), (p_, d)):
+        for s_ in senders:
+            counts = [hops[(s_, r)] for r in receivers if r != s_]
+            if "EPD" == roles[s_] or not counts or sum(counts) == 0:
+                continue
+            # a round robin over the downstream nodes: every one of them is visited, evenly
+            assert min(counts) > 0 and max(counts) - min(counts) <= 1, (s_, receivers, counts)
+    if len(p_) > 1 and len(d) > 1:
+        for rank in d:              # a D rank holds KV pulled from BOTH P pools
+            assert {m["path"][-2] for i, m in merged.items() if m["path"][-1] == rank} == set(p_), rank
 
 
 def test_rcb_wire_round_trip():
@@ -185,7 +223,10 @@ def test_rcb_wire_round_trip():
     assert back.sampling_params.max_tokens == rcb.sampling_params.max_tokens and first is not None
 
 
-@pytest.mark.parametrize("roles", [["EPD"], ["EP", "D"], ["E", "P", "D"], ["E", "P", "D", "D"]], ids="-".join)
+HYBRID_POOL = ["E", "E", "P", "P", "D", "D", "D", "D"]          # BASELINE configs[4], hydrainfer/config/cluster/hybrid.yaml
+
+
+@pytest.mark.parametrize("roles", [["EPD"], ["EP", "D"], ["E", "P", "D"], ["E", "P", "D", "D"], HYBRID_POOL], ids="-".join)
 def test_distributed_engine_protocol(roles):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -199,7 +240,7 @@ def test_distributed_engine_protocol(roles):
     assert sorted(results) == [(r, "ok") for r in range(len(roles))], results
 
 
-@pytest.mark.parametrize("roles", [["EP", "D"], ["E", "P", "D"]], ids="-".join)
+@pytest.mark.parametrize("roles", [["EP", "D"], ["E", "P", "D"], ["E", "P", "D", "D"], HYBRID_POOL], ids="-".join)
 def test_distributed_engine_send_recv_pull(roles):
     """The transfer path of ranks that cannot map each other's pool (different hosts, or
     intranode_migrate_backend='nccl'): the receiver asks the sender for its half of the send/recv
