@@ -50,6 +50,19 @@ def plan_block_tables(n_requests: int, prompt_len: int, n_generate: int, block_s
     return tables
 
 
+def ragged_contexts(kind, B=32, seed=0):
+    """The two ragged decode batches bench.py's `whole_step_ragged` times (BASELINE configs[2] "mixed image+text"):
+    'uniform' = lengths drawn uniformly from 64..959; 'bimodal' = half text-only requests (~130 keys) and half image
+    requests (~830 keys), in arrival (shuffled) order.  One definition for the benchmark and the tests."""
+    g = torch.Generator().manual_seed(seed)
+    if kind == "uniform":
+        return torch.randint(64, 960, (B,), generator=g).tolist()
+    assert kind == "bimodal"
+    lens = [130 + int(j) for j in torch.randint(-8, 9, (B // 2,), generator=g)] + \
+           [830 + int(j) for j in torch.randint(-8, 9, (B - B // 2,), generator=g)]
+    return [lens[i] for i in torch.randperm(B, generator=g).tolist()]
+
+
 @dataclass
 class RunnerConfig:
     batch: int = 32
@@ -198,6 +211,16 @@ class DecodeRunner:
         prefill (the cache then holds its randn fill — used by kernel-only measurements)."""
         self.positions.fill_(kv_len - 1)
         self.kv_lens.fill_(kv_len)
+        if input_ids is not None:
+            self.input_ids.copy_(input_ids)
+        self.tokens = []
+
+    def set_state_lens(self, kv_lens: List[int], input_ids: Optional[Tensor] = None) -> None:
+        """set_state with one length per sequence (a ragged decode batch)."""
+        assert len(kv_lens) == self.cfg.batch and max(kv_lens) + 1 <= self.max_len and min(kv_lens) >= 1
+        lens = torch.tensor(kv_lens, dtype=torch.int32, device=self.dev)
+        self.positions.copy_(lens - 1)
+        self.kv_lens.copy_(lens)
         if input_ids is not None:
             self.input_ids.copy_(input_ids)
         self.tokens = []

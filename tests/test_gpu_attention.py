@@ -224,6 +224,37 @@ def test_decode_property_at_full_size(dt, H):
     assert_close_t(o3, 0.5 * o1 + o2, 3 * tol, 3 * tol, what="linearity in V")
 
 
+from hydrainfer_amd.model.runner import ragged_contexts  # noqa: E402  (one definition for bench.py and the tests)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "bimodal"])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_ragged_decode_at_full_size(dt, kind):
+    """The reference's scheduler makes ragged decode batches every step (hydrainfer/engine/scheduler.py:99-194): B=32,
+    H=32, D=128 with the benchmark's two ragged length sets; the shortest, the longest and three more sequences against
+    the oracle, every split setting, plus linearity in V over ALL sequences."""
+    from oracle import ops
+    B, H, D = 32, 32, 128
+    tol = ATTN_TOL[dt][0]
+    kv = ragged_contexts(kind)
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(B, H, H, D, kv, [1] * B, dt, seed=4)
+    outs = {s_: _run(q, kc, vc, cu_q, cu_k, bt, cu_b, 1, max(kv), num_splits=s_) for s_ in (0, 1, 3)}
+    order = sorted(range(B), key=lambda b: kv[b])
+    for b in (order[0], order[-1], order[B // 2], 0, B - 1):
+        sl = slice(b, b + 1)
+        ref = ops.paged_attention(q[sl], kc, vc, torch.tensor([0, 1], dtype=torch.int32),
+                                  torch.tensor([0, kv[b]], dtype=torch.int32),
+                                  bt[int(cu_b[b]):int(cu_b[b + 1])],
+                                  torch.tensor([0, int(cu_b[b + 1] - cu_b[b])], dtype=torch.int32))
+        for s_, out in outs.items():
+            assert_close_t(out[sl], ref, tol, tol, what=f"ragged {kind} seq {b} (kv {kv[b]}) splits={s_}")
+    v2 = torch.randn(vc.shape, generator=torch.Generator().manual_seed(2)).to(dt)
+    o1 = outs[0].float()
+    o2 = _run(q, kc, v2, cu_q, cu_k, bt, cu_b, 1, max(kv)).float()
+    o3 = _run(q, kc, (0.5 * vc.float() + v2.float()).to(dt), cu_q, cu_k, bt, cu_b, 1, max(kv)).float()
+    assert_close_t(o3, 0.5 * o1 + o2, 3 * tol, 3 * tol, what="linearity in V, ragged")
+
+
 def test_argument_errors_raise():
     from hydrainfer_amd._C.kernel.flash_attn import mha_varlen_fwd
     from hydrainfer_amd._lib import HydraHipError
