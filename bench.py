@@ -69,6 +69,8 @@ def parse():
                         "incl. building 13 GB of weights): cpu_baseline.config0_full and full_over_extrapolated")
     p.add_argument("--no-13b", action="store_true", help="skip the short LLaVA-1.5-13B leg (BASELINE configs[2])")
     p.add_argument("--steps-13b", type=int, default=20)
+    p.add_argument("--no-ranked", action="store_true",
+                   help="decode attention on the static (head, sequence) grid instead of the length-ranked one (A/B; attn_decode.hip)")
     p.add_argument("--no-ragged", action="store_true", help="skip whole_step_ragged (the decode step on ragged batches)")
     p.add_argument("--no-null-step", action="store_true",
                    help="skip whole_step.null_step (the launch structure's ceiling: the step with math-free stand-in launches)")
@@ -205,7 +207,7 @@ def time_attention_kernel(runner, ctxs):
     the timed region, HIP events on the launch stream (torch's current stream).  MEAN over
     launches and replays, not the best one."""
     import math
-    from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, mha_varlen_fwd
+    from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, decode_rank, mha_varlen_fwd
     sh = runner.model.shape
     B = runner.cfg.batch
     H, HK, D = sh.num_attention_heads, sh.num_key_value_heads, sh.head_dim
@@ -234,7 +236,7 @@ def time_attention_kernel(runner, ctxs):
         if fused:
             decode_attention_fused(out, q, k_new, v_new, kc, vc, runner.positions, runner.model.cos_sin,
                                    ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens,
-                                   ap.block_tables, ap.cu_blocks_lens, runner.max_len, scale, 0, slabs, n_slabs)
+                                   ap.block_tables, ap.cu_blocks_lens, runner.max_len, scale, 0, slabs, n_slabs, ap.decode_rank)
         else:
             mha_varlen_fwd(out, q, kc, vc, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
                            ap.cu_blocks_lens, None, 1, runner.max_len, scale, 0.0, -1, 0, 0)
@@ -254,16 +256,17 @@ def time_attention_kernel(runner, ctxs):
             cu = [0]
             for l_ in lens:
                 cu.append(cu[-1] + l_)
+            cu_t = torch.tensor(cu, **i32)
             metas.append((torch.tensor([l_ - 1 for l_ in lens], **i32),
                           torch.tensor([runner.tables[b][(lens[b] - 1) // bs] * bs + (lens[b] - 1) % bs for b in range(B)], **i32),
-                          torch.tensor(cu, **i32)))
+                          cu_t, decode_rank(cu_t)))      # (the step's rank descriptor, as its step head would leave it)
 
         def launch_step(m, i=0):
             kc, vc = layer_caches[i % len(layer_caches)]
             if fused:
                 decode_attention_fused(out, q, k_new, v_new, kc, vc, m[0], runner.model.cos_sin, m[1],
                                        ap.q_cu_seq_lens, m[2], ap.block_tables, ap.cu_blocks_lens,
-                                       runner.max_len, scale, 0, slabs, n_slabs)
+                                       runner.max_len, scale, 0, slabs, n_slabs, m[3])
             else:
                 mha_varlen_fwd(out, q, kc, vc, ap.q_cu_seq_lens, m[2], ap.block_tables, ap.cu_blocks_lens, None, 1,
                                runner.max_len, scale, 0.0, -1, 0, 0)
@@ -1050,7 +1053,9 @@ def leg_ragged(model, runner, args, steps=20, regions=TIMED_REGIONS):
                    "(host clock around synchronize, the step replayed as in the headline); `even` = the same sum of contexts "
                    "spread evenly; attention = that launch alone on the same lengths (hipGraph of the steps' launches, HIP events)",
            "attention_grid": "one workgroup per (head, sequence) [the reference: one CTA per (m_block, seq, head), "
-                             "flash_fwd_launch_template.h:77], 4 waves interleaving the sequence's 16-key tiles"}
+                             "flash_fwd_launch_template.h:77], 4 waves interleaving the sequence's 16-key tiles"
+                             + ("" if args.no_ranked else "; ragged batches: the pairs are taken in length-ranked snake order over "
+                                "the CUs (attn_decode.hip, RANKED)")}
     for kind in ("uniform", "bimodal"):
         cap = runner.max_len - 1 - steps
         lens0 = [min(l, cap) for l in ragged_contexts(kind, B)]
@@ -1337,6 +1342,8 @@ def main():
     from hydrainfer_amd.model.llama import LlamaForCausalLM
     from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
     _lib.lib()   # no library, no benchmark
+    if args.no_ranked:
+        _lib.check(_lib.lib().hx_debug_set_option(b"decode_ranked", 0), "decode_ranked")
 
     shape, model_name = model_shape(args.model)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16

@@ -119,11 +119,14 @@ def decode_attention_fused(out: Tensor, q: Tensor, k_new: Tensor, v_new: Tensor,
                            new_cache_slots: Tensor, cu_seqlens_q: Tensor, cu_seqlens_k: Tensor,
                            block_table: Tensor, cu_block_lens: Tensor, max_seqlen_k: int,
                            softmax_scale: float, num_splits: int = 0,
-                           qkv_partial: Optional[Tensor] = None, qkv_splits: int = 0) -> None:
+                           qkv_partial: Optional[Tensor] = None, qkv_splits: int = 0,
+                           rank_desc: Optional[Tensor] = None) -> None:
     """Extension: apply_rotary_pos_emb(q, k_new) + set_kv_cache(new_cache_slots, k_new, v_new) +
     mha_varlen_fwd(paged, causal) for an all-decode batch, as ONE launch.  q / k_new / v_new are
     the un-rotated projections [batch, heads, head_dim]; cu_seqlens_k already counts the new
-    token.  Bit-identical to the three separate ops (q and k_new are NOT modified in place)."""
+    token.  Bit-identical to the three separate ops (q and k_new are NOT modified in place).
+    rank_desc (optional, int32 [1 + batch] on the device: decode_rank / the runner's step head / the engine's host-built
+    step): a big ragged batch is then laid over the CUs in length-ranked snake order — same results bit for bit."""
     _lib.require_gpu(out, q, k_new, v_new, key_cache, value_cache, positions, cos_sin, new_cache_slots,
                      cu_seqlens_q, cu_seqlens_k, block_table, cu_block_lens)
     if q.dtype not in (torch.float16, torch.bfloat16):
@@ -169,6 +172,11 @@ def decode_attention_fused(out: Tensor, q: Tensor, k_new: Tensor, v_new: Tensor,
         fz.qkv_partial, fz.qkv_splits = qkv_partial.data_ptr(), int(qkv_splits)
     else:
         fz.qkv_partial, fz.qkv_splits = None, 0
+    fz.rank_desc = None
+    if rank_desc is not None:
+        if rank_desc.dtype != torch.int32 or not rank_desc.is_contiguous() or not rank_desc.is_cuda or rank_desc.numel() < batch + 1:
+            raise _lib.HydraHipError("decode_attention_fused: rank_desc must be a contiguous int32 device tensor [1 + batch]")
+        fz.rank_desc = rank_desc.data_ptr()
     l = _lib.lib()
     need = l.hx_mha_varlen_fwd_workspace_bytes(ctypes.byref(a))
     if need > 0:
@@ -177,3 +185,20 @@ def decode_attention_fused(out: Tensor, q: Tensor, k_new: Tensor, v_new: Tensor,
     with torch.cuda.device(q.device):
         _lib.check(l.hx_decode_attention_fused(ctypes.byref(a), ctypes.byref(fz), _lib.current_stream()),
                    "decode_attention_fused")
+
+
+def decode_rank(cu_seqlens_k: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """Extension: the RANK DESCRIPTOR of a decode batch (hx_decode_rank; include/hydra_hip.h, hx_fused_decode_args) —
+    int32 [1 + batch]: [0] = 1 when some sequence holds more than 1.125 x the mean + 16 keys, [1 + r] = the sequence with
+    the r-th most keys (ties: the lower number first).  A batch of more than 256 sequences is declared even."""
+    _lib.require_gpu(cu_seqlens_k, out)
+    if cu_seqlens_k.dtype != torch.int32 or not cu_seqlens_k.is_contiguous() or cu_seqlens_k.numel() < 2:
+        raise _lib.HydraHipError("decode_rank: cu_seqlens_k must be contiguous int32 [batch + 1]")
+    batch = cu_seqlens_k.numel() - 1
+    if out is None:
+        out = torch.empty(batch + 1, dtype=torch.int32, device=cu_seqlens_k.device)
+    elif out.dtype != torch.int32 or not out.is_contiguous() or out.numel() < batch + 1:
+        raise _lib.HydraHipError("decode_rank: out must be contiguous int32 [1 + batch]")
+    with torch.cuda.device(cu_seqlens_k.device):
+        _lib.check(_lib.lib().hx_decode_rank(cu_seqlens_k.data_ptr(), batch, out.data_ptr(), _lib.current_stream()), "decode_rank")
+    return out

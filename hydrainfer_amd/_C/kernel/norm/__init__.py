@@ -97,6 +97,7 @@ class StepHead:
     batch: int = 0
     block_size: int = 16
     stride: int = 1
+    rank_desc: Optional[Tensor] = None      # int32 [1 + batch]: receives the advanced batch's rank descriptor (attn_decode.hip)
     # hx_decode_feed_ids arguments (both or neither)
     feed_src: Optional[Tensor] = None       # int32 [rows]
     feed_prev: Optional[Tensor] = None      # int64: the previous launch's samples
@@ -132,6 +133,11 @@ def decode_step_head(ids: Tensor, table: Tensor, weight: Tensor, epsilon: float,
                 raise _lib.HydraHipError("decode_step_head: advance arguments shorter than the batch")
             (a.positions, a.kv_lens, a.cu_seqlens_k, a.new_cache_slots, a.block_table, a.cu_block_lens) = (t.data_ptr() for t in adv)
             a.batch, a.block_size, a.stride = int(head.batch), int(head.block_size), int(head.stride)
+            if head.rank_desc is not None:
+                rd = head.rank_desc
+                if rd.dtype != torch.int32 or not rd.is_contiguous() or not rd.is_cuda or rd.numel() < head.batch + 1:
+                    raise _lib.HydraHipError("decode_step_head: rank_desc must be a contiguous int32 device tensor [1 + batch]")
+                a.rank_desc = rd.data_ptr()
         if (head.feed_src is None) != (head.feed_prev is None):
             raise _lib.HydraHipError("decode_step_head: feed_src and feed_prev come together")
         if head.feed_src is not None:

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("HX_LIB_PATH") or os.path.join(_HERE, "lib", "libhydra
 
 HX_F32, HX_F16, HX_BF16 = 0, 1, 2
 HX_IPC_HANDLE_BYTES = 64
-HX_ABI_VERSION = 2            # include/hydra_hip.h
+HX_ABI_VERSION = 3            # include/hydra_hip.h
 HX_ATTN_LOCAL_WINDOW = 1
 
 _DTYPE = {torch.float32: HX_F32, torch.float16: HX_F16, torch.bfloat16: HX_BF16}
@@ -51,7 +51,7 @@ class hx_fused_decode_args(ctypes.Structure):
         ("k_new", c_void_p), ("v_new", c_void_p), ("k_new_row_stride", c_int64),
         ("v_new_row_stride", c_int64), ("positions", c_void_p), ("cos_sin", c_void_p),
         ("new_cache_slots", c_void_p), ("rotary_dim", c_int32), ("interleaved", c_int32),
-        ("qkv_partial", c_void_p), ("qkv_splits", c_int32),
+        ("qkv_partial", c_void_p), ("qkv_splits", c_int32), ("rank_desc", c_void_p),
     ]
 
 
@@ -71,7 +71,7 @@ class hx_step_head_args(ctypes.Structure):
         ("positions", c_void_p), ("kv_lens", c_void_p), ("cu_seqlens_k", c_void_p), ("new_cache_slots", c_void_p),
         ("block_table", c_void_p), ("cu_block_lens", c_void_p),
         ("rows", c_int64), ("hidden", c_int64), ("vocab", c_int64), ("epsilon", c_float), ("ids_are_int64", c_int32),
-        ("dtype", c_int32), ("batch", c_int32), ("block_size", c_int32), ("stride", c_int32),
+        ("dtype", c_int32), ("batch", c_int32), ("block_size", c_int32), ("stride", c_int32), ("rank_desc", c_void_p),
     ]
 
 
@@ -133,6 +133,8 @@ _SIGNATURES = {
     "hx_moe_unpermute": (c_int, [c_void_p] * 4 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_moe_sum_out": (c_int, [c_void_p] * 2 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_int32, c_void_p]),
+    "hx_decode_advance_ranked": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "hx_decode_rank": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "hx_decode_feed_ids": (c_int, [c_void_p] * 4 + [c_int32, c_void_p]),
     "hx_collect_errors": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     "hx_copy_words2": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),

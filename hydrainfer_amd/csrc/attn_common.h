@@ -89,6 +89,7 @@ struct AttnParams {
   int32_t qkv_splits;
   int64_t qkv_slab_stride;  // batch * row length
   int64_t qkv_row;          // (n_heads + 2*n_kv_heads) * D
+  const int32_t* rank_desc; // decode kernel, RANKED form: [0] ragged?, [1 + r] the sequence with the r-th most keys (null: static grid)
 };
 
 }  // namespace hx

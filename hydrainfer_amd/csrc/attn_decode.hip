@@ -21,6 +21,22 @@
 //     numerics; the reference CUDA kernel rounds P to T first).
 //   * The 16 partial states of a workgroup (4 waves x 4 groups) are merged through LDS
 //     once; kv_splits > 1 write (m, l, o) partials that attn_decode_combine merges.
+//   * RANKED form (round 6; big batches, template flag RANKED).  Measured (tools/probes/probe_cu_balance.hip,
+//     tools/ragged_timeline.py): the dispatcher deals the workgroups of a launch round-robin — workgroups w, w + 256,
+//     w + 512, w + 768 share a CU — and ONE CU streams at most ~30-32 GB/s, 1.3x its fair share of the HBM rate.  The
+//     static (head, sequence) grid — the reference's own partition, flash_fwd_launch_template.h:77 — therefore makes a
+//     RAGGED batch (hydrainfer/engine/scheduler.py:99-194 builds one every step) as slow as its heaviest CU: the four
+//     sequences that happen to be 256 workgroup numbers apart.  Here the step's sequences are ranked by length ONCE (the
+//     RANK DESCRIPTOR: hx_decode_step_head / hx_decode_advance_ranked / hx_decode_rank on the device, or the host that
+//     builds the step) and a workgroup takes its (sequence, head) in SNAKE order over the CUs — round 0 the longest to CUs
+//     0..255, round 1 the next ones to CUs 255..0, ... — so that every CU gets the same bytes within a few per cent.  No
+//     counter, no workspace, no second launch, the same results bit for bit; a batch whose lengths are all within 12.5 %
+//     of the mean keeps the static numbering and pays nothing (the descriptor's flag arrives with the sequence's own
+//     metadata, one batch of scalar loads).
+//     (Tried and dropped in the same round: key ranges dealt from a counter — one word serves ~88 draws / us, and every
+//     item's start-up is two or three dependent loads of 8-17 us each under load (a CU keeps ~256 KiB of tile requests
+//     queued); cutting outlier sequences with a last-arriver merge — no gain over ranking whole sequences on any batch
+//     measured; ranking inside every workgroup from the lengths — four serial rounds of scalar loads, 2 us per launch.)
 #include <cstring>
 #include "attn_common.h"
 
@@ -221,13 +237,13 @@ __device__ __forceinline__ void compute_tile(const KVTile<D>& buf, const u16x8 (
 
 // launch bound: 4 workgroups of 4 waves (or 2 of 8) per CU => <= 128 VGPRs for D <= 128; the
 // D = 256 instantiation needs more registers and runs at half that occupancy.
-template <typename T, int D, int NW, bool NT, bool FUSE>
+template <typename T, int D, int NW, bool NT, bool FUSE, bool RANKED = false>
 __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kernel(
     const void* __restrict__ h_k, const void* __restrict__ h_v, const int32_t* __restrict__ h_cu_k,
     const int32_t* __restrict__ h_cu_q, const int32_t* __restrict__ h_block_table,
     const int32_t* __restrict__ h_cu_block_lens, const int32_t h_meta, const int32_t h_block_size,
-    const AttnParams p_in) {
-  // Leading scalars (14 dwords) = what the head of the dependent chain  kernarg -> cu_* -> page ids -> first K / V tile
+    const int32_t* __restrict__ h_rank_desc, const AttnParams p_in) {
+  // Leading scalars (16 dwords) = what the head of the dependent chain  kernarg -> cu_* -> page ids -> first K / V tile
   // needs; they arrive in SGPRs WITH the wave (gemm_xreg.hip, KERNARG PRELOADING).  h_meta = group | n_splits << 8 |
   // (block_shift & 0xff) << 16.  Round 5: the prologue used to be three scalar round trips in a row (the struct, then
   // cu_k, then cu_block_lens + the rest of the struct) with two runtime integer divisions between them; now ONE batch of
@@ -243,7 +259,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   __shared__ __attribute__((aligned(16))) char s_k[NW][KLds<D>::BYTES];
   __shared__ __attribute__((aligned(16))) u16 s_qkv[FUSE ? 3 : 1][FUSE ? D : 8];
 
-  const int h = blockIdx.x, b = blockIdx.y, split = blockIdx.z;
+  int h = blockIdx.x, b = blockIdx.y;      // (RANKED: a flat grid — both are worked out below)
+  const int split = blockIdx.z;
 #if HX_EXPERIMENTS
   // in-kernel time stamps (100 MHz), 16 per workgroup, wave 0 only: tools/decode_timeline.py
   auto STAMP = [&](int k) {
@@ -257,12 +274,41 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  // the sequence's metadata: one batch of scalar loads
-  const int32_t ck0 = h_cu_k[b], ck1 = h_cu_k[b + 1], cbl = h_cu_block_lens[b], q_row = h_cu_q[b];
-  const int hk = p.group == 1 ? h : h / p.group;
-
   constexpr int KPL = TileGeom<D>::KPL, TK = TileGeom<D>::TK, SH = TileGeom<D>::SH;
-  const int kv_len = ck1 - ck0;
+  int32_t kv_len, cbl, q_row;
+  if (RANKED) {
+    // Grid (heads, sequences) like the static form; workgroup number q = blockIdx.y * n_heads + blockIdx.x runs on CU
+    // q mod n_cus in the dispatcher's round R = q / n_cus.  The descriptor's flag travels with the metadata of the
+    // sequence the STATIC numbering would give this workgroup: an even batch (flag 0) has lost nothing; a ragged one
+    // takes item k of the length-ranked list in snake order and fetches that sequence's metadata in a second round.
+    int32_t ck0 = h_cu_k[b], ck1 = h_cu_k[b + 1];
+    cbl = h_cu_block_lens[b];
+    q_row = h_cu_q[b];
+    if (h_rank_desc[0]) {
+      const uint32_t n_heads = gridDim.x, q = blockIdx.y * n_heads + blockIdx.x, n_items = n_heads * gridDim.y;
+      const uint32_t nc = (uint32_t)p_in.n_cus, R = q / nc, cq = q - R * nc, in_round = min(nc, n_items - R * nc);
+      const uint32_t k = R * nc + ((R & 1u) ? in_round - 1u - cq : cq);
+      const uint32_t rho = k / n_heads;
+      h = (int)(k - rho * n_heads);
+      b = h_rank_desc[1 + rho];
+      ck0 = h_cu_k[b];
+      ck1 = h_cu_k[b + 1];
+      cbl = h_cu_block_lens[b];
+      q_row = h_cu_q[b];
+    }
+    kv_len = ck1 - ck0;
+#if HX_EXPERIMENTS
+    if (p_in.stamps && threadIdx.x == 0)      // who this workgroup is: tools/ragged_timeline.py
+      p_in.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 8] = 1ull << 40 | (unsigned long long)b << 16 | (unsigned long long)h;
+#endif
+  } else {
+    // the sequence's metadata: one batch of scalar loads
+    const int32_t ck0 = h_cu_k[b], ck1 = h_cu_k[b + 1];
+    cbl = h_cu_block_lens[b];
+    q_row = h_cu_q[b];
+    kv_len = ck1 - ck0;
+  }
+  const int hk = p.group == 1 ? h : h / p.group;
   const int n_tiles = (kv_len + TK - 1) >> SH;
   const int per_split = p.n_splits == 1 ? n_tiles : (n_tiles + p.n_splits - 1) / p.n_splits;
   const int t_begin = split * per_split;
@@ -529,23 +575,44 @@ inline int32_t decode_meta(const AttnParams& p) {      // attn_decode_kernel's h
   return (p.group & 0xff) | ((p.n_splits & 0xff) << 8) | ((p.block_shift & 0xff) << 16);
 }
 
+int g_ranked = 1;             // the RANKED form for big batches (hx_debug_set_option("decode_ranked", 0) = the static grid)
+
+int ranked_n_cus() {
+  static int n = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  return n;
+}
+
 template <typename T, int D>
 int launch_decode(const AttnParams& p, int batch, hipStream_t stream) {
   if (p.group > 255 || p.n_splits > 255) return HX_ERR_SHAPE;
+  // big batches, no key split, the step's rank descriptor at hand: (sequence, head) pairs in length-ranked snake order
+  if (g_ranked && p.rank_desc && p.n_splits == 1 && (int64_t)batch * p.n_heads >= 768 && D <= 128) {
+    AttnParams pp = p;
+    pp.n_cus = ranked_n_cus();
+    const dim3 grid2(p.n_heads, batch);
+    if (p.k_new || p.qkv_partial) hx::launcher(attn_decode_kernel<T, D, 4, true, true, true>, grid2, 256, 0, stream)(pp.k, pp.v, pp.cu_k, pp.cu_q, pp.block_table, pp.cu_block_lens, decode_meta(pp), pp.block_size, pp.rank_desc, pp);
+    else hx::launcher(attn_decode_kernel<T, D, 4, true, false, true>, grid2, 256, 0, stream)(pp.k, pp.v, pp.cu_k, pp.cu_q, pp.block_table, pp.cu_block_lens, decode_meta(pp), pp.block_size, pp.rank_desc, pp);
+    return check_launch();
+  }
   dim3 grid(p.n_heads, batch, p.n_splits);
   // 160..576 (sequence, head) pairs and no key split: 8 waves per workgroup share the keys
   // (see decode_pick_splits)
   const int64_t pairs = (int64_t)batch * p.n_heads;
   const bool wide = pairs >= g_decode_small_lo && pairs <= g_decode_small_hi && p.n_splits == 1;
   if (p.k_new || p.qkv_partial) {
-    if (wide) hx::launcher(attn_decode_kernel<T, D, 8, true, true>, grid, 512, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
-    else hx::launcher(attn_decode_kernel<T, D, 4, true, true>, grid, 256, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
+    if (wide) hx::launcher(attn_decode_kernel<T, D, 8, true, true>, grid, 512, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, (const int32_t*)nullptr, p);
+    else hx::launcher(attn_decode_kernel<T, D, 4, true, true>, grid, 256, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, (const int32_t*)nullptr, p);
   } else if (g_decode_waves == 8 || wide) {
-    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 8, true, false>, grid, 512, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
-    else hx::launcher(attn_decode_kernel<T, D, 8, false, false>, grid, 512, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
+    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 8, true, false>, grid, 512, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, (const int32_t*)nullptr, p);
+    else hx::launcher(attn_decode_kernel<T, D, 8, false, false>, grid, 512, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, (const int32_t*)nullptr, p);
   } else {
-    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 4, true, false>, grid, 256, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
-    else hx::launcher(attn_decode_kernel<T, D, 4, false, false>, grid, 256, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, p);
+    if (g_decode_nt) hx::launcher(attn_decode_kernel<T, D, 4, true, false>, grid, 256, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, (const int32_t*)nullptr, p);
+    else hx::launcher(attn_decode_kernel<T, D, 4, false, false>, grid, 256, 0, stream)(p.k, p.v, p.cu_k, p.cu_q, p.block_table, p.cu_block_lens, decode_meta(p), p.block_size, (const int32_t*)nullptr, p);
   }
   int rc = check_launch();
   if (rc) return rc;
@@ -565,6 +632,7 @@ int decode_set_option(const char* name, int value) {
   if (!strcmp(name, "decode_nt")) { g_decode_nt = value ? 1 : 0; return HX_OK; }
   if (!strcmp(name, "decode_small_lo")) { g_decode_small_lo = value; return HX_OK; }
   if (!strcmp(name, "decode_small_hi")) { g_decode_small_hi = value; return HX_OK; }
+  if (!strcmp(name, "decode_ranked")) { g_ranked = value ? 1 : 0; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 

@@ -110,10 +110,19 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(
     int32_t* __restrict__ positions, int32_t* __restrict__ kv_lens,
     int32_t* __restrict__ cu_seqlens_k, int32_t* __restrict__ new_cache_slots,
     const int32_t* __restrict__ block_table, const int32_t* __restrict__ cu_block_lens,
-    int32_t batch, int32_t block_size, int32_t stride) {
+    int32_t batch, int32_t block_size, int32_t stride, int32_t* __restrict__ rank_desc) {
   __shared__ int32_t scan[256];
   hx::decode_advance_block(positions, kv_lens, cu_seqlens_k, new_cache_slots, block_table, cu_block_lens, batch,
                            block_size, stride, scan);
+  if (rank_desc) hx::decode_rank_block(kv_lens, batch, rank_desc, scan);
+}
+
+__global__ __launch_bounds__(256) void decode_rank_kernel(const int32_t* __restrict__ cu_seqlens_k, int32_t batch,
+                                                          int32_t* __restrict__ rank_desc) {
+  __shared__ int32_t lens[256], scratch[256];
+  if ((int)threadIdx.x < batch && batch <= 256) lens[threadIdx.x] = cu_seqlens_k[threadIdx.x + 1] - cu_seqlens_k[threadIdx.x];
+  __syncthreads();
+  hx::decode_rank_block(lens, batch, rank_desc, scratch);
 }
 
 }  // namespace
@@ -160,7 +169,27 @@ extern "C" int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* 
   if (batch <= 0 || block_size <= 0 || stride < 1) return HX_ERR_SHAPE;
   hx::launcher(decode_advance_kernel, 1, 256, 0, (hipStream_t)stream)(positions, kv_lens, cu_seqlens_k,
                                                             new_cache_slots, block_table,
-                                                            cu_block_lens, batch, block_size, stride);
+                                                            cu_block_lens, batch, block_size, stride, (int32_t*)nullptr);
+  return hx::check_launch();
+}
+
+extern "C" int hx_decode_advance_ranked(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_k,
+                                        int32_t* new_cache_slots, const int32_t* block_table,
+                                        const int32_t* cu_block_lens, int32_t batch, int32_t block_size,
+                                        int32_t stride, int32_t* rank_desc, hx_stream stream) {
+  if (!positions || !kv_lens || !cu_seqlens_k || !new_cache_slots || !block_table || !cu_block_lens || !rank_desc)
+    return HX_ERR_NULL;
+  if (batch <= 0 || block_size <= 0 || stride < 1) return HX_ERR_SHAPE;
+  hx::launcher(decode_advance_kernel, 1, 256, 0, (hipStream_t)stream)(positions, kv_lens, cu_seqlens_k, new_cache_slots,
+                                                                      block_table, cu_block_lens, batch, block_size, stride,
+                                                                      rank_desc);
+  return hx::check_launch();
+}
+
+extern "C" int hx_decode_rank(const int32_t* cu_seqlens_k, int32_t batch, int32_t* rank_desc, hx_stream stream) {
+  if (!cu_seqlens_k || !rank_desc) return HX_ERR_NULL;
+  if (batch <= 0) return HX_ERR_SHAPE;
+  hx::launcher(decode_rank_kernel, 1, 256, 0, (hipStream_t)stream)(cu_seqlens_k, batch, rank_desc);
   return hx::check_launch();
 }
 

@@ -249,6 +249,7 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
   p.qkv_partial = nullptr;
   p.qkv_splits = 0;
   p.qkv_slab_stride = p.qkv_row = 0;
+  p.rank_desc = nullptr;
   if (fused) {
     if (fused->qkv_partial) {
       p.qkv_partial = fused->qkv_partial;
@@ -263,6 +264,7 @@ static int attn_dispatch(const hx_attn_args* a, const hx_fused_decode_args* fuse
     p.positions = fused->positions;
     p.cos_sin = fused->cos_sin;
     p.new_slots = fused->new_cache_slots;
+    p.rank_desc = fused->rank_desc;
   }
 
   hipStream_t s = (hipStream_t)stream;

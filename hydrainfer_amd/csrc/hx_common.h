@@ -191,4 +191,33 @@ __device__ __forceinline__ void decode_advance_block(int32_t* __restrict__ posit
   }
 }
 
+// The RANK DESCRIPTOR of a decode batch (attn_decode.hip, RANKED form): rank_desc[0] = 1 when the batch is ragged — some
+// sequence holds more than 1.125 x the mean + 16 keys — else 0; rank_desc[1 + r] = the sequence with the r-th most keys
+// (ties: the lower sequence number first).  One 256-thread workgroup, `batch` <= 256 (a larger batch is declared even).
+// lens: this workgroup's LDS scratch of 256 ints, filled here from kv_lens (global, already current).
+#define HX_RANKED_THR 1.125f
+__device__ __forceinline__ void decode_rank_block(const int32_t* __restrict__ kv_lens, int32_t batch, int32_t* __restrict__ rank_desc,
+                                                  int32_t* lens) {
+  if (batch > 256) {
+    if (threadIdx.x == 0) rank_desc[0] = 0;
+    return;
+  }
+  const int b = threadIdx.x;
+  const int32_t mine = b < batch ? kv_lens[b] : 0;
+  __syncthreads();      // (lens may be the scratch of a scan that has just finished)
+  lens[b] = mine;
+  __syncthreads();
+  int64_t total = 0;
+  int rank = 0;
+  for (int i = 0; i < batch; ++i) {
+    const int32_t ln = lens[i];
+    total += ln;
+    rank += (ln > mine || (ln == mine && i < b)) ? 1 : 0;
+  }
+  const float mean = (float)total / (float)batch;
+  const int ragged = __syncthreads_or(b < batch && (float)mine > mean * HX_RANKED_THR + 16.f);
+  if (b < batch) rank_desc[1 + rank] = b;
+  if (b == 0) rank_desc[0] = ragged ? 1 : 0;
+}
+
 }  // namespace hx

@@ -215,7 +215,7 @@ struct StepHeadParams {
   void* h_out; void* x_out; const void* ids; const int32_t* feed_src; const int64_t* feed_prev; int64_t* fed_out;
   const void* table; const void* weight; uint32_t* zero_ptr;
   int32_t* positions; int32_t* kv_lens; int32_t* cu_seqlens_k; int32_t* new_cache_slots;
-  const int32_t* block_table; const int32_t* cu_block_lens;
+  const int32_t* block_table; const int32_t* cu_block_lens; int32_t* rank_desc;
   int64_t vocab, zero_words;
   float eps;
   int32_t ids_i64, rows, hidden, n_zero, batch, block_size, stride;
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void decode_step_head_kernel(const StepHeadPar
   } else {
     decode_advance_block(p.positions, p.kv_lens, p.cu_seqlens_k, p.new_cache_slots, p.block_table, p.cu_block_lens, p.batch,
                          p.block_size, p.stride, scan);
+    if (p.rank_desc) decode_rank_block(p.kv_lens, p.batch, p.rank_desc, scan);
   }
 }
 
@@ -935,7 +936,7 @@ extern "C" int hx_decode_step_head(const hx_step_head_args* a, hx_stream stream)
   p.h_out = a->h_out; p.x_out = a->x_out; p.ids = a->ids; p.feed_src = a->feed_src; p.feed_prev = a->feed_prev;
   p.fed_out = a->fed_out; p.table = a->table; p.weight = a->weight; p.zero_ptr = (uint32_t*)a->zero_ptr;
   p.positions = a->positions; p.kv_lens = a->kv_lens; p.cu_seqlens_k = a->cu_seqlens_k; p.new_cache_slots = a->new_cache_slots;
-  p.block_table = a->block_table; p.cu_block_lens = a->cu_block_lens;
+  p.block_table = a->block_table; p.cu_block_lens = a->cu_block_lens; p.rank_desc = a->batch > 0 ? a->rank_desc : nullptr;
   p.vocab = a->vocab; p.zero_words = a->zero_bytes >> 2; p.eps = a->epsilon; p.ids_i64 = a->ids_are_int64 ? 1 : 0;
   p.rows = (int32_t)a->rows; p.hidden = (int32_t)a->hidden; p.n_zero = (int32_t)((p.zero_words + 1023) / 1024);
   p.batch = a->batch; p.block_size = a->block_size; p.stride = a->stride;

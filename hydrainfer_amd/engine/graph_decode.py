@@ -27,7 +27,7 @@ import torch
 from hydrainfer_amd import _lib, launch_plan
 from hydrainfer_amd._lib import HydraHipError
 from hydrainfer_amd._C.kernel.norm import StepHead
-from hydrainfer_amd.layer.causal_attention import AttentionParameters
+from hydrainfer_amd.layer.causal_attention import AttentionParameters, decode_rank_descriptor
 from hydrainfer_amd.memory.kv_cache import KVCache
 from hydrainfer_amd.model.llama import LanguageModelParameters
 
@@ -51,8 +51,10 @@ class GraphedDecoder:
         self.max_batch = (max_batch + pad_to - 1) // pad_to * pad_to
         self.table_cap = self.max_batch * max_blocks_per_seq
         B = self.max_batch
+        # ("rank": the step's rank descriptor, [ragged?] + the rows by decreasing context — the fused decode attention lays a
+        # big ragged batch over the CUs in that order, csrc/attn_decode.hip RANKED; the host has the lengths, so it ranks)
         self.off = {"ids": 0, "pos": B, "slots": 2 * B, "src": 3 * B, "kv_cu": 4 * B, "cu_blocks": 5 * B + 1,
-                    "tables": 6 * B + 2}
+                    "rank": 6 * B + 2, "tables": 7 * B + 3}
         total = self.off["tables"] + self.table_cap
         self.static = torch.zeros(total, dtype=torch.int32, device=self.dev)
         # two pinned staging buffers used alternately, each with an event recorded behind its H2D copy:
@@ -90,7 +92,7 @@ class GraphedDecoder:
         o, s = self.off, self.static
         return (s[o["ids"]:o["ids"] + B], s[o["pos"]:o["pos"] + B], s[o["slots"]:o["slots"] + B],
                 s[o["kv_cu"]:o["kv_cu"] + B + 1], s[o["cu_blocks"]:o["cu_blocks"] + B + 1],
-                s[o["tables"]:], s[o["src"]:o["src"] + B])
+                s[o["tables"]:], s[o["src"]:o["src"] + B], s[o["rank"]:o["rank"] + B + 1])
 
     def _kv_bucket(self, B: int, kv_max: int) -> int:
         if B * self.model.shape.num_attention_heads >= 768:
@@ -101,11 +103,11 @@ class GraphedDecoder:
         return b
 
     def _params(self, B: int, kv_max: int) -> LanguageModelParameters:
-        ids, pos, slots, kv_cu, cu_blocks, tables, _ = self._views(B)
+        ids, pos, slots, kv_cu, cu_blocks, tables, _, rank = self._views(B)
         attn = [AttentionParameters(kv_cache=kc, q_cu_seq_lens=self.q_cu[:B + 1], kv_cu_seq_lens=kv_cu,
                                     new_cache_slots=slots, block_tables=tables, cu_blocks_lens=cu_blocks,
                                     num_sequences=B, all_sequences_decode=True, q_max_seq_len=1,
-                                    kv_max_seq_len=kv_max) for kc in self.kv_caches]
+                                    kv_max_seq_len=kv_max, decode_rank=rank) for kc in self.kv_caches]
         return LanguageModelParameters(attention_params=attn, all_sequences_decode=True)
 
     def _body(self, B: int, params):
@@ -192,6 +194,7 @@ class GraphedDecoder:
         st[o["slots"]:o["slots"] + B] = [r[2] for r in rows]
         st[o["kv_cu"]] = 0
         st[o["kv_cu"] + 1:o["kv_cu"] + B + 1] = np.cumsum([r[3] for r in rows])
+        st[o["rank"]:o["rank"] + B + 1] = decode_rank_descriptor([r[3] for r in rows])
         lens = [len(r[4]) for r in rows]
         st[o["cu_blocks"]] = 0
         st[o["cu_blocks"] + 1:o["cu_blocks"] + B + 1] = np.cumsum(lens)

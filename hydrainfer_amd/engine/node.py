@@ -40,9 +40,18 @@ class RoundRobin:
     def __init__(self):
         self.workers: Dict[int, list] = {int(s): [] for s in ScenarioType}
         self.cursor: Dict[int, int] = {int(s): 0 for s in ScenarioType}
+        self.lost_workers = 0
 
     def register_worker(self, key, worker) -> None:
         self.workers[int(key)].append(worker)
+
+    def remove_worker(self, worker) -> None:
+        """A downstream node died: the round robin goes on over the others."""
+        self.lost_workers += 1
+        for key, ws in self.workers.items():
+            if worker in ws:
+                ws.remove(worker)
+                self.cursor[key] = self.cursor[key] % len(ws) if ws else 0
 
     def _choice(self, key: int):
         ws = self.workers[key]
@@ -63,6 +72,9 @@ class RoundRobin:
         return None
 
 
+MAX_MIGRATE_ATTEMPTS = 2      # hydrainfer/cluster/epdnode.py:428: "max_retries = 2", then the request is terminated
+
+
 class EPDNode:
     def __init__(self, name: str, node_type: NodeType, scheduler: BatchScheduler,
                  executor: InstructionExecutor, kv_cache_block_manager, image_cache_block_manager,
@@ -79,6 +91,8 @@ class EPDNode:
         self.image_cache_block_manager = image_cache_block_manager
         self.ep_loadbalancer, self.pd_loadbalancer = RoundRobin(), RoundRobin()
         self.finished: List[RequestControlBlock] = []
+        self.failed: List[RequestControlBlock] = []      # requests this node terminated (terminate())
+        self.peer_alive = None      # callable(node) -> bool, set by engine.distributed.RankEngine (a dead process's pool is gone)
 
     # ---- migrate graph (epdnode.py:60-75): strict traffic only to nodes with a tight TPOT SLO
     def connect(self, ep_targets: List["EPDNode"], pd_targets: List["EPDNode"]) -> None:
@@ -170,6 +184,11 @@ class EPDNode:
             rcb.current_instruction().hop = "ep" if isinstance(inst, EPMigrate) else "pd"
             lb = self.ep_loadbalancer if isinstance(inst, EPMigrate) else self.pd_loadbalancer
             node = lb.choice(rcb.scenario_type)
+            if node is None and lb.lost_workers:
+                # every downstream node of this hop has died: the reference's hand-over RPC would fail twice and the
+                # request be terminated (epdnode.py:428-442) — nowhere to retry, so it ends here
+                self.terminate(rcb, f"{self.name}: no live {'prefill' if isinstance(inst, EPMigrate) else 'decode'} node to hand over to")
+                continue
             if node is None or node is self:
                 rcb.step()                          # stays here: skip the pull as well
                 self.batch_scheduler.schedule_running(rcb)
@@ -193,8 +212,9 @@ class EPDNode:
         self.batch_scheduler.schedule_new(rcb)
 
     # ---- 3. receiver: allocate local blocks, pull, then tell the sender to free
-    def _migrate_virtual_cache(self, src_cache, manager, src_node, which: str):
+    def _migrate_virtual_cache(self, src_cache, manager, src_node, which: str, pulled: list):
         dst = manager.allocate_virtual_cache()
+        pulled.append((manager, dst))
         manager.realloc(dst, src_cache.n_cache_tokens)
         # a send/recv transfer (ranks on different hosts, or intranode_migrate_backend='nccl') has two
         # halves: ask the sender for its half first (the reference's pull_virtual_cache.remote,
@@ -225,6 +245,12 @@ class EPDNode:
 
     def _execute_pull_cache(self, batch: BatchRequest) -> None:
         for rcb, inst in batch:
+            if self.peer_alive is not None and not self.peer_alive(inst.src_node):
+                # the sender's process is gone and its pool with it: nothing to pull, nobody to tell
+                self._unqueue(rcb)
+                rcb.virtual_kv_cache = rcb.virtual_image_cache = None      # (the sender's tables, not blocks of ours)
+                self.terminate(rcb, f"{self.name}: the node holding this request's cache blocks died before the pull")
+                continue
             if not self._can_pull(rcb):
                 continue
             # upstream stamps "first pull = ep, second = pd" (epdnode.py:384-387), which files a
@@ -233,24 +259,60 @@ class EPDNode:
             stamps = m.ep_transfer if inst.hop == "ep" else m.pd_transfer
             stamps.append(time.perf_counter())
             old = copy.copy(rcb)
-            if rcb.virtual_kv_cache is not None and self.node_type.has_kv_cache:
-                rcb.virtual_kv_cache = self._migrate_virtual_cache(rcb.virtual_kv_cache, self.kv_cache_block_manager,
-                                                                   inst.src_node, "kv")
-            else:
-                rcb.virtual_kv_cache = None
-            if rcb.virtual_image_cache is not None and self.node_type.has_image_cache:
-                rcb.virtual_image_cache = self._migrate_virtual_cache(rcb.virtual_image_cache,
-                                                                      self.image_cache_block_manager,
-                                                                      inst.src_node, "image")
-            else:
-                rcb.virtual_image_cache = None
-            # the sender may only free once the copy has been issued AND completed
-            for manager in (self.kv_cache_block_manager, self.image_cache_block_manager):
-                if manager is not None:
-                    manager.synchronize()
+            pulled = []       # (manager, cache) allocated here so far: returned to the pool if the pull fails
+            try:
+                new_kv = new_img = None
+                if old.virtual_kv_cache is not None and self.node_type.has_kv_cache:
+                    new_kv = self._migrate_virtual_cache(old.virtual_kv_cache, self.kv_cache_block_manager,
+                                                         inst.src_node, "kv", pulled)
+                if old.virtual_image_cache is not None and self.node_type.has_image_cache:
+                    new_img = self._migrate_virtual_cache(old.virtual_image_cache, self.image_cache_block_manager,
+                                                          inst.src_node, "image", pulled)
+                # the sender may only free once the copy has been issued AND completed
+                for manager in (self.kv_cache_block_manager, self.image_cache_block_manager):
+                    if manager is not None:
+                        manager.synchronize()
+            except RuntimeError as e:
+                # A pull that fails (the peer of a send/recv transfer never shows up: MigrationTimeout; the peer's pool
+                # cannot be mapped: HydraHipError) ends THIS REQUEST, not the rank — the reference retries the hand-over
+                # twice and then terminates the request with a None token (epdnode.py:428-442).  The blocks taken here
+                # go back; on the last attempt the sender is told to free its side.
+                for manager, vc in pulled:
+                    manager.realloc(vc, 0)
+                stamps.pop()
+                inst.attempts = getattr(inst, "attempts", 0) + 1
+                if inst.attempts < MAX_MIGRATE_ATTEMPTS:
+                    continue                          # still queued at its PullCache: tried again next step
+                self._unqueue(rcb)
+                inst.src_node.free_migrate_request(old)
+                rcb.virtual_kv_cache = rcb.virtual_image_cache = None
+                self.terminate(rcb, f"{self.name}: pulling the cache blocks failed {inst.attempts} times: {e!r}"[:400])
+                continue
+            rcb.virtual_kv_cache, rcb.virtual_image_cache = new_kv, new_img
             inst.src_node.free_migrate_request(old)
             rcb.step()
             stamps.append(time.perf_counter())
+
+    def _unqueue(self, rcb: RequestControlBlock) -> None:
+        """Take a request that step() has already re-queued out of the scheduler again."""
+        s = self.batch_scheduler
+        if rcb in s.running:
+            s.running.remove(rcb)
+        elif rcb in s.waiting:
+            s.waiting.remove(rcb)
+
+    def terminate(self, rcb: RequestControlBlock, reason: str) -> None:
+        """End one request without ending the node (epdnode.py:440-442: free its blocks, push `(request_id, None)` to
+        the stream): its caches here are freed, every output processor is told (OutputTokenProcessor.fail — a None
+        token unless the processor knows better), and it is listed under `failed`."""
+        self._free_cache(rcb)
+        rcb.virtual_kv_cache = rcb.virtual_image_cache = None
+        rcb.failed = reason
+        rcb.metric.finished_time = time.perf_counter()
+        for p_ in rcb.output_token_processors:
+            p_.fail(RuntimeError(reason))
+        rcb.release_instructions()
+        self.failed.append(rcb)
 
     # ---- 4. sender: release the blocks of a request that has been pulled
     def free_migrate_request(self, rcb: RequestControlBlock) -> None:

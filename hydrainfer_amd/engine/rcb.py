@@ -54,6 +54,11 @@ class OutputTokenProcessor:
     def append_token_id(self, token_id: int, is_last_token: bool = False) -> None:
         raise NotImplementedError
 
+    def fail(self, exc: BaseException) -> None:
+        """The request was terminated by the engine (a migration that failed twice, a node that died): the reference
+        pushes a None token to the stream (hydrainfer/cluster/epdnode.py:440-442, `(request_id, None)`)."""
+        self.append_token_id(None, True)
+
 
 class LogOutputTokenProcessor(OutputTokenProcessor):
     def __init__(self):
@@ -81,6 +86,7 @@ class RequestControlBlock:
                                                   # tokens to a client (engine/distributed.py: the reference pushes them
                                                   # over zmq from every node, hydrainfer/engine/output_token_processor.py:92-140)
         self.path: List[int] = []                 # multi-process serving: the ranks that have owned this request, in order
+        self.failed: Optional[str] = None         # why the engine terminated this request (EPDNode.terminate), if it did
 
     def current_instruction(self) -> Instruction:
         return self.instructions.curr

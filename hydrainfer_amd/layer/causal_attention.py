@@ -26,13 +26,31 @@ class AttentionParameters:
     all_sequences_decode: bool = False
     q_max_seq_len: int = 128
     kv_max_seq_len: int = 128
+    # MI355X extension (not in the reference): the rank descriptor of an all-decode batch, int32 [1 + n_seq] — [0] = 1
+    # when the batch is ragged, [1 + r] = the sequence with the r-th most keys.  The fused decode attention lays a big
+    # ragged batch over the CUs in that order (csrc/attn_decode.hip, RANKED); None = the static grid.
+    decode_rank: Tensor = None
 
     def to(self, device: torch.device) -> None:
         for f in ("q_cu_seq_lens", "kv_cu_seq_lens", "paged_kv_last_page_len", "new_cache_slots",
-                  "block_tables", "cu_blocks_lens"):
+                  "block_tables", "cu_blocks_lens", "decode_rank"):
             t = getattr(self, f)
             if t is not None:
                 setattr(self, f, t.to(device))
+
+
+RANKED_THR = 1.125      # csrc/hx_common.h HX_RANKED_THR: ragged = some sequence longer than this x the mean + 16 keys
+
+
+def decode_rank_descriptor(kv_lens: List[int]) -> List[int]:
+    """The rank descriptor of a decode batch, worked out on the host (the engine builds its steps there): the same words
+    as hx_decode_rank writes — [ragged?] + the sequences by decreasing length (ties: the lower number first)."""
+    n = len(kv_lens)
+    if n == 0 or n > 256:
+        return [0] + list(range(n))
+    mean = sum(kv_lens) / n
+    ragged = any(float(l) > mean * RANKED_THR + 16.0 for l in kv_lens)
+    return [1 if ragged else 0] + sorted(range(n), key=lambda b: (-kv_lens[b], b))
 
 
 class AttentionParametersBuilder:
@@ -77,8 +95,11 @@ class AttentionParametersBuilder:
     def _tensors(self):
         # one pinned staging buffer + one H2D copy for all six arrays (the reference issues
         # six torch.tensor(list, device=...) copies per step, causal_attention.py:163-168)
+        kv = self.kv_cu_seq_lens
+        rank = decode_rank_descriptor([kv[i + 1] - kv[i] for i in range(self.num_sequences)]) \
+            if self.all_sequences_decode and self.num_sequences > 0 else []
         lists = [self.q_cu_seq_lens, self.kv_cu_seq_lens, self.paged_kv_last_page_len,
-                 self.new_cache_slots, self.block_tables, self.cu_blocks_lens]
+                 self.new_cache_slots, self.block_tables, self.cu_blocks_lens, rank]
         flat = torch.tensor([x for l in lists for x in l], dtype=torch.int32)
         if self.device.type == "cuda":
             flat = flat.pin_memory().to(self.device, non_blocking=True)
@@ -89,13 +110,13 @@ class AttentionParametersBuilder:
         return outs
 
     def build_attention_parameters(self) -> List[AttentionParameters]:
-        q_cu, kv_cu, last_page, slots, tables, cu_blocks = self._tensors()
+        q_cu, kv_cu, last_page, slots, tables, cu_blocks, rank = self._tensors()
         return [AttentionParameters(
             kv_cache=kv_cache, q_cu_seq_lens=q_cu, kv_cu_seq_lens=kv_cu,
             paged_kv_last_page_len=last_page, new_cache_slots=slots, block_tables=tables,
             cu_blocks_lens=cu_blocks, num_sequences=self.num_sequences,
             all_sequences_decode=self.all_sequences_decode, q_max_seq_len=self.q_max_seq_len,
-            kv_max_seq_len=self.kv_max_seq_len) for kv_cache in self.kv_caches]
+            kv_max_seq_len=self.kv_max_seq_len, decode_rank=rank if rank.numel() else None) for kv_cache in self.kv_caches]
 
 
 @dataclass

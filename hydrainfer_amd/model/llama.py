@@ -401,7 +401,7 @@ class LlamaForCausalLM:
             # q / k_new / v_new arguments are shape carriers here: the kernel reads the slabs
             decode_attention_fused(o, o, o[:, :HK], o[:, :HK], kc, vc, position_ids, self.cos_sin,
                                    ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens, ap.block_tables,
-                                   ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws_q, s_qkv)
+                                   ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5, 0, ws_q, s_qkv, ap.decode_rank)
             s_qkv = None
             s_o = self._partial(o.view(n, q_size), f"l{l}.wo", ws)
             if xreg:
@@ -514,7 +514,8 @@ class LlamaForCausalLM:
                 # RoPE + cache append + paged attention, one launch
                 decode_attention_fused(o, q, k, v, kc, vc, position_ids, self.cos_sin,
                                        ap.new_cache_slots, ap.q_cu_seq_lens, ap.kv_cu_seq_lens,
-                                       ap.block_tables, ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5)
+                                       ap.block_tables, ap.cu_blocks_lens, ap.kv_max_seq_len, D ** -0.5,
+                                       rank_desc=ap.decode_rank)
             else:
                 # RoPE in place + append k/v to the paged cache, one launch; then attention
                 rope_set_kv_cache(q, k, v, position_ids, self.cos_sin, D, ap.new_cache_slots, kc, vc)

@@ -114,12 +114,15 @@ class DecodeRunner:
         self.cu_k = torch.zeros(B + 1, **i32)
         self.slots = torch.zeros(B, **i32)
         self.input_ids = torch.zeros(B, dtype=torch.int64, device=dev)
+        # the batch's rank descriptor (attn_decode.hip, RANKED): rewritten by every step's metadata advance
+        self.rank_desc = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        self.rank_desc[1:] = torch.arange(B, dtype=torch.int32, device=dev)
         self.decode_params = LanguageModelParameters(
             attention_params=[AttentionParameters(
                 kv_cache=kc, q_cu_seq_lens=self.q_cu, kv_cu_seq_lens=self.cu_k,
                 new_cache_slots=self.slots, block_tables=self.block_table,
                 cu_blocks_lens=self.cu_block_lens, num_sequences=B, all_sequences_decode=True,
-                q_max_seq_len=1, kv_max_seq_len=self.max_len) for kc in self.kv_caches],
+                q_max_seq_len=1, kv_max_seq_len=self.max_len, decode_rank=self.rank_desc) for kc in self.kv_caches],
             all_sequences_decode=True)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.executor_used = cfg.executor          # "plan" falls back to "graph" when the step is not recordable
@@ -227,10 +230,11 @@ class DecodeRunner:
 
     # ------------------------------------------------------------------ decode
     def _advance(self) -> None:
-        _lib.check(_lib.lib().hx_decode_advance(
+        _lib.check(_lib.lib().hx_decode_advance_ranked(
             self.positions.data_ptr(), self.kv_lens.data_ptr(), self.cu_k.data_ptr(),
             self.slots.data_ptr(), self.block_table.data_ptr(), self.cu_block_lens.data_ptr(),
-            self.cfg.batch, self.cfg.block_size, self.cfg.advance_stride, _lib.current_stream()), "decode_advance")
+            self.cfg.batch, self.cfg.block_size, self.cfg.advance_stride, self.rank_desc.data_ptr(),
+            _lib.current_stream()), "decode_advance")
 
     def _step_body(self) -> None:
         # the metadata advance rides in the step's first launch (hx_decode_step_head) when the model can take it
@@ -238,7 +242,7 @@ class DecodeRunner:
             self.decode_params.step_head = StepHead(
                 positions=self.positions, kv_lens=self.kv_lens, cu_seqlens_k=self.cu_k, new_cache_slots=self.slots,
                 block_table=self.block_table, cu_block_lens=self.cu_block_lens, batch=self.cfg.batch,
-                block_size=self.cfg.block_size, stride=self.cfg.advance_stride)
+                block_size=self.cfg.block_size, stride=self.cfg.advance_stride, rank_desc=self.rank_desc)
         else:
             self.decode_params.step_head = None
             self._advance()

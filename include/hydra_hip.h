@@ -23,7 +23,7 @@ extern "C" {
 /* 2: hx_attn_args.flags (was `reserved`) gates the local-window fields — a zero-filled tail of the struct means
  * "no softcap, no window"; launch plans; hx_decode_advance takes a stride; experiments moved to
  * hydra_hip_experimental.h */
-#define HX_ABI_VERSION 2
+#define HX_ABI_VERSION 3
 
 typedef enum hx_dtype {
   HX_F32 = 0,
@@ -395,6 +395,11 @@ typedef struct hx_fused_decode_args {
    * args->q, k_new, v_new are then ignored */
   const float* qkv_partial;
   int32_t qkv_splits;
+  /* optional (may be NULL): the batch's RANK DESCRIPTOR, int32 [1 + batch] on the device — [0] = 1 when the batch is
+   * ragged, [1 + r] = the sequence with the r-th most keys (hx_decode_rank / hx_decode_advance_ranked /
+   * hx_step_head_args.rank_desc write it).  With it a big ragged batch is laid over the CUs in length-ranked snake
+   * order (same results bit for bit, csrc/attn_decode.hip RANKED); without it: the static (head, sequence) grid. */
+  const int32_t* rank_desc;
 } hx_fused_decode_args;
 int hx_decode_attention_fused(const hx_attn_args* args, const hx_fused_decode_args* fused,
                               hx_stream stream);
@@ -477,6 +482,15 @@ int hx_decode_advance(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_
                       int32_t* new_cache_slots, const int32_t* block_table,
                       const int32_t* cu_block_lens, int32_t batch, int32_t block_size,
                       int32_t stride, hx_stream stream);
+/* hx_decode_advance that also leaves the advanced batch's rank descriptor (hx_fused_decode_args.rank_desc) in rank_desc
+ * (int32 [1 + batch]); hx_decode_rank: the descriptor alone, from cu_seqlens_k (int32 [batch + 1]).  A batch of more
+ * than 256 sequences is declared even ([0] = 0).  The engine's host-built steps write the same words from the host
+ * (hydrainfer_amd/layer/causal_attention.py::decode_rank_descriptor). */
+int hx_decode_advance_ranked(int32_t* positions, int32_t* kv_lens, int32_t* cu_seqlens_k,
+                             int32_t* new_cache_slots, const int32_t* block_table,
+                             const int32_t* cu_block_lens, int32_t batch, int32_t block_size,
+                             int32_t stride, int32_t* rank_desc, hx_stream stream);
+int hx_decode_rank(const int32_t* cu_seqlens_k, int32_t batch, int32_t* rank_desc, hx_stream stream);
 /* hx_decode_step_head: everything a decode step does before its first GEMM as ONE launch — hx_embed_rms_norm for
  * `rows` rows (each id optionally replaced by the previous launch's sample like hx_decode_feed_ids: feed_src /
  * feed_prev, both or neither; fed_out, if given, receives the ids used), hx_memset_zero of zero_bytes at zero_ptr
@@ -504,6 +518,7 @@ typedef struct hx_step_head_args {
   int32_t ids_are_int64;
   int32_t dtype;             /* HX_F16 | HX_BF16 */
   int32_t batch, block_size, stride;
+  int32_t* rank_desc;        /* NULL, or int32 [1 + batch]: the advanced batch's rank descriptor (hx_decode_advance_ranked) */
 } hx_step_head_args;
 int hx_decode_step_head(const hx_step_head_args* args, hx_stream stream);
 int hx_decode_feed_ids(int64_t* out, const int32_t* ids, const int32_t* src, const int64_t* prev,

@@ -46,7 +46,7 @@ def test_experiments_are_not_in_the_default_library():
 def test_python_binding_covers_the_header():
     assert sorted(_lib.exported_symbols()) == _declared()
     lib = _lib.lib()
-    assert lib.hx_abi_version() == _lib.HX_ABI_VERSION == 2
+    assert lib.hx_abi_version() == _lib.HX_ABI_VERSION == 3
     assert lib.hx_strerror(0) == b"ok"
     assert b"data type" in lib.hx_strerror(-1)
 

@@ -323,6 +323,77 @@ def test_fused_rope_cache_decode_attention_is_bit_identical(dt, heads, D):
         assert torch.equal(qb, dev(q)) and torch.equal(kb, dev(k_new))
 
 
+def test_decode_rank_descriptor_device_equals_host():
+    """The rank descriptor ([ragged?] + sequences by decreasing length, ties by number) as the device writes it
+    (hx_decode_rank, hx_decode_advance_ranked) and as the engine's host-built steps write it: the same integers."""
+    from hydrainfer_amd import _lib
+    from hydrainfer_amd._C.kernel.flash_attn import decode_rank
+    from hydrainfer_amd.layer.causal_attention import decode_rank_descriptor
+    g = torch.Generator().manual_seed(12)
+    cases = [[832] * 32, ragged_contexts("uniform"), ragged_contexts("bimodal"), [5], [7, 7, 7], [1, 900], [100] * 31 + [135],
+             [100] * 31 + [129], torch.randint(1, 4000, (64,), generator=g).tolist(), torch.randint(1, 50, (200,), generator=g).tolist(),
+             [9] * 300]
+    for lens in cases:
+        cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+        got = decode_rank(cu).tolist()
+        assert got[0] == decode_rank_descriptor(lens)[0], lens[:8]
+        if len(lens) <= 256:
+            assert got == decode_rank_descriptor(lens), lens[:8]
+    # the advance that leaves the descriptor behind: lengths + stride, then ranked
+    lens = ragged_contexts("uniform")
+    B, bs = len(lens), 16
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32, device=DEV)
+    pos, kv, cu, slots = i32([l - 1 for l in lens]), i32(lens), torch.zeros(B + 1, dtype=torch.int32, device=DEV), i32([0] * B)
+    table, cu_b = i32(list(range(B * 64))), i32([64 * i for i in range(B + 1)])
+    desc = torch.full((B + 1,), -1, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().hx_decode_advance_ranked(pos.data_ptr(), kv.data_ptr(), cu.data_ptr(), slots.data_ptr(), table.data_ptr(),
+                                                   cu_b.data_ptr(), B, bs, 3, desc.data_ptr(), _lib.current_stream()), "advance")
+    assert kv.tolist() == [l + 3 for l in lens] and desc.tolist() == decode_rank_descriptor([l + 3 for l in lens])
+
+
+@pytest.mark.parametrize("kind", ["uniform", "bimodal", "even", "one_long"])
+@pytest.mark.parametrize("dt,H", [(torch.bfloat16, 32), (torch.float16, 40)])
+def test_ranked_decode_is_bit_identical_to_the_static_grid(dt, H, kind):
+    """RANKED form of the decode kernel (a big ragged batch laid over the CUs in length-ranked snake order, the rank
+    descriptor handed in): only WHICH workgroup computes a (sequence, head) changes — output and cache bits equal the
+    static grid's, for 7B (1024 pairs = 4 rounds of CUs) and 13B (1280 pairs: a partial fifth round) head counts."""
+    from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, decode_rank
+    from oracle import ops
+    B, D, bs = 32, 128, 16
+    kv_lens = {"uniform": ragged_contexts("uniform"), "bimodal": ragged_contexts("bimodal"), "even": [500] * B,
+               "one_long": [200] * 7 + [959] + [200] * 24}[kind]
+    q, kc, vc, cu_q, cu_k, bt, cu_b = _random_paged(B, H, H, D, kv_lens, [1] * B, dt, seed=H)
+    g = torch.Generator().manual_seed(4)
+    k_new = torch.randn((B, H, D), generator=g).to(dt)
+    v_new = torch.randn((B, H, D), generator=g).to(dt)
+    pos = torch.tensor([l - 1 for l in kv_lens], dtype=torch.int32)
+    cs = ops.build_cos_sin_cache(D, 4096, 1e4, dt)
+    slots = torch.tensor([int(bt[int(cu_b[i]) + (l - 1) // bs]) * bs + (l - 1) % bs for i, l in enumerate(kv_lens)], dtype=torch.int32)
+    dev = lambda t: t.to(DEV)
+    rank = decode_rank(dev(cu_k))
+    assert int(rank[0]) == (0 if kind == "even" else 1)
+    outs = []
+    for rd in (None, rank):
+        kcb, vcb = dev(kc).clone(), dev(vc).clone()
+        ob = torch.empty((B, H, D), dtype=dt, device=DEV)
+        decode_attention_fused(ob, dev(q), dev(k_new), dev(v_new), kcb, vcb, dev(pos), dev(cs), dev(slots), dev(cu_q), dev(cu_k),
+                               dev(bt), dev(cu_b), max(kv_lens), 1 / math.sqrt(D), 0, rank_desc=rd)
+        torch.cuda.synchronize()
+        outs.append((ob, kcb, vcb))
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_), kind
+    # and against the oracle on three sequences (the new token appended to the cache the way the kernel did)
+    tol = ATTN_TOL[dt][0]
+    ob, kcb, vcb = outs[1]
+    order = sorted(range(B), key=lambda i: kv_lens[i])
+    for i in (order[0], order[-1], order[B // 2]):
+        qi, _ = ops.apply_rotary_pos_emb(q[i:i + 1], k_new[i:i + 1], pos[i:i + 1], cs, D, False)
+        ref = ops.paged_attention(qi, kcb.cpu(), vcb.cpu(), torch.tensor([0, 1], dtype=torch.int32),
+                                  torch.tensor([0, kv_lens[i]], dtype=torch.int32), bt[int(cu_b[i]):int(cu_b[i + 1])],
+                                  torch.tensor([0, int(cu_b[i + 1] - cu_b[i])], dtype=torch.int32))
+        assert_close_t(ob[i:i + 1], ref, tol, tol, what=f"ranked {kind} seq {i} (kv {kv_lens[i]})")
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_fused_attention_from_qkv_slabs_is_bit_identical(dt):
     """decode_attention_fused reading q/k/v from the qkv GEMM's split-K slabs == reducing the

@@ -40,9 +40,11 @@ def test_register_budgets_of_the_benchmarked_instantiations(table):
     # fused decode attention, head_dim 128: <= 128 registers = 4 workgroups of 4 waves per CU (the 1024 workgroups of a
     # batch-32 launch are all resident at once)
     for dt in ("BF16", "F16"):
-        r = by[f"attn_decode_kernel<{dt}, 128, 4, true, true>"]
-        assert r["vgpr_count"] <= 128, r                            # (.vgpr_count is the unified total, AGPRs included)
-        assert r["group_segment_fixed_size"] <= 40 * 1024           # four per CU inside 160 KiB
+        for ranked in ("false", "true"):      # the static grid, and the RANKED form the benchmark's big batches run
+            r = by[f"attn_decode_kernel<{dt}, 128, 4, true, true, {ranked}>"]
+            assert r["vgpr_count"] <= 128, r                            # (.vgpr_count is the unified total, AGPRs included)
+            assert r["group_segment_fixed_size"] <= 40 * 1024           # four per CU inside 160 KiB
+            assert r["kernarg_segment_size"] >= 64                      # 7 pointers + 2 ints in front of the struct: all preloaded
     # activations-in-registers GEMMs: one wave per SIMD by design (x and a weight buffer set fill the 512 registers)
     for name in ("gemm_xreg_kernel<BF16, 2, 32, 1, 0, 1>", "gemm_xreg_kernel<BF16, 2, 32, 0, 0, 1>",
                  "gemm_xreg_kernel<BF16, 2, 22, 0, 0, 0>", "gemm_xreg_kernel<BF16, 2, 40, 1, 0, 1>",
