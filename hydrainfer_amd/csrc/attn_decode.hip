@@ -36,7 +36,9 @@
 //     (Tried and dropped in the same round: key ranges dealt from a counter — one word serves ~88 draws / us, and every
 //     item's start-up is two or three dependent loads of 8-17 us each under load (a CU keeps ~256 KiB of tile requests
 //     queued); cutting outlier sequences with a last-arriver merge — no gain over ranking whole sequences on any batch
-//     measured; ranking inside every workgroup from the lengths — four serial rounds of scalar loads, 2 us per launch.)
+//     measured; ranking inside every workgroup from the lengths — four serial rounds of scalar loads, 2 us per launch;
+//     page ids through the scalar cache, one per tile two tiles ahead — the s_waitcnt lgkmcnt(0) each use needs also drains
+//     the tile's LDS traffic: 72 -> 92 us at 32 x 832 keys.)
 #include <cstring>
 #include "attn_common.h"
 
