@@ -255,3 +255,113 @@ def test_distributed_engine_send_recv_pull(roles):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(r, "ok") for r in range(len(roles))], results
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A rank dies in the middle of a trace (hydrainfer/cluster/epdnode.py:428-442: a hand-over that fails ends THAT request —
+# blocks freed on both sides, a None token to its stream — never the node that noticed).
+# ---------------------------------------------------------------------------------------------------------------------
+N_EARLY, N_LATE, T_LATE = 14, 6, 3.0
+
+
+def _kill_worker(rank, roles, port, q, victim, die_after):
+    try:
+        import time
+        os.environ["HX_PEER_DEAD_AFTER_S"] = "1.0"
+        import torch.distributed as dist
+        from hydrainfer_amd.engine import InstructionCreator
+        from hydrainfer_amd.engine.distributed import RankEngine, replay_distributed
+        world = len(roles)
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+        engine, kv, img = _build_engine(rank, roles, None)
+        if rank == victim:
+            real_step = engine.step
+
+            def step():
+                # dies once it has handed `die_after` requests on to D ranks while others are still queued or being pulled
+                handed = sum(1 for r in engine.node.finished) + len(engine.held) + getattr(engine, "n_freed", 0)
+                s_ = engine.node.batch_scheduler
+                if handed >= die_after and (s_.waiting or s_.running):
+                    os._exit(17)              # a fresh child process that never touched a GPU: it just stops
+                return real_step()
+            real_deliver = engine._deliver
+
+            def deliver(src, kind, payload):
+                if kind == "free":
+                    engine.n_freed = getattr(engine, "n_freed", 0) + 1
+                real_deliver(src, kind, payload)
+            engine._deliver, engine.step = deliver, step
+        reqs = _requests(N_EARLY + N_LATE)
+        arrivals = [0.002 * i for i in range(N_EARLY)] + [T_LATE + 0.002 * i for i in range(N_LATE)]
+        box = [time.perf_counter() + 0.05]
+        dist.broadcast_object_list(box, src=0)
+        engine.open_mailbox("kill")
+        dist.barrier()
+        try:
+            mine = replay_distributed(engine, InstructionCreator(IMAGE_TOKEN, N_IMG, BS), reqs, arrivals, box[0], deadline_s=40)
+        except TimeoutError as e:
+            n = engine.node
+            raise TimeoutError(f"{e}: finished {[r.request_id for r in n.finished]} failed {[(r.request_id, r.failed) for r in n.failed]} "
+                               f"held {list(engine.held)} dead {engine.dead} reaped {engine.reaped} n_reaped {engine.n_reaped} total "
+                               f"{engine.total_finished} waiting {[r.request_id for r in n.batch_scheduler.waiting]} running "
+                               f"{[(r.request_id, repr(r.current_instruction())) for r in n.batch_scheduler.running]} registered "
+                               f"{[(rid, engine.mailbox.owner_of(rid, er)) for rid, _, er in engine.mailbox.registered()]}")
+        sch = engine.node.batch_scheduler
+        state = {"queued": [(r.request_id, repr(r.current_instruction()), r.path) for r in list(sch.waiting) + list(sch.running)],
+                 "held": len(engine.held), "migrating": engine.node.batch_scheduler.migrating_cnt, "dead": sorted(engine.dead),
+                 "reaped": engine.n_reaped, "pinned": [m.n_blocks - len(m.shared_cache.to_be_evicted)
+                                                       for m in (engine.node.kv_cache_block_manager, engine.node.image_cache_block_manager)
+                                                       if m is not None]}
+        q.put((rank, "ok", mine, state))
+        # rank 0 hosts the store every rank's mailbox lives on: it leaves last
+        store = dist.distributed_c10d._get_default_store()
+        store.add("kill/left", 1)
+        t_end = time.monotonic() + 30
+        while rank == 0 and store.add("kill/left", 0) < world - 1 and time.monotonic() < t_end:
+            time.sleep(0.05)
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None))
+    q.close()
+    q.join_thread()
+    os._exit(0)          # (no collective teardown: one rank of the group is gone)
+
+
+def test_a_rank_dies_mid_trace_and_only_its_requests_end():
+    roles, victim = ["E", "P", "P", "D", "D"], 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kill_worker, args=(r, roles, port, q, victim, 3)) for r in range(len(roles))]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(len(roles) - 1):
+        rank, status, mine, state = q.get(timeout=240)
+        assert status == "ok", (rank, status)
+        results[rank] = (mine, state)
+    for p in procs:
+        p.join(timeout=60)
+    assert procs[victim].exitcode == 17 and sorted(results) == [0, 2, 3, 4]
+    reqs = _requests(N_EARLY + N_LATE)
+    finished, failed = {}, {}
+    for rank, (mine, state) in results.items():
+        for rid, r in mine.items():
+            assert rid not in finished and rid not in failed, f"request {rid} reported twice"
+            (failed if r.get("failed") else finished)[rid] = r
+        # every survivor noticed, holds nothing for the dead rank, and has all its blocks back
+        assert state["dead"] == [victim] and state["held"] == 0 and state["migrating"] == 0 and not any(state["pinned"]), \
+            (rank, str(state), sorted(mine), [(k, v.get("failed"), v["path"]) for k, v in mine.items()])
+    reaped = sum(state["reaped"] for _, state in results.values())
+    # every request ended exactly one way: finished, terminated by the rank that held it, or written off with the dead rank
+    assert len(finished) + len(failed) + reaped == len(reqs), (sorted(finished), sorted(failed), reaped)
+    assert len(failed) + reaped > 0, "the death cost nothing?"
+    for rid, r in finished.items():
+        assert r["tokens"] == expected_tokens(reqs[rid]), rid
+        assert roles[r["path"][-1]] == "D"
+    for rid, r in failed.items():
+        assert r["tokens"] != expected_tokens(reqs[rid]) and "died" in r["failed"], (rid, r["failed"])
+    # requests that entered after the death was noticed run over the surviving P rank only, and all of them finish
+    for rid in range(N_EARLY, N_EARLY + N_LATE):
+        assert rid in finished and victim not in finished[rid]["path"], (rid, finished.get(rid))
+    assert any(victim in r["path"] for r in finished.values()), "nothing went through the victim before it died"

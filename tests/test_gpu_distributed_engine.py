@@ -162,3 +162,133 @@ def test_engine_nodes_one_process_per_gpu(roles):
     if torch.cuda.device_count() < len(roles):
         pytest.skip(f"needs {len(roles)} GPUs, this box has {torch.cuda.device_count()}")
     _run(roles, per_device=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A P rank dies in the middle of a trace, with the real kernels and real IPC pulls (the CPU twin with the closed-form
+# model: tests/test_distributed_engine_cpu.py::test_a_rank_dies_mid_trace_and_only_its_requests_end).  The rank that
+# dies has touched the GPU: it leaves with os._exit (non-zero), nothing is re-exec'd, nobody waits for it.
+# ---------------------------------------------------------------------------------------------------------------------
+def _kill_worker(rank, roles, port, q, victim):
+    try:
+        import time
+        os.environ["HX_PEER_DEAD_AFTER_S"] = "2.0"
+        import torch.distributed as dist
+        from hydrainfer_amd._C.data_transfer import block_migration as bm
+        from hydrainfer_amd.engine.distributed import RankEngine, replay_distributed
+        from hydrainfer_amd.engine.scheduler import BatchSchedulerConfig
+        from hydrainfer_amd.engine.serve import build_node
+        from hydrainfer_amd.model.clip import ClipShape, LlavaVisionModel, random_state_dict
+        from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
+        from hydrainfer_amd.model.llava import LlavaLanguageModel
+        from tests.test_engine_e2e import N_IMG_TOK, creator, trace_requests
+        world = len(roles)
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+        dev, dt = torch.device("cuda:0"), torch.float16
+        torch.cuda.set_device(dev)
+        lshape, cshape = LlamaShape(**C.TINY_LLAMA), ClipShape(**C.TINY_CLIP)
+        lm = LlavaLanguageModel(LlamaForCausalLM.from_reference_state_dict(lshape, C.tiny_llama_state_dict(dt), dt, dev),
+                                image_token_id=C.TINY_IMAGE_TOKEN_ID)
+        vision = LlavaVisionModel(cshape, dt, dev, {k: v.to(dt).to(dev) for k, v in
+                                                    random_state_dict(cshape, seed=3, std=0.05).items()})
+        sched = BatchSchedulerConfig(priority="prefill", max_running_requests=6, chunked_prefill=True,
+                                     token_budgets=40, image_budgets=2)
+        engine = RankEngine(rank, roles, build_node(f"{roles[rank]}{rank}", roles[rank], lm, vision, lshape, dt, dev, 96, 14,
+                                                    N_IMG_TOK, sched, rank=rank, graph_decode=True, max_blocks_per_seq=8,
+                                                    world_size=world), None)
+        n = engine.node
+        pools = [None] * world
+        dist.all_gather_object(pools, {
+            "kv": n.kv_cache_block_manager.memory_handle if n.kv_cache_block_manager else None,
+            "image": n.image_cache_block_manager.memory_handle if n.image_cache_block_manager else None})
+        for r, role in enumerate(roles):          # map peers' pools before any graph exists
+            if r != rank and n.node_type.enable_prefill and "E" in role:
+                bm._open(pools[r]["image"])
+            if r != rank and n.node_type.enable_decode and "P" in role:
+                bm._open(pools[r]["kv"])
+        if rank == victim:
+            real_step, real_deliver = engine.step, engine._deliver
+
+            def step():
+                s_ = engine.node.batch_scheduler
+                if getattr(engine, "n_freed", 0) >= 2 and (s_.waiting or s_.running or engine.held):
+                    torch.cuda.synchronize(dev)
+                    os._exit(17)
+                return real_step()
+
+            def deliver(src, kind, payload):
+                if kind == "free":
+                    engine.n_freed = getattr(engine, "n_freed", 0) + 1
+                real_deliver(src, kind, payload)
+            engine.step, engine._deliver = step, deliver
+        base = [r for _, r in trace_requests()]
+        late = [r for _, r in trace_requests()]
+        for i, r in enumerate(late):
+            r.request_id = len(base) + i
+        reqs = base + late
+        arrivals = [0.01 * i for i in range(len(base))] + [6.0 + 0.01 * i for i in range(len(late))]
+        box = [time.perf_counter() + 0.1]
+        dist.broadcast_object_list(box, src=0)
+        engine.open_mailbox("kill")
+        dist.barrier()
+        mine = replay_distributed(engine, creator(), reqs, arrivals, box[0], dev, deadline_s=120)
+        pinned = []
+        for m in (n.kv_cache_block_manager, n.image_cache_block_manager):
+            if m is not None:
+                pinned.append(m.n_blocks - len(m.shared_cache.to_be_evicted)
+                              - (1 if m is n.kv_cache_block_manager and n.node_type.enable_decode else 0))   # the decoder's pad block
+        state = {"held": len(engine.held), "migrating": n.batch_scheduler.migrating_cnt, "dead": sorted(engine.dead),
+                 "reaped": engine.n_reaped, "pinned": pinned, "n_base": len(base),
+                 "max_tokens": {r.request_id: r.sampling_params.max_tokens for r in reqs}}
+        q.put((rank, "ok", {k: {"tokens": v["tokens"], "path": v["path"], "failed": v.get("failed")} for k, v in mine.items()}, state))
+        store = dist.distributed_c10d._get_default_store()
+        store.add("kill/left", 1)
+        t_end = time.monotonic() + 30
+        while rank == 0 and store.add("kill/left", 0) < world - 1 and time.monotonic() < t_end:
+            time.sleep(0.05)
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc(), None, None))
+    q.close()
+    q.join_thread()
+    torch.cuda.synchronize()
+    os._exit(0)
+
+
+@pytest.mark.gpu
+def test_a_prefill_rank_dies_mid_trace_on_the_gpu():
+    roles, victim = ["E", "P", "P", "D"], 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kill_worker, args=(r, roles, port, q, victim)) for r in range(len(roles))]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(len(roles) - 1):
+            rank, status, mine, state = q.get(timeout=300)
+            assert status == "ok", (rank, status[-2000:])
+            results[rank] = (mine, state)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert procs[victim].exitcode == 17 and sorted(results) == [0, 2, 3]
+    finished, failed = {}, {}
+    for rank, (mine, state) in results.items():
+        for rid, r in mine.items():
+            assert rid not in finished and rid not in failed, f"request {rid} reported twice"
+            (failed if r["failed"] else finished)[rid] = r
+        assert state["dead"] == [victim] and state["held"] == 0 and state["migrating"] == 0 and not any(state["pinned"]), (rank, state)
+    state = results[0][1]
+    n_base, max_tokens = state["n_base"], state["max_tokens"]
+    reaped = sum(st["reaped"] for _, st in results.values())
+    assert len(finished) + len(failed) + reaped == len(max_tokens), (sorted(finished), sorted(failed), reaped)
+    assert len(failed) + reaped > 0
+    for rid, r in finished.items():
+        assert len(r["tokens"]) == max_tokens[rid] and roles[r["path"][-1]] == "D"
+    for rid in range(n_base, len(max_tokens)):      # entered after the death was noticed: over the surviving P rank, all finish
+        assert rid in finished and victim not in finished[rid]["path"], (rid, finished.get(rid))
+    assert any(victim in r["path"] for r in finished.values()), "nothing went through the victim before it died"
