@@ -336,14 +336,15 @@ __global__ __launch_bounds__(NW * 64, (D <= 128 ? 4 : 2)) void attn_decode_kerne
   auto request_pages = [&]() {
     const int tj = chunk0 + NW * lane;
     my_page = (tj < t_end) ? bt[page_of(tj)] : 0;
-    n_my = min(64, (t_end - chunk0 + NW - 1) / NW);  // wave-uniform
+    n_my = max(0, min(64, (t_end - chunk0 + NW - 1) / NW));  // wave-uniform
   };
-  // (UNCONDITIONAL in the prologue: a wave without a tile — a sequence shorter than 16 w keys — reads rows of page 0
-  // that nobody uses.  Under a branch the compiler's wait-count model merges the two paths and makes the prologue wait
-  // for the tile it has just requested.)
+  // (UNCONDITIONAL in the prologue — under a branch the compiler's wait-count model merges the two paths and makes the
+  // prologue wait for the tile it has just requested — but a wave without a tile (a sequence shorter than 16 w keys, a
+  // late split) touches no memory: its buffer resource has zero records, as in the main loop.  Round-5 ADVICE: it used to
+  // read rows of physical block 0, i.e. relied on block 0 of whatever view the caller passed being mapped.)
   auto request_first_tile = [&]() {
-    load_tile<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0),
-                        row0_of(chunk0), max(1, kv_len - (chunk0 << SH)), lane);
+    load_tile_b<T, D, NT>(bufA, p, kbase, vbase, __builtin_amdgcn_readlane(my_page, 0), row0_of(chunk0),
+                          kv_len - (chunk0 << SH), lane, chunk0 < t_end);
   };
   auto begin_chunk = [&]() { request_pages(); request_first_tile(); };
   // (D = 256 with the fused prologue: the prologue's q / new-key fragments and the first tile together do not fit the

@@ -1239,7 +1239,15 @@ extern "C" int hx_gate_up_silu_wide_xreg_supported(int64_t M, int64_t inter, int
   if (M < 33 || M > 64 || !hx_gate_up_xreg_supported(M, inter, K, 1)) return 0;
   int S, KW, pkP, sp;
   if (!wide_plan(2 * inter, K, true, &S, &KW, &pkP, &sp)) return 0;
-  return KW == 16 && S == 2 && sp == 1 && pkP == 2 * 4 * KW ? 1 : 0;      // one packing split of two full halves (K = 4096)
+  if (!(KW == 16 && S == 2 && sp == 1 && pkP == 2 * 4 * KW)) return 0;      // one packing split of two full halves (K = 4096)
+  // the launch's LDS (launch_wide_kw, EPI = 1: 64 KiB + 8 KiB per unit of a workgroup) depends on the CU count of the
+  // device: on a smaller or partitioned one the units per workgroup grow — answer what the launch itself would (round-5
+  // ADVICE: the plan said yes, the launch HX_ERR_SHAPE, and the 33 .. 64-row step had no other path)
+  constexpr int RG = wide_rg(16);
+  const int n_units = (int)((2 * inter) >> 4) / RG;
+  const int nb = std::max(1, std::min(n_cus(), n_units));
+  const size_t lds = (size_t)2 * RG * 4 * 4 * 1024 + (size_t)((n_units + nb - 1) / nb) * RG * 4 * 1024;
+  return lds <= 150 * 1024 ? 1 : 0;
 }
 
 extern "C" int hx_norm_gate_up_silu_wide_xreg(void* act, void* residual, const float* slabs_in, int32_t n_splits_in,

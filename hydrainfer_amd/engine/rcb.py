@@ -97,7 +97,7 @@ class RequestControlBlock:
     def is_finished(self) -> bool:
         if self.instructions.curr is None or self.eos_hit:
             return True
-        if len(self.output_token_ids) == self.sampling_params.max_tokens:
+        if len(self.output_token_ids) >= self.sampling_params.max_tokens:      # (>=: a cancelled stream lowers max_tokens, api_server.py)
             return True
         return bool(self.output_token_ids) and self.output_token_ids[-1] in self.sampling_params.eos_token_ids
 

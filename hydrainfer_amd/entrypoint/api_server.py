@@ -10,6 +10,7 @@ ZmqOutputTokenProcessor, hydrainfer/engine/output_token_processor.py:41-110).  S
 Non-streaming requests are refused exactly where the reference raises (api_server.py:150)."""
 import asyncio
 import io
+import itertools
 import json
 import queue
 import threading
@@ -31,6 +32,8 @@ class StreamOutputTokenProcessor(OutputTokenProcessor):
         self.loop, self.tokenizer = loop, tokenizer
         self.queue: asyncio.Queue = asyncio.Queue()
         self.n_tokens = 0
+        self.on_end: Optional[Callable[["StreamOutputTokenProcessor"], None]] = None     # set by the front end: its registry of live streams
+        self.ended = False
 
     def _put(self, item) -> None:
         try:
@@ -38,14 +41,26 @@ class StreamOutputTokenProcessor(OutputTokenProcessor):
         except RuntimeError:        # the loop is gone (server shut down while the engine drains)
             pass
 
+    def _end(self) -> None:
+        if not self.ended:
+            self.ended = True
+            if self.on_end is not None:
+                self.on_end(self)
+
     def append_token_id(self, token_id: int, is_last_token: bool = False) -> None:
+        if token_id is None:        # the engine terminated the request (EPDNode.terminate: the reference's None token)
+            self.fail(RuntimeError("the request was terminated by the engine"))
+            return
         self.n_tokens += 1
         self._put(self.tokenizer.decode(token_id))
         if is_last_token:
             self._put(None)
+            self._end()
 
     def fail(self, exc: BaseException) -> None:
-        self._put(exc)
+        if not self.ended:
+            self._put(exc)
+        self._end()
 
 
 class EngineFrontend:
@@ -59,6 +74,16 @@ class EngineFrontend:
         self.thread: Optional[threading.Thread] = None
         self.error: Optional[BaseException] = None
         self.n_admitted = 0
+        # every stream that has been submitted and has not ended: should the engine thread die, ALL of them are failed —
+        # those still in the inbox and those already attached to a request (round-5 ADVICE: the latter used to wait for ever)
+        self.live: dict = {}
+        self.live_lock = threading.Lock()
+        self.rcb_of: dict = {}          # processor id -> its request (local engine): what a cancelled stream ends
+
+    def _forget(self, processor) -> None:
+        with self.live_lock:
+            self.live.pop(id(processor), None)
+        self.rcb_of.pop(id(processor), None)
 
     def start(self) -> None:
         self.running = True
@@ -71,10 +96,17 @@ class EngineFrontend:
             self.thread.join(timeout)
 
     def submit(self, request: TokenRequest, processor: StreamOutputTokenProcessor) -> None:
-        if self.error is not None:
-            processor.fail(RuntimeError(f"the engine thread has stopped: {self.error!r}"))
-            return
+        processor.on_end = self._forget
+        with self.live_lock:
+            self.live[id(processor)] = processor
         self.inbox.put((request, processor))
+        if self.error is not None:      # (checked AFTER the put: a loop that died in between drains nothing any more)
+            processor.fail(RuntimeError(f"the engine thread has stopped: {self.error!r}"))
+
+    def cancel(self, processor: StreamOutputTokenProcessor) -> None:
+        """The client of this stream has gone: stop generating for it (its request ends at its next token and frees its
+        blocks the ordinary way) instead of decoding to max_tokens for nobody."""
+        self.inbox.put((None, processor))
 
     def _admit(self) -> int:
         n = 0
@@ -84,6 +116,11 @@ class EngineFrontend:
             except queue.Empty:
                 break
             n += 1
+            if request is None:
+                self._cancel(processor)
+                continue
+            if processor.ended:          # cancelled or failed before it got here
+                continue
             try:
                 self._start(request, processor)
                 self.n_admitted += 1
@@ -94,7 +131,15 @@ class EngineFrontend:
     def _start(self, request: TokenRequest, processor: StreamOutputTokenProcessor) -> None:
         rcb = self.creator.process(request)           # ValueError: prompt + max_tokens past the rotary table
         rcb.register_output_token_processor(processor)
+        self.rcb_of[id(processor)] = rcb
         self.cluster.add_request(rcb)
+
+    def _cancel(self, processor: StreamOutputTokenProcessor) -> None:
+        rcb = self.rcb_of.get(id(processor))
+        if rcb is not None and rcb.sampling_params is not None:
+            rcb.sampling_params.max_tokens = max(1, len(rcb.output_token_ids))      # finished at its next look
+        processor.ended = True
+        self._forget(processor)
 
     def _loop(self) -> None:
         try:
@@ -111,12 +156,10 @@ class EngineFrontend:
         except BaseException as e:          # a failing step must not leave streams waiting for ever
             self.error = e
             self.running = False
-            while True:
-                try:
-                    _, processor = self.inbox.get_nowait()
-                    processor.fail(e)
-                except queue.Empty:
-                    break
+            with self.live_lock:
+                stranded = list(self.live.values())
+            for processor in stranded:       # in the inbox or attached to a request: every open stream ends now
+                processor.fail(e)
             raise
 
 
@@ -159,7 +202,7 @@ def serve_worker(engine, creator: InstructionCreator, should_stop: Callable[[], 
 
 
 _REASONS = {200: "OK", 400: "Bad Request", 404: "Not Found", 405: "Method Not Allowed", 413: "Payload Too Large",
-            500: "Internal Server Error", 501: "Not Implemented"}
+            500: "Internal Server Error", 501: "Not Implemented", 503: "Service Unavailable"}
 
 
 class ApiServer:
@@ -170,7 +213,7 @@ class ApiServer:
         self.frontend, self.tokenizer, self.image_processor = frontend, tokenizer, image_processor
         self.host, self.port, self.max_body_bytes, self.image_size = host, port, max_body_bytes, image_size
         self.server: Optional[asyncio.base_events.Server] = None
-        self._next_id = 0
+        self._ids = itertools.count(1)          # (request ids are drawn on executor threads)
         self.n_streams_open = 0
 
     # ------------------------------------------------------------------ request -> engine
@@ -191,8 +234,7 @@ class ApiServer:
             pixels = self.image_processor.process(image)
             import xxhash
             image_hash = xxhash.xxh64(req.image_png).intdigest() >> 1             # content hash: the prefix cache's image key
-        self._next_id += 1
-        return TokenRequest(request_id=self._next_id, token_ids=token_ids, pixel_values=pixels, image_size=size,
+        return TokenRequest(request_id=next(self._ids), token_ids=token_ids, pixel_values=pixels, image_size=size,
                             image_hash=image_hash, sampling_params=SamplingParameters(max_tokens=req.max_tokens))
 
     # ------------------------------------------------------------------ HTTP
@@ -224,7 +266,12 @@ class ApiServer:
                 k, _, v = h.decode("latin-1").partition(":")
                 headers[k.strip().lower()] = v.strip()
             if path == "/health":
-                await self._send(writer, 200 if method == "GET" else 405)
+                if method != "GET":
+                    await self._send(writer, 405)
+                elif self.frontend.error is not None:       # the engine thread is gone: nothing will ever be served
+                    await self._send(writer, 503, json.dumps({"detail": f"engine stopped: {self.frontend.error!r}"[:300]}).encode())
+                else:
+                    await self._send(writer, 200)
                 return
             if path != "/v1/chat/completions":
                 await self._send(writer, 404, b'{"detail":"Not Found"}')
@@ -232,7 +279,13 @@ class ApiServer:
             if method != "POST":
                 await self._send(writer, 405, b'{"detail":"Method Not Allowed"}')
                 return
-            n = int(headers.get("content-length", "0") or 0)
+            try:
+                n = int(headers.get("content-length", "0") or 0)
+                if n < 0:
+                    raise ValueError
+            except ValueError:
+                await self._send(writer, 400, b'{"detail":"content-length must be a non-negative integer"}')
+                return
             if n > self.max_body_bytes:
                 await self._send(writer, 413, b'{"detail":"request body too large"}')
                 return
@@ -243,7 +296,8 @@ class ApiServer:
                     # api_server.py:149-150: `raise Exception('not support non stream chat completion')`
                     await self._send(writer, 501, json.dumps({"detail": "not support non stream chat completion"}).encode())
                     return
-                token_request = self._token_request(req)
+                # PNG decode + CLIP preprocessing + tokenizer: off the event loop, which is writing other streams' chunks
+                token_request = await asyncio.get_running_loop().run_in_executor(None, self._token_request, req)
             except (proto.ProtocolError, json.JSONDecodeError, UnicodeDecodeError) as e:
                 await self._send(writer, 400, json.dumps({"detail": str(e)}).encode())
                 return
@@ -283,6 +337,9 @@ class ApiServer:
                 if item:                 # api_server.py:135: empty pieces are not sent
                     await self._chunk(writer, proto.chat_stream_chunk(request_id, created, req.model, item))
             await self._chunk(writer, proto.DONE)
+        except (ConnectionError, asyncio.CancelledError):
+            self.frontend.cancel(processor)        # the client has gone: stop generating for it
+            raise
         finally:
             self.n_streams_open -= 1
             try:

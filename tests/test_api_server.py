@@ -173,6 +173,86 @@ def test_engine_failure_and_oversized_prompt_end_the_stream_loudly():
     assert done and n_events == 3 and front.error is None
 
 
+def test_engine_thread_death_ends_every_open_stream_and_health_says_so():
+    """Round-5 ADVICE: when the engine thread dies, the streams of requests already ADMITTED used to wait for ever (only
+    the inbox was failed) and /health kept answering 200."""
+    server, front, tok = _tiny_server()
+    steps = [0]
+    real_step = front.cluster.step
+
+    def step():
+        steps[0] += 1
+        if steps[0] > 6 and front.n_admitted >= 2:
+            raise RuntimeError("injected: the engine step blew up")
+        return real_step()
+    front.cluster.step = step
+
+    async def one(base, payload):
+        import httpx
+        async with httpx.AsyncClient(timeout=20) as c:
+            async with c.stream("POST", f"{base}/chat/completions", json=payload) as r:
+                return [l async for l in r.aiter_lines() if l.startswith("data: ")]
+
+    async def go():
+        await server.start()
+        front.start()
+        base = f"http://127.0.0.1:{server.port}/v1"
+        try:
+            import httpx
+            streams = await asyncio.gather(one(base, _payload("a b c d e f", _png(1), 200)), one(base, _payload("hello there", None, 200)))
+            async with httpx.AsyncClient() as c:
+                health = await c.get(f"http://127.0.0.1:{server.port}/health")
+                late = await one(base, _payload("anyone?", None, 3))        # submitted to a dead engine: fails at once
+            reader, writer = await asyncio.open_connection("127.0.0.1", server.port)     # (httpx will not send this itself)
+            writer.write(b"POST /v1/chat/completions HTTP/1.1\r\nhost: x\r\ncontent-length: nonsense\r\n\r\n{}")
+            await writer.drain()
+            bad = (await reader.readline()).decode()
+            writer.close()
+            return streams, health, late, bad
+        finally:
+            front.stop()
+            await server.close()
+    streams, health, late, bad = asyncio.run(go())
+    assert isinstance(front.error, RuntimeError) and not front.live
+    for lines in streams + [late]:
+        last = json.loads(lines[-1][6:])
+        assert "error" in last and ("blew up" in last["error"]["message"] or "engine thread has stopped" in last["error"]["message"]), lines[-1]
+        assert "data: [DONE]" not in lines
+    assert health.status_code == 503 and "engine stopped" in health.json()["detail"]
+    assert bad.startswith("HTTP/1.1 400"), bad
+
+
+def test_a_client_that_disconnects_stops_its_request():
+    """Round-5 ADVICE: a stream whose client went away kept decoding to max_tokens, holding its KV blocks."""
+    server, front, tok = _tiny_server()
+
+    async def go():
+        await server.start()
+        front.start()
+        try:
+            reader, writer = await asyncio.open_connection("127.0.0.1", server.port)
+            body = json.dumps(_payload("tell me a very long story", None, 100)).encode()
+            writer.write(b"POST /v1/chat/completions HTTP/1.1\r\nhost: x\r\ncontent-type: application/json\r\ncontent-length: "
+                         + str(len(body)).encode() + b"\r\n\r\n" + body)
+            await writer.drain()
+            seen = b""
+            while seen.count(b"data: ") < 3:          # a few tokens have come
+                seen += await reader.read(4096)
+            writer.close()                           # ... and the client hangs up
+            node = front.cluster.nodes[0]
+            for _ in range(400):                      # the engine drains: the request ends long before 100 tokens
+                await asyncio.sleep(0.01)             # (idle() alone is racy from this thread: a step in flight holds its batch)
+                if node.finished and front.cluster.idle() and server.n_streams_open == 0:
+                    break
+            return [len(r.output_token_ids) for r in node.finished], front.cluster.idle()
+        finally:
+            front.stop()
+            await server.close()
+    n_tokens, idle = asyncio.run(go())
+    assert idle and len(n_tokens) == 1 and 3 <= n_tokens[0] < 60, n_tokens
+    assert not front.live and front.error is None
+
+
 def test_stream_processor_hands_tokens_across_threads():
     import threading
 

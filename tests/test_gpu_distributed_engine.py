@@ -206,6 +206,15 @@ def _kill_worker(rank, roles, port, q, victim):
                 bm._open(pools[r]["image"])
             if r != rank and n.node_type.enable_decode and "P" in role:
                 bm._open(pools[r]["kv"])
+        # warm-up epoch with everybody alive: graph captures, lazy library loads (seconds on a fresh box) happen HERE, so
+        # that the timed epoch below runs at the engine's real pace and "late" really is after the death
+        box = [time.perf_counter() + 0.1]
+        dist.broadcast_object_list(box, src=0)
+        engine.open_mailbox("warm")
+        dist.barrier()
+        warm = [r for _, r in trace_requests()]
+        replay_distributed(engine, creator(), warm, [0.01 * i for i in range(len(warm))], box[0], dev, deadline_s=120)
+        dist.barrier()
         if rank == victim:
             real_step, real_deliver = engine.step, engine._deliver
 
