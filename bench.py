@@ -569,6 +569,45 @@ def measured_traffic(args, model_name, algorithmic_bytes):
         return None, None
 
 
+def measured_gemm_traffic(args, model_name, weight_bytes_per_layer):
+    """HBM bytes of one layer's four decode GEMM launches from the committed PMC passes (FETCH_SIZE x2 gfx950 correction
+    + WRITE_SIZE, separate rocprofv3 --pmc runs): the norm-fused qkv and gate|up+silu launches and the down launch
+    from profiles/r5_gemm_xreg_pmc.json, the o launch from profiles/r2_gemm_packed_pmc.json.  Only for the workload
+    that was profiled (7B, 32 rows, bf16).  Returns (bytes, source) or (None, None)."""
+    if not (args.model == "7b" and args.batch == 32 and args.dtype == "bf16"):
+        return None, None
+    try:
+        xr = {s_["name"]: s_ for s_ in json.load(open(os.path.join(ROOT, "profiles", "r5_gemm_xreg_pmc.json")))["shapes"]}
+        pk = {s_["name"]: s_ for s_ in json.load(open(os.path.join(ROOT, "profiles", "r2_gemm_packed_pmc.json")))["shapes"]}
+        parts = [xr["norm+qkv"], xr["norm+gate_up+silu"], xr["down"], pk["o"]]
+        traffic = sum(p_["fetch_bytes_corrected"] + p_["write_bytes"] for p_ in parts)
+        alg = sum(p_["algorithmic_weight_bytes"] for p_ in parts)
+        if alg != weight_bytes_per_layer:
+            return None, None
+        return int(traffic), ("profiles/r5_gemm_xreg_pmc.json (norm+qkv, norm+gate|up+silu, down) + profiles/r2_gemm_packed_pmc.json (o): "
+                              f"fetch (x2) + write bytes of the four launches = {traffic / alg:.4f} x the weight bytes "
+                              "(the rest: the activations, the slabs in and out, the residual)")
+    except Exception:
+        return None, None
+
+
+def in_step_attention(args, model_name):
+    """The attention launch's duration INSIDE the decode step, from the last committed rocprofv3 kernel trace of this
+    command (profiles/*_in_step.json, written by tools/decode_timeline_summary.py): the standalone figure of `roofline`
+    is the conservative one, this is the one the step's time is made of.  Returns a dict or None."""
+    if not (args.model == "7b" and args.batch == 32 and args.dtype == "bf16"):
+        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench7b_in_step.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            return {"in_step_us": d["attention_us"], "in_step_frac": d.get("attention_frac"),
+                    "in_step_source": f"profiles/{os.path.basename(path)} ({d.get('source', 'rocprofv3 --kernel-trace of this command')})"}
+        except Exception:
+            continue
+    return None
+
+
 def time_decode_gemms(runner, reps=3):
     """Summed duration of the four decode GEMM launches of a layer (qkv, o, gate|up, down: the
     weight-streaming HIP kernel exactly as the decode step calls it), HIP events over one graph
@@ -923,6 +962,87 @@ def cpu_config0_full(shape, dtype, n_threads, n_generate=16):
             "weight_build_s": round(t_build, 1)}
 
 
+def parity_probe(dtype, dev, executor, steps=4):
+    """`parity_probe` (round-5 review, item 5): the tokens/s above travels with evidence FROM THE SAME PROCESS that the path
+    it timed computes what the reference computes.  A 2-layer model of the headline's width (hidden 4096, 32 heads x 128,
+    inter 11008, vocab 32064; random weights, seed 3) is run through the benchmarked configuration — 32 rows, the decode
+    step replayed by the same executor, default flags — for `steps` decode steps behind a 40-token prefill, and the CPU
+    oracle (oracle/model.py: the reference's eager torch path restated; a CHECKER here, like the cpu_baseline leg — never
+    part of the measured path) is teacher-forced with the device's tokens on the same weights and block tables.
+    tests/test_gpu_bench_config.py is the full form of this check (8 steps, both widths, both executors, both dtypes)."""
+    from hydrainfer_amd.model.llama import LlamaForCausalLM, LlamaShape
+    from hydrainfer_amd.model.runner import DecodeRunner, RunnerConfig
+    from oracle.model import OracleAttnMeta, OracleLlama
+    B, P, bs = 32, 40, 16
+    tol = {torch.bfloat16: 1.5e-1, torch.float16: 3e-2}[dtype]
+    tol32 = {torch.bfloat16: 1e-1, torch.float16: 2e-2}[dtype]
+    ulp = {torch.bfloat16: 2.0 ** -6, torch.float16: 2.0 ** -9}[dtype]
+    shape = LlamaShape(4096, 11008, 2, 32, 32, 128, 32064)
+    model = LlamaForCausalLM.random_init(shape, dtype, dev, seed=3)
+    runner = DecodeRunner(model, RunnerConfig(batch=B, prompt_len=P, n_generate=steps + 4, use_graph=True, executor=executor), seed=4)
+    oracle = OracleLlama(shape, model.to_reference_state_dict(), dtype)
+    pool0 = runner.pool.cpu().clone()
+    prompts = torch.randint(5, 32000, (B, P), generator=torch.Generator().manual_seed(11))
+    stash = {}
+    orig, orig_hidden = model.forward_logits, model.forward_hidden
+    model.forward_logits = lambda *a, **k: stash.__setitem__("logits", orig(*a, **k)) or stash["logits"]
+    model.forward_hidden = lambda *a, **k: stash.__setitem__("x", orig_hidden(*a, **k)) or stash["x"]
+    toks = [runner.prefill(prompts.to(dev)).cpu()]
+    logits, xs = [], []
+    for _ in range(steps):
+        runner.step()
+        torch.cuda.synchronize(dev)
+        logits.append(stash["logits"].float().cpu().clone())
+        xs.append(stash["x"].float().cpu().clone())
+        toks.append(runner.input_ids.cpu().clone())
+    if model.handover_failed():
+        return {"error": "a norm-fused launch gave up waiting for its producer workgroups"}
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)
+    caches = [(pool0[l, 0], pool0[l, 1]) for l in range(shape.num_hidden_layers)]
+    tables, n_pb = runner.tables, (P + bs - 1) // bs
+    meta = OracleAttnMeta(i32([P * r for r in range(B + 1)]), i32([P * r for r in range(B + 1)]),
+                          i32([tables[r][p_ // bs] * bs + p_ % bs for r in range(B) for p_ in range(P)]),
+                          i32([b for r in range(B) for b in tables[r][:n_pb]]), i32([n_pb * r for r in range(B + 1)]))
+    w32 = oracle.sd["lm_head.weight"].float()
+    n_rows = n_cmp = n_cmp32 = n_same = n_bad = n_far = 0
+    worst = worst32 = 0.0
+    with torch.inference_mode():
+        oracle.forward_logits(prompts.reshape(-1), i32(list(range(P)) * B), meta, caches, torch.arange(P - 1, B * P, P))   # fills the oracle's cache
+        for s_ in range(steps):
+            ctx_, pos = P + s_ + 1, P + s_
+            nb = (ctx_ + bs - 1) // bs
+            meta = OracleAttnMeta(i32(list(range(B + 1))), i32([ctx_ * r for r in range(B + 1)]),
+                                  i32([tables[r][pos // bs] * bs + pos % bs for r in range(B)]),
+                                  i32([b for r in range(B) for b in tables[r][:nb]]), i32([nb * r for r in range(B + 1)]))
+            ref_x = oracle.forward_hidden(toks[s_], i32([pos] * B), meta, caches)
+            ref = torch.nn.functional.linear(ref_x, oracle.sd["lm_head.weight"]).float()
+            ref32, hip32 = ref_x.float() @ w32.t(), xs[s_] @ w32.t()
+            worst = max(worst, (logits[s_] - ref).abs().max().item())
+            worst32 = max(worst32, (hip32 - ref32).abs().max().item())
+            top = ref.sort(dim=-1).values
+            clear = (top[:, -1] - top[:, -2]) > 2 * tol
+            top32 = ref32.sort(dim=-1).values
+            clear32 = (top32[:, -1] - top32[:, -2]) > 2 * tol32 + 2 * ulp
+            same, same32 = toks[s_ + 1] == ref.argmax(-1), toks[s_ + 1] == ref32.argmax(-1)
+            gap = ref.max(-1).values - ref.gather(1, toks[s_ + 1][:, None])[:, 0]      # every row: how far below the oracle's top-1
+            n_far += int((gap > 2 * tol).sum())
+            n_bad += int((clear & ~same).sum()) + int((clear32 & ~same32).sum())
+            n_rows += B
+            n_cmp += int(clear.sum())
+            n_cmp32 += int(clear32.sum())
+            n_same += int(same.sum())
+    model.forward_logits, model.forward_hidden = orig, orig_hidden
+    model.release()
+    return {"what": f"2-layer model of the headline's width, {B} rows, {steps} decode steps replayed by the '{runner.executor_used}' executor behind a "
+                    f"{P}-token prefill, teacher-forced against oracle/model.py on the host (checker only)",
+            "dtype": str(dtype).split(".")[-1], "max_abs_dlogit": round(worst, 4), "logit_tolerance": tol,
+            "max_abs_dlogit_fp32_head": round(worst32, 4), "fp32_head_tolerance": tol32,
+            "rows": n_rows, "tokens_compared_by_margin": n_cmp, "tokens_compared_by_fp32_head_margin": n_cmp32,
+            "tokens_identical_regardless_of_margin": n_same, "compared_tokens_that_differ": n_bad,
+            "tokens_further_than_2_tol_below_the_oracles_top1": n_far,
+            "ok": bool(n_bad == 0 and n_far == 0 and worst <= tol and worst32 <= tol32)}
+
+
 TIMED_REGIONS = 3
 
 
@@ -1162,12 +1282,16 @@ def roofline_objects(model, runner, ctxs, ms_per_step, args, model_name, with_ge
         roofline_gemm = {"bound": "hbm", "kernel": gemm_kernels + ": qkv + o + gate|up + down of one layer, as the "
                                                    "decode step launches them",
                          "achieved": round(wb / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(wb / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(wb / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                          "weight_bytes_per_layer": wb, "us_per_layer": round(us, 2),
                          "per_projection": {k: {"us": v["us"], "GBps": round(v["weight_bytes"] / v["us"] / 1e3, 1)}
                                             for k, v in gemm_t.items()},
                          "what": "algorithmic bytes = the weights; HIP events (mean of 3 replays) over one graph "
                                  "walking all layers' weights (cold), one launch per layer and projection"}
+        roofline_gemm["traffic"], roofline_gemm["traffic_source"] = measured_gemm_traffic(args, model_name, wb)
+    ins = in_step_attention(args, model_name)
+    if ins:
+        roofline.update(ins)
     whole = {"algorithmic_bytes": int(step_bytes), "achieved_GBps": round(step_gbs, 1),
              "frac_of_hbm_peak": round(step_gbs / HBM_PEAK_GBS, 4), "weight_bytes": model.weight_bytes(),
              "weight_bytes_resident": model.weight_bytes_resident()}
@@ -1505,6 +1629,10 @@ def main():
             "ttft": ttft, "serving": serving, "migration": None,
         }
         if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
+            try:
+                out["parity_probe"] = parity_probe(dtype, dev, args.executor) if args.model == "7b" else None
+            except Exception as e:      # evidence, not the headline
+                out["parity_probe"] = {"error": repr(e)[:300]}
             out["cpu_baseline"] = cpu_baseline(shape, dtype, args.batch, mid_ctx, args.cpu_layers)
             cb = out["cpu_baseline"]
             if args.cpu_full:
@@ -1597,7 +1725,7 @@ def main():
         # a reader of this line must treat a non-empty legs_failed / wedged_ranks as RED for those legs: the headline
         # (value, roofline, whole_step) was measured before any of them ran and stands
         out["legs_failed"] = [dict(f, rank=r) for r, v in enumerate(views) if v is not None for f in json.loads(v)["failed"]]
-        for extra in ("whole_step_64", "whole_step_ragged", "serving"):
+        for extra in ("whole_step_64", "whole_step_ragged", "serving", "parity_probe"):
             if isinstance(out.get(extra), dict) and "error" in out[extra]:
                 out["legs_failed"].append({"leg": extra, "error": str(out[extra]["error"])[:200], "rank": 0})
         out["wedged_ranks"] = wedged_ranks

@@ -1355,6 +1355,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32p_kernel(const AttnParams p)
     lookup_page(min(1, t_last));
     // The first tile's requests are older than the O stores: when all NQI of them were issued (a wave whose 32 rows all
     // exist), waiting for everything but the NQI youngest operations waits for the tile and not for the stores.
+    // The rule this rests on (MI355X_MICROARCH.md, "s_waitcnt vmcnt(N)"; GFX9 ISA, S_WAITCNT): a wave's loads, stores,
+    // atomics and LDS-DMA count on ONE counter and complete IN ISSUE ORDER — with the single exception of flat_*
+    // instructions, of which this translation unit has none (global_ / buffer_ only: tests/test_kernel_resources.py holds
+    // the built code object to that).  The 60-case fuzz of the persistent form against the per-item one
+    // (tests/test_gpu_attention.py::test_prefill_persistent_fuzz) runs with every wave shape this seam sees.
     stamp(23);
     if (e_q_row0 >= 0 && !STAMPS) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NQI) : "memory");
     else tiles_landed();

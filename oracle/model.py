@@ -66,10 +66,19 @@ class OracleLlama:
             h = F.embedding(input_ids_or_embeds.long(), self.sd["model.embed_tokens.weight"])
         else:
             h = input_ids_or_embeds
+        h = self.forward_hidden(h, position_ids, meta, caches, select)
+        return F.linear(h, self.sd["lm_head.weight"])
+
+    def forward_hidden(self, input_ids_or_embeds: Tensor, position_ids: Tensor, meta: OracleAttnMeta, caches: List,
+                       select: Optional[Tensor] = None) -> Tensor:
+        """The lm_head's input: the decoder layers + the final norm (llama.py:88-98)."""
+        if input_ids_or_embeds.dtype in (torch.int32, torch.int64):
+            h = F.embedding(input_ids_or_embeds.long(), self.sd["model.embed_tokens.weight"])
+        else:
+            h = input_ids_or_embeds
         for l in range(self.n_layers):
             h = self.layer(l, h, position_ids, meta, caches[l][0], caches[l][1], select)
-        h = ops.rms_norm_torch(h, self.sd["model.norm.weight"], self.shape.rms_norm_eps)
-        return F.linear(h, self.sd["lm_head.weight"])
+        return ops.rms_norm_torch(h, self.sd["model.norm.weight"], self.shape.rms_norm_eps)
 
     def forward(self, *a, **k) -> Tensor:
         return torch.argmax(self.forward_logits(*a, **k), dim=-1)

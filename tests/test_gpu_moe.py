@@ -52,6 +52,30 @@ def test_grouped_topk_sigmoid(cfg):
     assert torch.allclose(w.cpu(), w_ref, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("n_experts,n_groups", [(128, 4), (128, 8), (256, 8), (256, 16)])
+@pytest.mark.parametrize("topk_group,topk", [(1, 2), (2, 4), (4, 8)])
+def test_grouped_topk_sigmoid_equals_the_lane_level_emulation(n_experts, n_groups, topk_group, topk):
+    """hx_grouped_topk_sigmoid against the lane-level emulator of the reference kernel's butterflies and tie rules
+    (tests/moe_lane_emulator.py; grouped_topk_sigmoid_kernel.cu:64-180) on tie-heavy inputs, for the four (experts, groups)
+    pairs the reference instantiates: indices exact, weights = the raw sigmoid.  (The oracle is held to the same emulator
+    on the CPU: tests/test_moe_lane_emulator.py.  Still restatements on both sides: the row stays "parity unpinned".)"""
+    import numpy as np
+    from hydrainfer_amd._C.kernel.moe import grouped_topk_sigmoid
+    from tests.moe_lane_emulator import grouped_topk_sigmoid_lanes, tie_heavy_inputs
+    if topk > topk_group * (n_experts // n_groups):
+        pytest.skip("more experts asked for than the kept groups hold")
+    for seed in (1, 2, 3):
+        logits, bias = tie_heavy_inputs(n_experts, 40, seed + n_experts + n_groups)
+        lt = torch.from_numpy(logits)
+        scores = (1.0 / (1.0 + torch.exp(-lt))).numpy()
+        w_emu, i_emu = grouped_topk_sigmoid_lanes(scores, bias, n_groups, topk_group, topk)
+        w = torch.empty((40, topk), device=DEV)
+        i = torch.empty((40, topk), dtype=torch.int32, device=DEV)
+        grouped_topk_sigmoid(lt.to(DEV), torch.from_numpy(bias).to(DEV), n_groups, topk_group, topk, 2.5, w, i)
+        assert np.array_equal(i.cpu().numpy(), i_emu), seed
+        assert np.allclose(w.cpu().numpy(), w_emu, rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("n_tokens", [1, 2, 16, 300])
 @pytest.mark.parametrize("dim", [16, 64, 7])
 @pytest.mark.parametrize("n_experts", [4, 8, 16])

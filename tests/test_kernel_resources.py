@@ -63,3 +63,34 @@ def test_kernel_arguments_of_the_hot_kernels_fit_the_preload_window(table):
     by = {r["name"]: r for r in table}
     r = by["gemm_xreg_kernel<BF16, 2, 32, 0, 0, 1>"]
     assert r["kernarg_segment_size"] >= 56 + 100          # 5 pointers + 4 ints, then the by-value struct
+
+
+def test_prefill_attention_has_no_flat_memory_instructions():
+    """attn_fwd.hip's persistent kernel waits with a COUNTED s_waitcnt vmcnt(N) at the seam between two items (first tile
+    of the next item in flight behind the O stores of this one).  That is sound because a wave's vector-memory operations
+    complete in issue order — except flat_* ones (MI355X_MICROARCH.md; GFX9 ISA, S_WAITCNT).  The built prefill kernels
+    must therefore contain none."""
+    import re
+    import subprocess
+    import tempfile
+    lib = os.path.join(ROOT, "hydrainfer_amd", "lib", "libhydra_hip.so")
+    n_fwd = n_flat = 0
+    for img in kernel_table.code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(img); f.flush()
+            syms = subprocess.run([os.path.join(kernel_table.LLVM, "llvm-readelf"), "--symbols", "--wide", f.name],
+                                  capture_output=True, text=True).stdout
+            if "attn_fwd32" not in syms:
+                continue
+            asm = subprocess.run([os.path.join(kernel_table.LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", f.name],
+                                 capture_output=True, text=True).stdout
+        cur = None
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                n_fwd += "attn_fwd32" in cur
+            elif cur and "attn_fwd32" in cur and re.search(r"\bflat_(load|store|atomic)", line):
+                n_flat += 1
+    assert n_fwd >= 8, "the prefill kernels were not found in the library's code objects"
+    assert n_flat == 0, f"{n_flat} flat_* memory instructions in the prefill attention kernels: the counted vmcnt seam is unsound"

@@ -84,6 +84,15 @@ def main():
     print(txt)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(txt + "\n")
+    if len(sys.argv) > 3:      # machine-readable: what bench.py's roofline.in_step_us quotes (profiles/r*_bench7b_in_step.json)
+        import json
+        att_k = [k for k in busy if "attn_decode_kernel" in k]
+        if att_k:
+            k = max(att_k, key=lambda k: busy[k])
+            json.dump({"attention_kernel": k, "attention_us": round(busy[k] / calls[k] / 1e3, 2), "calls_per_step": calls[k],
+                       "steps": len(steps), "step_span_us": round(span / 1e3, 1),
+                       "source": "rocprofv3 --kernel-trace of bench.py --steps 64 (tools/prof_step.sh), median decode step, mean over its attention launches"},
+                      open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":
