@@ -135,6 +135,7 @@ _SIGNATURES = {
     "hx_decode_advance": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_int32, c_void_p]),
     "hx_decode_advance_ranked": (c_int, [c_void_p] * 6 + [c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "hx_decode_rank": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "hx_stage_decode": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     "hx_decode_feed_ids": (c_int, [c_void_p] * 4 + [c_int32, c_void_p]),
     "hx_collect_errors": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p]),
     "hx_copy_words2": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),

@@ -222,6 +222,33 @@ __global__ __launch_bounds__(256) void copy_words2_kernel(uint32_t* __restrict__
 }
 }  // namespace
 
+namespace {
+// staging: [head words] [n_runs] then n_runs x ([dst word offset] [count] [count values]): the head is copied to dst[0 ..),
+// every run to dst[offset ..).  One workgroup: the runs are few and short (a block id per sequence that crossed a block
+// boundary, a whole table for a sequence that has just joined the batch).
+__global__ __launch_bounds__(256) void stage_decode_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ staging,
+                                                           int32_t head_words, int64_t dst_words) {
+  for (int i = threadIdx.x; i < head_words; i += 256) dst[i] = staging[i];
+  const uint32_t n_runs = staging[head_words];
+  int64_t at = (int64_t)head_words + 1;
+  for (uint32_t r = 0; r < n_runs; ++r) {
+    const int64_t off = staging[at];
+    const uint32_t cnt = staging[at + 1];
+    if (off + cnt <= dst_words)
+      for (uint32_t i = threadIdx.x; i < cnt; i += 256) dst[off + i] = staging[at + 2 + i];
+    at += 2 + cnt;
+  }
+}
+}  // namespace
+
+extern "C" int hx_stage_decode(void* dst, int64_t dst_words, const void* staging, int32_t head_words, hx_stream stream) {
+  if (!dst || !staging) return HX_ERR_NULL;
+  if (head_words < 0 || dst_words < head_words) return HX_ERR_SHAPE;
+  if ((((uintptr_t)dst | (uintptr_t)staging) & 3) != 0) return HX_ERR_STRIDE;
+  hx::launcher(stage_decode_kernel, 1, 256, 0, (hipStream_t)stream)((uint32_t*)dst, (const uint32_t*)staging, head_words, dst_words);
+  return hx::check_launch();
+}
+
 extern "C" int hx_copy_words2(void* dst0, const void* src0, int32_t n0_words, void* dst1, const void* src1, int32_t n1_words,
                               hx_stream stream) {
   if (n0_words < 0 || n1_words < 0) return HX_ERR_SHAPE;

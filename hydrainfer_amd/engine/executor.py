@@ -44,20 +44,23 @@ class BatchFillExecutor:
     def _decode_rows(self, batch: BatchRequest):
         """(token, position, slot, kv_len, block_table) per request if the whole batch is decode.
         A token still on the device is encoded as -(row + 1) of the pending launch."""
-        rows, n_blocks = [], 0
+        rows, max_blocks = [], 0
+        bs = self.kv_manager.block_size
+        pending_launch = self.pending[0] if self.pending is not None else None
         for rcb, inst in batch:
             if len(inst.token_ids) != 1 or not inst.sample:
                 return None
             token = inst.token_ids[0]
             if isinstance(token, PendingToken):
-                if self.pending is None or token.launch != self.pending[0]:
+                if token.launch != pending_launch:
                     return None
                 token = -(token.row + 1)
-            vc = rcb.virtual_kv_cache
+            bt = rcb.virtual_kv_cache.block_table
             c = inst.cache_ids[0]
-            rows.append((token, inst.position_ids[0], self.kv_manager.v2p(vc, [c])[0], c + 1, vc.block_table))
-            n_blocks += len(vc.block_table)
-        return rows if self.graph_decoder.fits(len(rows), n_blocks) else None
+            rows.append((token, inst.position_ids[0], bt[c // bs] * bs + c % bs, c + 1, bt, rcb.sid))      # (v2p inline)
+            if len(bt) > max_blocks:
+                max_blocks = len(bt)
+        return rows if self.graph_decoder.fits(len(rows), max_blocks) else None
 
     def _launch_decode(self, batch: BatchRequest, rows) -> None:
         """Enqueue the step, hand every request a placeholder for its new token, THEN read the

@@ -6,8 +6,13 @@ keep ahead of the GPU.  Here the step's integer inputs live in ONE static device
 
     [ input_ids | positions | new_cache_slots | kv_cu | cu_blocks_lens | block_tables ... ]
 
-filled by one pinned H2D copy per step, and the forward over views of that buffer is captured
-once per padded batch size.  Batches are padded to a multiple of `pad_to` rows; padding rows are
+and the forward over views of that buffer is captured once per padded batch size.  The block tables
+are RESIDENT (SURVEY.md §8(f) rank 1 as written: "a persistent device-side block-table buffer with
+incremental append"): every live sequence owns a fixed slice of the table region, a step stages its
+head (ids, positions, slots, cumulative lengths, table offsets, rank descriptor — 7 words a row) and
+only the block ids that are NEW since the sequence's last step (DecodeStager), and one kernel
+(hx_stage_decode) applies both from pinned memory.  The reference rebuilds every table and copies
+six tensors per step (hydrainfer/engine/parameters_builder.py:46-97, layer/causal_attention.py:147-168).  Batches are padded to a multiple of `pad_to` rows; padding rows are
 1-token sequences that write into a scratch block reserved from the pool, so they never touch a
 live request.  The attention kernel reads each sequence's true length from kv_cu, so one graph
 serves every context length (the captured max length only seeds the split heuristic).
@@ -32,6 +37,95 @@ from hydrainfer_amd.memory.kv_cache import KVCache
 from hydrainfer_amd.model.llama import LanguageModelParameters
 
 
+class DecodeStager:
+    """The host side of a decode step's integer inputs — numpy only, no device (tests/test_decode_stager.py drives it on
+    the CPU).  Layout of the static device buffer it fills (word offsets; B = max_batch, cap = blocks per sequence):
+
+        [ ids B | pos B | slots B | src B | kv_cu B+1 | cu_blocks B+1 | rank B+1 | tables (2B + 1) x cap ]
+
+    cu_blocks[r] = the word offset of row r's table INSIDE the tables region (the kernels only ever use it as a start
+    offset).  Table slot 0 is the padding rows' ([pad_block]); a sequence (keyed by the scheduler's sid) keeps its slot
+    from its first decode step until it has not been seen while the slots ran out (least recently seen goes first).
+    stage() writes one staging buffer: the head, then [n_runs] and the runs ([dst word offset] [count] [values]) that bring
+    the resident tables up to date — hx_stage_decode's input."""
+
+    def __init__(self, max_batch: int, cap: int, block_size: int, pad_block: int, max_pos: int, vocab: int):
+        B = self.max_batch = max_batch
+        self.cap, self.block_size, self.pad_block, self.max_pos, self.vocab = cap, block_size, pad_block, max_pos, vocab
+        self.off = {"ids": 0, "pos": B, "slots": 2 * B, "src": 3 * B, "kv_cu": 4 * B, "cu_blocks": 5 * B + 1, "rank": 6 * B + 2}
+        self.head_words = 7 * B + 3
+        self.n_table_slots = 2 * B + 1
+        self.tables_off = self.head_words
+        self.total_words = self.head_words + self.n_table_slots * cap
+        self.staging_words = self.head_words + 1 + (B + 1) * (2 + cap)
+        self.slot_of: Dict[int, list] = {}        # sid -> [table slot, blocks written, last block id written, last step seen]
+        self.free = list(range(self.n_table_slots - 1, 0, -1))
+        self.pad_written = False
+        self.step_no = 0
+
+    def _alloc(self) -> int:
+        if self.free:
+            return self.free.pop()
+        victim = min((sid for sid, e in self.slot_of.items() if e[3] != self.step_no), key=lambda sid: self.slot_of[sid][3])
+        return self.slot_of.pop(victim)[0]
+
+    def stage(self, st: "np.ndarray", rows: List[tuple], B: int) -> int:
+        """rows: (token, position, slot, kv_len, block_table, sid) per live sequence (sid None: a padding / warm-up row);
+        a token < 0 means "the sample of row -(token + 1) of the previous launch".  Pads to B rows.  Returns the largest
+        kv_len."""
+        self.step_no += 1
+        o, cap, n = self.off, self.cap, len(rows)
+        if not all(0 <= r[1] < self.max_pos for r in rows):    # the RoPE / attention kernels index cos_sin unchecked
+            raise HydraHipError(f"decode position outside the rotary table (max_position_embeddings = {self.max_pos})")
+        if not all(r[0] < self.vocab for r in rows):           # hx_embed_rms_norm would clamp, torch.embedding raises
+            raise HydraHipError(f"token id outside the vocabulary ({self.vocab})")
+        pad = B - n
+        toks = [r[0] for r in rows]
+        st[o["ids"]:o["ids"] + B] = [t if t > 0 else 0 for t in toks] + [0] * pad
+        st[o["src"]:o["src"] + B] = [-(t + 1) if t < 0 else -1 for t in toks] + [-1] * pad
+        st[o["pos"]:o["pos"] + B] = [r[1] for r in rows] + [0] * pad
+        st[o["slots"]:o["slots"] + B] = [r[2] for r in rows] + [self.pad_block * self.block_size] * pad
+        kv = [r[3] for r in rows] + [1] * pad
+        st[o["kv_cu"]] = 0
+        np.cumsum(kv, out=st[o["kv_cu"] + 1:o["kv_cu"] + B + 1])
+        st[o["rank"]:o["rank"] + B + 1] = decode_rank_descriptor(kv)
+        at = self.head_words + 1
+        n_runs = 0
+        if not self.pad_written:
+            st[at:at + 3] = (self.tables_off, 1, self.pad_block)
+            at += 3
+            n_runs += 1
+            self.pad_written = True
+        starts = []
+        for r in rows:
+            sid, tbl = r[5], r[4]
+            if sid is None:
+                starts.append(0)
+                continue
+            nb = len(tbl)
+            if nb > cap:
+                raise HydraHipError(f"a sequence of {nb} blocks in a decoder built for {cap}")
+            e = self.slot_of.get(sid)
+            if e is None:
+                e = self.slot_of[sid] = [self._alloc(), 0, -1, self.step_no]
+            e[3] = self.step_no
+            if nb < e[1] or (e[1] and tbl[e[1] - 1] != e[2]):
+                e[1] = 0                       # not the table this slot holds a prefix of: written again in full
+            if nb > e[1]:
+                new = tbl[e[1]:]
+                st[at] = self.tables_off + e[0] * cap + e[1]
+                st[at + 1] = len(new)
+                st[at + 2:at + 2 + len(new)] = new
+                at += 2 + len(new)
+                n_runs += 1
+                e[1], e[2] = nb, tbl[-1]
+            starts.append(e[0] * cap)
+        st[o["cu_blocks"]:o["cu_blocks"] + B] = starts + [0] * pad
+        st[o["cu_blocks"] + B] = 0
+        st[self.head_words] = n_runs
+        return max(kv)
+
+
 class GraphedDecoder:
     def __init__(self, language_model, kv_cache_block_manager, max_batch: int = 64,
                  max_blocks_per_seq: int = 256, pad_to: int = 4, executor: str = None):
@@ -42,26 +136,27 @@ class GraphedDecoder:
         # schedules, stages and runs eager prefill steps — at 16 req/s Poisson the plan measured TPOT p50 7.7 ms and
         # TTFT p50 84 ms against 6.5 / 51 for the graph (tools/bench_engine.py, round 3)
         self.executor = executor or os.environ.get("HX_ENGINE_EXECUTOR", "graph")
-        self.kernel_copies = os.environ.get("HX_ENGINE_KERNEL_COPIES", "1") == "1"      # (0: hipMemcpyAsync, for A/B runs)
         self.lm = language_model                       # LlavaLanguageModel
         self.model = language_model.language_model     # LlamaForCausalLM
         self.kv = kv_cache_block_manager
         self.dev = self.kv.device
         self.pad_to = pad_to
         self.max_batch = (max_batch + pad_to - 1) // pad_to * pad_to
-        self.table_cap = self.max_batch * max_blocks_per_seq
+        self.cap = max_blocks_per_seq
         B = self.max_batch
-        # ("rank": the step's rank descriptor, [ragged?] + the rows by decreasing context — the fused decode attention lays a
-        # big ragged batch over the CUs in that order, csrc/attn_decode.hip RANKED; the host has the lengths, so it ranks)
-        self.off = {"ids": 0, "pos": B, "slots": 2 * B, "src": 3 * B, "kv_cu": 4 * B, "cu_blocks": 5 * B + 1,
-                    "rank": 6 * B + 2, "tables": 7 * B + 3}
-        total = self.off["tables"] + self.table_cap
-        self.static = torch.zeros(total, dtype=torch.int32, device=self.dev)
-        # two pinned staging buffers used alternately, each with an event recorded behind its H2D copy:
-        # with one step of look-ahead the host fills launch N+1 while launch N's copy may still be
+        # scratch block for padding rows
+        self.pad_cache = self.kv.allocate_virtual_cache()
+        self.kv.realloc(self.pad_cache, 1)
+        self.pad_block = self.pad_cache.block_table[0]
+        self.stager = DecodeStager(B, self.cap, self.kv.block_size, self.pad_block, self.model.shape.max_position_embeddings,
+                                   self.model.shape.vocab_size)
+        self.off = self.stager.off
+        self.static = torch.zeros(self.stager.total_words, dtype=torch.int32, device=self.dev)
+        # two pinned staging buffers used alternately, each with an event recorded behind the kernel that reads it:
+        # with one step of look-ahead the host fills launch N+1 while launch N's staging may still be
         # queued (a vision encode or a prefill chunk ahead of it on the stream) — a buffer is
-        # refilled only after the copy that last read it has run
-        self.staging = [torch.zeros(total, dtype=torch.int32).pin_memory() for _ in range(2)]
+        # refilled only after the launch that last read it has run
+        self.staging = [torch.zeros(self.stager.staging_words, dtype=torch.int32).pin_memory() for _ in range(2)]
         self.stage = [t.numpy() for t in self.staging]
         self.copy_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.fills = 0
@@ -78,21 +173,18 @@ class GraphedDecoder:
         self.launch_rows = {}              # launch id -> number of live rows
         n_layers = self.model.shape.num_hidden_layers
         self.kv_caches = [KVCache.from_token_cache(self.kv.get_layer_cache(l)) for l in range(n_layers)]
-        # scratch block for padding rows
-        self.pad_cache = self.kv.allocate_virtual_cache()
-        self.kv.realloc(self.pad_cache, 1)
-        self.pad_block = self.pad_cache.block_table[0]
         self.graphs: Dict[Tuple[int, int], tuple] = {}
 
-    def fits(self, n_seqs: int, n_blocks: int) -> bool:
+    def fits(self, n_seqs: int, max_blocks: int) -> bool:
+        """n_seqs rows whose longest block table has max_blocks entries."""
         padded = (n_seqs + self.pad_to - 1) // self.pad_to * self.pad_to
-        return padded <= self.max_batch and n_blocks + (padded - n_seqs) <= self.table_cap
+        return padded <= self.max_batch and max_blocks <= self.cap
 
     def _views(self, B: int):
         o, s = self.off, self.static
         return (s[o["ids"]:o["ids"] + B], s[o["pos"]:o["pos"] + B], s[o["slots"]:o["slots"] + B],
                 s[o["kv_cu"]:o["kv_cu"] + B + 1], s[o["cu_blocks"]:o["cu_blocks"] + B + 1],
-                s[o["tables"]:], s[o["src"]:o["src"] + B], s[o["rank"]:o["rank"] + B + 1])
+                s[self.stager.tables_off:], s[o["src"]:o["src"] + B], s[o["rank"]:o["rank"] + B + 1])
 
     def _kv_bucket(self, B: int, kv_max: int) -> int:
         if B * self.model.shape.num_attention_heads >= 768:
@@ -171,48 +263,21 @@ class GraphedDecoder:
                 out, err = self._body(B, params)
         return graph, out, err
 
-    def _fill(self, rows: List[Tuple[int, int, int, int, List[int]]], B: int) -> int:
-        """rows: (token, position, slot, kv_len, block_table) per live sequence; a token < 0 means
-        "the sample of row -(token + 1) of the previous launch"."""
+    def _fill(self, rows: List[tuple], B: int) -> int:
+        """Stage the step (DecodeStager.stage) and enqueue the kernel that applies it to the resident buffer."""
         which = self.fills % 2
         self.fills += 1
         self.copy_done[which].synchronize()      # no-op until the buffer has been used once
-        o, st = self.off, self.stage[which]
-        n = len(rows)
-        bs = self.kv.block_size
-        pad = (0, 0, self.pad_block * bs, 1, [self.pad_block])
-        max_pos = self.model.shape.max_position_embeddings
-        if not all(0 <= r[1] < max_pos for r in rows):    # the RoPE / attention kernels index cos_sin unchecked
-            raise HydraHipError(f"decode position outside the rotary table (max_position_embeddings = {max_pos})")
-        vocab = self.model.shape.vocab_size
-        if not all(r[0] < vocab for r in rows):           # hx_embed_rms_norm would clamp, torch.embedding raises
-            raise HydraHipError(f"token id outside the vocabulary ({vocab})")
-        rows = rows + [pad] * (B - n)
-        st[o["ids"]:o["ids"] + B] = [max(r[0], 0) for r in rows]
-        st[o["src"]:o["src"] + B] = [-(r[0] + 1) if r[0] < 0 else -1 for r in rows]
-        st[o["pos"]:o["pos"] + B] = [r[1] for r in rows]
-        st[o["slots"]:o["slots"] + B] = [r[2] for r in rows]
-        st[o["kv_cu"]] = 0
-        st[o["kv_cu"] + 1:o["kv_cu"] + B + 1] = np.cumsum([r[3] for r in rows])
-        st[o["rank"]:o["rank"] + B + 1] = decode_rank_descriptor([r[3] for r in rows])
-        lens = [len(r[4]) for r in rows]
-        st[o["cu_blocks"]] = 0
-        st[o["cu_blocks"] + 1:o["cu_blocks"] + B + 1] = np.cumsum(lens)
-        flat = [b for r in rows for b in r[4]]
-        st[o["tables"]:o["tables"] + len(flat)] = flat
-        used = o["tables"] + len(flat)
-        if self.kernel_copies:
-            # the step's integers go in by a KERNEL that reads the pinned buffer (hx_copy_words2, include/hydra_hip.h): a
-            # memcpy between two graph launches left the stream idle for ~0.1 ms per step
-            _lib.check(_lib.lib().hx_copy_words2(self.static.data_ptr(), self.staging[which].data_ptr(), used, None, None, 0,
-                                                 _lib.current_stream()), "copy_words2")
-        else:
-            self.static[:used].copy_(self.staging[which][:used], non_blocking=True)
+        kv_max = self.stager.stage(self.stage[which], rows, B)
+        # (a kernel reading the pinned buffer, not a memcpy: a memcpy between two graph launches left the stream idle
+        # for ~0.1 ms per step)
+        _lib.check(_lib.lib().hx_stage_decode(self.static.data_ptr(), self.static.numel(), self.staging[which].data_ptr(),
+                                              self.stager.head_words, _lib.current_stream()), "stage_decode")
         self.copy_done[which].record()
-        return max(r[3] for r in rows)
+        return kv_max
 
     def warmup(self, batch_sizes: List[int], kv_max: int = 1024) -> None:
-        rows = [(1, 0, self.pad_block * self.kv.block_size, 1, [self.pad_block])]
+        rows = [(1, 0, self.pad_block * self.kv.block_size, 1, [self.pad_block], None)]
         for n in batch_sizes:
             B = (n + self.pad_to - 1) // self.pad_to * self.pad_to
             key = (B, self._kv_bucket(B, kv_max))
@@ -233,15 +298,11 @@ class GraphedDecoder:
         graph.replay()
         self.launches += 1
         slot = self.launches % 2
-        if self.kernel_copies:      # tokens (int64: 2 words each) and the give-up word leave by one launch, straight into pinned memory
-            _lib.check(_lib.lib().hx_copy_words2(self.host_tokens[slot].data_ptr(), out.data_ptr(), 2 * n,
-                                                 self.host_err[slot].data_ptr() if err is not None else None,
-                                                 err.data_ptr() if err is not None else None, 1 if err is not None else 0,
-                                                 _lib.current_stream()), "copy_words2")
-        else:
-            self.host_tokens[slot][:n].copy_(out[:n], non_blocking=True)
-            if err is not None:
-                self.host_err[slot].copy_(err.view(1), non_blocking=True)
+        # tokens (int64: 2 words each) and the give-up word leave by one launch, straight into pinned memory
+        _lib.check(_lib.lib().hx_copy_words2(self.host_tokens[slot].data_ptr(), out.data_ptr(), 2 * n,
+                                             self.host_err[slot].data_ptr() if err is not None else None,
+                                             err.data_ptr() if err is not None else None, 1 if err is not None else 0,
+                                             _lib.current_stream()), "copy_words2")
         self.launch_has_err[self.launches] = err is not None
         self.events[slot].record()
         self.launch_rows[self.launches] = n

@@ -133,6 +133,11 @@ class BatchRequest:
     def __getitem__(self, idx: int) -> Tuple[RequestControlBlock, Instruction]:
         return self.rcbs[idx], self.rcbs[idx].instructions.curr
 
+    def __iter__(self):
+        # (a generator, not the index protocol: `for rcb, inst in batch` runs a dozen times per engine step)
+        for rcb in self.rcbs:
+            yield rcb, rcb.instructions.curr
+
     def append(self, rcb: RequestControlBlock) -> None:
         self.rcbs.append(rcb)
 

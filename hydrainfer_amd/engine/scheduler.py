@@ -84,7 +84,10 @@ class BatchScheduler:
 
     @staticmethod
     def _stamp_end(rcb: RequestControlBlock) -> None:
-        m, now = rcb.metric, time.perf_counter()
+        m = rcb.metric
+        if len(m.decode_queueing) == 2:          # every phase closed long ago: the steady decode steps of a request
+            return
+        now = time.perf_counter()
         for phase in (m.encode_queueing, m.prefill_queueing, m.decode_queueing):
             if len(phase) == 1:
                 phase.append(now)
@@ -126,6 +129,14 @@ class BatchScheduler:
         for rcb in self.running:
             inst = rcb.current_instruction()
             if isinstance(inst, Fill):
+                vc = rcb.virtual_kv_cache
+                if vc is not None and len(inst.cache_ids) == 1:
+                    # a decode step (one token): 15 times of 16 its slot lies inside the last block already
+                    want = inst.cache_ids[0] + 1
+                    if want <= len(vc.block_table) * kv.block_size:
+                        if want > vc.n_cache_tokens:
+                            vc.n_cache_tokens = want
+                        continue
                 if rcb.virtual_kv_cache is None:
                     if not fits(kv, None, max(inst.cache_ids) + 1):
                         deferred.add(id(rcb))

@@ -207,8 +207,9 @@ def realloc(block_allocator: BlockAllocator, shared_cache: SharedCache,
     """token_cache_manger.py:149-158."""
     n_need = (n_tokens + block_size - 1) // block_size
     if n_tokens > virtual_cache.n_cache_tokens:
-        virtual_cache.block_table += allocate_new_blocks(
-            block_allocator, shared_cache, n_need - len(virtual_cache.block_table))
+        more = n_need - len(virtual_cache.block_table)
+        if more > 0:          # (15 decode steps of 16 grow inside the last block: nothing to allocate)
+            virtual_cache.block_table += allocate_new_blocks(block_allocator, shared_cache, more)
     else:
         shared_cache.unpin(virtual_cache.block_table[n_need:])
         virtual_cache.block_table = virtual_cache.block_table[:n_need]

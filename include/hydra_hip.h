@@ -521,6 +521,13 @@ typedef struct hx_step_head_args {
   int32_t* rank_desc;        /* NULL, or int32 [1 + batch]: the advanced batch's rank descriptor (hx_decode_advance_ranked) */
 } hx_step_head_args;
 int hx_decode_step_head(const hx_step_head_args* args, hx_stream stream);
+/* hx_stage_decode: a decode step's integer inputs into the engine's RESIDENT device buffer (engine/graph_decode.py) —
+ * the step's head (ids, positions, slots, cumulative lengths, table offsets, rank descriptor: head_words words, copied to
+ * dst[0 ..)) and the block-table DELTAS behind it: staging[head_words] = n_runs, then per run [dst word offset] [count]
+ * [count values].  A sequence's table stays where it is on the device; a step writes only the block ids that are new
+ * (the reference rebuilds and re-copies every table every step: hydrainfer/engine/parameters_builder.py:46-97).
+ * staging: host memory the device can read (pinned); dst_words bounds every write. */
+int hx_stage_decode(void* dst, int64_t dst_words, const void* staging, int32_t head_words, hx_stream stream);
 int hx_decode_feed_ids(int64_t* out, const int32_t* ids, const int32_t* src, const int64_t* prev,
                        int32_t n, hx_stream stream);
 int hx_collect_errors(uint32_t* out, const uint32_t* areas, int32_t n_areas, int64_t stride_words,

@@ -170,7 +170,7 @@ class FakeGraphDecoder:
     def launch(self, rows):
         prev = self.tokens.get(self.launches, [])
         out = []
-        for token, pos, slot, kv_len, table in rows:
+        for token, pos, slot, kv_len, table, _sid in rows:
             if token < 0:
                 token = prev[-(token + 1)]
                 self.n_launch_ahead += 1

@@ -1,10 +1,10 @@
 #!/bin/bash
-# PMC passes (round tag: ROUND, default r5) (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, as MI355X_MICROARCH.md's HBM section prescribes) over
+# PMC passes (round tag: ROUND, default r6) (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, as MI355X_MICROARCH.md's HBM section prescribes) over
 # the decode attention kernel and the activations-in-registers GEMMs, as the 7B decode step launches them:
-#   [ROUND=r5] bash tools/pmc_decode.sh        ->  gpurun_out/$ROUND/${ROUND}_attn_decode_pmc.json, ${ROUND}_gemm_xreg_pmc.json
+#   [ROUND=r6] bash tools/pmc_decode.sh        ->  gpurun_out/$ROUND/${ROUND}_attn_decode_pmc.json, ${ROUND}_gemm_xreg_pmc.json
 set -eu
 R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT to the repo root (gpurun exports it)}
-ROUND=${ROUND:-r5}
+ROUND=${ROUND:-r6}
 O=$R/gpurun_out/$ROUND
 mkdir -p "$O"
 cd /tmp; export TMPDIR=/tmp
@@ -31,7 +31,7 @@ w, _, _ = med("/tmp/pmc_prof_attn_decode_WRITE_SIZE", "WRITE_SIZE")
 toks = open("/tmp/attn_bytes.txt").read().split()
 alg, slab = int(toks[1]), int(toks[3])
 fb, wb = f * 1024 * 2, w * 1024
-json.dump({"kernel": "attn_decode_kernel<BF16,128,4,nt,fused>",
+json.dump({"kernel": "attn_decode_kernel<BF16,128,4,nt,fused,ranked>",
            "shape": "B=32 H=HK=32 D=128 ctx=832 block_size=16 bf16 (LLaVA-1.5-7B decode, mean context of the generation); q/k/v from the ONE fp32 slab of the qkv GEMM + RoPE + cache append + attention",
            "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 tools/prof_attn_decode.py (separate passes; bash tools/pmc_decode.sh)",
            "launches": n, "FETCH_SIZE_KiB_median": f, "WRITE_SIZE_KiB_median": w,

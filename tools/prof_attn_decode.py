@@ -5,7 +5,7 @@ the target program for `rocprofv3 --pmc ...` counter passes."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused
+from hydrainfer_amd._C.kernel.flash_attn import decode_attention_fused, decode_rank
 from hydrainfer_amd.model.llama import LLAVA_1_5_7B, build_cos_sin
 
 dev = torch.device("cuda:0")
@@ -33,9 +33,10 @@ wqkv = (torch.randn((3 * H * D, H * D), generator=g, device=dev, dtype=torch.flo
 # (round 2: layers >= 1 get ONE slab from the activations-in-registers GEMM)
 slabs = torch.empty(hip_gemm.xreg_workspace_floats(B, 3 * H * D, H * D), dtype=torch.float32, device=dev)
 n_slabs = hip_gemm.linear_decode_partial_xreg(x, hip_gemm.pack_weight_xreg(wqkv), 3 * H * D, slabs)
+rank = decode_rank(cu_k)      # (round 6: the step hands the launch its rank descriptor — an even batch: flag 0, the RANKED kernel's static numbering)
 for i in range(12):
     decode_attention_fused(out, q, k_new, v_new, pool[i % L, 0], pool[i % L, 1], pos, cs, slots, cu_q, cu_k,
-                           perm, cu_b, ctx, 1 / math.sqrt(D), 1, slabs, n_slabs)
+                           perm, cu_b, ctx, 1 / math.sqrt(D), 1, slabs, n_slabs, rank)
 torch.cuda.synchronize()
 nbytes = 2 * (2 * H * D * ctx * B + 2 * B * H * D) + 4 * B * nb_seq
 print("algorithmic_bytes_per_launch", nbytes, "qkv_slab_bytes", n_slabs * B * 3 * H * D * 4)
