@@ -98,3 +98,36 @@ def test_stager_refuses_what_the_kernels_cannot_take():
         stg.stage(st, [(100, 3, 0, 4, [0], 1)], 4)              # token outside the vocabulary
     with pytest.raises(HydraHipError):
         stg.stage(st, [(5, 3, 0, 4, [0, 1, 2, 3, 4], 1)], 4)    # more blocks than the decoder was built for
+
+
+@pytest.mark.gpu
+def test_hx_stage_decode_applies_head_and_runs_like_the_numpy_model():
+    """The device side of the stager: hx_stage_decode on pinned staging buffers == apply_staging, over a random trace."""
+    import torch
+    from hydrainfer_amd import _lib
+    rnd = random.Random(3)
+    max_batch, cap, bs = 16, 20, 16
+    stg = DecodeStager(max_batch, cap, bs, 555, max_pos=4096, vocab=32000)
+    host = np.full(stg.total_words, -7, dtype=np.int32)
+    dev = torch.full((stg.total_words,), -7, dtype=torch.int32, device="cuda:0")
+    staging = [torch.zeros(stg.staging_words, dtype=torch.int32).pin_memory() for _ in range(2)]
+    tables = {sid: list(range(sid * 100, sid * 100 + rnd.randint(1, 6))) for sid in range(1, 40)}
+    kv = {sid: len(t) * bs - rnd.randint(0, 15) for sid, t in tables.items()}
+    for step in range(60):
+        batch = rnd.sample(list(tables), rnd.randint(1, max_batch))
+        rows = []
+        for sid in batch:
+            kv[sid] += 1
+            if (kv[sid] + bs - 1) // bs > len(tables[sid]) and len(tables[sid]) < cap:
+                tables[sid].append(sid * 100 + len(tables[sid]))
+            kv[sid] = min(kv[sid], len(tables[sid]) * bs)
+            pos = kv[sid] - 1
+            rows.append((rnd.randint(1, 31999), pos, tables[sid][pos // bs] * bs + pos % bs, kv[sid], list(tables[sid]), sid))
+        B = (len(rows) + 3) // 4 * 4
+        st = staging[step % 2]
+        torch.cuda.synchronize()
+        stg.stage(st.numpy(), rows, B)
+        apply_staging(host, st.numpy(), stg.head_words)
+        _lib.check(_lib.lib().hx_stage_decode(dev.data_ptr(), dev.numel(), st.data_ptr(), stg.head_words, _lib.current_stream()), "stage")
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.cpu().numpy(), host), step
