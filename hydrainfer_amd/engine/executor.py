@@ -5,14 +5,17 @@ language model on the HIP path, hand each sampled token to its request.
 BatchImageEmbedExecutor: run the vision tower + projector and scatter the embeddings into the
 image cache.  Both run on the current stream; `InstructionExecutor` can put the vision side on
 its own stream (executor.py:247-249)."""
+import os
 import time
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 from hydrainfer_amd._lib import HydraHipError
 
-from hydrainfer_amd.engine.isa import Fill
+from hydrainfer_amd.engine import rcb as rcb_module
+from hydrainfer_amd.engine.isa import Fill, TextFill
 from hydrainfer_amd.engine.parameters_builder import LanguageModelParametersBuilder
 from hydrainfer_amd.engine.rcb import BatchRequest
 from hydrainfer_amd.model.llama import LanguageModelParameters
@@ -30,6 +33,34 @@ class PendingToken:
         return f"<pending {self.launch}:{self.row}>"
 
 
+class DecodeCohort:
+    """The steady state of a decode batch — the SAME sequences step after step, each one token further — kept as arrays
+    instead of being rediscovered from every request's instruction chain every step (the
+    reference's per-step Python over every running request, hydrainfer/engine/scheduler.py:99-194 +
+    parameters_builder.py:46-97, is what bounds a decode loop once the kernels are fast).  While the cohort lasts a step
+    touches a request object only when it enters a new block or streams a token to a client; when it ends (anything
+    else wants to happen: an arrival, a request about to finish, a cancelled stream) the requests are brought up to date
+    in one pass and the general path goes on as if it had run every step itself."""
+
+    def __init__(self, rcbs, running_ref, bs):
+        n = self.n = len(rcbs)
+        self.rcbs, self.running_ref, self.bs = rcbs, running_ref, bs
+        self.pos = np.zeros(n, dtype=np.int32)          # rotary position of the NEXT launch's token, per row
+        self.cid = np.zeros(n, dtype=np.int32)          # its virtual cache id
+        self.left = np.zeros(n, dtype=np.int32)         # tokens the row has still to sample, the next launch's included
+        self.nblk = np.zeros(n, dtype=np.int32)         # blocks in the row's table
+        self.last_block = np.zeros(n, dtype=np.int32)   # the block the next cache id falls into (valid when cid // bs < nblk)
+        self.starts = np.zeros(n, dtype=np.int32)       # the row's table offset in the decoder's resident buffer
+        self.sids = [r.sid for r in rcbs]
+        self.streams = [(i, r.output_token_processors) for i, r in enumerate(rcbs) if r.output_token_processors]
+        self.first_inst = [r.current_instruction() for r in rcbs]
+        self.k = 0                                      # cohort launches so far
+        self.launch = None                              # the one in flight
+        self.tok_log: List[List[int]] = []              # tokens of cohort launches 1 .. k - 1 (resolved)
+        self.t_log: List[float] = []
+        self.epoch = rcb_module.MUTATIONS[0]
+
+
 class BatchFillExecutor:
     def __init__(self, language_model, kv_cache_block_manager, image_cache_block_manager,
                  dtype: torch.dtype, device: torch.device, graph_decoder=None):
@@ -40,6 +71,10 @@ class BatchFillExecutor:
         self.dtype, self.device = dtype, device
         self.graph_decoder = graph_decoder              # engine.graph_decode.GraphedDecoder or None
         self.pending = None        # (launch id, [(rcb, inst, index into rcb.output_token_ids)])
+        self.cohort: Optional[DecodeCohort] = None
+        self.cohort_enabled = os.environ.get("HX_DECODE_COHORT", "1") == "1"
+        self.cohort_refused = None # the pending launch a cohort could not be formed behind (not tried again until the next one)
+        self.n_cohort_steps = 0
 
     def _decode_rows(self, batch: BatchRequest):
         """(token, position, slot, kv_len, block_table) per request if the whole batch is decode.
@@ -99,8 +134,114 @@ class BatchFillExecutor:
             for p in rcb.output_token_processors:
                 p.append_token_id(token, last)
 
+    # ------------------------------------------------------------------ the steady-state cohort
+    def cohort_step(self, scheduler) -> int:
+        """Called by EPDNode.step() in front of the scheduler.  Launches the next decode step of the cohort and returns
+        its row count — or ends / declines the cohort and returns 0: the general path then runs the step."""
+        dec = self.graph_decoder
+        if not self.cohort_enabled or dec is None or not hasattr(dec, "launch_cohort"):
+            return 0
+        co = self.cohort
+        if co is None:
+            if self.pending is None or self.pending[0] == self.cohort_refused:
+                return 0
+            co = self._cohort_begin(scheduler)
+            if co is None:
+                self.cohort_refused = self.pending[0]
+                return 0
+        elif (scheduler.waiting or scheduler.running is not co.running_ref or len(scheduler.running) != co.n
+              or co.epoch != rcb_module.MUTATIONS[0] or int(co.left.min()) < 2 or co.n > scheduler.token_budgets):
+            self._cohort_end()
+            return 0
+        bs = co.bs
+        # rows whose next token opens a new block: the only per-row work of a step (one row in sixteen)
+        grown = []
+        need = np.nonzero(co.cid // bs >= co.nblk)[0]
+        if len(need):
+            if len(need) > len(self.kv_manager.shared_cache.to_be_evicted):
+                self._cohort_end()              # the pool cannot give every row its block now: the scheduler's business
+                return 0
+            for r in need.tolist():
+                vc = co.rcbs[r].virtual_kv_cache
+                self.kv_manager.realloc(vc, int(co.cid[r]) + 1)
+                grown.append((co.sids[r], int(co.nblk[r]), vc.block_table[-1]))
+                co.nblk[r] += 1
+                co.last_block[r] = vc.block_table[-1]
+        slots = co.last_block * bs + co.cid % bs
+        launch = dec.launch_cohort(co.n, co.pos, slots, co.starts, grown)
+        previous, co.launch = co.launch, launch
+        co.k += 1
+        co.pos += 1
+        co.cid += 1
+        co.left -= 1
+        self.n_cohort_steps += 1
+        if previous is None:                    # the launch the cohort was formed behind: the general bookkeeping
+            pending, self.pending = self.pending, None
+            self._resolve(pending)
+        else:
+            tokens = dec.fetch(previous)
+            co.tok_log.append(tokens)
+            co.t_log.append(time.perf_counter())
+            for r, processors in co.streams:    # tokens go out as they come (never a request's last: those end the cohort)
+                for p in processors:
+                    p.append_token_id(tokens[r], False)
+        return co.n
+
+    def _cohort_begin(self, scheduler) -> Optional[DecodeCohort]:
+        launch, entries = self.pending
+        rcbs = [e[0] for e in entries]
+        if scheduler.waiting or scheduler.running != rcbs or len(rcbs) > scheduler.token_budgets:
+            return None
+        bs = self.kv_manager.block_size
+        co = DecodeCohort(rcbs, scheduler.running, bs)
+        slot_of, cap = self.graph_decoder.stager.slot_of, self.graph_decoder.stager.cap
+        for r, (rcb, inst) in enumerate(zip(rcbs, co.first_inst)):
+            tok = inst.token_ids[0] if isinstance(inst, TextFill) and inst.token_ids and len(inst.token_ids) == 1 else None
+            if (not isinstance(tok, PendingToken) or tok.launch != launch or tok.row != r or not inst.sample or rcb.eos_hit
+                    or rcb.sampling_params.eos_token_ids or rcb.sid not in slot_of):
+                return None
+            vc = rcb.virtual_kv_cache
+            c = inst.cache_ids[0]
+            co.pos[r], co.cid[r] = inst.position_ids[0], c
+            co.left[r] = rcb.sampling_params.max_tokens - len(rcb.output_token_ids)
+            co.nblk[r] = len(vc.block_table)
+            co.last_block[r] = vc.block_table[c // bs] if c // bs < len(vc.block_table) else -1
+            co.starts[r] = slot_of[rcb.sid][0] * cap
+        if int(co.left.min()) < 2:
+            return None
+        self.cohort = co
+        return co
+
+    def _cohort_end(self) -> None:
+        """Bring every request of the cohort up to date: tokens, stamps, instruction chain, cache size — and leave the
+        last launch pending the way the general path would have."""
+        co, self.cohort = self.cohort, None
+        if co is None or co.k == 0:
+            return
+        entries = []
+        for r, rcb in enumerate(co.rcbs):
+            out = rcb.output_token_ids
+            out.extend(t[r] for t in co.tok_log)
+            placeholder = PendingToken(co.launch, r)
+            out.append(placeholder)
+            rcb.metric.token_times.extend(co.t_log)
+            inst = co.first_inst[r]
+            for _ in range(co.k - 1):
+                inst = inst.next                # the instructions of the launches that have been resolved
+            if inst.sample_dst is not None:
+                inst.sample_dst.token_ids = [placeholder]
+            rcb.instructions.curr = inst.next
+            vc = rcb.virtual_kv_cache
+            if int(co.cid[r]) > vc.n_cache_tokens:
+                vc.n_cache_tokens = int(co.cid[r])
+            entries.append((rcb, inst, len(out) - 1, placeholder))
+        self.pending = (co.launch, entries)
+        self.graph_decoder.stager.touch(co.sids)
+
     def resolve_pending(self) -> None:
         """Read back the tokens of the decode step that is still in flight (if any)."""
+        if self.cohort is not None:
+            self._cohort_end()
         if self.pending is not None:
             pending, self.pending = self.pending, None
             self._resolve(pending)

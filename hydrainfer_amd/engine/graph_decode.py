@@ -32,7 +32,7 @@ import torch
 from hydrainfer_amd import _lib, launch_plan
 from hydrainfer_amd._lib import HydraHipError
 from hydrainfer_amd._C.kernel.norm import StepHead
-from hydrainfer_amd.layer.causal_attention import AttentionParameters, decode_rank_descriptor
+from hydrainfer_amd.layer.causal_attention import RANKED_THR, AttentionParameters, decode_rank_descriptor
 from hydrainfer_amd.memory.kv_cache import KVCache
 from hydrainfer_amd.model.llama import LanguageModelParameters
 
@@ -62,6 +62,7 @@ class DecodeStager:
         self.free = list(range(self.n_table_slots - 1, 0, -1))
         self.pad_written = False
         self.step_no = 0
+        self._arange = np.arange(max_batch, dtype=np.int32)
 
     def _alloc(self) -> int:
         if self.free:
@@ -97,11 +98,15 @@ class DecodeStager:
             n_runs += 1
             self.pad_written = True
         starts = []
-        for r in rows:
-            sid, tbl = r[5], r[4]
-            if sid is None:
-                starts.append(0)
-                continue
+        for i, r in enumerate(rows):
+            tbl = r[4]
+            if len(r) > 5:
+                sid, anonymous = r[5], False
+                if sid is None:
+                    starts.append(0)
+                    continue
+            else:                              # a caller that does not name its sequences: row i's table is written in full
+                sid, anonymous = ("row", i), True
             nb = len(tbl)
             if nb > cap:
                 raise HydraHipError(f"a sequence of {nb} blocks in a decoder built for {cap}")
@@ -109,7 +114,7 @@ class DecodeStager:
             if e is None:
                 e = self.slot_of[sid] = [self._alloc(), 0, -1, self.step_no]
             e[3] = self.step_no
-            if nb < e[1] or (e[1] and tbl[e[1] - 1] != e[2]):
+            if anonymous or nb < e[1] or (e[1] and tbl[e[1] - 1] != e[2]):
                 e[1] = 0                       # not the table this slot holds a prefix of: written again in full
             if nb > e[1]:
                 new = tbl[e[1]:]
@@ -124,6 +129,61 @@ class DecodeStager:
         st[o["cu_blocks"] + B] = 0
         st[self.head_words] = n_runs
         return max(kv)
+
+
+    def stage_cohort(self, st: "np.ndarray", n: int, B: int, pos: "np.ndarray", slots: "np.ndarray", starts: "np.ndarray",
+                     grown: List[Tuple[int, int, int]]) -> int:
+        """The steady-state form of stage(): the SAME n sequences as the previous launch, in the same order, one token
+        further — every row's input id is the previous launch's sample of the same row (src[r] = r), positions / slots /
+        table offsets come as arrays, and `grown` lists the rows that entered a new block: (sid, blocks before, new
+        block id).  No per-row Python except for those."""
+        self.step_no += 1
+        o, pad = self.off, B - n
+        if int(pos[:n].max()) >= self.max_pos:
+            raise HydraHipError(f"decode position outside the rotary table (max_position_embeddings = {self.max_pos})")
+        st[o["ids"]:o["ids"] + B] = 0
+        st[o["src"]:o["src"] + n] = self._arange[:n]
+        st[o["pos"]:o["pos"] + n] = pos[:n]
+        st[o["slots"]:o["slots"] + n] = slots[:n]
+        st[o["cu_blocks"]:o["cu_blocks"] + n] = starts[:n]
+        if pad:
+            st[o["src"] + n:o["src"] + B] = -1
+            st[o["pos"] + n:o["pos"] + B] = 0
+            st[o["slots"] + n:o["slots"] + B] = self.pad_block * self.block_size
+            st[o["cu_blocks"] + n:o["cu_blocks"] + B] = 0
+        st[o["cu_blocks"] + B] = 0
+        kv = st[o["kv_cu"] + 1:o["kv_cu"] + B + 1]
+        kv[:n] = pos[:n]
+        kv[:n] += 1
+        kv[n:] = 1
+        # the rank descriptor (layer/causal_attention.py::decode_rank_descriptor, the same words) without a Python loop
+        kv_max = int(kv.max())
+        if B <= 256:
+            st[o["rank"]] = 1 if float(kv_max) > float(kv.sum()) / B * RANKED_THR + 16.0 else 0
+            st[o["rank"] + 1:o["rank"] + B + 1] = np.argsort(-kv, kind="stable")
+        else:
+            st[o["rank"]] = 0
+            st[o["rank"] + 1:o["rank"] + B + 1] = self._arange_b(B)
+        st[o["kv_cu"]] = 0
+        np.cumsum(kv, out=kv)
+        at = self.head_words + 1
+        for sid, before, block in grown:
+            e = self.slot_of[sid]
+            st[at:at + 3] = (self.tables_off + e[0] * self.cap + before, 1, block)
+            at += 3
+            e[1], e[2] = before + 1, block
+        st[self.head_words] = len(grown)
+        return kv_max
+
+    def _arange_b(self, B: int):
+        return np.arange(B, dtype=np.int32)
+
+    def touch(self, sids) -> None:
+        """The sequences of a cohort episode were seen until now (least-recently-seen bookkeeping)."""
+        for sid in sids:
+            e = self.slot_of.get(sid)
+            if e is not None:
+                e[3] = self.step_no
 
 
 class GraphedDecoder:
@@ -286,11 +346,25 @@ class GraphedDecoder:
                 self.graphs[key] = self._capture(*key)
         torch.cuda.synchronize(self.dev)
 
-    def launch(self, rows: List[Tuple[int, int, int, int, List[int]]]) -> int:
+    def launch_cohort(self, n: int, pos, slots, starts, grown) -> int:
+        """launch() for the same n sequences as the previous launch, one token further (DecodeStager.stage_cohort)."""
+        B = (n + self.pad_to - 1) // self.pad_to * self.pad_to
+        which = self.fills % 2
+        self.fills += 1
+        self.copy_done[which].synchronize()
+        kv_max = self.stager.stage_cohort(self.stage[which], n, B, pos, slots, starts, grown)
+        _lib.check(_lib.lib().hx_stage_decode(self.static.data_ptr(), self.static.numel(), self.staging[which].data_ptr(),
+                                              self.stager.head_words, _lib.current_stream()), "stage_decode")
+        self.copy_done[which].record()
+        return self._replay(n, B, kv_max)
+
+    def launch(self, rows: List[tuple]) -> int:
         """Enqueue one decode step; returns a launch id for `fetch`.  Does not wait for the GPU."""
         n = len(rows)
         B = (n + self.pad_to - 1) // self.pad_to * self.pad_to
-        kv_max = self._fill(rows, B)
+        return self._replay(n, B, self._fill(rows, B))
+
+    def _replay(self, n: int, B: int, kv_max: int) -> int:
         key = (B, self._kv_bucket(B, kv_max))
         if key not in self.graphs:
             self.graphs[key] = self._capture(*key)

@@ -112,6 +112,13 @@ class EPDNode:
 
     # ---- one engine step (epdnode.py:238-337)
     def step(self) -> int:
+        fe = self.executor.fill_executor
+        if fe is not None and fe.graph_decoder is not None:
+            # the steady state of a decode batch runs without the scheduler (executor.DecodeCohort); anything else —
+            # an arrival, a request about to finish, a hand-over — ends it and takes the general path below
+            n = fe.cohort_step(self.batch_scheduler)
+            if n:
+                return n
         with profile("schedule"):
             batch = self.batch_scheduler.step()
         if len(batch) == 0:

@@ -50,6 +50,12 @@ class ScenarioClassifier:
         return ScenarioType.Strict if strict else ScenarioType.Relaxed
 
 
+# Bumped by whoever changes a live request behind the engine's back (a cancelled stream lowering max_tokens:
+# entrypoint/api_server.py).  The executor's steady-state decode cohort (engine/executor.py) compares it instead of
+# re-reading every request every step.
+MUTATIONS = [0]
+
+
 class OutputTokenProcessor:
     def append_token_id(self, token_id: int, is_last_token: bool = False) -> None:
         raise NotImplementedError

@@ -138,6 +138,8 @@ class EngineFrontend:
         rcb = self.rcb_of.get(id(processor))
         if rcb is not None and rcb.sampling_params is not None:
             rcb.sampling_params.max_tokens = max(1, len(rcb.output_token_ids))      # finished at its next look
+            from hydrainfer_amd.engine import rcb as rcb_module
+            rcb_module.MUTATIONS[0] += 1                                            # (the decode cohort must look again)
         processor.ended = True
         self._forget(processor)
 

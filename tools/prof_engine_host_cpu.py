@@ -41,6 +41,13 @@ class HostOnlyDecoder:
         self.rows_of[self.launches] = len(rows)
         return self.launches
 
+    def launch_cohort(self, n, pos, slots, starts, grown):
+        self.launches += 1
+        B = (n + 3) // 4 * 4
+        self.stager.stage_cohort(self.st[self.launches % 2], n, B, pos, slots, starts, grown)
+        self.rows_of[self.launches] = n
+        return self.launches
+
     def fetch(self, launch_id):
         return [7] * self.rows_of.pop(launch_id)
 
@@ -70,10 +77,10 @@ for i in range(rows_n):
     cluster.add_request(creator.process(TokenRequest(i, torch.randint(1000, 31999, (prompt,), generator=g).tolist(), None, (336, 336), i,
                                                      SamplingParameters(max_tokens=256))))
 with quiet_gc():
-    while any(len(r.output_token_ids) < 3 for r in node.batch_scheduler.running) or node.batch_scheduler.waiting:
+    n_prefill = (rows_n * prompt + 2047) // 2048 + 2          # (the cohort keeps a request's token list for its end: count steps)
+    for _ in range(n_prefill + 10):
         cluster.step()
-    for _ in range(10):
-        cluster.step()
+    assert len(node.batch_scheduler.running) == rows_n and not node.batch_scheduler.waiting
     ts = []
     prof = cProfile.Profile() if "--profile" in sys.argv else None
     for i in range(200):
@@ -85,7 +92,8 @@ with quiet_gc():
     if prof:
         prof.disable()
 ts.sort()
-print(f"{rows_n} rows, prompt {prompt}: host time of a decode step: median {ts[len(ts) // 2] * 1e6:.0f} us, p90 {ts[int(len(ts) * 0.9)] * 1e6:.0f} us, "
+fe = node.executor.fill_executor
+print(f"cohort steps {fe.n_cohort_steps}; " f"{rows_n} rows, prompt {prompt}: host time of a decode step: median {ts[len(ts) // 2] * 1e6:.0f} us, p90 {ts[int(len(ts) * 0.9)] * 1e6:.0f} us, "
       f"min {ts[0] * 1e6:.0f} us")
 if prof:
     pstats.Stats(prof).sort_stats("tottime").print_stats(22)
