@@ -54,6 +54,7 @@ class DecodeCohort:
         self.sids = [r.sid for r in rcbs]
         self.streams = [(i, r.output_token_processors) for i, r in enumerate(rcbs) if r.output_token_processors]
         self.first_inst = [r.current_instruction() for r in rcbs]
+        self.eos_rows: List[int] = []                   # rows whose request names end-of-sequence ids
         self.k = 0                                      # cohort launches so far
         self.launch = None                              # the one in flight
         self.tok_log: List[List[int]] = []              # tokens of cohort launches 1 .. k - 1 (resolved)
@@ -75,6 +76,7 @@ class BatchFillExecutor:
         self.cohort_enabled = os.environ.get("HX_DECODE_COHORT", "1") == "1"
         self.cohort_refused = None # the pending launch a cohort could not be formed behind (not tried again until the next one)
         self.n_cohort_steps = 0
+        self.ended_rows: Optional[List] = None   # the rows of a cohort that ended inside its own step (an end-of-sequence id came back)
 
     def _decode_rows(self, batch: BatchRequest):
         """(token, position, slot, kv_len, block_table) per request if the whole batch is decode.
@@ -178,13 +180,26 @@ class BatchFillExecutor:
         if previous is None:                    # the launch the cohort was formed behind: the general bookkeeping
             pending, self.pending = self.pending, None
             self._resolve(pending)
+            if co.eos_rows and any(co.rcbs[r].eos_hit for r in co.eos_rows):
+                self._cohort_end()              # one of them has just ended: over before it began
         else:
             tokens = dec.fetch(previous)
             co.tok_log.append(tokens)
             co.t_log.append(time.perf_counter())
-            for r, processors in co.streams:    # tokens go out as they come (never a request's last: those end the cohort)
+            ended = [r for r in co.eos_rows if tokens[r] in co.rcbs[r].sampling_params.eos_token_ids] if co.eos_rows else ()
+            for r, processors in co.streams:    # tokens go out as they come (a request's last one only as an end-of-sequence id)
                 for p in processors:
-                    p.append_token_id(tokens[r], False)
+                    p.append_token_id(tokens[r], r in ended)
+            if ended:
+                # an end-of-sequence id, read one step late like every token: the launch just made ran past it for those
+                # rows — their extra sample is dropped, the general path frees them at its next step (as it would have)
+                self._cohort_end()
+                for r in ended:
+                    rcb = co.rcbs[r]
+                    del rcb.output_token_ids[-1:]          # the placeholder of the launch that ran past the end
+                    rcb.eos_hit = True
+        if self.cohort is None:                 # it ended inside this step: the node looks at every row the way it does after any step
+            self.ended_rows = co.rcbs
         return co.n
 
     def _cohort_begin(self, scheduler) -> Optional[DecodeCohort]:
@@ -198,8 +213,10 @@ class BatchFillExecutor:
         for r, (rcb, inst) in enumerate(zip(rcbs, co.first_inst)):
             tok = inst.token_ids[0] if isinstance(inst, TextFill) and inst.token_ids and len(inst.token_ids) == 1 else None
             if (not isinstance(tok, PendingToken) or tok.launch != launch or tok.row != r or not inst.sample or rcb.eos_hit
-                    or rcb.sampling_params.eos_token_ids or rcb.sid not in slot_of):
+                    or rcb.sid not in slot_of):
                 return None
+            if rcb.sampling_params.eos_token_ids:
+                co.eos_rows.append(r)
             vc = rcb.virtual_kv_cache
             c = inst.cache_ids[0]
             co.pos[r], co.cid[r] = inst.position_ids[0], c
@@ -221,10 +238,11 @@ class BatchFillExecutor:
         entries = []
         for r, rcb in enumerate(co.rcbs):
             out = rcb.output_token_ids
-            out.extend(t[r] for t in co.tok_log)
             placeholder = PendingToken(co.launch, r)
-            out.append(placeholder)
-            rcb.metric.token_times.extend(co.t_log)
+            if not rcb.eos_hit:                 # (a request that ended at the cohort's first resolve keeps what it has)
+                out.extend(t[r] for t in co.tok_log)
+                out.append(placeholder)
+                rcb.metric.token_times.extend(co.t_log)
             inst = co.first_inst[r]
             for _ in range(co.k - 1):
                 inst = inst.next                # the instructions of the launches that have been resolved

@@ -118,6 +118,22 @@ class EPDNode:
             # an arrival, a request about to finish, a hand-over — ends it and takes the general path below
             n = fe.cohort_step(self.batch_scheduler)
             if n:
+                if fe.ended_rows is not None:
+                    # an end-of-sequence id came back: what the loop at the end of a general step does, row by row in batch
+                    # order — the first finished request makes the pending launch's tokens known, which may end others
+                    rows, fe.ended_rows = fe.ended_rows, None
+                    now = time.perf_counter()
+                    keep = []
+                    for rcb in rows:
+                        if rcb.is_finished():
+                            self.executor.resolve_pending()
+                            rcb.metric.finished_time = now
+                            self._free_cache(rcb)
+                            rcb.release_instructions()
+                            self.finished.append(rcb)
+                        else:
+                            keep.append(rcb)
+                    self.batch_scheduler.running = keep
                 return n
         with profile("schedule"):
             batch = self.batch_scheduler.step()

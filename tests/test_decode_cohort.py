@@ -80,7 +80,7 @@ class ResidentDecoder:
         pass
 
 
-def _run_trace(seed, cohort, with_streams=False):
+def _run_trace(seed, cohort, with_streams=False, with_eos=False):
     rnd = random.Random(seed)
     shape = NS(num_hidden_layers=1, num_attention_heads=1, num_key_value_heads=1, head_dim=8, max_position_embeddings=4096)
 
@@ -105,8 +105,10 @@ def _run_trace(seed, cohort, with_streams=False):
     n_req = rnd.randint(3, 14)
     reqs, arrive, logs = [], [], {}
     for i in range(n_req):
+        # a third of the requests name end-of-sequence ids — a tenth of the sampler's range, so some end early
+        eos = [t for t in range(100, 30100) if t % 10 == i % 10] if with_eos and i % 3 == 0 else []
         reqs.append(TokenRequest(i, [rnd.randint(1000, 31000) for _ in range(rnd.randint(3, 70))], None, (8, 8), 100 + i,
-                                 SamplingParameters(max_tokens=rnd.randint(1, 90))))
+                                 SamplingParameters(max_tokens=rnd.randint(1, 90), eos_token_ids=eos)))
         arrive.append(rnd.choice((0, 0, 0, rnd.randint(1, 40), rnd.randint(40, 160))))
     rcbs = [None] * n_req
     step = 0
@@ -131,13 +133,17 @@ def _run_trace(seed, cohort, with_streams=False):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_the_cohort_changes_nothing(seed):
-    on, off = _run_trace(seed, True, with_streams=seed % 3 == 0), _run_trace(seed, False, with_streams=seed % 3 == 0)
+    kw = dict(with_streams=seed % 3 == 0, with_eos=seed % 2 == 1)
+    on, off = _run_trace(seed, True, **kw), _run_trace(seed, False, **kw)
     assert off["n_cohort"] == 0
     for k in ("tokens", "stamps", "streams", "n_launches", "steps"):
         assert on[k] == off[k], k
     assert on["inputs"] == off["inputs"]              # every launch saw the same rows, tables and tokens on the device
     for toks in on["tokens"]:
         assert all(isinstance(t, int) for t in toks)
+    if kw["with_eos"]:
+        on_early = _run_trace(seed, True, **kw)
+        assert on_early["tokens"] == on["tokens"]          # (deterministic)
 
 
 def test_the_cohort_is_actually_used():
