@@ -356,6 +356,9 @@ def measure_serving(model, vision, pixels, shape, dtype, dev, batch, n_text, max
     res = replay(cluster, creator, reqs, [0.0] * batch, dev)
     gd = node.executor.fill_executor.graph_decoder
     res["engine_executor"] = gd.executor        # what replays the engine's decode steps: "graph" (hipGraph) or "plan"
+    # how many of the engine's decode launches ran as steady-state cohort steps (engine/executor.py::DecodeCohort: no scheduler,
+    # no per-request object work — 23 us of host time at 64 rows against 0.39 ms for a general step, tools/prof_engine_host_cpu.py)
+    res["decode_launches"], res["decode_cohort_steps"] = gd.launches, node.executor.fill_executor.n_cohort_steps
     # HBM held by all weight layouts once this leg has announced its largest decode batch: batches of 33 .. 64 rows add
     # the LDS-slice copies of the projections the <= 32-row layer runs on the activations-in-registers layout
     res["weight_bytes_resident"] = model.weight_bytes_resident()
