@@ -69,6 +69,9 @@ def parse():
                         "incl. building 13 GB of weights): cpu_baseline.config0_full and full_over_extrapolated")
     p.add_argument("--no-13b", action="store_true", help="skip the short LLaVA-1.5-13B leg (BASELINE configs[2])")
     p.add_argument("--steps-13b", type=int, default=20)
+    p.add_argument("--leg-13b-in-process", action="store_true",
+                   help="run the 13B leg inside this process behind the 7B legs instead of in a fresh child process")
+    p.add_argument("--as-13b-leg", action="store_true", help=argparse.SUPPRESS)      # set by leg_13b_child only
     p.add_argument("--no-ranked", action="store_true",
                    help="decode attention on the static (head, sequence) grid instead of the length-ranked one (A/B; attn_decode.hip)")
     p.add_argument("--no-ragged", action="store_true", help="skip whole_step_ragged (the decode step on ragged batches)")
@@ -1448,6 +1451,33 @@ def leg_13b(ctx, args, dtype, dev, rank):
             "whole_step_64": whole_64}
 
 
+def leg_13b_child(args):
+    """The 13B leg in a FRESH process (started only after this one has released the 7B model): `python bench.py --model 13b`
+    with this run's flags, its one JSON line reshaped to leg_13b's object.  Why a child: weights allocated behind the 7B
+    legs' allocations and frees stream 1.5-3 % slower through the same GEMM kernels than in a process that allocated them
+    first (profiles/r6_13b_alone_vs_after7b.md: gate|up 51.7 against 50.1 us, attention unchanged) — an engine holds ONE
+    model from start-up, so the fresh process is the case to quote.  The child is spawned, never exec'd."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--model", "13b", "--as-13b-leg", "--gpus", "1",
+           "--steps", str(args.steps_13b), "--warmup", str(args.warmup), "--batch", str(args.batch), "--dtype", args.dtype,
+           "--executor", args.executor, "--no-cpu-baseline", "--no-serving", "--no-ttft", "--no-ragged"]
+    for flag in ("no_graph", "lib_gemm", "no_fused_attention", "no_ranked", "no_null_step", "no_serving_64"):
+        if getattr(args, flag):
+            cmd.append("--" + flag.replace("_", "-"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"13B child exited {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}")
+    d = json.loads(lines[-1])
+    leg = {"workload": d["config"]["workload"], "process": "child: python bench.py --model 13b (fresh process, after this one "
+                                                           "released the 7B model)"}
+    for k in ("value", "unit", "steps", "ms_per_step", "timed_regions", "ms_per_step_min", "ms_per_step_max", "ms_per_step_all",
+              "roofline", "roofline_gemm", "whole_step", "whole_step_64"):
+        if k in d:
+            leg[k] = d[k]
+    return leg
+
+
 def main():
     args = parse()
     launch_ranks_if_needed(args)             # N > 1 without WORLD_SIZE: this process only starts the ranks
@@ -1571,7 +1601,7 @@ def main():
             serving["twice_the_batch"] = measure_serving(model, vision, pixels, shape, dtype, dev, 2 * args.batch,
                                                          prompt_len - 576, n_generate)
     whole_64 = None
-    if rank == 0 and world == 1 and args.model == "7b" and not args.no_serving_64:
+    if rank == 0 and world == 1 and (args.model == "7b" or args.as_13b_leg) and not args.no_serving_64:
         try:
             whole_64 = leg_64_rows(ctx, model, args, dev, prompt_len, n_generate)
         except SystemExit:
@@ -1699,7 +1729,16 @@ def main():
             del model
             import gc
             gc.collect(); torch.cuda.empty_cache()
-            llava_13b = leg_13b(ctx, args, dtype, dev, rank)
+            print(f"[bench] before the 13B leg: {torch.cuda.memory_allocated() / 2**30:.2f} GiB allocated, "
+                  f"{torch.cuda.memory_reserved() / 2**30:.2f} GiB reserved", file=sys.stderr)
+            if args.leg_13b_in_process:
+                llava_13b = dict(leg_13b(ctx, args, dtype, dev, rank), process="this one, behind the 7B legs")
+            else:
+                try:
+                    llava_13b = leg_13b_child(args)
+                except Exception as e:      # e.g. a sandbox without child processes: the in-process leg, and say so
+                    llava_13b = dict(leg_13b(ctx, args, dtype, dev, rank),
+                                     process=f"this one, behind the 7B legs (the child process failed: {repr(e)[:200]})")
         except SystemExit:
             raise
         except Exception as e:      # an extra leg must never cost the headline
