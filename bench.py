@@ -599,7 +599,7 @@ def measured_gemm_traffic(args, model_name, weight_bytes_per_layer):
 
 def in_step_attention(args, model_name):
     """The attention launch's duration INSIDE the decode step, from the last committed rocprofv3 kernel trace of this
-    command (profiles/*_in_step.json, written by tools/decode_timeline_summary.py): the standalone figure of `roofline`
+    command (profiles/*_in_step.json, written by tools/layer_timeline.py through tools/prof_step.sh): the standalone figure of `roofline`
     is the conservative one, this is the one the step's time is made of.  Returns a dict or None."""
     if not (args.model == "7b" and args.batch == 32 and args.dtype == "bf16"):
         return None

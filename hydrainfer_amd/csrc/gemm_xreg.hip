@@ -240,7 +240,7 @@ __device__ __forceinline__ bool norm_row_256(const float* __restrict__ partial, 
 // 16-row groups interleaved (group 2j = gate rows 16j.., group 2j+1 = up rows 16j..); a workgroup
 // takes whole pairs and writes act = silu(gate) * up with the rounding of hx_silu_and_mul_slabs on the
 // one-slab result (sum -> T, silu -> T, product -> T), fragment-major for the down projection.
-template <typename T, int MB, int KW, int EPI = 0, int DBG = 0, int NORM = 0>
+template <typename T, int MB, int KW, int EPI = 0, int DBG = 0, int NORM = 0, int RM = 0>
 __global__ __launch_bounds__(256) void gemm_xreg_kernel(HX_XREG_HOT_SIG, const XregParams p_in) {
   HX_XREG_UNPACK_HOT(NORM)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -276,12 +276,22 @@ __global__ __launch_bounds__(256) void gemm_xreg_kernel(HX_XREG_HOT_SIG, const X
   // k-step of slot t: rot(t) = (j0 + t) mod KW; slots whose k-step is past the wave's range are
   // padding: x fragment zero, weight address clamped to a valid fragment
   auto rot = [&](int t) { const int r = j0 + t; return r >= KW ? r - KW : r; };
-  const u16* wbase = reinterpret_cast<const u16*>(p.w) + 8 * lane + ((int64_t)ks0 * n_rg) * 512;
+  // RM = 1: the weight is the ROW-MAJOR [N][K] tensor itself (the one the library prefill GEMMs read: an E/P/EPD node
+  // then holds ONE copy).  The fragment of (row group, k-step) is then 16 rows x 64 bytes, lane (c, g) at row c, bytes
+  // 16 g: the same elements in the same lanes as the packed fragment, so the sums are bit-identical.
+  constexpr int64_t jstride = RM ? 32 : 512;
+  const u16* wbase = RM ? reinterpret_cast<const u16*>(p.w) + (int64_t)c * p.K + 8 * g + (int64_t)ks0 * 32
+                        : reinterpret_cast<const u16*>(p.w) + 8 * lane + ((int64_t)ks0 * n_rg) * 512;
+  auto rg_off = [&](int rg) -> int64_t {
+    if constexpr (!RM) return (int64_t)rg * nks * 512;
+    else if (EPI || p.interleaved) return ((int64_t)(rg & 1) * (p.N >> 1) + (int64_t)(rg >> 1) * 16) * p.K;
+    else return (int64_t)rg * 16 * p.K;
+  };
   const int wave_k0 = min(w * KW, max(nks - 1, 0));
   auto frag_ptr = [&](int rg, int t) {
     const int r = rot(t);
     const int j = wave_k0 + (r < kw ? r : 0);
-    return wbase + ((int64_t)rg * nks + j) * 512;
+    return wbase + rg_off(rg) + j * jstride;
   };
 
   u16x8 buf[NBUF][8];
@@ -803,6 +813,7 @@ __global__ __launch_bounds__(256) void pack_xreg_kernel(u16* __restrict__ packed
 int g_stagger = 1;
 int g_no_producers = 0;   // test hook (xreg_no_producers): 1 = the norm-fused launches rely on the rescue path alone; 2 = no producers and no rescue: every such launch gives up (error word) after 2 ms
 int g_dbg = 0;
+int g_row_major = 0;   // EXPERIMENTS builds (xreg_row_major): every 32-row launch reads its weight argument as the row-major [N][K] tensor
 int g_timeline = 0;      // diagnostic (xreg_timeline): phase time stamps of the NORM launches into their sync areas
 int g_force_wgs = 0;     // tuning: cap on workgroups per launch (0 = the CU count)
 
@@ -906,6 +917,14 @@ int launch_kw(const XregParams& p, int S, hipStream_t stream) {
     else HX_XREG_LAUNCH(T, MB, KW, 0, 3);
     return check_launch();
   }
+#if HX_EXPERIMENTS
+  // measured and not taken (round 6, profiles/rejected.md): the same kernel over the ROW-MAJOR tensor — one weight copy
+  // on a collocated node — streams 16 x 64-byte pieces per wave instruction and is 10-30 % slower (7B, 32 rows)
+  if constexpr (MB == 2 && (KW == 32 || KW == 22 || KW == 29)) if (p.stagger & 16) {
+    HX_XREG_LAUNCH(T, MB, KW, EPI, 0, NORM, 1);
+    return check_launch();
+  }
+#endif
   HX_XREG_LAUNCH(T, MB, KW, EPI, 0, NORM);
 #undef HX_XREG_LAUNCH
   return check_launch();
@@ -1014,13 +1033,14 @@ int xreg_set_option(const char* name, int value) {
   if (!strcmp(name, "xreg_wgs")) { g_force_wgs = value; return HX_OK; }
   if (!strcmp(name, "xreg_no_producers")) { g_no_producers = value; return HX_OK; }
   if (!strcmp(name, "xreg_dbg")) { g_dbg = value; return HX_OK; }
+  if (!strcmp(name, "xreg_row_major")) { g_row_major = value ? 1 : 0; return HX_OK; }
   return HX_ERR_UNSUPPORTED;
 }
 }  // namespace hx
 
 namespace {
 int stagger_bits() {
-  return (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0);
+  return (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0) | (g_row_major ? 16 : 0);
 }
 
 // plain product of <= 64 rows over a packing (plain or gate|up-interleaved) with the wide kernel; returns the slab count
@@ -1112,7 +1132,7 @@ extern "C" int hx_linear_decode_partial_xreg(float* partial, const void* x, cons
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x; p.w = packed_weight; p.partial = partial; p.ldx = ldx; p.act = nullptr;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = x_fragment_major ? 1 : 0;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = stagger_bits(); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f; p.interleaved = 0; p.pk_P = 0;
   const int rc = launch_any<0>(p, S, KW, dtype, (hipStream_t)stream);
   return rc ? rc : S;
@@ -1136,7 +1156,7 @@ extern "C" int hx_gate_up_silu_xreg(void* act, const void* x, const void* packed
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
   p.x = x; p.w = packed_gate_up; p.partial = nullptr; p.ldx = ldx; p.act = act;
-  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = x_fragment_major ? 1 : 0;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = stagger_bits(); p.x_packed = x_fragment_major ? 1 : 0;
   p.nm_partial = nullptr; p.nm_residual = nullptr; p.nm_weight = nullptr; p.sync = nullptr; p.nm_splits = 0; p.nm_eps = 0.f; p.interleaved = 0; p.pk_P = 0;
   return launch_any<1>(p, 1, KW, dtype, (hipStream_t)stream);
 }
@@ -1181,7 +1201,7 @@ extern "C" int hx_norm_linear_decode_xreg(float* partial, void* residual, const 
   xreg_plan(N, K, &S, &KW);
   XregParams p;
   p.x = x_frag; p.w = packed_weight; p.partial = partial; p.ldx = K; p.act = nullptr;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = 1;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K; p.stagger = stagger_bits(); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
   p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.interleaved = 0; p.pk_P = 0;
   rc = launch_any<0, 1>(p, S, KW, dtype, (hipStream_t)stream);
@@ -1202,7 +1222,7 @@ extern "C" int hx_norm_gate_up_silu_xreg(void* act, void* residual, const float*
   xreg_plan(2 * inter, K, &S, &KW, true);
   XregParams p;
   p.x = x_frag; p.w = packed_gate_up; p.partial = nullptr; p.ldx = K; p.act = act;
-  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = (g_stagger ? 1 : 0) | (g_no_producers == 1 ? 2 : 0) | (g_no_producers == 2 ? 4 : 0) | (g_timeline ? 8 : 0); p.x_packed = 1;
+  p.M = (int)M; p.N = (int)(2 * inter); p.K = (int)K; p.stagger = stagger_bits(); p.x_packed = 1;
   p.nm_partial = slabs_in; p.nm_residual = residual; p.nm_weight = norm_weight; p.sync = (uint32_t*)sync;
   p.nm_splits = n_splits_in; p.nm_eps = epsilon; p.interleaved = 0; p.pk_P = 0;
   return launch_any<1, 1>(p, 1, KW, dtype, (hipStream_t)stream);

@@ -46,9 +46,9 @@ def test_register_budgets_of_the_benchmarked_instantiations(table):
             assert r["group_segment_fixed_size"] <= 40 * 1024           # four per CU inside 160 KiB
             assert r["kernarg_segment_size"] >= 64                      # 7 pointers + 2 ints in front of the struct: all preloaded
     # activations-in-registers GEMMs: one wave per SIMD by design (x and a weight buffer set fill the 512 registers)
-    for name in ("gemm_xreg_kernel<BF16, 2, 32, 1, 0, 1>", "gemm_xreg_kernel<BF16, 2, 32, 0, 0, 1>",
-                 "gemm_xreg_kernel<BF16, 2, 22, 0, 0, 0>", "gemm_xreg_kernel<BF16, 2, 40, 1, 0, 1>",
-                 "gemm_xreg_kernel<BF16, 2, 40, 0, 0, 1>", "gemm_xreg_kernel<BF16, 2, 27, 0, 0, 0>",
+    for name in ("gemm_xreg_kernel<BF16, 2, 32, 1, 0, 1, 0>", "gemm_xreg_kernel<BF16, 2, 32, 0, 0, 1, 0>",
+                 "gemm_xreg_kernel<BF16, 2, 22, 0, 0, 0, 0>", "gemm_xreg_kernel<BF16, 2, 40, 1, 0, 1, 0>",
+                 "gemm_xreg_kernel<BF16, 2, 40, 0, 0, 1, 0>", "gemm_xreg_kernel<BF16, 2, 27, 0, 0, 0, 0>",
                  "gemm_xreg_wide_kernel<BF16, 16, 1, 2, 0>", "gemm_xreg_wide_kernel<BF16, 16, 1, 2, 1>",
                  "gemm_xreg_wide_kernel<BF16, 11, 0, 2, 0>", "gemm_xreg_wide_kernel<BF16, 20, 1, 1, 0>",
                  "gemm_xreg_wide_kernel<BF16, 14, 0, 2, 0>"):
@@ -61,7 +61,7 @@ def test_kernel_arguments_of_the_hot_kernels_fit_the_preload_window(table):
     PRELOADING): the struct that follows must not have displaced them — the explicit arguments in front of the struct
     are 9 x 8-byte / 4-byte slots = 56 bytes (14 dwords, what gfx950 preloads)."""
     by = {r["name"]: r for r in table}
-    r = by["gemm_xreg_kernel<BF16, 2, 32, 0, 0, 1>"]
+    r = by["gemm_xreg_kernel<BF16, 2, 32, 0, 0, 1, 0>"]
     assert r["kernarg_segment_size"] >= 56 + 100          # 5 pointers + 4 ints, then the by-value struct
 
 

@@ -53,15 +53,23 @@ for name, (N, K) in {"qkv": (3 * hid, hid), "o": (hid, hid), "gate_up": (2 * int
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     sb2 = gemm.linear_decode_partial_xreg(x, px[0], N, b, frag_shape=fs)
     same = torch.equal(got, b[: sb2 * M * N].view(sb2, M, N).sum(0))
+    t3 = same_rm = None
+    if os.environ.get("ROW_MAJOR", "0") == "1" and M <= 32:      # the same kernel over the row-major tensor (RM = 1)
+        assert _lib.lib().hx_debug_set_option(b"xreg_row_major", 1) == 0
+        sb3 = gemm.linear_decode_partial_xreg(x, ws[0], N, b, frag_shape=fs)
+        same_rm = sb3 == sb and torch.equal(got, b[: sb3 * M * N].view(sb3, M, N).sum(0))
+        t3 = graph_time(lambda: [gemm.linear_decode_partial_xreg(x, ws[i % nc], N, b, frag_shape=fs) for i in range(12)], 12)
+        assert _lib.lib().hx_debug_set_option(b"xreg_row_major", 0) == 0
     del ws
     t0 = graph_time(lambda: [gemm.linear_decode_partial_packed(x_rm, pk[i % nc], N, a) for i in range(12)], 12)
     t1 = graph_time(lambda: [gemm.linear_decode_partial_xreg(x, px[i % nc], N, b, frag_shape=fs) for i in range(12)], 12)
     nb = N * K * 2 // 8192 * 8192
     l = _lib.lib()
-    t2 = graph_time(lambda: [_lib.check(l.hx_debug_stream_read(px[i % nc].data_ptr(), nb, 0, 0, 8, 1, 1024, sink.data_ptr(),
+    t2 = float("nan") if not hasattr(l, "hx_debug_stream_read") else graph_time(lambda: [_lib.check(l.hx_debug_stream_read(px[i % nc].data_ptr(), nb, 0, 0, 8, 1, 1024, sink.data_ptr(),
                                                                _lib.current_stream()), "s") for i in range(12)], 12)
     tot["packed"] += t0; tot["xreg"] += t1; tot["read"] += t2
     print(f"{name:8s} N={N:6d} K={K:6d}: packed {t0:6.2f} us | xreg {t1:6.2f} us {N*K*2/t1/1e6:5.2f} TB/s slabs={sb} "
-          f"rel.err {err:.1e} repeatable {same} | pure read {t2:6.2f} us", flush=True)
+          f"rel.err {err:.1e} repeatable {same} | pure read {t2:6.2f} us"
+          + (f" | row-major W {t3:6.2f} us, bit-identical {same_rm}" if t3 is not None else ""), flush=True)
     del pk, px
 print(f"layer: packed {tot['packed']:.1f} us, xreg {tot['xreg']:.1f} us, pure read {tot['read']:.1f} us   opts={opts}")

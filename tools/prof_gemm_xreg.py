@@ -51,8 +51,9 @@ def counters(d, counter):
         for r in csv.DictReader(open(f)):
             if "gemm_xreg_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 key = r["Kernel_Name"].split("gemm_xreg_kernel")[1].split("(")[0].replace("hx::", "").replace(" ", "")
-                if key.count(",") == 4:
-                    key = key[:-1] + ",0>"
+                parts = key.strip("<>").split(",")      # <T, MB, KW, EPI, DBG, NORM[, RM]>: defaults appended by round
+                parts = (parts + ["0"] * 6)[:6] if len(parts) <= 6 else parts[:6]
+                key = "<" + ",".join(parts) + ">"
                 out.setdefault(key, []).append(float(r["Counter_Value"]))
     return out
 
