@@ -173,6 +173,7 @@ def test_engine_failure_and_oversized_prompt_end_the_stream_loudly():
     assert done and n_events == 3 and front.error is None
 
 
+@pytest.mark.filterwarnings("ignore::pytest.PytestUnhandledThreadExceptionWarning")      # the injected failure is re-raised by the engine thread on purpose
 def test_engine_thread_death_ends_every_open_stream_and_health_says_so():
     """Round-5 ADVICE: when the engine thread dies, the streams of requests already ADMITTED used to wait for ever (only
     the inbox was failed) and /health kept answering 200."""
