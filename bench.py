@@ -578,19 +578,22 @@ def measured_traffic(args, model_name, algorithmic_bytes):
 def measured_gemm_traffic(args, model_name, weight_bytes_per_layer):
     """HBM bytes of one layer's four decode GEMM launches from the committed PMC passes (FETCH_SIZE x2 gfx950 correction
     + WRITE_SIZE, separate rocprofv3 --pmc runs): the norm-fused qkv and gate|up+silu launches and the down launch
-    from profiles/r5_gemm_xreg_pmc.json, the o launch from profiles/r2_gemm_packed_pmc.json.  Only for the workload
+    from the latest profiles/r*_gemm_xreg_pmc.json, the o launch from profiles/r2_gemm_packed_pmc.json.  Only for the workload
     that was profiled (7B, 32 rows, bf16).  Returns (bytes, source) or (None, None)."""
     if not (args.model == "7b" and args.batch == 32 and args.dtype == "bf16"):
         return None, None
     try:
-        xr = {s_["name"]: s_ for s_ in json.load(open(os.path.join(ROOT, "profiles", "r5_gemm_xreg_pmc.json")))["shapes"]}
+        import glob
+        xr_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_xreg_pmc.json")))[-1]      # the latest round's passes
+        xr_name = os.path.basename(xr_path)
+        xr = {s_["name"]: s_ for s_ in json.load(open(xr_path))["shapes"]}
         pk = {s_["name"]: s_ for s_ in json.load(open(os.path.join(ROOT, "profiles", "r2_gemm_packed_pmc.json")))["shapes"]}
         parts = [xr["norm+qkv"], xr["norm+gate_up+silu"], xr["down"], pk["o"]]
         traffic = sum(p_["fetch_bytes_corrected"] + p_["write_bytes"] for p_ in parts)
         alg = sum(p_["algorithmic_weight_bytes"] for p_ in parts)
         if alg != weight_bytes_per_layer:
             return None, None
-        return int(traffic), ("profiles/r5_gemm_xreg_pmc.json (norm+qkv, norm+gate|up+silu, down) + profiles/r2_gemm_packed_pmc.json (o): "
+        return int(traffic), (f"profiles/{xr_name} (norm+qkv, norm+gate|up+silu, down) + profiles/r2_gemm_packed_pmc.json (o): "
                               f"fetch (x2) + write bytes of the four launches = {traffic / alg:.4f} x the weight bytes "
                               "(the rest: the activations, the slabs in and out, the residual)")
     except Exception:
