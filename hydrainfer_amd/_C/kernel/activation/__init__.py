@@ -18,6 +18,19 @@ def silu(input: Tensor) -> Tensor:
     return out
 
 
+def quick_gelu(input: Tensor) -> Tensor:
+    """Extension: x * sigmoid(1.702 x) in one pass with the three T roundings of the reference's three torch ops
+    (hydrainfer/layer/activation.py:17-22, the CLIP MLP's activation)."""
+    _lib.require_gpu(input)
+    x = input.reshape(-1, input.shape[-1])
+    if x.stride(1) != 1:
+        raise _lib.HydraHipError("quick_gelu: input must have a contiguous last dimension")
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().hx_quick_gelu(out.data_ptr(), x.data_ptr(), x.size(0), x.size(1), x.stride(0),
+                                        _lib.dtype_code(x), _lib.current_stream()), "quick_gelu")
+    return out.view(input.shape)
+
+
 def silu_and_mul(gate: Tensor, up: Tensor) -> Tensor:
     """Extension: (T)silu(gate) * up in one pass (model_forward.py:36 fused)."""
     _lib.require_gpu(gate, up)

@@ -40,6 +40,27 @@ def add_rms_norm(out: Tensor, residual: Tensor, x: Tensor, weight: Tensor, epsil
         x.size(0), x.size(1), _lib.dtype_code(x), _lib.current_stream()), "add_rms_norm")
 
 
+def add_layer_norm(out: Tensor, residual: Tensor, x: Optional[Tensor], weight: Tensor, bias: Tensor,
+                   epsilon: float) -> None:
+    """Extension (vision tower): residual += x (in place, one T rounding); out = layer_norm(residual) * weight + bias —
+    `h = h + y; x = nn.LayerNorm(h)` of the CLIP encoder layer in one pass.  x=None: plain layer norm of `residual`."""
+    _lib.require_gpu(out, residual, weight, bias)
+    hidden = residual.shape[-1]
+    tensors = [out, residual, weight, bias] + ([x] if x is not None else [])
+    if out.shape != residual.shape or (x is not None and x.shape != residual.shape):
+        raise _lib.HydraHipError("add_layer_norm: shapes must match")
+    for t in tensors:
+        if not t.is_contiguous() or t.dtype != residual.dtype:
+            raise _lib.HydraHipError("add_layer_norm: tensors must be contiguous and of one dtype")
+    if weight.numel() != hidden or bias.numel() != hidden:
+        raise _lib.HydraHipError("add_layer_norm: weight / bias shape mismatch")
+    if x is not None:
+        _lib.require_gpu(x)
+    _lib.check(_lib.lib().hx_add_layer_norm(
+        out.data_ptr(), residual.data_ptr(), x.data_ptr() if x is not None else None, weight.data_ptr(), bias.data_ptr(),
+        float(epsilon), residual.numel() // hidden, hidden, _lib.dtype_code(residual), _lib.current_stream()), "add_layer_norm")
+
+
 def add_rms_norm_slabs(out: Tensor, residual: Tensor, partial: Tensor, n_splits: int, weight: Tensor,
                        epsilon: float, fragment_major: bool = False) -> None:
     """Extension: x = (T) sum of the n_splits fp32 slabs in `partial` ([n_splits, rows, hidden]);

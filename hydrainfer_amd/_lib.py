@@ -90,6 +90,8 @@ _SIGNATURES = {
     "hx_rope_set_kv_cache": (c_int, [c_void_p] * 8 + [c_int64] * 11 + [c_int, c_void_p]),
     "hx_silu": (c_int, [c_void_p] * 2 + [c_int64] * 3 + [c_int, c_void_p]),
     "hx_silu_and_mul": (c_int, [c_void_p] * 3 + [c_int64] * 4 + [c_int, c_void_p]),
+    "hx_quick_gelu": (c_int, [c_void_p] * 2 + [c_int64] * 3 + [c_int, c_void_p]),
+    "hx_add_layer_norm": (c_int, [c_void_p] * 5 + [c_float, c_int64, c_int64, c_int, c_void_p]),
     "hx_linear_decode_workspace_bytes": (c_int64, [c_int64] * 3),
     "hx_linear_decode": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_void_p, c_int64, c_int, c_void_p]),
     "hx_linear_decode_partial": (c_int, [c_void_p] * 3 + [c_int64] * 6 + [c_int, c_void_p]),

@@ -146,6 +146,147 @@ int launch_rms(void* out, void* residual, const void* input, const void* weight,
 }
 
 // ---------------------------------------------------------------------------
+// Vision tower (CLIP ViT) fusions — extensions; the reference runs these as separate torch ops
+// (hydrainfer/model/clip.py: residual add + nn.LayerNorm; hydrainfer/layer/activation.py:17-22 QuickGELU).
+// At 577 x 1024 every one of those ops is a ~5 us launch-bound kernel: two launches per fused op are saved.
+// add_layer_norm: h = residual + x (one T rounding), residual <- h, out = (T)((h - mean) * rstd * w + b) with the
+// moments in fp32 over the T-rounded h — torch.nn.functional.layer_norm's arithmetic (its reduction order is
+// the library's own: results agree to the last place of T except where a tie falls between two roundings).
+// ---------------------------------------------------------------------------
+template <typename T, int MAXV, bool ADD>
+__global__ __launch_bounds__(256) void layer_norm_vec_kernel(
+    typename T::storage* __restrict__ out, typename T::storage* __restrict__ residual,
+    const typename T::storage* __restrict__ input, const typename T::storage* __restrict__ weight,
+    const typename T::storage* __restrict__ bias, float eps, int32_t hidden) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  __shared__ float red[2][4];
+  const int64_t row = blockIdx.x;
+  const int nvec = hidden / N;
+  const V* in_v = ADD ? reinterpret_cast<const V*>(input + row * hidden) : nullptr;
+  V* res_v = reinterpret_cast<V*>(residual + row * hidden);
+  V* out_v = reinterpret_cast<V*>(out + row * hidden);
+  float x[MAXV][N];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < nvec) {
+      const V r = res_v[i];
+      if (ADD) {
+        const V v = in_v[i];
+        V h;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          x[j][e] = round_to<T>(T::to_float(v[e]) + T::to_float(r[e]));
+          h[e] = T::from_float(x[j][e]);
+        }
+        res_v[i] = h;
+      } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) x[j][e] = T::to_float(r[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < N; ++e) sum += x[j][e];
+    }
+  }
+  const float mean = block_sum_256(sum, red[0]) / (float)hidden;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < nvec) {
+#pragma unroll
+      for (int e = 0; e < N; ++e) { const float d = x[j][e] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(block_sum_256(sq, red[1]) / (float)hidden + eps);
+  const V* w_v = reinterpret_cast<const V*>(weight);
+  const V* b_v = reinterpret_cast<const V*>(bias);
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) {
+    const int i = threadIdx.x + j * 256;
+    if (i < nvec) {
+      const V w = w_v[i], b = b_v[i];
+      V o;
+#pragma unroll
+      for (int e = 0; e < N; ++e) o[e] = T::from_float((x[j][e] - mean) * rstd * T::to_float(w[e]) + T::to_float(b[e]));
+      out_v[i] = o;
+    }
+  }
+}
+
+template <typename T, bool ADD>
+int launch_layer_norm(void* out, void* residual, const void* input, const void* weight, const void* bias, float eps,
+                      int64_t rows, int64_t hidden, hipStream_t stream) {
+  typedef typename T::storage S;
+  constexpr int N = VecOf<T>::N;
+  if (hidden % N || hidden / N > 256 * 4) return HX_ERR_SHAPE;      // rows of up to 8192 (4096 fp32) elements
+  if (!aligned16(out) || !aligned16(residual) || (ADD && !aligned16(input)) || !aligned16(weight) || !aligned16(bias))
+    return HX_ERR_STRIDE;
+  const dim3 grid((unsigned)rows);
+  const int nv = (int)(hidden / N);
+#define HX_LN(MV) hx::launcher(layer_norm_vec_kernel<T, MV, ADD>, grid, 256, 0, stream)((S*)out, (S*)residual, (const S*)input, \
+                                                                                     (const S*)weight, (const S*)bias, eps, (int)hidden)
+  if (nv <= 256) HX_LN(1);
+  else if (nv <= 512) HX_LN(2);
+  else HX_LN(4);
+#undef HX_LN
+  return check_launch();
+}
+
+// quick_gelu: out = x * sigmoid(1.702 x) with the reference's three T roundings (the scaled copy, the sigmoid, the
+// product: activation.py:17-22 runs them as three torch ops); exact expf — the op is memory-bound
+template <typename T>
+__global__ __launch_bounds__(256) void quick_gelu_vec_kernel(typename T::storage* __restrict__ out,
+                                                             const typename T::storage* __restrict__ in, int32_t nvec,
+                                                             int64_t in_stride, int64_t out_stride) {
+  typedef typename VecOf<T>::type V;
+  constexpr int N = VecOf<T>::N;
+  const int64_t row = blockIdx.y;
+  const V* g = reinterpret_cast<const V*>(in + row * in_stride);
+  V* o = reinterpret_cast<V*>(out + row * out_stride);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+    const V v = g[i];
+    V r;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      // each product is rounded to fp32 FIRST, as the torch ops round it (opmath float, then the store's conversion): left
+      // to itself the compiler folds product + conversion into v_fma_mixlo_f16 — ONE rounding — and 4 in 10^4 fp16
+      // results land on the other side of a tie
+      const float a = T::to_float(v[e]);
+      float p1 = 1.702f * a;
+      asm volatile("" : "+v"(p1));
+      const float t = round_to<T>(p1);
+      const float sg = round_to<T>(1.0f / (1.0f + expf(-t)));
+      float p2 = a * sg;
+      asm volatile("" : "+v"(p2));
+      r[e] = T::from_float(p2);
+    }
+    o[i] = r;
+  }
+}
+
+template <typename T>
+int launch_quick_gelu(void* out, const void* in, int64_t rows, int64_t n, int64_t in_stride, hipStream_t stream) {
+  typedef typename T::storage S;
+  constexpr int N = VecOf<T>::N;
+  if (n % N || in_stride % N) return HX_ERR_SHAPE;
+  if (!aligned16(out) || !aligned16(in)) return HX_ERR_STRIDE;
+  const int nvec = (int)(n / N);
+  int gx = (nvec + 255) / 256;
+  if (gx > 64) gx = 64;
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hx::launcher(quick_gelu_vec_kernel<T>, dim3((unsigned)gx, (unsigned)nr), 256, 0, stream)(
+        (S*)out + r0 * n, (const S*)in + r0 * in_stride, nvec, in_stride, n);
+    const int rc = check_launch();
+    if (rc) return rc;
+  }
+  return HX_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Step-edge fusions of the decode loop (extensions; each bit-identical to the two ops it replaces).
 // embed_rms_norm: h = table[ids] (torch.nn.functional.embedding, hydrainfer/model/llama.py:80-83) and
 // x = rms_norm(h) * w in one launch — same arithmetic and reduction as rms_norm_vec_kernel.
@@ -720,6 +861,39 @@ extern "C" int hx_add_rms_norm(void* out, void* residual, const void* x, const v
     case HX_F32: return launch_rms<F32, true>(out, residual, x, weight, epsilon, rows, hidden, s);
     case HX_F16: return launch_rms<F16, true>(out, residual, x, weight, epsilon, rows, hidden, s);
     case HX_BF16: return launch_rms<BF16, true>(out, residual, x, weight, epsilon, rows, hidden, s);
+    default: return HX_ERR_DTYPE;
+  }
+}
+
+extern "C" int hx_add_layer_norm(void* out, void* residual, const void* x, const void* weight, const void* bias,
+                                 float epsilon, int64_t rows, int64_t hidden, int dtype, hx_stream stream) {
+  if (rows < 0 || hidden <= 0) return HX_ERR_SHAPE;
+  if (rows == 0) return HX_OK;
+  if (!out || !residual || !weight || !bias) return HX_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  // x == NULL: plain layer norm of `residual` (which is left untouched)
+#define HX_LN_T(T) (x ? launch_layer_norm<T, true>(out, residual, x, weight, bias, epsilon, rows, hidden, s) \
+                      : launch_layer_norm<T, false>(out, residual, nullptr, weight, bias, epsilon, rows, hidden, s))
+  switch (dtype) {
+    case HX_F32: return HX_LN_T(F32);
+    case HX_F16: return HX_LN_T(F16);
+    case HX_BF16: return HX_LN_T(BF16);
+    default: return HX_ERR_DTYPE;
+  }
+#undef HX_LN_T
+}
+
+extern "C" int hx_quick_gelu(void* out, const void* input, int64_t rows, int64_t n, int64_t in_stride, int dtype,
+                             hx_stream stream) {
+  if (rows < 0 || n < 0) return HX_ERR_SHAPE;
+  if (rows == 0 || n == 0) return HX_OK;
+  if (!out || !input) return HX_ERR_NULL;
+  if (in_stride < n) return HX_ERR_STRIDE;
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case HX_F32: return launch_quick_gelu<F32>(out, input, rows, n, in_stride, s);
+    case HX_F16: return launch_quick_gelu<F16>(out, input, rows, n, in_stride, s);
+    case HX_BF16: return launch_quick_gelu<BF16>(out, input, rows, n, in_stride, s);
     default: return HX_ERR_DTYPE;
   }
 }

@@ -33,6 +33,7 @@ class MultiHeadAttention(nn.Module):
         super().__init__()
         self.n_heads = config.n_heads
         self.head_dim = config.head_dim
+        self._cu = {}      # (batch, seq_len, device) -> cumulative lengths: built once, not by a launch per call
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor,
                 params: MultiHeadAttentionParameters) -> MultiHeadAttentionOutput:
@@ -44,7 +45,14 @@ class MultiHeadAttention(nn.Module):
         v = value.reshape(batch_size * seq_len, self.n_heads, self.head_dim)
         o = torch.empty((batch_size * seq_len, self.n_heads, self.head_dim), dtype=query.dtype,
                         device=query.device)
-        cu = torch.arange(0, (batch_size + 1) * seq_len, seq_len, dtype=torch.int32, device=query.device)
+        key_cu = (batch_size, seq_len, query.device)
+        cu = self._cu.get(key_cu)
+        if cu is None:
+            cu = torch.arange(0, (batch_size + 1) * seq_len, seq_len, dtype=torch.int32, device=query.device)
+            if not (query.is_cuda and torch.cuda.is_current_stream_capturing()):      # (a tensor born inside a capture holds
+                if len(self._cu) > 64:                                                #  nothing until the graph has run)
+                    self._cu.clear()
+                self._cu[key_cu] = cu
         mha_varlen_fwd(o, q, k, v, cu, cu, None, None, None, seq_len, seq_len,
                        1.0 / math.sqrt(self.head_dim), 0, -1, -1, 0)
         return MultiHeadAttentionOutput(o=o.view(batch_size, seq_len, hidden_size), attention_scores=None)

@@ -3,8 +3,10 @@
 Mirrors hydrainfer/model/clip.py:10-135 (pre-LN encoder layers, quick-GELU MLP, class +
 position embeddings, layers 0..vision_feature_layer) and hydrainfer/model/llava.py:30-41,99-107
 (2-layer GELU projector, CLS token dropped).  Attention runs on the HIP dense kernel
-(mha_varlen_fwd, non-causal, hydrainfer/layer/multihead_attention.py:114-160); conv / LayerNorm
-/ linears are library ops (host PyTorch-ROCm)."""
+(mha_varlen_fwd, non-causal, hydrainfer/layer/multihead_attention.py:114-160); the linears are library
+GEMMs (q, k, v as ONE product over the three weights laid side by side); on the GPU the residual add + LayerNorm pairs
+and the quick-GELU run as one hand-written launch each (hx_add_layer_norm, hx_quick_gelu): 8 launches per encoder
+layer instead of 16 at a size (577 x 1024) where every launch is ~5 us whatever it does."""
 from dataclasses import dataclass
 from typing import Dict
 
@@ -12,6 +14,8 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
+from hydrainfer_amd._C.kernel.activation import quick_gelu
+from hydrainfer_amd._C.kernel.norm import add_layer_norm
 from hydrainfer_amd.layer.multihead_attention import (MultiHeadAttention, MultiHeadAttentionConfig,
                                                       MultiHeadAttentionParameters)
 
@@ -46,6 +50,7 @@ class LlavaVisionModel:
             shape.num_attention_heads, shape.hidden_size // shape.num_attention_heads))
         L = shape.num_hidden_layers
         self.n_run = (shape.vision_feature_layer + L) % L + 1   # clip.py:106-108
+        self._qkv: Dict[int, tuple] = {}
 
     def required_tensor_names(self):
         """The reference-named tensors forward() reads (layers past vision_feature_layer are never run)."""
@@ -58,21 +63,43 @@ class LlavaVisionModel:
         return cls(shape, dtype, device,
                    {k: v.to(dtype).to(device) for k, v in random_state_dict(shape, seed, std).items()})
 
-    def _layer(self, l: int, h: Tensor) -> Tensor:
+    def _fused_qkv(self, l: int):
+        """q, k and v projections as one [3h, h] weight / [3h] bias: built on first use; the reference-named tensors in
+        `state` become views of it (no second copy)."""
+        hit = self._qkv.get(l)
+        if hit is None:
+            s = self.state
+            p = f"vision_tower.vision_model.encoder.layers.{l}.self_attn."
+            names = ("q_proj", "k_proj", "v_proj")
+            w = torch.cat([s[p + n + ".weight"] for n in names], dim=0)
+            b = torch.cat([s[p + n + ".bias"] for n in names], dim=0)
+            h = self.shape.hidden_size
+            for i, n in enumerate(names):
+                s[p + n + ".weight"], s[p + n + ".bias"] = w[i * h:(i + 1) * h], b[i * h:(i + 1) * h]
+            hit = self._qkv[l] = (w, b)
+        return hit
+
+    def _layer(self, l: int, h: Tensor, x: Tensor):
+        """h: the residual stream; x = layer_norm1(h) (computed by the previous layer's last launch).  Returns the new
+        (h, x) — x is layer_norm1 of the NEXT layer, or None after the last layer that runs."""
         s, sh = self.state, self.shape
         p = f"vision_tower.vision_model.encoder.layers.{l}."
-        x = F.layer_norm(h, (sh.hidden_size,), s[p + "layer_norm1.weight"], s[p + "layer_norm1.bias"],
-                         sh.layer_norm_eps)
-        q = F.linear(x, s[p + "self_attn.q_proj.weight"], s[p + "self_attn.q_proj.bias"])
-        k = F.linear(x, s[p + "self_attn.k_proj.weight"], s[p + "self_attn.k_proj.bias"])
-        v = F.linear(x, s[p + "self_attn.v_proj.weight"], s[p + "self_attn.v_proj.bias"])
+        hid = sh.hidden_size
+        wqkv, bqkv = self._fused_qkv(l)
+        qkv = F.linear(x, wqkv, bqkv)
+        q, k, v = qkv[..., :hid], qkv[..., hid:2 * hid], qkv[..., 2 * hid:]       # views: the kernel takes the row stride
         o = self.attn(q, k, v, MultiHeadAttentionParameters()).o
-        h = h + F.linear(o, s[p + "self_attn.out_proj.weight"], s[p + "self_attn.out_proj.bias"])
-        x = F.layer_norm(h, (sh.hidden_size,), s[p + "layer_norm2.weight"], s[p + "layer_norm2.bias"],
-                         sh.layer_norm_eps)
-        x = F.linear(x, s[p + "mlp.fc1.weight"], s[p + "mlp.fc1.bias"])
-        x = x * torch.sigmoid(1.702 * x)                       # QuickGELU, activation.py:17-22
-        return h + F.linear(x, s[p + "mlp.fc2.weight"], s[p + "mlp.fc2.bias"])
+        y = F.linear(o, s[p + "self_attn.out_proj.weight"], s[p + "self_attn.out_proj.bias"])
+        x = torch.empty_like(h)
+        add_layer_norm(x, h, y, s[p + "layer_norm2.weight"], s[p + "layer_norm2.bias"], sh.layer_norm_eps)       # h += y
+        x = quick_gelu(F.linear(x, s[p + "mlp.fc1.weight"], s[p + "mlp.fc1.bias"]))    # QuickGELU, activation.py:17-22
+        m = F.linear(x, s[p + "mlp.fc2.weight"], s[p + "mlp.fc2.bias"])
+        if l + 1 == self.n_run:
+            return h.add_(m), None
+        pn = f"vision_tower.vision_model.encoder.layers.{l + 1}."
+        x = torch.empty_like(h)
+        add_layer_norm(x, h, m, s[pn + "layer_norm1.weight"], s[pn + "layer_norm1.bias"], sh.layer_norm_eps)     # h += m
+        return h, x
 
     def forward(self, pixel_values: Tensor) -> Tensor:
         """pixel_values (n_images, C, H, W) -> image_features (n_images, n_patches, lm_hidden)."""
@@ -90,8 +117,10 @@ class LlavaVisionModel:
         h = torch.cat([cls_tok, patches], dim=1) + s[pre + "embeddings.position_embedding.weight"][None]
         h = F.layer_norm(h, (sh.hidden_size,), s[pre + "pre_layrnorm.weight"], s[pre + "pre_layrnorm.bias"],
                          sh.layer_norm_eps)
+        p0 = pre + "encoder.layers.0."
+        x = F.layer_norm(h, (sh.hidden_size,), s[p0 + "layer_norm1.weight"], s[p0 + "layer_norm1.bias"], sh.layer_norm_eps)
         for l in range(self.n_run):
-            h = self._layer(l, h)
+            h, x = self._layer(l, h, x)
         feat = h[:, 1:]                                        # drop CLS (llava.py:104)
         x = F.linear(feat, s["multi_modal_projector.linear_1.weight"], s["multi_modal_projector.linear_1.bias"])
         x = F.gelu(x)

@@ -145,6 +145,19 @@ int hx_silu(void* out, const void* input, int64_t rows, int64_t n, int64_t in_st
 int hx_silu_and_mul(void* out, const void* gate, const void* up, int64_t rows, int64_t n,
                     int64_t gate_stride, int64_t up_stride, int dtype, hx_stream stream);
 
+/* Extensions for the vision tower (CLIP ViT; round 6): the reference runs these as separate torch ops, at 577 x 1024 each
+ * a ~5 us launch-bound kernel.
+ * hx_quick_gelu: out = x * sigmoid(1.702 x) — hydrainfer/layer/activation.py:17-22 (QuickGELU) — with its three T
+ *   roundings (scaled copy, sigmoid, product); input rows strided by in_stride elements, out contiguous [rows, n];
+ *   n and in_stride multiples of 8 (4 for fp32).
+ * hx_add_layer_norm: residual[r,:] += x[r,:] (one T rounding, in place); out[r,:] = (T)((h - mean) * rstd * weight + bias),
+ *   moments in fp32 over the T-rounded h, biased variance — `h = h + y; x = nn.LayerNorm(h)` of the encoder layer
+ *   (hydrainfer/model/clip.py: CLIPEncoderLayer.forward) in one pass.  x == NULL: plain layer norm of `residual`
+ *   (left untouched).  Contiguous rows, hidden % 8 == 0 (4 for fp32), hidden <= 8192 (4096 for fp32). */
+int hx_quick_gelu(void* out, const void* input, int64_t rows, int64_t n, int64_t in_stride, int dtype, hx_stream stream);
+int hx_add_layer_norm(void* out, void* residual, const void* x, const void* weight, const void* bias, float epsilon,
+                      int64_t rows, int64_t hidden, int dtype, hx_stream stream);
+
 /* ------------------------------------------------------------------------
  * Extension: decode-batch linear layer  out[M,N] = x[M,K] @ weight[N,K]^T  (M <= 64) as a
  * weight-streaming HIP kernel — the nn.Linear calls of hydrainfer/model/llama.py:24-27,48-50

@@ -168,6 +168,56 @@ def test_silu_and_mul_equals_unfused():
         assert torch.equal(got, want)
 
 
+def test_quick_gelu_equals_the_three_torch_ops():
+    """hx_quick_gelu against the reference's `x * torch.sigmoid(1.702 * x)` (activation.py:17-22) run op by op: the same
+    three roundings — bit-identical for fp16 / bf16."""
+    act, *_ = _ops()
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        for shape in ((577, 4096), (3, 577, 256), (5, 64)):
+            x = (3 * torch.randn(shape, device=DEV)).to(dt)
+            want = x * torch.sigmoid(1.702 * x)
+            got = act.quick_gelu(x)
+            assert got.shape == x.shape and got.dtype == dt
+            if dt == torch.float32:
+                assert_ulp_close(got.cpu(), want.cpu(), max_ulp=8, what=f"{dt} {shape}")
+            else:                         # the same three roundings, each product through fp32 first: bit for bit
+                assert torch.equal(got, want), f"{dt} {shape}: {(got != want).sum().item()} elements differ"
+    x = (3 * torch.randn((9, 2 * 512), device=DEV)).to(torch.bfloat16)            # row-strided input
+    assert torch.equal(act.quick_gelu(x[:, :512]), x[:, :512] * torch.sigmoid(1.702 * x[:, :512]))
+    with pytest.raises(RuntimeError):
+        act.quick_gelu(torch.zeros((4, 12), dtype=torch.bfloat16, device=DEV))    # n % 8
+
+
+def test_add_layer_norm_equals_add_then_layer_norm():
+    """hx_add_layer_norm against `h = h + y; F.layer_norm(h)`: the residual bit-exact, the normalised rows to the last
+    place of T (fp32 moments on both sides, different summation orders) and against an fp64 reference of the same h."""
+    import torch.nn.functional as F
+    from hydrainfer_amd._C.kernel import norm
+    for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2), (torch.float32, 2e-6)):
+        for rows, hidden in ((577, 1024), (33, 128), (5, 4096), (2, 8192 if dt != torch.float32 else 4096)):
+            h = torch.randn((rows, hidden), device=DEV).to(dt)
+            y = (0.5 * torch.randn((rows, hidden), device=DEV)).to(dt)
+            w = (1 + 0.1 * torch.randn(hidden, device=DEV)).to(dt)
+            b = (0.1 * torch.randn(hidden, device=DEV)).to(dt)
+            h_ref = h + y
+            want = F.layer_norm(h_ref, (hidden,), w, b, 1e-5)
+            res, out = h.clone(), torch.empty_like(h)
+            norm.add_layer_norm(out, res, y, w, b, 1e-5)
+            assert torch.equal(res, h_ref)
+            exact = F.layer_norm(h_ref.double(), (hidden,), w.double(), b.double(), 1e-5)
+            assert (out.double() - exact).abs().max().item() <= tol * 4, (dt, rows, hidden)
+            if dt != torch.float32:      # (fp32: an output next to zero is a cancellation — ulps mean nothing there)
+                assert_ulp_close(out.cpu(), want.cpu(), max_ulp=2, min_exact_frac=0.98, what=f"{dt} {rows}x{hidden}")
+            else:
+                assert (out - want).abs().max().item() <= 4e-6
+            res2, out2 = h_ref.clone(), torch.empty_like(h)
+            norm.add_layer_norm(out2, res2, None, w, b, 1e-5)                 # plain layer norm: residual untouched
+            assert torch.equal(res2, h_ref) and torch.equal(out2, out)
+    with pytest.raises(RuntimeError):
+        z = torch.zeros((2, 20), dtype=torch.bfloat16, device=DEV)
+        norm.add_layer_norm(z.clone(), z, None, z[0], z[0], 1e-5)             # hidden % 8
+
+
 def test_rope_set_kv_cache_equals_two_ops():
     from oracle import ops
     from hydrainfer_amd._C.kernel import kv_cache_kernels, position_embedding as pe
