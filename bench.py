@@ -68,6 +68,8 @@ def parse():
                    help="also run BASELINE configs[0] IN FULL on the host cores (all decoder + CLIP layers of the oracle, ~1 min "
                         "incl. building 13 GB of weights): cpu_baseline.config0_full and full_over_extrapolated")
     p.add_argument("--no-13b", action="store_true", help="skip the short LLaVA-1.5-13B leg (BASELINE configs[2])")
+    p.add_argument("--no-tune", action="store_true",
+                   help="skip the start-up autotuning of the library's prefill GEMMs in front of the TTFT leg (serve.tune_library_gemms)")
     p.add_argument("--steps-13b", type=int, default=20)
     p.add_argument("--leg-13b-in-process", action="store_true",
                    help="run the 13B leg inside this process behind the 7B legs instead of in a fresh child process")
@@ -1592,8 +1594,28 @@ def main():
     tokens = args.batch * steps * n_gpus
     value = tokens / elapsed
 
+    # The prefill side of the TTFT leg is library GEMM (82 % of a single request's TTFT): an engine tunes the four projections
+    # for its configured prompt length ONCE at start-up (torch's TunableOp over the library's own kernels, switched off again
+    # behind the pass — engine/serve.py).  Only those four shapes, only in front of this leg, TunableOp disabled again behind
+    # it: a wider pass (2048-row chunks, the vision tower for 8 images) in front of the serving leg ended in a GPU memory
+    # fault inside the library (profiles/rejected.md) — the serving legs run the library's defaults as before.
+    tuned = None
+    if (world == 1 and vision is not None and not args.no_tune and not args.skip_prefill and not args.no_ttft
+            and args.model == "7b"):
+        try:
+            from hydrainfer_amd.engine.serve import tune_library_gemms
+            tuned = tune_library_gemms(model, rows=(prompt_len,))
+        except Exception as e:      # a convenience of the library, never the benchmark's problem
+            tuned = {"error": repr(e)[:200]}
     ttft = None if args.skip_prefill or args.no_ttft else measure_ttft(runner, prompts, shape, dtype, dev, rank,
                                                                          vision, pixels)
+    if ttft is not None:
+        ttft["library_gemms_tuned"] = tuned
+    if tuned is not None:
+        try:
+            torch.cuda.tunable.enable(False)
+        except Exception:
+            pass
     serving = None
     if rank == 0 and world == 1 and vision is not None and not args.no_serving:
         serving = measure_serving(model, vision, pixels, shape, dtype, dev, args.batch, prompt_len - 576, n_generate)

@@ -3,6 +3,7 @@ Used by bench.py's `serving` leg and tools/bench_engine.py; mirrors what
 hydrainfer/cluster/epdnode.py:_update_engine assembles and what benchmark/benchmark.py drives."""
 import contextlib
 import gc
+import os
 import time
 from typing import List, Optional, Tuple
 
@@ -86,6 +87,49 @@ def warm_library_gemms(language_model, token_budget: int, max_decode_rows: int =
         for n in range(1, image_budget + 1):
             vision_model.forward(px.expand(n, -1, -1, -1))
     torch.cuda.synchronize(dev)
+
+
+def tune_library_gemms(language_model, rows=(704,), vision_model=None, pixel_values: Optional[torch.Tensor] = None,
+                       image_counts=(1,), rotating_buffer_mb: int = 512) -> dict:
+    """Start-up autotuning of the LIBRARY GEMMs this deployment will run most often: the four prefill projections at
+    `rows` tokens (the prompt lengths / chunk sizes to expect) and the vision tower for `image_counts` images per step.
+    torch's TunableOp times the library's own candidate kernels for each of those shapes on THIS GPU (over rotating
+    buffers larger than the Infinity Cache: the weights of a 7B layer are never cache-hot in the pipeline) and keeps the
+    fastest; tuning is switched OFF again before this returns, so no later shape — a chunk of some other length — ever
+    pauses to tune: it takes the library's default kernel as before.  ~1 s per shape at start-up; a 704-token prefill
+    went 11.4 -> 10.6-10.8 ms (tools/bench_ttft_tunable.py), single-request TTFT 14.4 -> 13.4 ms.  The results file is kept
+    out of the working directory.  CAUTION (round 6): the pass RUNS every candidate kernel of the library.  The four 7B
+    projections at 704 rows have been through it many times; a pass over 2048-row chunks plus the vision tower for 8
+    images was followed by a GPU memory fault in the serving leg behind it — widen the set one shape at a time.
+    Returns {"shapes": n, "seconds": t}."""
+    import tempfile
+    import torch.cuda.tunable as tunable
+    model = getattr(language_model, "language_model", language_model)
+    st, dev, dt = model.state, model.device, model.dtype
+    t0 = time.perf_counter()
+    tunable.set_filename(os.path.join(tempfile.gettempdir(), f"hx_tunableop_{os.getpid()}.csv"))
+    if rotating_buffer_mb is not None:
+        tunable.set_rotating_buffer_size(int(rotating_buffer_mb))
+    tunable.enable(True)
+    tunable.tuning_enable(True)
+    n = 0
+    try:
+        for name in ("l0.wqkv", "l0.wo", "l0.wgu", "l0.wdown"):
+            w = st[name]
+            if w.device.type == "meta":          # decode-only node: no prefill GEMMs
+                continue
+            for m in rows:
+                torch.matmul(torch.zeros((int(m), w.shape[1]), dtype=dt, device=dev), w.t())
+                n += 1
+        if vision_model is not None and pixel_values is not None:
+            px = pixel_values.to(device=dev, dtype=dt)
+            for k in image_counts:
+                vision_model.forward(px.expand(int(k), -1, -1, -1))
+                n += 6
+        torch.cuda.synchronize(dev)
+    finally:
+        tunable.tuning_enable(False)             # tuned shapes keep their kernels; nothing else is ever tuned
+    return {"shapes": n, "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def synthetic_requests(n: int, n_text: int, max_tokens: int, image_token_id: int, pixels: Optional[torch.Tensor],

@@ -18,12 +18,14 @@ def main():
     ap.add_argument("--max-running", type=int, default=64)
     ap.add_argument("--max-tokens", type=int, default=1024, help="upper bound of prompt + generated tokens per request (cache sizing)")
     ap.add_argument("--tokenizer", default=None, help="checkpoint directory for transformers.AutoTokenizer (default: synthetic)")
+    ap.add_argument("--tune-rows", default="", help="comma-separated prompt lengths to autotune the library's prefill GEMMs for at start-up "
+                    "(serve.tune_library_gemms; opt-in: the pass runs every candidate kernel of the library — read its caution)")
     a = ap.parse_args()
     from hydrainfer_amd import _lib
     from hydrainfer_amd.engine.node import LocalCluster
     from hydrainfer_amd.engine.request_processor import InstructionCreator
     from hydrainfer_amd.engine.scheduler import BatchSchedulerConfig
-    from hydrainfer_amd.engine.serve import build_node, warm_library_gemms
+    from hydrainfer_amd.engine.serve import build_node, tune_library_gemms, warm_library_gemms
     from hydrainfer_amd.entrypoint import ApiServer, EngineFrontend, HFTokenizer, SyntheticTokenizer
     from hydrainfer_amd.model.clip import CLIP_VIT_L_14_336, ClipShape, LlavaVisionModel
     from hydrainfer_amd.model.llama import LLAVA_1_5_7B, LLAVA_1_5_13B, LlamaForCausalLM, LlamaShape
@@ -47,6 +49,8 @@ def main():
     node = build_node("EPD0", "EPD", lm, vision, shape, dt, dev, kv_blocks=a.max_running * per_req + 64,
                       image_blocks=2 * a.max_running, n_image_tokens=576, sched=sched, max_blocks_per_seq=per_req)
     warm_library_gemms(lm, sched.token_budgets, a.max_running)
+    if a.tune_rows:
+        print("library GEMMs tuned:", tune_library_gemms(lm, rows=tuple(int(r) for r in a.tune_rows.split(","))), flush=True)
     creator = InstructionCreator(image_token_id=itid, n_image_tokens_per_image=576, block_size=16,
                                  max_position_embeddings=shape.max_position_embeddings)
     tok = HFTokenizer(a.tokenizer) if a.tokenizer else SyntheticTokenizer(image_token_id=itid)

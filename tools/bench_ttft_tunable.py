@@ -17,6 +17,10 @@ model = LlamaForCausalLM.random_init(shape, dtype, dev, seed=0)
 runner = DecodeRunner(model, RunnerConfig(batch=1, prompt_len=704, n_generate=8, use_graph=True), seed=0)
 prompts = bench.synth_prompts(1, 704, shape.vocab_size, dev)
 feats = torch.zeros(1, 576, shape.hidden_size, dtype=dtype, device=dev)
+if os.environ.get("HX_TUNE"):          # the engine's own start-up pass (serve.tune_library_gemms), tuning off again behind it
+    from hydrainfer_amd.engine.serve import tune_library_gemms
+    rot = os.environ.get("HX_TUNE_ROT")
+    print("tune_library_gemms:", tune_library_gemms(model, rows=(704,), rotating_buffer_mb=int(rot) if rot else None))
 t0 = time.perf_counter()
 for _ in range(3):
     runner.prefill(prompts, feats, 32000, requests=[0])[0].item()
