@@ -69,7 +69,7 @@ def parse():
                         "incl. building 13 GB of weights): cpu_baseline.config0_full and full_over_extrapolated")
     p.add_argument("--no-13b", action="store_true", help="skip the short LLaVA-1.5-13B leg (BASELINE configs[2])")
     p.add_argument("--no-tune", action="store_true",
-                   help="skip the start-up autotuning of the library's prefill GEMMs in front of the TTFT leg (serve.tune_library_gemms)")
+                   help="skip the start-up autotuning of the library's prefill GEMMs in front of the TTFT / serving legs (serve.tune_library_gemms)")
     p.add_argument("--steps-13b", type=int, default=20)
     p.add_argument("--leg-13b-in-process", action="store_true",
                    help="run the 13B leg inside this process behind the 7B legs instead of in a fresh child process")
@@ -1594,28 +1594,24 @@ def main():
     tokens = args.batch * steps * n_gpus
     value = tokens / elapsed
 
-    # The prefill side of the TTFT leg is library GEMM (82 % of a single request's TTFT): an engine tunes the four projections
-    # for its configured prompt length ONCE at start-up (torch's TunableOp over the library's own kernels, switched off again
-    # behind the pass — engine/serve.py).  Only those four shapes, only in front of this leg, TunableOp disabled again behind
-    # it: a wider pass (2048-row chunks, the vision tower for 8 images) in front of the serving leg ended in a GPU memory
-    # fault inside the library (profiles/rejected.md) — the serving legs run the library's defaults as before.
+    # The prefill side of the TTFT and serving legs is library GEMM (82 % of a single request's TTFT, 24 of the 29 ms of a
+    # 2048-token chunk): an engine tunes the four projections for its configured prompt length and chunk budget ONCE at
+    # start-up (torch's TunableOp over the library's own kernels, switched off again behind the pass — engine/serve.py).
+    # Only the decoder's projections: the same pass over the vision tower for 8 images ends in a GPU memory fault inside a
+    # candidate kernel of the library (tools/probes/tune_probe.py, profiles/rejected.md).  N = 1 only; TunableOp is
+    # disabled again behind the two legs (the decode loop timed above and the legs below run the library's defaults).
     tuned = None
-    if (world == 1 and vision is not None and not args.no_tune and not args.skip_prefill and not args.no_ttft
-            and args.model == "7b"):
+    if (world == 1 and vision is not None and not args.no_tune and not args.skip_prefill and args.model == "7b"
+            and not (args.no_ttft and args.no_serving)):
         try:
             from hydrainfer_amd.engine.serve import tune_library_gemms
-            tuned = tune_library_gemms(model, rows=(prompt_len,))
+            tuned = tune_library_gemms(model, rows=(prompt_len,) if args.no_serving else (prompt_len, 2048))
         except Exception as e:      # a convenience of the library, never the benchmark's problem
             tuned = {"error": repr(e)[:200]}
     ttft = None if args.skip_prefill or args.no_ttft else measure_ttft(runner, prompts, shape, dtype, dev, rank,
                                                                          vision, pixels)
     if ttft is not None:
         ttft["library_gemms_tuned"] = tuned
-    if tuned is not None:
-        try:
-            torch.cuda.tunable.enable(False)
-        except Exception:
-            pass
     serving = None
     if rank == 0 and world == 1 and vision is not None and not args.no_serving:
         serving = measure_serving(model, vision, pixels, shape, dtype, dev, args.batch, prompt_len - 576, n_generate)
@@ -1625,6 +1621,13 @@ def main():
             # silu launches (13B) resp. the 6-launch wide layer (7B) — DESIGN.md section 4
             serving["twice_the_batch"] = measure_serving(model, vision, pixels, shape, dtype, dev, 2 * args.batch,
                                                          prompt_len - 576, n_generate)
+    if tuned is not None:
+        if serving is not None:
+            serving["library_gemms_tuned"] = tuned
+        try:
+            torch.cuda.tunable.enable(False)
+        except Exception:
+            pass
     whole_64 = None
     if rank == 0 and world == 1 and (args.model == "7b" or args.as_13b_leg) and not args.no_serving_64:
         try:

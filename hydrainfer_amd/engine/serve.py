@@ -80,8 +80,8 @@ def warm_library_gemms(language_model, token_budget: int, max_decode_rows: int =
         for m in rows:
             torch.matmul(x[:m], w.t())
     x = torch.zeros((max_decode_rows, st["lm_head"].shape[1]), dtype=dt, device=dev)
-    for m in (1, 2, 4, 8, 16, 32, max_decode_rows):
-        torch.matmul(x[:m], st["lm_head"].t())
+    for m in (1, 2, 4, 8, 16, 32, max_decode_rows):      # (NOT every row count: warming 64 shapes was followed by 70-400 ms
+        torch.matmul(x[:m], st["lm_head"].t())           #  stalls in the first prefill chunks — the library re-loading kernels)
     if vision_model is not None and pixel_values is not None:      # the tower for 1 .. image_budget images
         px = pixel_values.to(device=dev, dtype=dt)
         for n in range(1, image_budget + 1):
@@ -98,9 +98,10 @@ def tune_library_gemms(language_model, rows=(704,), vision_model=None, pixel_val
     fastest; tuning is switched OFF again before this returns, so no later shape — a chunk of some other length — ever
     pauses to tune: it takes the library's default kernel as before.  ~1 s per shape at start-up; a 704-token prefill
     went 11.4 -> 10.6-10.8 ms (tools/bench_ttft_tunable.py), single-request TTFT 14.4 -> 13.4 ms.  The results file is kept
-    out of the working directory.  CAUTION (round 6): the pass RUNS every candidate kernel of the library.  The four 7B
-    projections at 704 rows have been through it many times; a pass over 2048-row chunks plus the vision tower for 8
-    images was followed by a GPU memory fault in the serving leg behind it — widen the set one shape at a time.
+    out of the working directory.  CAUTION (round 6): the pass RUNS every candidate kernel of the library for each shape.
+    The four 7B projections at 704 and at 2048 rows tune cleanly (a 2048-token chunk: 29.3 -> 24.9 ms); the vision
+    tower for 8 images does NOT — one candidate faults (`Memory access fault by GPU`, tools/probes/tune_probe.py), which
+    is why bench.py never passes `vision_model`.  Widen the set one shape at a time, under a timeout.
     Returns {"shapes": n, "seconds": t}."""
     import tempfile
     import torch.cuda.tunable as tunable

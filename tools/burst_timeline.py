@@ -15,6 +15,7 @@ from hydrainfer_amd.model.llama import LlamaForCausalLM
 from hydrainfer_amd.model.llava import LlavaLanguageModel
 
 SYNC = os.environ.get("SYNC", "1") == "1"
+PROFILE = os.environ.get("PROFILE") == "1"
 B = int(os.environ.get("B", "32"))
 dev, dtype = torch.device("cuda:0"), torch.bfloat16
 shape, _ = bench.model_shape("7b")
@@ -27,6 +28,9 @@ node = build_node("EPD0", "EPD", lm, vision, shape, dtype, dev, per_req * (B + 2
 node.executor.fill_executor.graph_decoder.warmup(list(range(4, B + 1, 4)), kv_max=1024)
 node.executor.image_embed_executor.warmup(pixels, sched.image_budgets)
 warm_library_gemms(lm, sched.token_budgets, B, vision, pixels, sched.image_budgets)
+if os.environ.get("TUNE"):      # the four prefill projections autotuned for the chunk budget (serve.tune_library_gemms)
+    from hydrainfer_amd.engine.serve import tune_library_gemms
+    print("tuned:", tune_library_gemms(model, rows=(2048,)), flush=True)
 cluster = LocalCluster([node])
 creator = InstructionCreator(image_token_id=32000, n_image_tokens_per_image=576, block_size=16,
                              max_position_embeddings=shape.max_position_embeddings)
@@ -63,8 +67,19 @@ for rep in range(2):
                 rcbs.append(rcb); nxt += 1; admitted += 1
             a1 = time.perf_counter()
             del log[:]
+            prof = None
+            if PROFILE and rep and len(rows) < 8:
+                import cProfile
+                prof = cProfile.Profile(); prof.enable()
             cluster.step()
             a2 = time.perf_counter()
+            if prof is not None:
+                prof.disable()
+                if a2 - a1 > 0.045:      # a stalled step: where was the host?
+                    import io, pstats
+                    buf = io.StringIO()
+                    pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(8)
+                    print(f"--- step at {1e3 * (a0 - t0):.1f} ms took {1e3 * (a2 - a1):.1f} ms:", "\n".join(buf.getvalue().splitlines()[6:20]), flush=True)
             if SYNC:
                 torch.cuda.synchronize()
             a3 = time.perf_counter()
