@@ -348,6 +348,7 @@ class BatchImageEmbedExecutor:
         self.dtype, self.device = dtype, device
         self.use_graphs = use_graphs and device.type == "cuda"
         self.graphs = {}       # n_images -> (graph, static pixel buffer, static output)
+        self._stages, self._stage_free = {}, {}      # pinned staging buffers for the pixel upload, and the event behind their last copy
 
     def _encode(self, pixels: torch.Tensor) -> torch.Tensor:
         if not self.use_graphs or torch.cuda.is_current_stream_capturing():
@@ -370,6 +371,33 @@ class BatchImageEmbedExecutor:
         graph.replay()
         return static_out          # consumed (scattered into the image cache) before the next replay: same stream
 
+    def _upload(self, pixels: List[torch.Tensor]) -> torch.Tensor:
+        """The step's images as ONE device tensor of the model's dtype.  Host images go through a pinned staging buffer
+        (one per image count, kept) and ONE asynchronous copy: a `.to(device)` per pageable image is a synchronous copy
+        each, for which the runtime locks the pages first — 8 of those per step, and the occasional 10-50 ms the lock
+        took showed up as the burst's slow third step (tools/burst_timeline.py)."""
+        if self.device.type != "cuda" or any(p.is_cuda for p in pixels):
+            return torch.cat([p.to(device=self.device, dtype=self.dtype) for p in pixels], dim=0)
+        n = sum(p.shape[0] for p in pixels)
+        key = (n, tuple(pixels[0].shape[1:]), pixels[0].dtype)
+        stage = self._stages.get(key)
+        if stage is None:
+            if len(self._stages) > 16:
+                self._stages.clear()
+            stage = self._stages[key] = torch.empty((n,) + key[1], dtype=key[2]).pin_memory()
+        else:
+            self._stage_free[key].synchronize()        # the copy that last read this buffer has long finished: no wait in practice
+        i = 0
+        for p in pixels:
+            stage[i:i + p.shape[0]].copy_(p)
+            i += p.shape[0]
+        dev_px = stage.to(self.device, non_blocking=True)
+        ev = self._stage_free.get(key)
+        if ev is None:
+            ev = self._stage_free[key] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return dev_px.to(self.dtype)
+
     def warmup(self, pixel_values: torch.Tensor, max_images: int) -> None:
         """Capture the graphs for 1 .. max_images images ahead of serving."""
         px = pixel_values.to(device=self.device, dtype=self.dtype)
@@ -384,10 +412,10 @@ class BatchImageEmbedExecutor:
         slots: List[int] = []
         pixels = []
         for rcb, inst in batch:
-            pixels.append(inst.pixel_values.to(device=self.device, dtype=self.dtype))
+            pixels.append(inst.pixel_values)
             inst.pixel_values = None
             slots += self.manager.v2p(rcb.virtual_image_cache, inst.cache_ids)
-        feats = self._encode(torch.cat(pixels, dim=0))                  # (n_img, 576, hidden)
+        feats = self._encode(self._upload(pixels))                      # (n_img, 576, hidden)
         tokens = feats.reshape(-1, self.n_qo_heads, self.head_dim)
         slot_t = torch.tensor(slots, dtype=torch.int32)
         if self.device.type == "cuda":
