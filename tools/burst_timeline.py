@@ -31,6 +31,8 @@ warm_library_gemms(lm, sched.token_budgets, B, vision, pixels, sched.image_budge
 if os.environ.get("TUNE"):      # the four prefill projections autotuned for the chunk budget (serve.tune_library_gemms)
     from hydrainfer_amd.engine.serve import tune_library_gemms
     print("tuned:", tune_library_gemms(model, rows=(2048,)), flush=True)
+if os.environ.get("VISION_EAGER"):      # A/B: the vision tower launched kernel by kernel instead of replayed from its hipGraph
+    node.executor.image_embed_executor.use_graphs = False
 cluster = LocalCluster([node])
 creator = InstructionCreator(image_token_id=32000, n_image_tokens_per_image=576, block_size=16,
                              max_position_embeddings=shape.max_position_embeddings)
