@@ -272,14 +272,20 @@ __global__ __launch_bounds__(256) void unpermute_kernel(
   }
 }
 
+// sum_out: the reference's topk_sum_kernel (align_block_kernel.cu:172-188) keeps its running sum in scalar_t — every partial
+// sum is rounded to T — for topk in {2, 3, 4, 8}; any other topk goes to torch::sum_out (fp32 accumulation, one rounding;
+// align_block_kernel.cu:262-271).  t_accum selects the former.
 template <typename T>
 __global__ __launch_bounds__(256) void sum_out_kernel(const typename T::storage* __restrict__ in,
                                                       typename T::storage* __restrict__ out,
-                                                      int topk, int64_t dim) {
+                                                      int topk, int64_t dim, int t_accum) {
   const int64_t t = blockIdx.x;
   for (int64_t i = threadIdx.x; i < dim; i += 256) {
     float acc = 0.f;
-    for (int k = 0; k < topk; ++k) acc += T::to_float(in[(t * topk + k) * dim + i]);
+    for (int k = 0; k < topk; ++k) {
+      acc += T::to_float(in[(t * topk + k) * dim + i]);
+      if (t_accum) acc = round_to<T>(acc);
+    }
     out[t * dim + i] = T::from_float(acc);
   }
 }
@@ -344,7 +350,8 @@ __global__ __launch_bounds__(256) void unpermute_vec_kernel(
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sum_out_vec_kernel(const u16* __restrict__ in, u16* __restrict__ out, int topk, int64_t dim) {
+__global__ __launch_bounds__(256) void sum_out_vec_kernel(const u16* __restrict__ in, u16* __restrict__ out, int topk, int64_t dim,
+                                                          int t_accum) {
   const int64_t t = blockIdx.x;
   const int64_t n_chunks = dim >> 3;
   for (int64_t ch = (int64_t)blockIdx.y * 256 + threadIdx.x; ch < n_chunks; ch += (int64_t)gridDim.y * 256) {
@@ -359,12 +366,18 @@ __global__ __launch_bounds__(256) void sum_out_vec_kernel(const u16* __restrict_
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += T::to_float(v[u][e]);
+        for (int e = 0; e < 8; ++e) {
+          acc[e] += T::to_float(v[u][e]);
+          if (t_accum) acc[e] = round_to<T>(acc[e]);      // the reference's scalar_t running sum (sum_out_kernel above)
+        }
     }
     for (; k < topk; ++k) {
       const u16x8 v = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(in + (t * topk + k) * dim) + ch);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += T::to_float(v[e]);
+      for (int e = 0; e < 8; ++e) {
+        acc[e] += T::to_float(v[e]);
+        if (t_accum) acc[e] = round_to<T>(acc[e]);
+      }
     }
     u16x8 o;
 #pragma unroll
@@ -550,21 +563,22 @@ extern "C" int hx_moe_sum_out(const void* in, void* out, int64_t n_tokens, int64
   if (n_tokens == 0) return HX_OK;
   if (!in || !out) return HX_ERR_NULL;
   hipStream_t s = (hipStream_t)stream;
+  const int ta = (topk == 2 || topk == 3 || topk == 4 || topk == 8) ? 1 : 0;      // topk_sum_kernel's instantiations
   if ((dtype == HX_F16 || dtype == HX_BF16) && dim % 8 == 0 && aligned16(in) && aligned16(out)) {
     const dim3 grid((unsigned)n_tokens, row_splits(n_tokens, dim));
-    if (dtype == HX_F16) hx::launcher(sum_out_vec_kernel<F16>, grid, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim);
-    else hx::launcher(sum_out_vec_kernel<BF16>, grid, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim);
+    if (dtype == HX_F16) hx::launcher(sum_out_vec_kernel<F16>, grid, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim, ta);
+    else hx::launcher(sum_out_vec_kernel<BF16>, grid, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim, ta);
     return check_launch();
   }
   switch (dtype) {
     case HX_F32:
-      hx::launcher(sum_out_kernel<F32>, (unsigned)n_tokens, 256, 0, s)((const float*)in, (float*)out, (int)topk, dim);
+      hx::launcher(sum_out_kernel<F32>, (unsigned)n_tokens, 256, 0, s)((const float*)in, (float*)out, (int)topk, dim, ta);
       break;
     case HX_F16:
-      hx::launcher(sum_out_kernel<F16>, (unsigned)n_tokens, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim);
+      hx::launcher(sum_out_kernel<F16>, (unsigned)n_tokens, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim, ta);
       break;
     case HX_BF16:
-      hx::launcher(sum_out_kernel<BF16>, (unsigned)n_tokens, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim);
+      hx::launcher(sum_out_kernel<BF16>, (unsigned)n_tokens, 256, 0, s)((const u16*)in, (u16*)out, (int)topk, dim, ta);
       break;
     default: return HX_ERR_DTYPE;
   }

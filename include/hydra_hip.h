@@ -638,7 +638,9 @@ int hx_moe_permute(const void* tokens, void* permuted, const int32_t* row_id_map
 int hx_moe_unpermute(const void* permuted, void* out, const int32_t* row_id_map,
                      const void* probs, int64_t n_tokens, int64_t n_rows, int64_t dim,
                      int dtype, hx_stream stream);
-/* out[t,:] = sum_k in[t,k,:], fp32 accumulate (align_block_kernel.cu:242-272, sum_out). */
+/* out[t,:] = sum_k in[t,k,:] with the reference's arithmetic (align_block_kernel.cu:172-188,242-272): topk in {2,3,4,8} —
+ * topk_sum_kernel's instantiations — keep the running sum in T (every partial sum rounded), any other topk accumulates in
+ * fp32 and rounds once (torch::sum_out). */
 int hx_moe_sum_out(const void* in, void* out, int64_t n_tokens, int64_t topk, int64_t dim,
                    int dtype, hx_stream stream);
 

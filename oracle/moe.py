@@ -12,7 +12,8 @@ tests/test_oracle_golden.py holds this module to it.  PINNED (to the reference's
 topk_softmax, permute / unpermute with index map, permute / unpermute with mask map.
 PARITY UNPINNED: grouped_topk_sigmoid — the reference has no test or torch reference for it; it is
 transcribed from the kernel's control flow (csrc/kernel/moe/grouped_topk_sigmoid_kernel.cu:64-180,
-including its tie-breaks) — and sum_out (align_block_kernel.cu:242-272, a plain sum)."""
+including its tie-breaks) — and sum_out (align_block_kernel.cu:172-188,242-272: the running sum in scalar_t for
+topk in {2, 3, 4, 8}, torch::sum_out otherwise)."""
 from typing import Tuple
 
 import torch
@@ -112,3 +113,17 @@ def unpermute_rows(permuted: Tensor, row_id_map: Tensor, probs: Tensor) -> Tenso
         contrib = (permuted[idx.clamp_min(0)] * w).to(dt)
         out = torch.where(ok[:, None], (out + contrib).to(dt), out)
     return out
+
+
+def sum_out(x: Tensor) -> Tensor:
+    """align_block_kernel.cu:242-272.  x [n_tokens, topk, dim] -> [n_tokens, dim].  topk in {2, 3, 4, 8} run
+    topk_sum_kernel (:172-188): `scalar_t sum = 0; sum += input[k]` — the running sum lives in scalar_t, so EVERY
+    partial sum is rounded to the tensor's dtype; any other topk falls to torch::sum_out (fp32 accumulation, one
+    rounding).  PARITY UNPINNED (no reference-side test or torch form exists for this op)."""
+    n_tokens, topk, dim = x.shape
+    if topk in (2, 3, 4, 8):
+        acc = torch.zeros((n_tokens, dim), dtype=x.dtype)
+        for k in range(topk):
+            acc = (acc.float() + x[:, k].float()).to(x.dtype)      # one T rounding per add (exact for fp32)
+        return acc
+    return torch.sum(x, dim=1)

@@ -129,11 +129,24 @@ def test_permute_mask(n_tokens, dim, n_experts, topk, dtype):
 @pytest.mark.parametrize("dtype", [torch.float, torch.half, torch.bfloat16])
 def test_sum_out(topk, dtype):
     from hydrainfer_amd._C.kernel.moe import sum_out
-    x = torch.randn((33, topk, 72)).to(dtype)
-    out = torch.empty((33, 72), dtype=dtype, device=DEV)
-    sum_out(x.to(DEV), out)
-    ref = x.float().sum(dim=1).to(dtype)
-    assert torch.allclose(out.cpu().float(), ref.float(), atol=1e-2, rtol=1e-2)
+    from oracle import moe
+    for dim, scale in ((36, 1.0), (72, 1.0), (264, 50.0)):      # 36: the scalar form (not a multiple of 8); the others the 16-byte form
+        x = (torch.randn((33, topk, dim)) * scale).to(dtype)
+        out = torch.empty((33, dim), dtype=dtype, device=DEV)
+        sum_out(x.to(DEV), out)
+        ref = x.float().sum(dim=1).to(dtype)
+        loose = 6e-2 if dtype == torch.bfloat16 else 1e-2      # (a bf16 running sum of 8 terms is up to ~4 ulp of bf16 from the fp32 sum)
+        assert torch.allclose(out.cpu().float(), ref.float(), atol=loose * scale, rtol=loose)
+        # the reference kernel's own arithmetic (oracle.moe.sum_out: scalar_t running sum for topk in {2,3,4,8}): bit for bit
+        want = moe.sum_out(x)
+        if topk in (2, 3, 4, 8) or dtype == torch.float:
+            if dtype == torch.float and topk not in (2, 3, 4, 8):
+                assert torch.allclose(out.cpu(), want, atol=1e-5 * scale, rtol=1e-5)      # torch's fp32 reduction order is its own
+            else:
+                assert torch.equal(out.cpu(), want), f"{(out.cpu() != want).sum().item()} elements differ"
+        else:
+            from tests.util import assert_ulp_close
+            assert_ulp_close(out.cpu(), want, max_ulp=1, what=f"topk {topk} {dtype}")
 
 
 @pytest.mark.parametrize("dtype", [torch.half, torch.bfloat16])

@@ -38,3 +38,28 @@ def test_the_tie_rules_are_exercised():
     scores[0, :16] = 0.25                   # group 0 is the weakest: dropped first, then groups 7, 6, 5, 4
     w, i = grouped_topk_sigmoid_lanes(scores, np.zeros(n_experts, np.float32), n_groups, 3, 4)
     assert i[0].tolist() == [16, 17, 18, 19]
+
+
+def test_sum_out_oracle_follows_the_kernels_scalar_t_running_sum():
+    """oracle.moe.sum_out against the literal loop of topk_sum_kernel (align_block_kernel.cu:180-187), element by element:
+    a scalar_t running sum (rounded after every add) for topk in {2, 3, 4, 8}; for other topk torch::sum_out.  On inputs
+    where the two arithmetics differ (large cancelling terms) the oracle must be on the kernel's side."""
+    import torch
+    from oracle import moe
+    g = torch.Generator().manual_seed(7)
+    for dt in (torch.float16, torch.bfloat16, torch.float32):
+        for topk in (2, 3, 4, 8):
+            x = (torch.randn((5, topk, 24), generator=g) * torch.tensor([1e3, 1.0, 1e-2] * 8)).to(dt)
+            want = torch.empty((5, 24), dtype=dt)
+            for t in range(5):
+                for i in range(24):
+                    s_ = torch.zeros((), dtype=dt)
+                    for k in range(topk):
+                        s_ = (s_.float() + x[t, k, i].float()).to(dt)       # `sum += input[...]` in scalar_t
+                    want[t, i] = s_
+            got = moe.sum_out(x)
+            assert torch.equal(got, want), (dt, topk)
+            if dt != torch.float32 and topk == 8:      # the two arithmetics really differ on such inputs
+                assert not torch.equal(got, x.float().sum(dim=1).to(dt))
+        x = torch.randn((4, 5, 16), generator=g).to(dt)
+        assert torch.equal(moe.sum_out(x), torch.sum(x, dim=1))
